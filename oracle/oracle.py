@@ -1,0 +1,148 @@
+"""ctypes loader for the CPU oracle (oracle/sliceslice_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, from __graft_entry__.smoke()
+and from bench.py's cpu_baseline leg - never from the sliceslice-rs_amd package.
+The names mirror the reference API so parity tests read like the reference's:
+``OracleSearcher(needle)`` ~ ``DynamicAvx2Searcher::new`` (src/x86.rs:454),
+``OracleSearcher.with_position`` ~ ``::with_position`` (src/x86.rs:468),
+``.search_in(haystack)`` ~ ``::search_in`` (src/x86.rs:523).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsliceslice_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds).  Idempotent."""
+    src = os.path.join(_HERE, "sliceslice_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "clean", "all"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        vp, sz, u8p, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint64
+        L.oracle_searcher_init.argtypes = [ctypes.POINTER(vp), u8p, sz, sz]
+        L.oracle_searcher_init.restype = ctypes.c_int
+        L.oracle_searcher_init_default.argtypes = [ctypes.POINTER(vp), u8p, sz]
+        L.oracle_searcher_init_default.restype = ctypes.c_int
+        L.oracle_searcher_free.argtypes = [vp]
+        L.oracle_searcher_free.restype = None
+        L.oracle_searcher_force_scalar.argtypes = [vp, ctypes.c_int]
+        L.oracle_searcher_force_scalar.restype = None
+        L.oracle_search_in.argtypes = [vp, u8p, sz]
+        L.oracle_search_in.restype = ctypes.c_int
+        L.oracle_search_in_mt.argtypes = [vp, u8p, sz, ctypes.c_int]
+        L.oracle_search_in_mt.restype = ctypes.c_int
+        L.oracle_naive.argtypes = [u8p, sz, u8p, sz]
+        L.oracle_naive.restype = ctypes.c_int
+        L.oracle_sweep_short.argtypes = [u8p, vp, sz, ctypes.c_int]
+        L.oracle_sweep_short.restype = ctypes.c_longlong
+        L.oracle_sweep_long.argtypes = [u8p, sz, u8p, vp, sz, ctypes.c_int]
+        L.oracle_sweep_long.restype = ctypes.c_longlong
+        L.oracle_bench_long.argtypes = [u8p, sz, u8p, vp, sz, ctypes.c_int]
+        L.oracle_bench_long.restype = ctypes.c_longlong
+        L.oracle_fill_random.argtypes = [u8p, u64, sz, u64]
+        L.oracle_fill_random.restype = None
+        L.oracle_have_avx2.argtypes = []
+        L.oracle_have_avx2.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _buf(b):
+    """(keepalive, address, length) for bytes / bytearray / numpy uint8 array."""
+    if isinstance(b, np.ndarray):
+        a = np.ascontiguousarray(b, dtype=np.uint8)
+        return a, a.ctypes.data, a.size
+    if isinstance(b, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(bytes(b) if not isinstance(b, bytes) else b, dtype=np.uint8)
+        return (a, b), (a.ctypes.data if a.size else 0), a.size
+    raise TypeError(type(b))
+
+
+class OraclePositionError(AssertionError):
+    """What the reference expresses as a panic (src/x86.rs:300,473)."""
+
+
+class OracleSearcher:
+    def __init__(self, needle, position=None, force_scalar=False):
+        self._h = ctypes.c_void_p()
+        keep, addr, n = _buf(needle)
+        if position is None:
+            rc = lib().oracle_searcher_init_default(ctypes.byref(self._h), addr, n)
+        else:
+            rc = lib().oracle_searcher_init(ctypes.byref(self._h), addr, n, position % (1 << 64))
+        if rc == 1:
+            raise OraclePositionError("position %r invalid for needle of %d bytes" % (position, n))
+        if rc != 0:
+            raise MemoryError()
+        if force_scalar:
+            lib().oracle_searcher_force_scalar(self._h, 1)
+
+    @classmethod
+    def with_position(cls, needle, position, **kw):
+        return cls(needle, position, **kw)
+
+    def search_in(self, haystack, threads=1):
+        keep, addr, n = _buf(haystack)
+        if threads > 1:
+            return bool(lib().oracle_search_in_mt(self._h, addr, n, threads))
+        return bool(lib().oracle_search_in(self._h, addr, n))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().oracle_searcher_free(h)
+
+
+def naive_contains(haystack, needle):
+    """haystack.windows(n).any(|w| w == needle)  (src/lib.rs:371-373); n == 0 -> True."""
+    k1, a1, n1 = _buf(haystack)
+    k2, a2, n2 = _buf(needle)
+    return bool(lib().oracle_naive(a1, n1, a2, n2))
+
+
+def pack_words(words):
+    """blob + offsets for the C sweep loops."""
+    off = np.zeros(len(words) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(w) for w in words], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(words), dtype=np.uint8)
+    return blob, off
+
+
+def sweep_short(words_sorted, mode=0):
+    blob, off = pack_words(words_sorted)
+    return int(lib().oracle_sweep_short(blob.ctypes.data, off.ctypes.data, len(words_sorted), mode))
+
+
+def sweep_long(haystack, words, mode=0):
+    blob, off = pack_words(words)
+    k, a, n = _buf(haystack)
+    return int(lib().oracle_sweep_long(a, n, blob.ctypes.data, off.ctypes.data, len(words), mode))
+
+
+def bench_long(haystack, words, iters):
+    blob, off = pack_words(words)
+    k, a, n = _buf(haystack)
+    return int(lib().oracle_bench_long(a, n, blob.ctypes.data, off.ctypes.data, len(words), iters))
+
+
+def fill_random(length, seed, global_offset=0):
+    out = np.empty(length, dtype=np.uint8)
+    lib().oracle_fill_random(out.ctypes.data, global_offset, length, seed)
+    return out
+
+
+def have_avx2():
+    return bool(lib().oracle_have_avx2())
