@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py - haystack GB/s of the MI355X substring scan (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One *step* = one complete `search_in` of the whole logical haystack for a 16-byte ABSENT needle
+(position = 15, the `new` default): every rank scans its range shard (shards overlap by n-1 bytes),
+the found flags are combined by ONE all-reduce(MAX) over RCCL, and the boolean is read back to the
+host.  The haystack is synthetic (SURVEY.md 8d generator), generated on the device, resident in HBM
+before the timed region starts.  The logical haystack has a FIXED total size (default 64 GiB, the size
+BASELINE.json's target is quoted on; it fits one 288 GB MI355X), so scaling is "strong".
+
+stdout: ONE JSON line (rank 0).  Everything else goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SEED_HAY = 0x5EED0001
+SEED_NEEDLE = 0x5EED0002
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def absent_needle(ss, n):
+    """Generator bytes with one 0xFF byte; 0xFF never occurs in the haystack."""
+    nd = bytearray(ss.fill_random_host(n, SEED_NEEDLE).tobytes())
+    nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+    return bytes(nd)
+
+
+def cpu_baseline(needle, sample_bytes):
+    """The oracle's AVX2 restatement of the reference path, timed on this host (kind = "port":
+    the Rust reference itself cannot be built in this image)."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    hay = O.fill_random(sample_bytes, SEED_HAY)
+    gen_s = time.perf_counter() - t0
+    s = O.OracleSearcher(needle)
+    assert s.search_in(hay[: 1 << 20]) is False
+
+    def best(threads, reps):
+        b = float("inf")
+        for _ in range(reps):
+            t = time.perf_counter()
+            r = s.search_in(hay, threads=threads)
+            b = min(b, time.perf_counter() - t)
+            assert r is False
+        return sample_bytes / b / 1e9
+    one = best(1, 3)
+    allc = best(cores, 8) if cores > 1 else one
+    out = {
+        "value": round(allc, 2), "unit": "GB/s", "cores": cores, "kind": "port",
+        "single_thread_value": round(one, 2), "avx2": bool(O.have_avx2()),
+        "sample": "%d MiB of the same synthetic haystack in host RAM, same 16-byte absent needle; C/AVX2 "
+                  "restatement of DynamicAvx2Searcher (oracle/sliceslice_oracle.c), best of 8 runs on %d threads "
+                  "(range shards, n-1 overlap) and best of 3 on 1 thread" % (sample_bytes >> 20, cores),
+    }
+    # BASELINE.json configs[0]: data/i386.txt x data/words.txt, shape of bench/benches/i386.rs:246-256
+    try:
+        gd = os.path.join(ROOT, "tests", "golden", "data")
+        i386 = open(os.path.join(gd, "i386.txt"), "rb").read()
+        words = [w for w in open(os.path.join(gd, "words.txt"), "rb").read().split(b"\n") if w]
+        iters = 5
+        t = time.perf_counter()
+        hits = O.bench_long(i386, words, iters)
+        out["i386_long_ms_per_iter"] = round((time.perf_counter() - t) / iters * 1e3, 2)
+        out["i386_long_hits_per_iter"] = hits // iters
+        out["i386_long_published_ms_i7_6700"] = 35.181
+    except Exception as e:      # pragma: no cover
+        out["i386_long_error"] = repr(e)
+    out["host_generate_s"] = round(gen_s, 2)
+    try:
+        with open("/proc/cpuinfo") as fh:
+            models = [l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")]
+        out["cpu_model"] = models[0] if models else "?"
+    except Exception:
+        pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--haystack-gib", type=float, default=64.0, help="TOTAL logical haystack size")
+    ap.add_argument("--needle-len", type=int, default=16)
+    ap.add_argument("--transport", choices=["torch", "rccl"], default="torch",
+                    help="flag all-reduce: torch.distributed (RCCL backend) or native RCCL via the C ABI")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--ceiling", action="store_true", help="also measure the plain streaming-read ceiling")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the scan has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import sliceslice_rs_amd as ss
+    ss.lib()
+    info = ss.device_info()
+
+    n = args.needle_len
+    total = int(args.haystack_gib * (1 << 30))
+    free_b, _ = torch.cuda.mem_get_info()
+    while (total + world - 1) // world + n > 0.92 * free_b and total > (1 << 28):
+        total //= 2                                            # a smaller device: say so in config
+    begin, end = ss.shard_range(total, n, world, rank)
+    shard = torch.empty(end - begin, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(shard, SEED_HAY, begin)
+    torch.cuda.synchronize()
+    needle = absent_needle(ss, n)
+
+    if world > 1:
+        searcher = ss.ShardedSearcher(needle, group=None, backend=args.transport)
+        inner = searcher._searcher
+    else:
+        searcher = ss.DynamicHipSearcher.new(needle)
+        inner = searcher
+    inner.set_variant(args.variant)
+    inner.set_grid(args.grid)
+    inner.set_timing(True)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        assert searcher.search_in(shard) is False
+    kernel_ms = []
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        found = searcher.search_in(shard)                      # launch -> (all-reduce) -> bool on the host
+        kernel_ms.append(inner.last_kernel_ms())               # hipEvents on the launch stream
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    assert found is False
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ceiling = None
+    if args.ceiling and rank == 0:
+        ceiling = ss.read_ceiling_gbps(shard[: (shard.numel() // 16) * 16], reps=5)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total * args.steps / elapsed / 1e9
+        k_ms = float(np.mean(kernel_ms))
+        achieved = shard.numel() / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            try:
+                pj = json.load(open(tj))
+                traffic = pj["hbm_read_bytes_per_haystack_byte"] * shard.numel()
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "haystack GB/s scanned (and % HBM roofline), 16-byte needle, 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": "%.4g GiB synthetic random-byte haystack (0xFF-free), %d-byte absent needle, position %d; "
+                            "range-sharded over %d GPU(s) with %d B overlap, one all-reduce(MAX) of the found flag"
+                            % (total / (1 << 30), n, n - 1, world, n - 1),
+                "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n,
+                "transport": args.transport if world > 1 else "none", "variant": args.variant,
+                "device": info["name"], "compute_units": info["compute_units"],
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "kernel": "ss::scan_kernel", "kernel_ms_avg": round(k_ms, 4),
+                "algorithmic_bytes_per_launch": shard.numel(),
+                "frac_of_whole_job_value": round(value / world / HBM_PEAK_GBPS, 4),
+            },
+        }
+        if ceiling is not None:
+            out["roofline"]["read_ceiling_gbps"] = round(ceiling, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(needle, args.cpu_sample_mib << 20)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        if hasattr(searcher, "close"):
+            searcher.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/*
+ * sliceslice_hip.h - C ABI of the MI355X (gfx950) substring searcher.
+ *
+ * This is the drop-in boundary for ONE hot path of cloudflare/sliceslice-rs:
+ * `DynamicAvx2Searcher::{new, with_position, search_in}` -> bool.  The reference
+ * has no FFI on this path (its public surface is the Rust API); the entry points
+ * below are what a Rust `extern "C"` block, a cgo / ctypes stub or a C++ caller
+ * binds in order to replace that path (INTEGRATION.md shows the bindings).  The
+ * style - pointer + length pairs, integer status - follows the reference's only
+ * FFI precedent, bench/sse4-strstr/src/wrapper.h:7
+ *     size_t avx2_strstr_v2(const char* s, size_t n, const char* needle, size_t k);
+ *
+ * All citations are paths under /root/reference (sliceslice-rs @ 2024_08_07).
+ *
+ * Semantics (bit-identical to DynamicAvx2Searcher, src/x86.rs:498-519, 356-361,
+ * src/lib.rs:130-136):
+ *     n == 0            -> found = 1 (even for an empty haystack)
+ *     n == 1            -> found = (needle[0] occurs in haystack); empty -> 0
+ *     len <  n          -> found = 0
+ *     otherwise         -> found = exists i in [0, len-n]: hay[i..i+n] == needle
+ * `position` selects the second filter byte and never changes the result
+ * (src/lib.rs:375-378).
+ *
+ * Errors: the reference panics on contract violations (src/x86.rs:300,473);
+ * nothing unwinds across this ABI - every function returns an ss_status.
+ *
+ * Threading: a searcher is immutable after construction; any number of threads
+ * may call ss_search_* on one handle concurrently (each call uses its own flag
+ * slot).  A call synchronises only the stream it was given.
+ *
+ * No CPU fallback exists: every ss_search_* that has to look at haystack bytes
+ * launches a HIP kernel, and fails with SS_ERR_NO_DEVICE / SS_ERR_HIP otherwise.
+ */
+#ifndef SLICESLICE_HIP_H
+#define SLICESLICE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ss_status {
+    SS_OK = 0,
+    SS_ERR_POSITION = 1,   /* reference panic: `assert!(position < needle.size())` x86.rs:300,
+                              `assert_eq!(position, 0)` for one-byte needles x86.rs:473 */
+    SS_ERR_ARGUMENT = 2,   /* NULL where a pointer is required, bad offsets, ... */
+    SS_ERR_NO_DEVICE = 3,  /* no gfx950-class HIP device visible */
+    SS_ERR_HIP = 4,        /* a HIP runtime call failed; see ss_last_error() */
+    SS_ERR_RCCL = 5,       /* an RCCL call failed / librccl not loadable */
+    SS_ERR_NOMEM = 6
+} ss_status;
+
+/* Opaque searcher: owns a host copy and a device copy of the needle, `position`,
+ * and the two filter bytes (needle[0], needle[position]) - the counterpart of
+ * `DynamicAvx2Searcher<N>` (src/x86.rs:405-442) and of the pre-splatted
+ * `VectorHash` (src/lib.rs:165-176). */
+typedef struct ss_searcher ss_searcher;
+
+/* DynamicAvx2Searcher::new (src/x86.rs:454-459): position = n - 1 (wrapping for n == 0). */
+int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out);
+
+/* DynamicAvx2Searcher::with_position (src/x86.rs:468-493).
+ *   n == 0: any position accepted (N0);  n == 1: position must be 0;  n >= 2: position < n.
+ * Violations return SS_ERR_POSITION (the reference panics).  The needle bytes are copied; the
+ * caller keeps ownership of its buffer (the reference copies n in 2..=16 too, x86.rs:476-490). */
+int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out);
+
+void ss_searcher_free(ss_searcher *s);
+
+size_t ss_searcher_needle_len(const ss_searcher *s);
+size_t ss_searcher_position(const ss_searcher *s);
+
+/* DynamicAvx2Searcher::search_in (src/x86.rs:523-525) on a haystack ALREADY RESIDENT in device
+ * memory (any alignment, any length up to the device's memory).  Enqueues on `hip_stream`
+ * (a hipStream_t; NULL = the default stream), waits for that stream, writes 0/1 to *found. */
+int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,
+                     int *found);
+
+/* Same scan without the host round trip: ORs the result into the caller's device flag
+ * (`*d_found`, int32, caller-zeroed) and returns after enqueueing.  This is the building block of
+ * the range-sharded multi-GPU search: each rank scans its shard, then ONE all-reduce(MAX) of the
+ * flag combines them (ss_comm_allreduce_flag or torch.distributed). */
+int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t len,
+                           void *hip_stream, int *d_found);
+
+/* Drop-in form of search_in(&[u8]) for a HOST haystack: stages the bytes to the device in
+ * double-buffered pinned chunks (needle_len-1 bytes of carry between chunks) and scans them there.
+ * PCIe-bound by construction; never used for roofline numbers. */
+int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
+
+/* Batched search, one launch (BASELINE.json config 5): problem i searches needle i
+ * (needles + needle_off[i] .. needle_off[i+1]) in haystack i (d_haystacks + hay_off[i] ..
+ * hay_off[i+1]); all buffers in device memory; offsets are count+1 uint64 each; position[i]
+ * follows the with_position rules (pass NULL for the `new` default n_i - 1).  Writes count int32
+ * flags to d_found (device) with the same semantics as ss_search_device per problem.  Validation
+ * of positions happens on the host copy `h_needle_off`/`h_position` when given. */
+int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_off, const void *d_needles,
+                      const uint64_t *d_needle_off, const uint64_t *d_position, size_t count,
+                      void *hip_stream, int *d_found);
+
+/* Kernel timing hook for bench.py's roofline line: when enabled, every scan launched through `s`
+ * is bracketed by hipEvents ON THE LAUNCH STREAM; ss_searcher_last_kernel_ms returns the elapsed
+ * time of the most recent completed scan kernel (milliseconds). */
+int ss_searcher_set_timing(ss_searcher *s, int enabled);
+int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);
+
+/* Kernel-variant override for tuning/tests: 0 = automatic.  See DESIGN.md "Kernels". */
+int ss_searcher_set_variant(ss_searcher *s, int variant);
+/* Grid-size override (blocks); 0 = automatic. */
+int ss_searcher_set_grid(ss_searcher *s, int blocks);
+
+/* Synthetic haystack generator (not part of the reference):
+ *   byte(i) = (splitmix64(seed ^ (i >> 3)) >> (8 * (i & 7))) & 0xFF, then 0xFF -> 0x00,
+ * with i = global_offset + k the GLOBAL byte index, so that range shards on different GPUs hold
+ * slices of one logical haystack.  Device and host versions are bit-identical. */
+int ss_fill_random_device(void *d_dst, uint64_t global_offset, size_t len, uint64_t seed,
+                          void *hip_stream);
+int ss_fill_random_host(uint8_t *dst, uint64_t global_offset, size_t len, uint64_t seed);
+
+/* Plain streaming read of `len` bytes (sum-reduced so it cannot be elided): the empirical
+ * "achievable HBM read" ceiling printed next to the scan's GB/s.  ms = kernel time by hipEvents. */
+int ss_read_ceiling(const void *d_src, size_t len, void *hip_stream, int reps, float *ms_per_rep);
+
+/* ---- multi-GPU: one process per GPU, native RCCL ------------------------------------------- */
+/* The found flag of a range-sharded search is combined by ONE ncclAllReduce(int32, ncclMax)
+ * (OR over {0,1} == MAX; RCCL has no bitwise-OR op).  librccl is dlopen()ed on first use. */
+typedef struct ss_comm ss_comm;
+#define SS_UNIQUE_ID_BYTES 128
+int ss_comm_unique_id(uint8_t id[SS_UNIQUE_ID_BYTES]);                       /* rank 0, then broadcast */
+int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank, ss_comm **out);
+void ss_comm_free(ss_comm *c);
+/* In-place all-reduce(MAX) of one int32 device flag on `hip_stream`, then (if found != NULL)
+ * stream-synchronise and copy the combined flag to *found. */
+int ss_comm_allreduce_flag(ss_comm *c, int *d_flag, void *hip_stream, int *found);
+/* ss_search_device_async + ss_comm_allreduce_flag on one stream: the whole sharded search_in. */
+int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, ss_comm *c,
+                      void *hip_stream, int *found);
+
+/* Range partition used by every sharded caller: rank r of G scans bytes
+ * [r*S, min(len, (r+1)*S + n-1)) with S = ceil(len/G): an overlap of n-1 bytes, so a match that
+ * straddles a boundary is seen by exactly the left rank. */
+int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *begin, size_t *end);
+
+/* Diagnostics */
+const char *ss_last_error(void);      /* thread-local, static storage */
+int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *total_mem);
+const char *ss_version(void);
+/* Device self-test of the cross-lane primitives the scan relies on (DPP wave_shl:1, v_alignbyte):
+ * fills out[0..192) (host memory); see tests/test_gpu_parity.py::test_cross_lane_primitives. */
+int ss_selftest_dpp(uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLICESLICE_HIP_H */

@@ -1,0 +1,365 @@
+// scan_kernels.hpp - device side of the MI355X (gfx950, wave64) substring scan.
+//
+// What the reference does per 32 candidate offsets with two AVX2 loads, two vpcmpeqb, a vpand and a
+// vpmovmskb (vector_search_in_chunk, /root/reference/src/lib.rs:199-251; __m256i ops
+// src/x86.rs:202-235) is re-expressed here for a 64-lane wavefront:
+//
+//   * a *piece* is 64 consecutive 16-byte chunks (1 KiB) of the haystack, one chunk per lane, fetched
+//     by ONE coalesced global_load_dwordx4 per lane from a 16-byte-aligned address.  Every load is an
+//     aligned chunk that contains at least one in-range byte, so no load can cross into an unmapped
+//     page (the guarantee the reference gets from its overlapped tail chunk, lib.rs:276-284).
+//   * the "first byte" filter (hay[i] == needle[0]) and the "position byte" filter
+//     (hay[i+position] == needle[position]) are evaluated on 4 bytes per VALU op with the zero-byte
+//     trick  z(x) = (x - 0x01010101) & ~x  (bit 7 of every byte of x that is zero is set; it can also
+//     flag a 0x01 byte sitting above a zero byte - a false POSITIVE only, and candidates are
+//     verified, so the boolean is unaffected).
+//   * position = 16*d + 4*Q + r.  The position-byte flags of lane l's candidates live in the flag
+//     dwords of chunk c+d (and c+d+1): d is folded into the load address of a second stream (d == 0,
+//     i.e. position < 16 - every needle of <= 16 bytes - needs no second load at all), the chunk
+//     c+d+1 part comes from the neighbouring lane with one DPP wave_shl:1 per dword, Q selects the
+//     dword window at compile time and r is a v_alignbyte_b32.
+//   * lane 63 of a piece only supplies that neighbour data: pieces advance by 63 chunks, so every
+//     piece is self-contained (no cross-piece state).  The re-read chunk hits L1/L2.
+//   * `__ballot(any flag)` is the wave's movemask; if it is zero (2^-16 per offset on random bytes) the
+//     wave moves on.  Otherwise every flagged lane walks its flags lowest-first (`__ffs`, clear lowest
+//     set bit - lib.rs:220-247) and compares the needle (staged in LDS once per workgroup) with the
+//     haystack bytes; the first equal candidate sets the found flag (lib.rs:242-244).
+//   * the found flag is polled once per tile by every wave, so a hit stops the whole grid early, which
+//     is the reference's early `return true`.
+//
+// Nothing here depends on block->XCD placement; all inter-workgroup traffic is one relaxed
+// agent-scope int (monotonic 0 -> 1), read with a relaxed agent-scope load.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ss {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;              // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kNeedleLds = 2048;         // needle bytes staged in LDS; longer needles continue from global
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// One haystack/needle problem in "aligned coordinates": a = byte offset from `base` (16-B aligned).
+struct Problem {
+    const uint8_t *base;      // hay - mis
+    const uint8_t *hay;       // the caller's pointer
+    const uint8_t *needle;    // device copy of the needle
+    uint64_t n;               // needle length (>= 1)
+    uint64_t end;             // number of candidate offsets = len - n + 1   (>= 1)
+    uint64_t nchunks_all;     // ceil((mis + len) / 16): chunks that contain a haystack byte
+    uint64_t npieces;         // ceil(ceil((mis + end) / 16) / stride)
+    uint64_t d;               // position / 16: chunk displacement of the second stream
+    uint32_t mis;             // hay - base, 0..15
+    uint32_t r;               // (position % 16) % 4: byte part of the shift
+    uint32_t n0x4, nlx4;      // needle[0] and needle[position] splatted over a dword
+};
+
+__device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) { return (x - 0x01010101u) & ~x; }
+
+// lane l receives lane l+1's value; lane 63 receives 0 (DPP wave_shl:1, bound_ctrl).
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load_chunk(const uint8_t *base, uint64_t chunk)
+{
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(base) + chunk;
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// Full comparison of the needle with hay[i .. i+n).  Lane-private (divergent) on purpose: on random
+// data almost every candidate dies on the first byte or two.
+__device__ __forceinline__ bool verify_candidate(const Problem &pr, const uint8_t *s_needle, uint64_t i)
+{
+    const uint8_t *h = pr.hay + i;
+    const uint64_t n_lds = pr.n < (uint64_t)kNeedleLds ? pr.n : (uint64_t)kNeedleLds;
+    for (uint64_t k = 0; k < n_lds; ++k)
+        if (h[k] != s_needle[k]) return false;
+    for (uint64_t k = n_lds; k < pr.n; ++k)
+        if (h[k] != pr.needle[k]) return false;
+    return true;
+}
+
+// Filter one piece.  A = this lane's chunk of the first-byte stream, B = its chunk of the position-byte
+// stream (B == A when d == 0).  Returns per-dword candidate flags (bit 7 of each candidate byte).
+template <int Q, bool ONE_BYTE>
+__device__ __forceinline__ void filter_piece(const u32x4 &A, const u32x4 &B, const Problem &pr, uint32_t g[4])
+{
+    const uint32_t f0 = zero_byte_flags(A.x ^ pr.n0x4), f1 = zero_byte_flags(A.y ^ pr.n0x4);
+    const uint32_t f2 = zero_byte_flags(A.z ^ pr.n0x4), f3 = zero_byte_flags(A.w ^ pr.n0x4);
+    if (ONE_BYTE) {
+        g[0] = f0; g[1] = f1; g[2] = f2; g[3] = f3;
+        return;
+    }
+    uint32_t w[8];
+    w[0] = zero_byte_flags(B.x ^ pr.nlx4);
+    w[1] = zero_byte_flags(B.y ^ pr.nlx4);
+    w[2] = zero_byte_flags(B.z ^ pr.nlx4);
+    w[3] = zero_byte_flags(B.w ^ pr.nlx4);
+    // dwords Q .. Q+4 of the 8-dword window {this lane, next lane} are needed; fetch only those.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[4 + j] = (j <= Q) ? from_next_lane(w[j]) : 0u;
+    g[0] = f0 & __builtin_amdgcn_alignbyte(w[Q + 1], w[Q + 0], pr.r);
+    g[1] = f1 & __builtin_amdgcn_alignbyte(w[Q + 2], w[Q + 1], pr.r);
+    g[2] = f2 & __builtin_amdgcn_alignbyte(w[Q + 3], w[Q + 2], pr.r);
+    g[3] = f3 & __builtin_amdgcn_alignbyte(w[Q + 4], w[Q + 3], pr.r);
+}
+
+// Candidate verification for one lane's flags; returns true when the needle was found.
+template <bool ONE_BYTE>
+__device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk, const Problem &pr,
+                                             const uint8_t *s_needle)
+{
+    bool hit = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t m = g[j] & 0x80808080u;
+        while (m != 0 && !hit) {
+            const int bit = __ffs((int)m) - 1;          // lowest flagged byte first (tzcnt, lib.rs:221)
+            m &= m - 1;                                 // clear lowest set bit        (lib.rs:247)
+            const uint64_t a = chunk * 16 + (uint64_t)(j * 4 + (bit >> 3));
+            const uint64_t i = a - pr.mis;              // wraps for bytes in front of the haystack
+            if (i < pr.end) {
+                if (ONE_BYTE) hit = pr.hay[i] == (uint8_t)pr.n0x4;
+                else hit = verify_candidate(pr, s_needle, i);
+            }
+        }
+    }
+    return hit;
+}
+
+__device__ __forceinline__ int poll_found(const int *found)
+{
+    return __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__device__ __forceinline__ void publish_found(int *found)
+{
+    __hip_atomic_store(found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Scan tiles tile0, tile0+tile_step, ... of one problem with the calling workgroup.
+// A tile is kWavesPerBlock*U consecutive pieces; wave w handles pieces tile*4U + 4u + w, so each load
+// instruction of the workgroup covers 4 consecutive KiB.
+// STRIDE = chunks a piece advances by: 63 (lane 63 = neighbour data only) or 64 for one-byte needles.
+template <int Q, bool TWO, bool ONE_BYTE, int U, bool NT>
+__device__ __forceinline__ void scan_tiles(const Problem &pr, const uint8_t *s_needle, uint64_t tile0,
+                                           uint64_t tile_step, int *found)
+{
+    constexpr uint64_t STRIDE = ONE_BYTE ? 64 : 63;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
+    const uint32_t live = (ONE_BYTE || lane != kWave - 1) ? 0x80808080u : 0u;
+    const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+
+    for (uint64_t tile = tile0; tile < ntiles; tile += tile_step) {
+        u32x4 A[U], B[U];
+        uint64_t chunk[U];
+        const uint64_t piece0 = tile * (kWavesPerBlock * U) + (uint64_t)wave;
+        const bool full = (piece0 + (uint64_t)kWavesPerBlock * (U - 1)) * STRIDE + 64 + pr.d <= pr.nchunks_all;
+        if (full) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                chunk[u] = (piece0 + (uint64_t)kWavesPerBlock * u) * STRIDE + (uint64_t)lane;
+                A[u] = load_chunk<NT>(pr.base, chunk[u]);
+                if (TWO) B[u] = load_chunk<NT>(pr.base, chunk[u] + pr.d);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                chunk[u] = (piece0 + (uint64_t)kWavesPerBlock * u) * STRIDE + (uint64_t)lane;
+                A[u] = u32x4{0, 0, 0, 0};
+                if (chunk[u] < pr.nchunks_all) A[u] = load_chunk<NT>(pr.base, chunk[u]);
+                if (TWO) {
+                    B[u] = u32x4{0, 0, 0, 0};
+                    if (chunk[u] + pr.d < pr.nchunks_all) B[u] = load_chunk<NT>(pr.base, chunk[u] + pr.d);
+                }
+            }
+        }
+        const int stop = poll_found(found);   // issued behind the data loads, consumed after them
+
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t g[4];
+            filter_piece<Q, ONE_BYTE>(A[u], TWO ? B[u] : A[u], pr, g);
+            const uint32_t any = (g[0] | g[1] | g[2] | g[3]) & live;
+            if (__ballot(any != 0) != 0) {              // the wave's "movemask != 0"
+                g[0] &= live; g[1] &= live; g[2] &= live; g[3] &= live;
+                hit |= verify_flags<ONE_BYTE>(g, chunk[u], pr, s_needle);
+            }
+        }
+        if (__ballot(hit) != 0) {
+            if (hit) publish_found(found);
+            return;
+        }
+        if (stop) return;
+    }
+}
+
+__device__ __forceinline__ void stage_needle(uint8_t *s_needle, const uint8_t *needle, uint64_t n)
+{
+    const uint32_t m = n < (uint64_t)kNeedleLds ? (uint32_t)n : (uint32_t)kNeedleLds;
+    for (uint32_t k = threadIdx.x; k < m; k += kBlock) s_needle[k] = needle[k];
+    __syncthreads();
+}
+
+// ---- K1/K2/K3: one needle, one haystack ---------------------------------------------------------
+template <int Q, bool TWO, bool ONE_BYTE, int U, bool NT>
+__global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, int *found)
+{
+    __shared__ uint8_t s_needle[kNeedleLds];
+    stage_needle(s_needle, pr.needle, pr.n);
+    scan_tiles<Q, TWO, ONE_BYTE, U, NT>(pr, s_needle, blockIdx.x, gridDim.x, found);
+}
+
+// ---- K4: batched, one grid for many (needle, haystack) problems ----------------------------------
+// blockIdx.y = problem, blockIdx.x = slice of that problem's tiles.  Per-problem flags, no
+// cross-problem early exit.  The problem descriptor is built per workgroup from the CSR offsets.
+struct BatchArgs {
+    const uint8_t *haystacks;
+    const uint64_t *hay_off;
+    const uint8_t *needles;
+    const uint64_t *needle_off;
+    const uint64_t *position;   // may be null: n_i - 1
+    int *found;
+};
+
+template <int U, bool NT>
+__global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
+{
+    __shared__ uint8_t s_needle[kNeedleLds];
+    const uint64_t prob = blockIdx.y;
+    const uint64_t h0 = a.hay_off[prob], h1 = a.hay_off[prob + 1];
+    const uint64_t n0 = a.needle_off[prob], n1 = a.needle_off[prob + 1];
+    const uint64_t len = h1 - h0, n = n1 - n0;
+    int *found = a.found + prob;
+    if (n == 0) {                                   // N0: found everywhere (x86.rs:500)
+        if (blockIdx.x == 0 && threadIdx.x == 0) publish_found(found);
+        return;
+    }
+    if (len < n) return;                            // flag stays 0
+    uint64_t position = a.position ? a.position[prob] : n - 1;
+    if (position >= n) position = n - 1;            // validated on the host when it can be; never UB here
+
+    Problem pr;
+    pr.hay = a.haystacks + h0;
+    pr.mis = (uint32_t)((uintptr_t)pr.hay & 15);
+    pr.base = pr.hay - pr.mis;
+    pr.needle = a.needles + n0;
+    pr.n = n;
+    pr.end = len - n + 1;
+    pr.nchunks_all = (pr.mis + len + 15) / 16;
+    const uint64_t stride = n == 1 ? 64 : 63;
+    pr.npieces = ((pr.mis + pr.end + 15) / 16 + stride - 1) / stride;
+    pr.d = position / 16;
+    const uint32_t s = (uint32_t)(position % 16);
+    pr.r = s % 4;
+    pr.n0x4 = 0x01010101u * pr.needle[0];
+    pr.nlx4 = 0x01010101u * pr.needle[position];
+    stage_needle(s_needle, pr.needle, pr.n);
+
+    const uint64_t t0 = blockIdx.x, ts = gridDim.x;
+    if (n == 1) {
+        scan_tiles<0, false, true, U, NT>(pr, s_needle, t0, ts, found);
+        return;
+    }
+    const int q = (int)(s / 4);
+    if (pr.d == 0) {
+        switch (q) {
+        case 0: scan_tiles<0, false, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        case 1: scan_tiles<1, false, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        case 2: scan_tiles<2, false, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        default: scan_tiles<3, false, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        }
+    } else {
+        switch (q) {
+        case 0: scan_tiles<0, true, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        case 1: scan_tiles<1, true, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        case 2: scan_tiles<2, true, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        default: scan_tiles<3, true, false, U, NT>(pr, s_needle, t0, ts, found); break;
+        }
+    }
+}
+
+// ---- synthetic haystack generator (not part of the reference) ------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// 8 generated bytes of global word index w, with 0xFF remapped to 0x00.
+__host__ __device__ __forceinline__ uint64_t synth_word(uint64_t seed, uint64_t w)
+{
+    const uint64_t v = splitmix64(seed ^ w);
+    // bytes equal to 0xFF: ~v has a zero byte there.  Exact per-byte zero detection (no borrow):
+    const uint64_t x = ~v;
+    const uint64_t zero = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);
+    const uint64_t ffmask = (zero >> 7) * 0xFFull;   // 0xFF in every byte of v that equals 0xFF
+    return v & ~ffmask;
+}
+
+__global__ void __launch_bounds__(kBlock) fill_random_kernel(uint8_t *dst, uint64_t global_offset,
+                                                             uint64_t len, uint64_t seed)
+{
+    // word-granular body on the GLOBAL index grid; bytes outside [0, len) are not written.
+    const uint64_t first_word = global_offset >> 3;
+    const uint64_t last_word = (global_offset + len + 7) >> 3;          // exclusive
+    const uint64_t nwords = last_word - first_word;
+    for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < nwords;
+         k += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t w = first_word + k;
+        const uint64_t v = synth_word(seed, w);
+        const int64_t o = (int64_t)(w << 3) - (int64_t)global_offset;    // dst offset of byte 0 of the word
+        if (o >= 0 && (uint64_t)o + 8 <= len && (((uintptr_t)(dst + o)) & 7) == 0) {
+            *reinterpret_cast<uint64_t *>(dst + o) = v;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int64_t ob = o + b;
+                if (ob >= 0 && (uint64_t)ob < len) dst[ob] = (uint8_t)(v >> (8 * b));
+            }
+        }
+    }
+}
+
+// ---- plain streaming read: the empirical "achievable HBM read" ceiling ------------------------------
+template <int U, bool NT>
+__global__ void __launch_bounds__(kBlock) read_ceiling_kernel(const u32x4 *src, uint64_t nvec, uint32_t *sink)
+{
+    u32x4 acc = {0, 0, 0, 0};
+    const uint64_t step = (uint64_t)gridDim.x * kBlock;
+    uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + (U - 1) * step < nvec; i += U * step) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * step) : src[i + u * step];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    for (; i < nvec; i += step) acc ^= src[i];
+    const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x9E3779B9u) sink[0] = r;      // practically never; keeps the loads alive
+}
+
+// DPP self-test: out[l] = value of lane l+1 (0 for lane 63), next to the __shfl_down statement of the same.
+__global__ void dpp_probe_kernel(uint32_t *out)
+{
+    const uint32_t v = 1000u + threadIdx.x;
+    out[threadIdx.x] = from_next_lane(v);
+    const uint32_t viaShfl = (uint32_t)__shfl_down((int)v, 1);
+    out[64 + threadIdx.x] = (threadIdx.x == 63) ? 0u : viaShfl;
+    out[128 + threadIdx.x] = __builtin_amdgcn_alignbyte(0x44332211u, 0xDDCCBBAAu, threadIdx.x & 3);
+}
+
+}  // namespace ss

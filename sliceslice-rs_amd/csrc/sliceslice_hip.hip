@@ -1,0 +1,697 @@
+// sliceslice_hip.hip - host side of the C ABI declared in include/sliceslice_hip.h.
+//
+// Mirrors, for the GPU, what the reference does on the CPU:
+//   ss_searcher_with_position   DynamicAvx2Searcher::with_position   /root/reference/src/x86.rs:468-493
+//   ss_searcher_new             DynamicAvx2Searcher::new             src/x86.rs:454-459
+//   ss_search_*                 DynamicAvx2Searcher::search_in       src/x86.rs:498-525
+//                               (N0 -> true x86.rs:500; N1 = MemchrSearcher lib.rs:130-136;
+//                                len < n -> false / len == n -> equality x86.rs:357-359)
+// The scan itself lives in scan_kernels.hpp.  There is no CPU search path in this file.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/sliceslice_hip.h"
+#include "scan_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorNoDevice ? SS_ERR_NO_DEVICE : SS_ERR_HIP, "%s: %s (%s:%d)",  \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+struct DeviceInfo {
+    int cus = 0;
+    bool ok = false;
+};
+
+int device_info(int dev, DeviceInfo *out)
+{
+    static std::mutex mu;
+    static std::vector<DeviceInfo> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)cache.size() <= dev) cache.resize(dev + 1);
+    if (!cache[dev].ok) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        cache[dev].cus = prop.multiProcessorCount;
+        cache[dev].ok = true;
+    }
+    *out = cache[dev];
+    return SS_OK;
+}
+
+// Per-device state of a searcher: the needle copy and a small pool of found-flag slots so that
+// concurrent ss_search_device calls on one handle never share mutable scratch.
+struct PerDevice {
+    int dev = -1;
+    uint8_t *d_needle = nullptr;
+    int *d_flags = nullptr;     // kSlots ints, zero whenever a slot is free
+    int *h_flags = nullptr;     // pinned mirror
+    uint64_t free_mask = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed_valid = false;
+};
+constexpr int kSlots = 64;
+
+}  // namespace
+
+struct ss_searcher {
+    std::vector<uint8_t> needle;
+    size_t n = 0;
+    size_t position = 0;
+    int variant = 0;
+    int grid = 0;
+    bool timing = false;
+    mutable std::mutex mu;
+    mutable std::vector<PerDevice> per;
+};
+
+namespace {
+
+int get_per_device(const ss_searcher *s, PerDevice **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(s->mu);
+    for (auto &p : s->per)
+        if (p.dev == dev) {
+            *out = &p;
+            return SS_OK;
+        }
+    PerDevice p;
+    p.dev = dev;
+    HIP_TRY(hipMalloc((void **)&p.d_needle, s->n ? s->n : 1));
+    if (s->n) HIP_TRY(hipMemcpy(p.d_needle, s->needle.data(), s->n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&p.d_flags, kSlots * sizeof(int)));
+    HIP_TRY(hipMemset(p.d_flags, 0, kSlots * sizeof(int)));
+    HIP_TRY(hipHostMalloc((void **)&p.h_flags, kSlots * sizeof(int), hipHostMallocDefault));
+    p.free_mask = ~0ull;
+    HIP_TRY(hipEventCreate(&p.ev0));
+    HIP_TRY(hipEventCreate(&p.ev1));
+    s->per.reserve(16);              // PerDevice pointers handed out must stay valid
+    s->per.push_back(p);
+    *out = &s->per.back();
+    return SS_OK;
+}
+
+int acquire_slot(const ss_searcher *s, PerDevice *p)
+{
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            if (p->free_mask) {
+                const int k = __builtin_ctzll(p->free_mask);
+                p->free_mask &= p->free_mask - 1;
+                return k;
+            }
+        }
+        sched_yield();   // > 64 concurrent searches on one handle: wait for a slot
+    }
+}
+
+void release_slot(const ss_searcher *s, PerDevice *p, int k)
+{
+    std::lock_guard<std::mutex> lock(s->mu);
+    p->free_mask |= 1ull << k;
+}
+
+// ---- kernel selection -------------------------------------------------------------------------------
+// variant = 10*U_code + NT, U_code in {2,4,8}; 0 = automatic.
+struct Launch {
+    int U;
+    bool NT;
+};
+
+Launch pick_variant(int variant)
+{
+    Launch l{4, false};
+    if (variant > 0) {
+        const int u = variant / 10;
+        if (u == 2 || u == 4 || u == 8) l.U = u;
+        l.NT = (variant % 10) != 0;
+    }
+    return l;
+}
+
+template <int U, bool NT>
+void launch_scan_un(const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st, int *flag)
+{
+    using namespace ss;
+    dim3 blk(kBlock);
+    if (one_byte) {
+        scan_kernel<0, false, true, U, NT><<<grid, blk, 0, st>>>(pr, flag);
+        return;
+    }
+#define SS_CASE(QQ, TT)                                                                            \
+    case (QQ) * 2 + (TT ? 1 : 0):                                                                  \
+        scan_kernel<QQ, TT, false, U, NT><<<grid, blk, 0, st>>>(pr, flag);                         \
+        break;
+    switch (q * 2 + (two ? 1 : 0)) {
+        SS_CASE(0, false) SS_CASE(0, true) SS_CASE(1, false) SS_CASE(1, true)
+        SS_CASE(2, false) SS_CASE(2, true) SS_CASE(3, false) SS_CASE(3, true)
+    }
+#undef SS_CASE
+}
+
+// Builds the Problem for (hay, len) and enqueues the scan; *d_flag is OR-ed (0 -> 1), never cleared.
+// Preconditions: 1 <= n <= len.
+int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st,
+                 int *d_flag)
+{
+    ss::Problem pr;
+    const size_t n = s->n;
+    pr.hay = static_cast<const uint8_t *>(d_hay);
+    pr.mis = (uint32_t)((uintptr_t)d_hay & 15);
+    pr.base = pr.hay - pr.mis;
+    pr.needle = pd->d_needle;
+    pr.n = n;
+    pr.end = (uint64_t)len - n + 1;
+    pr.nchunks_all = ((uint64_t)pr.mis + len + 15) / 16;
+    const bool one_byte = n == 1;
+    const uint64_t stride = one_byte ? 64 : 63;
+    pr.npieces = (((uint64_t)pr.mis + pr.end + 15) / 16 + stride - 1) / stride;
+    const size_t position = one_byte ? 0 : s->position;
+    pr.d = position / 16;
+    const uint32_t sh = (uint32_t)(position % 16);
+    pr.r = sh % 4;
+    pr.n0x4 = 0x01010101u * s->needle[0];
+    pr.nlx4 = 0x01010101u * s->needle[position];
+
+    const Launch l = pick_variant(s->variant);
+    const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
+    DeviceInfo di;
+    if (int rc = device_info(pd->dev, &di)) return rc;
+    uint64_t blocks = s->grid > 0 ? (uint64_t)s->grid : (uint64_t)di.cus * 8;   // 8 x 256 threads = 32 waves/CU
+    if (blocks > ntiles) blocks = ntiles;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks);
+
+    if (s->timing) HIP_TRY(hipEventRecord(pd->ev0, st));
+    const int q = (int)(sh / 4);
+    const bool two = pr.d != 0;
+#define SS_U(UU)                                                                                   \
+    if (l.NT) launch_scan_un<UU, true>(pr, q, two, one_byte, grid, st, d_flag);                    \
+    else launch_scan_un<UU, false>(pr, q, two, one_byte, grid, st, d_flag);
+    if (l.U == 2) { SS_U(2) } else if (l.U == 8) { SS_U(8) } else { SS_U(4) }
+#undef SS_U
+    HIP_TRY(hipGetLastError());
+    if (s->timing) {
+        HIP_TRY(hipEventRecord(pd->ev1, st));
+        pd->timed_valid = true;
+    }
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ss_last_error(void) { return g_err; }
+const char *ss_version(void) { return "sliceslice-hip 0.1 (gfx950)"; }
+
+int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out)
+{
+    if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (n && !needle) return fail(SS_ERR_ARGUMENT, "needle is NULL");
+    // x86.rs:468-493: [] -> N0 (position ignored); [c0] -> assert_eq!(position, 0); else position < n.
+    if (n == 1 && position != 0) return fail(SS_ERR_POSITION, "position must be 0 for a one-byte needle");
+    if (n >= 2 && position >= n) return fail(SS_ERR_POSITION, "position %zu out of range for needle of %zu bytes", position, n);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(SS_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    ss_searcher *s = new (std::nothrow) ss_searcher;
+    if (!s) return fail(SS_ERR_NOMEM, "out of memory");
+    s->needle.assign(needle, needle + n);
+    s->n = n;
+    s->position = position;
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) {      // uploads the needle to the current device now
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return SS_OK;
+}
+
+int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out)
+{
+    return ss_searcher_with_position(needle, n, n - 1 /* wrapping_sub(1), x86.rs:457 */, out);
+}
+
+void ss_searcher_free(ss_searcher *s)
+{
+    if (!s) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto &p : s->per) {
+        (void)hipSetDevice(p.dev);
+        (void)hipFree(p.d_needle);
+        (void)hipFree(p.d_flags);
+        (void)hipHostFree(p.h_flags);
+        if (p.ev0) (void)hipEventDestroy(p.ev0);
+        if (p.ev1) (void)hipEventDestroy(p.ev1);
+    }
+    (void)hipSetDevice(cur);
+    delete s;
+}
+
+size_t ss_searcher_needle_len(const ss_searcher *s) { return s ? s->n : 0; }
+size_t ss_searcher_position(const ss_searcher *s) { return s ? s->position : 0; }
+
+int ss_searcher_set_timing(ss_searcher *s, int enabled)
+{
+    if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
+    s->timing = enabled != 0;
+    return SS_OK;
+}
+
+int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms)
+{
+    if (!s || !ms) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    if (!pd->timed_valid) return fail(SS_ERR_ARGUMENT, "no timed scan has been launched");
+    HIP_TRY(hipEventSynchronize(pd->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, pd->ev0, pd->ev1));
+    return SS_OK;
+}
+
+int ss_searcher_set_variant(ss_searcher *s, int variant)
+{
+    if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
+    s->variant = variant;
+    return SS_OK;
+}
+
+int ss_searcher_set_grid(ss_searcher *s, int blocks)
+{
+    if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
+    s->grid = blocks;
+    return SS_OK;
+}
+
+int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,
+                           int *d_found)
+{
+    if (!s || !d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    if (s->n == 0) {                                    // N0: true for every haystack (x86.rs:500)
+        static const int one = 1;
+        HIP_TRY(hipMemcpyAsync(d_found, &one, sizeof one, hipMemcpyHostToDevice, st));
+        return SS_OK;
+    }
+    if (len < s->n) return SS_OK;                       // cannot occur; flag untouched
+    return enqueue_scan(s, pd, d_haystack, len, st, d_found);
+}
+
+int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, int *found)
+{
+    if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    if (s->n == 0) { *found = 1; return SS_OK; }        // x86.rs:500
+    if (len < s->n) { *found = 0; return SS_OK; }       // x86.rs:357-359 (len == n is decided on the device)
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    const int k = acquire_slot(s, pd);
+    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k);
+    if (rc == SS_OK) {
+        hipError_t e = hipMemcpyAsync(pd->h_flags + k, pd->d_flags + k, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
+    }
+    if (rc == SS_OK) {
+        *found = pd->h_flags[k] != 0;
+        if (*found) {                                   // slots are zero whenever they are free
+            hipError_t e = hipMemsetAsync(pd->d_flags + k, 0, sizeof(int), st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag reset: %s", hipGetErrorString(e));
+        }
+    } else {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(pd->d_flags + k, 0, sizeof(int));
+    }
+    release_slot(s, pd, k);
+    return rc;
+}
+
+int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found)
+{
+    if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    if (s->n == 0) { *found = 1; return SS_OK; }
+    if (len < s->n) { *found = 0; return SS_OK; }
+    // Chunked staging: chunk k covers haystack bytes [k*C - carry, (k+1)*C) with carry = n-1, so a
+    // match straddling a chunk edge is seen by the later chunk.  Two device buffers / two streams:
+    // the upload of chunk k+1 overlaps the scan of chunk k.
+    const size_t carry = s->n - 1;
+    size_t C = (size_t)64 << 20;
+    if (C < 4 * s->n) C = 4 * s->n;
+    if (C > len) C = len;
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    const int k = acquire_slot(s, pd);
+    uint8_t *dbuf[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    int rc = SS_OK;
+    auto cleanup = [&]() {
+        for (int b = 0; b < 2; ++b) {
+            if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
+            if (dbuf[b]) (void)hipFree(dbuf[b]);
+        }
+    };
+    const size_t nbuf = len > C ? 2 : 1;
+    for (size_t b = 0; b < nbuf && rc == SS_OK; ++b) {
+        if (hipMalloc((void **)&dbuf[b], C + carry) != hipSuccess || hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess)
+            rc = fail(SS_ERR_HIP, "staging allocation failed");
+    }
+    int result = 0;
+    size_t idx = 0;
+    for (size_t off = 0; off < len && rc == SS_OK && !result; off += C, ++idx) {
+        const int b = (int)(idx % nbuf);
+        const size_t lead = off == 0 ? 0 : carry;
+        const size_t bytes = (len - off < C ? len - off : C) + lead;
+        if (bytes < s->n) break;                         // tail shorter than the needle: nothing new can start here
+        hipError_t e = hipStreamSynchronize(st[b]);      // buffer b free again
+        if (e == hipSuccess && idx >= nbuf) {
+            // result of the scan that last used this buffer
+            e = hipMemcpy(pd->h_flags + k, pd->d_flags + k, sizeof(int), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && pd->h_flags[k]) { result = 1; break; }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(dbuf[b], haystack + off - lead, bytes, hipMemcpyHostToDevice, st[b]);
+        if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
+        rc = enqueue_scan(s, pd, dbuf[b], bytes, st[b], pd->d_flags + k);
+    }
+    for (size_t b = 0; b < nbuf; ++b)
+        if (st[b]) (void)hipStreamSynchronize(st[b]);
+    if (rc == SS_OK && !result) {
+        hipError_t e = hipMemcpy(pd->h_flags + k, pd->d_flags + k, sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
+        else result = pd->h_flags[k] != 0;
+    }
+    (void)hipMemset(pd->d_flags + k, 0, sizeof(int));
+    cleanup();
+    release_slot(s, pd, k);
+    if (rc == SS_OK) *found = result;
+    return rc;
+}
+
+int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_off, const void *d_needles,
+                      const uint64_t *d_needle_off, const uint64_t *d_position, size_t count,
+                      void *hip_stream, int *d_found)
+{
+    if (count == 0) return SS_OK;
+    if (!d_hay_off || !d_needle_off || !d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (count > 65535u * 1024u) return fail(SS_ERR_ARGUMENT, "too many problems");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo di;
+    if (int rc = device_info(dev, &di)) return rc;
+    HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
+    ss::BatchArgs a;
+    a.haystacks = static_cast<const uint8_t *>(d_haystacks);
+    a.hay_off = d_hay_off;
+    a.needles = static_cast<const uint8_t *>(d_needles);
+    a.needle_off = d_needle_off;
+    a.position = d_position;
+    a.found = d_found;
+    // enough slices per problem to fill the chip even for a handful of problems; a 1 MiB haystack is
+    // 66 tiles of 16 KiB, so 4 slices x 4096 problems keeps every workgroup busy for several tiles.
+    uint64_t slices = ((uint64_t)di.cus * 8 + count - 1) / count;
+    if (slices < 1) slices = 1;
+    if (slices > 1024) slices = 1024;
+    // gridDim.y is limited to 65535: fold larger counts by launching in bands.
+    size_t done = 0;
+    while (done < count) {
+        const size_t band = count - done < 65535 ? count - done : 65535;
+        ss::BatchArgs b = a;
+        b.hay_off = a.hay_off + done;
+        b.needle_off = a.needle_off + done;
+        b.position = a.position ? a.position + done : nullptr;
+        b.found = a.found + done;
+        dim3 grid((unsigned)slices, (unsigned)band);
+        ss::scan_batched_kernel<4, false><<<grid, dim3(ss::kBlock), 0, st>>>(b);
+        HIP_TRY(hipGetLastError());
+        done += band;
+    }
+    return SS_OK;
+}
+
+int ss_fill_random_device(void *d_dst, uint64_t global_offset, size_t len, uint64_t seed, void *hip_stream)
+{
+    if (len == 0) return SS_OK;
+    if (!d_dst) return fail(SS_ERR_ARGUMENT, "dst is NULL");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo di;
+    if (int rc = device_info(dev, &di)) return rc;
+    uint64_t words = (len + 15) / 8;
+    uint64_t blocks = (words + ss::kBlock - 1) / ss::kBlock;
+    if (blocks > (uint64_t)di.cus * 16) blocks = (uint64_t)di.cus * 16;
+    ss::fill_random_kernel<<<dim3((unsigned)blocks), dim3(ss::kBlock), 0, static_cast<hipStream_t>(hip_stream)>>>(
+        static_cast<uint8_t *>(d_dst), global_offset, len, seed);
+    HIP_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_fill_random_host(uint8_t *dst, uint64_t global_offset, size_t len, uint64_t seed)
+{
+    if (len && !dst) return fail(SS_ERR_ARGUMENT, "dst is NULL");
+    size_t k = 0;
+    while (k < len) {
+        const uint64_t i = global_offset + k;
+        uint64_t v = ss::synth_word(seed, i >> 3) >> (8 * (i & 7));
+        size_t take = 8 - (size_t)(i & 7);
+        if (take > len - k) take = len - k;
+        for (size_t j = 0; j < take; ++j, v >>= 8) dst[k + j] = (uint8_t)v;
+        k += take;
+    }
+    return SS_OK;
+}
+
+int ss_read_ceiling(const void *d_src, size_t len, void *hip_stream, int reps, float *ms_per_rep)
+{
+    if (!d_src || !ms_per_rep || reps < 1) return fail(SS_ERR_ARGUMENT, "bad argument");
+    if (((uintptr_t)d_src & 15) != 0) return fail(SS_ERR_ARGUMENT, "source must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo di;
+    if (int rc = device_info(dev, &di)) return rc;
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc((void **)&sink, 64));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const uint64_t nvec = len / 16;
+    dim3 grid((unsigned)(di.cus * 8));
+    auto launch = [&]() {
+        ss::read_ceiling_kernel<4, false><<<grid, dim3(ss::kBlock), 0, st>>>(static_cast<const ss::u32x4 *>(d_src), nvec, sink);
+    };
+    launch();                                                   // warm-up
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) launch();
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_rep = ms / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return SS_OK;
+}
+
+int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *begin, size_t *end)
+{
+    if (!begin || !end || nranks < 1 || rank < 0 || rank >= nranks) return fail(SS_ERR_ARGUMENT, "bad shard arguments");
+    const size_t S = (len + (size_t)nranks - 1) / (size_t)nranks;
+    size_t b = (size_t)rank * S;
+    if (b > len) b = len;
+    const size_t overlap = needle_len ? needle_len - 1 : 0;
+    size_t e = len - b <= S || len - b - S <= overlap ? len : b + S + overlap;
+    *begin = b;
+    *end = e;
+    return SS_OK;
+}
+
+int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *total_mem)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (total_mem) *total_mem = prop.totalGlobalMem;
+    return SS_OK;
+}
+
+// DPP / alignbyte self-test used by the GPU tests: out must hold 192 uint32 (host memory).
+int ss_selftest_dpp(uint32_t *out)
+{
+    if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 192 * sizeof(uint32_t)));
+    ss::dpp_probe_kernel<<<1, 64>>>(d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d, 192 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return SS_OK;
+}
+
+// ---- RCCL (dlopen'ed) -----------------------------------------------------------------------------
+
+}  // extern "C"
+
+namespace {
+
+struct Id128 {
+    char b[128];
+};
+
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128 /* ncclUniqueId, by value */, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            r.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+        }
+        if (!r.h) return;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    });
+    if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) return nullptr;
+    return &r;
+}
+
+constexpr int kNcclInt32 = 2;   // ncclInt32 / ncclInt  (rccl.h ncclDataType_t)
+constexpr int kNcclMax = 2;     // ncclMax              (rccl.h ncclRedOp_t: sum 0, prod 1, max 2, min 3)
+
+int rccl_fail(Rccl *r, int code, const char *what)
+{
+    return fail(SS_ERR_RCCL, "%s: %s", what, r && r->GetErrorString ? r->GetErrorString(code) : "rccl error");
+}
+
+}  // namespace
+
+struct ss_comm {
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+    int *d_flag = nullptr;      // scratch flag for ss_search_sharded
+    int *h_flag = nullptr;
+};
+
+extern "C" {
+
+int ss_comm_unique_id(uint8_t id[SS_UNIQUE_ID_BYTES])
+{
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    static_assert(SS_UNIQUE_ID_BYTES == sizeof(Id128), "ncclUniqueId is 128 bytes");
+    if (int rc = r->GetUniqueId(id)) return rccl_fail(r, rc, "ncclGetUniqueId");
+    return SS_OK;
+}
+
+int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank, ss_comm **out)
+{
+    if (!out || !id) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    ss_comm *c = new (std::nothrow) ss_comm;
+    if (!c) return fail(SS_ERR_NOMEM, "out of memory");
+    Id128 uid;
+    memcpy(uid.b, id, sizeof uid);
+    if (int rc = r->CommInitRank(&c->comm, nranks, uid, rank)) {
+        delete c;
+        return rccl_fail(r, rc, "ncclCommInitRank");
+    }
+    c->nranks = nranks;
+    c->rank = rank;
+    HIP_TRY(hipMalloc((void **)&c->d_flag, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void **)&c->h_flag, sizeof(int), hipHostMallocDefault));
+    *out = c;
+    return SS_OK;
+}
+
+void ss_comm_free(ss_comm *c)
+{
+    if (!c) return;
+    Rccl *r = rccl();
+    if (r && c->comm) r->CommDestroy(c->comm);
+    (void)hipFree(c->d_flag);
+    (void)hipHostFree(c->h_flag);
+    delete c;
+}
+
+int ss_comm_allreduce_flag(ss_comm *c, int *d_flag, void *hip_stream, int *found)
+{
+    if (!c || !d_flag) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    // OR over {0,1} == MAX; RCCL has no bitwise-OR reduction.
+    if (int rc = r->AllReduce(d_flag, d_flag, 1, kNcclInt32, kNcclMax, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    if (found) {
+        HIP_TRY(hipMemcpyAsync(c->h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *found = *c->h_flag != 0;
+    }
+    return SS_OK;
+}
+
+int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, ss_comm *c,
+                      void *hip_stream, int *found)
+{
+    if (!s || !c || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
+    if (int rc = ss_search_device_async(s, d_shard, shard_len, hip_stream, c->d_flag)) return rc;
+    return ss_comm_allreduce_flag(c, c->d_flag, hip_stream, found);
+}
+
+}  // extern "C"

@@ -1,0 +1,319 @@
+"""Python host-side mirror of the reference's searcher interface over the C ABI.
+
+Names and argument meaning follow the reference (all paths under /root/reference):
+
+    DynamicHipSearcher.new(needle)                  DynamicAvx2Searcher::new            src/x86.rs:454
+    DynamicHipSearcher.with_position(needle, pos)   DynamicAvx2Searcher::with_position  src/x86.rs:468
+    searcher.search_in(haystack) -> bool            DynamicAvx2Searcher::search_in      src/x86.rs:523
+    PositionError                                   the `assert!` panics                src/x86.rs:300,473
+
+``search_in`` accepts a CUDA/HIP ``torch.Tensor`` of dtype uint8 (device path, no copy), a raw
+``(device_pointer, length)`` pair, or host bytes / bytearray / numpy uint8 (uploaded, then scanned on
+the GPU).  There is no CPU search path: if the HIP library cannot be loaded, or no GPU is visible,
+construction raises.
+
+PyTorch is used only as plumbing (device memory, streams, torch.distributed); the C ABI has no torch
+types in its signatures and this module does not import torch unless a tensor is passed in.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+from . import _build
+
+SS_OK, SS_ERR_POSITION, SS_ERR_ARGUMENT, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_RCCL, SS_ERR_NOMEM = range(7)
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_u64 = ctypes.c_uint64
+_int = ctypes.c_int
+_pint = ctypes.POINTER(ctypes.c_int)
+_pvp = ctypes.POINTER(ctypes.c_void_p)
+
+# every symbol include/sliceslice_hip.h declares: name -> (restype, argtypes)
+ABI = {
+    "ss_searcher_new": (_int, [_vp, _sz, _pvp]),
+    "ss_searcher_with_position": (_int, [_vp, _sz, _sz, _pvp]),
+    "ss_searcher_free": (None, [_vp]),
+    "ss_searcher_needle_len": (_sz, [_vp]),
+    "ss_searcher_position": (_sz, [_vp]),
+    "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
+    "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
+    "ss_search_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ss_searcher_set_timing": (_int, [_vp, _int]),
+    "ss_searcher_last_kernel_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "ss_searcher_set_variant": (_int, [_vp, _int]),
+    "ss_searcher_set_grid": (_int, [_vp, _int]),
+    "ss_fill_random_device": (_int, [_vp, _u64, _sz, _u64, _vp]),
+    "ss_fill_random_host": (_int, [_vp, _u64, _sz, _u64]),
+    "ss_read_ceiling": (_int, [_vp, _sz, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
+    "ss_comm_unique_id": (_int, [_vp]),
+    "ss_comm_init_rank": (_int, [_vp, _int, _int, _pvp]),
+    "ss_comm_free": (None, [_vp]),
+    "ss_comm_allreduce_flag": (_int, [_vp, _vp, _vp, _pint]),
+    "ss_search_sharded": (_int, [_vp, _vp, _sz, _vp, _vp, _pint]),
+    "ss_shard_range": (_int, [_sz, _sz, _int, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_last_error": (ctypes.c_char_p, []),
+    "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, ctypes.POINTER(_sz)]),
+    "ss_version": (ctypes.c_char_p, []),
+    "ss_selftest_dpp": (_int, [_vp]),
+}
+
+
+class SlicesliceError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sliceslice_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class PositionError(SlicesliceError, AssertionError):
+    """The reference panics here (src/x86.rs:300 `assert!(position < needle.size())`,
+    src/x86.rs:473 `assert_eq!(position, 0)`)."""
+
+
+def lib():
+    """Loads csrc/libsliceslice_hip.so (building it with hipcc if it is missing).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if "torch" in sys.modules or os.environ.get("SLICESLICE_PRELOAD_TORCH", "1") == "1":
+            # torch wheels bundle their own libamdhip64 (same soname).  Loading torch first makes this
+            # library bind to the SAME HIP runtime, so torch streams/pointers are valid in it.
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
+        path = _build.build()
+        L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)          # AttributeError if the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != SS_OK:
+        msg = lib().ss_last_error().decode("utf-8", "replace")
+        raise (PositionError if rc == SS_ERR_POSITION else SlicesliceError)(rc, msg)
+
+
+def _host_view(b):
+    """(keepalive, address, length) of a host buffer."""
+    if isinstance(b, np.ndarray):
+        a = np.ascontiguousarray(b, dtype=np.uint8)
+        return a, (a.ctypes.data if a.size else 0), a.size
+    if isinstance(b, bytes):
+        a = np.frombuffer(b, dtype=np.uint8)
+        return (a, b), (a.ctypes.data if a.size else 0), a.size
+    if isinstance(b, (bytearray, memoryview)):
+        a = np.frombuffer(b, dtype=np.uint8)
+        return (a, b), (a.ctypes.data if a.size else 0), a.size
+    raise TypeError("unsupported haystack/needle type %r" % type(b))
+
+
+def _is_tensor(x):
+    return type(x).__module__.split(".")[0] == "torch" and hasattr(x, "data_ptr")
+
+
+def _current_stream_handle():
+    if "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_stream().cuda_stream
+    return 0
+
+
+class DynamicHipSearcher:
+    """GPU counterpart of ``sliceslice::x86::DynamicAvx2Searcher`` (src/x86.rs:405-525)."""
+
+    def __init__(self, needle, position=None):
+        nb = needle.astype(np.uint8).tobytes() if isinstance(needle, np.ndarray) else bytes(needle)
+        k, addr, n = _host_view(nb)
+        self._h = ctypes.c_void_p()
+        self._needle = nb
+        if position is None:
+            _check(lib().ss_searcher_new(addr, n, ctypes.byref(self._h)))
+        else:
+            _check(lib().ss_searcher_with_position(addr, n, position % (1 << 64), ctypes.byref(self._h)))
+
+    # -- reference-shaped constructors ---------------------------------------------------------------
+    @classmethod
+    def new(cls, needle):
+        return cls(needle)
+
+    @classmethod
+    def with_position(cls, needle, position):
+        return cls(needle, position)
+
+    @property
+    def needle(self):
+        return self._needle
+
+    @property
+    def position(self):
+        return lib().ss_searcher_position(self._h)
+
+    # -- the hot path ------------------------------------------------------------------------------------
+    def search_in(self, haystack, stream=None):
+        """bool: does the needle occur in ``haystack``?  (DynamicAvx2Searcher::search_in)"""
+        found = ctypes.c_int(0)
+        if _is_tensor(haystack):
+            if not haystack.is_cuda:
+                return self.search_in(haystack.numpy())
+            if haystack.dtype.itemsize != 1 or not haystack.is_contiguous():
+                raise TypeError("device haystack must be a contiguous 1-byte tensor")
+            st = stream if stream is not None else _current_stream_handle()
+            _check(lib().ss_search_device(self._h, haystack.data_ptr(), haystack.numel(), st, ctypes.byref(found)))
+        elif isinstance(haystack, tuple):
+            ptr, length = haystack
+            st = stream if stream is not None else _current_stream_handle()
+            _check(lib().ss_search_device(self._h, ptr, length, st, ctypes.byref(found)))
+        else:
+            k, addr, n = _host_view(haystack)
+            _check(lib().ss_search_host(self._h, addr, n, ctypes.byref(found)))
+        return bool(found.value)
+
+    inlined_search_in = search_in       # src/x86.rs:498
+
+    def search_in_async(self, haystack, d_flag, stream=None):
+        """Enqueue only: OR the result into the int32 device tensor ``d_flag`` (caller-zeroed)."""
+        st = stream if stream is not None else _current_stream_handle()
+        _check(lib().ss_search_device_async(self._h, haystack.data_ptr(), haystack.numel(), st, d_flag.data_ptr()))
+
+    # -- tuning / measurement hooks ------------------------------------------------------------------
+    def set_timing(self, on=True):
+        _check(lib().ss_searcher_set_timing(self._h, int(on)))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float(0)
+        _check(lib().ss_searcher_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def set_variant(self, variant):
+        _check(lib().ss_searcher_set_variant(self._h, int(variant)))
+
+    def set_grid(self, blocks):
+        _check(lib().ss_searcher_set_grid(self._h, int(blocks)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.ss_searcher_free(h)
+
+
+def shard_range(length, needle_len, nranks, rank):
+    """Byte range [begin, end) of `rank`'s shard: S = ceil(len/G), n-1 bytes of overlap to the right."""
+    b, e = _sz(0), _sz(0)
+    _check(lib().ss_shard_range(length, needle_len, nranks, rank, ctypes.byref(b), ctypes.byref(e)))
+    return b.value, e.value
+
+
+class ShardedSearcher:
+    """Range-sharded search over the GPUs of one node: one process per GPU, each holding its shard.
+
+    ``search_in(shard)`` scans the local shard and combines the found flag with ONE all-reduce(MAX)
+    (OR over {0,1}; RCCL has no OR).  Two transports:
+      * ``backend="rccl"``  - native RCCL through the C ABI (ss_comm_*), all on one HIP stream;
+      * ``backend="torch"`` - torch.distributed.all_reduce on the given process group (RCCL on GPUs,
+        gloo on CPU - used by the CPU tests with an injected shard searcher).
+    """
+
+    def __init__(self, needle, position=None, group=None, backend="torch", local_search=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.nranks = dist.get_world_size(group)
+        self.needle = bytes(needle)
+        self.backend = backend
+        self._local_search = local_search
+        self._searcher = None if local_search is not None else DynamicHipSearcher(needle, position)
+        self._comm = None
+        self._flag = None
+        if backend == "rccl":
+            self._init_rccl()
+
+    def shard_range(self, total_len):
+        return shard_range(total_len, len(self.needle), self.nranks, self.rank)
+
+    def _init_rccl(self):
+        import torch
+        uid = (ctypes.c_uint8 * 128)()
+        if self.rank == 0:
+            _check(lib().ss_comm_unique_id(uid))
+        box = [bytes(uid)]
+        self._dist.broadcast_object_list(box, src=0, group=self.group)
+        uid = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        comm = ctypes.c_void_p()
+        _check(lib().ss_comm_init_rank(uid, self.nranks, self.rank, ctypes.byref(comm)))
+        self._comm = comm
+        torch.cuda.synchronize()
+
+    def search_in(self, shard, stream=None):
+        import torch
+        if self._local_search is not None:                       # CPU tests: injected shard searcher
+            flag = torch.tensor([1 if self._local_search(shard) else 0], dtype=torch.int32)
+            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX, group=self.group)
+            return bool(flag.item())
+        st = stream if stream is not None else _current_stream_handle()
+        if self.backend == "rccl":
+            found = ctypes.c_int(0)
+            _check(lib().ss_search_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), self._comm, st,
+                                           ctypes.byref(found)))
+            return bool(found.value)
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=shard.device)
+        self._flag.zero_()
+        self._searcher.search_in_async(shard, self._flag, st)
+        self._dist.all_reduce(self._flag, op=self._dist.ReduceOp.MAX, group=self.group)
+        return bool(self._flag.item())
+
+    def close(self):
+        if self._comm is not None and _lib is not None:
+            _lib.ss_comm_free(self._comm)
+            self._comm = None
+
+
+def search_batched(haystacks, hay_off, needles, needle_off, position=None, stream=None):
+    """One launch for many (needle_i, haystack_i) problems; all arguments are device tensors
+    (uint8 blobs, uint64-compatible int64 offsets of length count+1).  Returns an int32 device tensor."""
+    import torch
+    count = hay_off.numel() - 1
+    found = torch.empty(count, dtype=torch.int32, device=haystacks.device)
+    st = stream if stream is not None else _current_stream_handle()
+    _check(lib().ss_search_batched(haystacks.data_ptr(), hay_off.data_ptr(), needles.data_ptr(),
+                                   needle_off.data_ptr(), position.data_ptr() if position is not None else None,
+                                   count, st, found.data_ptr()))
+    return found
+
+
+def fill_random_device(tensor, seed, global_offset=0, stream=None):
+    st = stream if stream is not None else _current_stream_handle()
+    _check(lib().ss_fill_random_device(tensor.data_ptr(), global_offset, tensor.numel(), seed, st))
+    return tensor
+
+
+def fill_random_host(length, seed, global_offset=0):
+    out = np.empty(length, dtype=np.uint8)
+    _check(lib().ss_fill_random_host(out.ctypes.data, global_offset, length, seed))
+    return out
+
+
+def read_ceiling_gbps(tensor, reps=10, stream=None):
+    ms = ctypes.c_float(0)
+    st = stream if stream is not None else _current_stream_handle()
+    _check(lib().ss_read_ceiling(tensor.data_ptr(), tensor.numel(), st, reps, ctypes.byref(ms)))
+    return tensor.numel() / (ms.value * 1e-3) / 1e9
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    cus, mem = ctypes.c_int(0), _sz(0)
+    _check(lib().ss_device_info(name, 256, ctypes.byref(cus), ctypes.byref(mem)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "total_mem": mem.value}

@@ -1,0 +1,413 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the reference's own vectors.
+
+Every test here needs a real MI355X: run with ``pytest -m gpu``.  The comparisons are bit-exact
+(booleans).  Reference citations are paths under /root/reference.
+"""
+import os
+import random
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import sliceslice_rs_amd as m
+    assert torch.cuda.is_available(), "these tests must run on the GPU box"
+    m.lib()                      # loads the in-tree HIP library; raises if it is missing
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(b):
+    """host bytes/ndarray -> uint8 device tensor"""
+    a = np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else np.asarray(b, dtype=np.uint8)
+    if a.size == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda")
+    return torch.from_numpy(a.copy()).cuda()
+
+
+def test_library_is_the_in_tree_hip_build(ss):
+    assert os.path.samefile(ss.library_path(), os.path.join(os.path.dirname(ss.__file__), "csrc", "libsliceslice_hip.so"))
+    info = ss.device_info()
+    assert "gfx950" in info["name"], info
+    assert info["compute_units"] >= 200
+
+
+def test_cross_lane_primitives(ss):
+    import ctypes
+    out = (ctypes.c_uint32 * 192)()
+    rc = ss.lib().ss_selftest_dpp(out)
+    assert rc == 0
+    out = list(out)
+    want = [1000 + l + 1 for l in range(63)] + [0]
+    assert out[0:64] == want            # DPP wave_shl:1 = "value of lane l+1", 0 into lane 63
+    assert out[64:128] == want          # the same via __shfl_down
+    hi, lo = 0x44332211, 0xDDCCBBAA
+    for l in range(64):
+        r = l & 3
+        assert out[128 + l] == (((hi << 32) | lo) >> (8 * r)) & 0xFFFFFFFF
+
+
+def test_generic_kats_every_position(ss, kat):
+    # src/lib.rs:370-381 - device-resident and host haystack paths
+    for row in kat["generic"]:
+        hay, needle = row["haystack"].encode(), row["needle"].encode()
+        dh = dev(hay)
+        for position in range(len(needle)):
+            s = ss.DynamicHipSearcher.with_position(needle, position)
+            assert s.search_in(dh) == row["expected"], (row, position)
+        s = ss.DynamicHipSearcher.new(needle)
+        assert s.search_in(dh) == row["expected"], row
+        assert s.search_in(hay) == row["expected"], row         # ss_search_host
+
+
+def test_memchr_kats(ss, kat):
+    # src/lib.rs:303-331
+    for row in kat["memchr"]:
+        hay, needle = row["haystack"].encode(), row["needle"].encode()
+        assert ss.DynamicHipSearcher.new(needle).search_in(dev(hay)) == row["expected"], row
+
+
+def test_constructor_contract(ss, kat):
+    # src/x86.rs:468-475, 533-543
+    for row in kat["contract"]:
+        needle = row["needle"].encode()
+        if row["ok"]:
+            ss.DynamicHipSearcher.with_position(needle, row["position"])
+        else:
+            with pytest.raises(ss.PositionError):
+                ss.DynamicHipSearcher.with_position(needle, row["position"])
+
+
+def test_empty_needle_and_short_haystacks(ss):
+    e = dev(b"")
+    assert ss.DynamicHipSearcher.new(b"").search_in(e) is True          # x86.rs:500
+    assert ss.DynamicHipSearcher.new(b"").search_in(dev(b"abc")) is True
+    assert ss.DynamicHipSearcher.new(b"a").search_in(e) is False         # lib.rs:131-133
+    assert ss.DynamicHipSearcher.new(b"ab").search_in(e) is False
+    assert ss.DynamicHipSearcher.new(b"ab").search_in(dev(b"a")) is False
+    assert ss.DynamicHipSearcher.new(b"ab").search_in(dev(b"ab")) is True  # x86.rs:357-359
+    assert ss.DynamicHipSearcher.new(b"ab").search_in(dev(b"ba")) is False
+    assert ss.DynamicHipSearcher.new(b"").search_in(b"") is True
+    assert ss.DynamicHipSearcher.new(b"a").search_in(b"") is False
+
+
+def test_long_haystack_sweep(ss, corpus, checksums):
+    # tests/i386.rs:61-70 (lossy haystack) and bench/benches/i386.rs:281-284 (raw bytes): 4585/4585
+    raw = corpus["i386"]
+    lossy = raw.decode("utf-8", errors="replace").encode("utf-8")
+    for hay, key in ((raw, "long_haystack_hits_raw"), (lossy, "long_haystack_hits_lossy")):
+        dh = dev(hay)
+        hits = sum(ss.DynamicHipSearcher.new(w).search_in(dh) for w in corpus["words"])
+        assert hits == checksums[key] == 4585
+
+
+def test_long_haystack_absent_words(ss, O, corpus):
+    # the same corpus with needles that do NOT occur: candidate-heavy text, full scans
+    dh = dev(corpus["i386"])
+    rng = random.Random(7)
+    for w in rng.sample(corpus["words"], 150):
+        for needle in (w + b"\x00", b"\x00" + w, w[:1] + b"\x7f" + w[1:], w + b" qq"):
+            want = needle in corpus["i386"]
+            assert ss.DynamicHipSearcher.new(needle).search_in(dh) == want, needle
+            p = rng.randrange(len(needle))
+            assert ss.DynamicHipSearcher.with_position(needle, p).search_in(dh) == want, (needle, p)
+
+
+def test_random_grid(ss, corpus, checksums):
+    # bench/benches/random.rs:16
+    for row in checksums["random_grid"]:
+        n, h = corpus["needle"][: row["needle_len"]], corpus["haystack"][: row["haystack_len"]]
+        assert ss.DynamicHipSearcher.new(n).search_in(dev(h)) == row["expected"], row
+
+
+NEEDLE_LENS = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 255, 1000, 2048, 2049, 3000]
+
+
+def test_boundary_sweep_vs_oracle(ss, O):
+    """`end` across the reference's width ladder (x86.rs:363-375) and across lane (16 B), piece
+    (63*16 B), tile and workgroup edges of the GPU kernel; every pointer misalignment 0..15."""
+    rng = random.Random(99)
+    big = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    ends = [1, 2, 3, 4, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1007, 1008, 1009, 1024, 4031, 4032, 4033,
+            16127, 16128, 16129, 64512, 64513, 100000]
+    for n in NEEDLE_LENS:
+        for end in rng.sample(ends, 9):
+            ln = end + n - 1
+            mis = rng.randrange(16)
+            hay = np.frombuffer(bytes(rng.choice(b"abc") for _ in range(ln)), dtype=np.uint8).copy()
+            needle = bytes(rng.choice(b"abc") for _ in range(n))
+            if rng.random() < 0.5:
+                at = rng.choice([0, end - 1, end // 2, max(0, end - 2), min(end - 1, 1007), min(end - 1, 1008)])
+                hay[at:at + n] = np.frombuffer(needle, dtype=np.uint8)
+            want = O.OracleSearcher(needle).search_in(hay)
+            assert want == O.naive_contains(hay, needle)
+            view = big[mis:mis + ln]
+            view.copy_(torch.from_numpy(hay))
+            for position in {0, n - 1, n // 2, rng.randrange(n)}:
+                got = ss.DynamicHipSearcher.with_position(needle, position).search_in(view)
+                assert got == want, (n, end, mis, position)
+
+
+def test_single_match_at_every_kind_of_edge(ss):
+    """One planted match in an otherwise needle-free haystack, at offsets that straddle lane, piece,
+    tile and grid-stride edges, for first/last/middle filter positions."""
+    ln = 3 << 20
+    base = torch.full((ln + 64,), 0x2E, dtype=torch.uint8, device="cuda")
+    for n in (2, 5, 16, 17, 40, 200):
+        needle = bytes(range(65, 65 + min(n, 26))) + bytes(97 + (k % 26) for k in range(max(0, n - 26)))
+        assert len(needle) == n
+        nd = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+        for mis in (0, 5):
+            hay = base[mis:mis + ln]
+            edges = [0, 1, 15, 16, 1007, 1008, 1009, 16 * 63 * 16 - 3, 16 * 63 * 16, (1 << 20) - 7, (2 << 20) + 1000,
+                     ln - n - 1, ln - n]
+            for at in edges:
+                for shift in (0, -(n // 2), -(n - 1)):
+                    a = at + shift
+                    if a < 0 or a + n > ln:
+                        continue
+                    hay[a:a + n] = nd
+                    for position in {0, n - 1, n // 2}:
+                        s = ss.DynamicHipSearcher.with_position(needle, position)
+                        assert s.search_in(hay) is True, (n, mis, a, position)
+                    hay[a:a + n] = 0x2E
+            assert ss.DynamicHipSearcher.new(needle).search_in(hay) is False
+
+
+def test_no_read_or_match_beyond_len(ss):
+    """GPU analogue of the reference's ASAN job (.github/workflows/check.yml:42-58): bytes just past
+    `len` and just before the pointer are poisoned with the needle, and a copy of the needle straddles
+    the end (starts in range, ends out of range); none of them may be reported."""
+    for n in (1, 2, 16, 33):
+        needle = bytes([0x51 + k for k in range(n)])
+        nd = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+        for ln in (n, n + 1, 100, 1008 * 16 + 3, 70000):
+            for mis in (0, 1, 9, 15):
+                for k in sorted({0, 1, n // 2, n - 1}):       # k needle bytes lie inside the haystack
+                    buf = torch.full((48 + ln + 2 * n + 64,), 0x2E, dtype=torch.uint8, device="cuda")
+                    lo = 48 + mis                               # haystack = buf[lo : lo+ln]
+                    buf[lo - n:lo] = nd                         # needle right before the start
+                    if k < n and ln >= k:
+                        buf[lo + ln - k: lo + ln - k + n] = nd   # straddles (k > 0) or follows (k == 0) the end
+                    hay = buf[lo:lo + ln]
+                    assert ss.DynamicHipSearcher.new(needle).search_in(hay) is False, (n, ln, mis, k)
+                    hay[ln - n:ln] = nd                          # a real match flush with the end
+                    assert ss.DynamicHipSearcher.new(needle).search_in(hay) is True, (n, ln, mis, k)
+
+
+def test_haystack_flush_against_end_of_allocation(ss):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    size = 1 << 20
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(size)) == 0
+    try:
+        assert hip.hipMemset(p, 0x2E, ctypes.c_size_t(size)) == 0
+        for n in (2, 16, 100):
+            needle = bytes([0x30 + (k % 40) for k in range(n)])
+            for ln in (n, 4097, 65536 + 5):
+                ptr = p.value + size - ln                     # last byte of haystack = last byte of allocation
+                s = ss.DynamicHipSearcher.new(needle)
+                assert s.search_in((ptr, ln)) is False
+    finally:
+        hip.hipFree(p)
+
+
+def test_generator_device_equals_host_and_oracle(ss, O):
+    for off, ln in ((0, 4096), (13, 100003), (8, 8), (3, 1), (1 << 33, 70001)):
+        t = torch.empty(ln, dtype=torch.uint8, device="cuda")
+        ss.fill_random_device(t, 0x5EED0001, off)
+        a = t.cpu().numpy()
+        assert (a == ss.fill_random_host(ln, 0x5EED0001, off)).all()
+        assert (a == O.fill_random(ln, 0x5EED0001, off)).all()
+        assert not (a == 0xFF).any()
+
+
+def absent_needle(ss, n, seed=0x5EED0002):
+    """generator bytes with one 0xFF byte (0xFF never occurs in the haystack)."""
+    nd = bytearray(ss.fill_random_host(n, seed).tobytes())
+    if n == 1:
+        nd[0] = 0xFF
+    elif n == 2:
+        nd[1] = 0xFF
+    else:
+        nd[n // 2] = 0xFF
+    return bytes(nd)
+
+
+def test_synthetic_vs_oracle_medium(ss, O):
+    ln = 32 << 20
+    t = torch.empty(ln, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0x5EED0001)
+    host = t.cpu().numpy()
+    for n in (1, 2, 4, 8, 16, 32, 128):
+        nd = absent_needle(ss, n)
+        assert O.OracleSearcher(nd).search_in(host) is False
+        assert ss.DynamicHipSearcher.new(nd).search_in(t) is False, n
+        # needles cut from the haystack: present
+        for at in (0, 12345, ln - n):
+            cut = host[at:at + n].tobytes()
+            assert ss.DynamicHipSearcher.new(cut).search_in(t) is True, (n, at)
+    # random two-byte needles: oracle decides
+    rng = random.Random(5)
+    for _ in range(40):
+        n = rng.choice([2, 3, 4])
+        nd = bytes(rng.randrange(255) for _ in range(n))
+        assert ss.DynamicHipSearcher.new(nd).search_in(t) == O.OracleSearcher(nd).search_in(host), nd
+
+
+def test_all_kernel_variants_agree(ss, O):
+    ln = (8 << 20) + 777
+    t = torch.empty(ln + 16, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0xABCDEF)
+    t = t[3:3 + ln]
+    host = t.cpu().numpy()
+    cases = [absent_needle(ss, n) for n in (1, 2, 16, 20, 200)]
+    cases += [host[ln - n:].tobytes() for n in (1, 2, 16, 20, 200)]
+    for nd in cases:
+        want = O.OracleSearcher(nd).search_in(host)
+        for variant in (20, 21, 40, 41, 80, 81):
+            for grid in (0, 1, 7, 4096):
+                s = ss.DynamicHipSearcher.new(nd)
+                s.set_variant(variant)
+                s.set_grid(grid)
+                assert s.search_in(t) == want, (len(nd), variant, grid)
+
+
+def test_candidate_heavy_inputs(ss, O):
+    # adversarial: every offset passes the filter ("why position is caller-tunable")
+    ln = 1 << 20
+    a = torch.full((ln,), 0x61, dtype=torch.uint8, device="cuda")
+    assert ss.DynamicHipSearcher.new(b"a" * 31 + b"b").search_in(a) is False
+    assert ss.DynamicHipSearcher.with_position(b"a" * 31 + b"b", 5).search_in(a) is False
+    assert ss.DynamicHipSearcher.new(b"ab" + b"a" * 30).search_in(a) is False
+    assert ss.DynamicHipSearcher.new(b"a" * 32).search_in(a) is True
+    a[ln - 1] = 0x62
+    assert ss.DynamicHipSearcher.new(b"a" * 31 + b"b").search_in(a) is True
+    # zero bytes + 0x01 bytes: the zero-byte trick's false positives must not leak into the result
+    z = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    z[1::2] = 1
+    host = z.cpu().numpy()
+    for nd in (b"\x01\x01", b"\x00\x00", b"\x01\x00\x01\x01", b"\x01", b"\x02", b"\x00\x01" * 20):
+        assert ss.DynamicHipSearcher.new(nd).search_in(z) == O.naive_contains(host, nd), nd
+
+
+def test_host_haystack_path_chunking(ss, O):
+    # ss_search_host stages 64 MiB chunks with n-1 bytes of carry: plant across the chunk edge
+    ln = (64 << 20) + 4096
+    host = np.zeros(ln, dtype=np.uint8)
+    needle = bytes(range(1, 41))
+    s = ss.DynamicHipSearcher.new(needle)
+    assert s.search_in(host) is False
+    at = (64 << 20) - 17
+    host[at:at + 40] = np.frombuffer(needle, dtype=np.uint8)
+    assert s.search_in(host) is True
+    host[at:at + 40] = 0
+    host[ln - 40:] = np.frombuffer(needle, dtype=np.uint8)
+    assert s.search_in(host) is True
+
+
+def test_concurrent_search_on_one_searcher(ss):
+    t = torch.zeros(4 << 20, dtype=torch.uint8, device="cuda")
+    t[-5:] = torch.tensor([9, 8, 7, 6, 5], dtype=torch.uint8)
+    s_yes = ss.DynamicHipSearcher.new(bytes([9, 8, 7, 6, 5]))
+    s_no = ss.DynamicHipSearcher.new(bytes([9, 8, 7, 6, 6]))
+    errs = []
+
+    def work():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(50):
+                    assert s_yes.search_in(t) is True
+                    assert s_no.search_in(t) is False
+        except Exception as e:     # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work) for _ in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+
+
+def test_batched_vs_oracle(ss, O):
+    rng = random.Random(11)
+    hays, needles, want = [], [], []
+    for i in range(300):
+        ln = rng.choice([0, 1, 5, 16, 100, 1008, 5000, 70000])
+        n = rng.choice([0, 1, 2, 3, 8, 16, 17, 40])
+        h = np.frombuffer(bytes(rng.choice(b"abcd") for _ in range(ln)), dtype=np.uint8).copy()
+        nd = bytes(rng.choice(b"abcd") for _ in range(n))
+        if ln >= n > 0 and rng.random() < 0.4:
+            at = rng.randrange(ln - n + 1)
+            h[at:at + n] = np.frombuffer(nd, dtype=np.uint8)
+        hays.append(h)
+        needles.append(nd)
+        want.append(O.OracleSearcher(nd).search_in(h))
+    hay_off = np.zeros(len(hays) + 1, dtype=np.int64)
+    hay_off[1:] = np.cumsum([h.size for h in hays])
+    nd_off = np.zeros(len(needles) + 1, dtype=np.int64)
+    nd_off[1:] = np.cumsum([len(x) for x in needles])
+    blob = torch.from_numpy(np.concatenate(hays + [np.zeros(1, dtype=np.uint8)])).cuda()
+    nblob = torch.from_numpy(np.frombuffer(b"".join(needles) + b"\0", dtype=np.uint8).copy()).cuda()
+    found = ss.search_batched(blob, torch.from_numpy(hay_off).cuda(), nblob, torch.from_numpy(nd_off).cuda())
+    got = [bool(x) for x in found.cpu().tolist()]
+    assert got == want
+
+
+def test_short_haystack_sweep_sample_batched(ss, O, corpus):
+    # tests/i386.rs:46-59 shape (word in word), a 200k-pair sample through the batched entry point
+    words = sorted(corpus["words"], key=len)
+    rng = random.Random(3)
+    pairs = []
+    for _ in range(200000):
+        i = rng.randrange(len(words))
+        j = rng.randrange(i, len(words))
+        pairs.append((words[i], words[j]))
+    want = [n in h for n, h in pairs]
+    hay_off = np.zeros(len(pairs) + 1, dtype=np.int64)
+    hay_off[1:] = np.cumsum([len(h) for _, h in pairs])
+    nd_off = np.zeros(len(pairs) + 1, dtype=np.int64)
+    nd_off[1:] = np.cumsum([len(n) for n, _ in pairs])
+    blob = torch.from_numpy(np.frombuffer(b"".join(h for _, h in pairs), dtype=np.uint8).copy()).cuda()
+    nblob = torch.from_numpy(np.frombuffer(b"".join(n for n, _ in pairs), dtype=np.uint8).copy()).cuda()
+    found = ss.search_batched(blob, torch.from_numpy(hay_off).cuda(), nblob, torch.from_numpy(nd_off).cuda())
+    got = [bool(x) for x in found.cpu().tolist()]
+    assert got == want
+    assert sum(got) == sum(want) > 0
+
+
+def test_full_size_properties_1gib(ss):
+    """BASELINE.json config 2 at full size: 1 GiB synthetic haystack, 16-byte needle, position 15.
+    Size-independent properties instead of a CPU re-scan: absent by construction -> False; planted at
+    len-16 -> True; planted across a 4 GiB/mid boundary of the grid-stride -> True; erased -> False."""
+    ln = 1 << 30
+    t = torch.empty(ln, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0x5EED0001)
+    nd = absent_needle(ss, 16)
+    s = ss.DynamicHipSearcher.new(nd)
+    assert s.position == 15
+    assert s.search_in(t) is False
+    present = bytes(ss.fill_random_host(16, 0x5EED0003).tobytes())
+    assert 0xFF not in present
+    sp = ss.DynamicHipSearcher.new(present)
+    pn = torch.from_numpy(np.frombuffer(present, dtype=np.uint8).copy()).cuda()
+    for at in (ln - 16, (ln // 2) - 8, 0, 1008 * 12345 - 5):
+        saved = t[at:at + 16].clone()
+        before = sp.search_in(t)
+        t[at:at + 16] = pn
+        assert sp.search_in(t) is True, at
+        t[at:at + 16] = saved
+        assert sp.search_in(t) == before
+    assert s.search_in(t) is False

@@ -1,0 +1,89 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the
+constructor fails loudly without a GPU (there is no CPU search path), shard ranges, the generator."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sliceslice_rs_amd as ss
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sliceslice_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(ss.build())
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for name in syms:
+        assert hasattr(L, name), name
+    # and the Python binding table covers exactly the header
+    assert sorted(ss.searcher.ABI) == syms
+
+
+def test_no_cpu_fallback_constructor_fails_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ss.SlicesliceError) as e:
+        ss.DynamicHipSearcher.new(b"needle")
+    assert e.value.code == ss.searcher.SS_ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sliceslice-rs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                body = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in body.lower() or f == "__init__.py" and "oracle" not in body, (dirpath, f)
+
+
+def test_position_validation_is_done_before_touching_the_device():
+    # contract errors are reported as SS_ERR_POSITION even on a box without a GPU (x86.rs:300,473)
+    h = ctypes.c_void_p()
+    L = ss.lib()
+    assert L.ss_searcher_with_position(b"foo", 3, 3, ctypes.byref(h)) == ss.searcher.SS_ERR_POSITION
+    assert L.ss_searcher_with_position(b"f", 1, 1, ctypes.byref(h)) == ss.searcher.SS_ERR_POSITION
+    assert b"position" in L.ss_last_error()
+
+
+def test_shard_ranges_cover_with_overlap():
+    for total in (0, 1, 15, 16, 17, 1000, 12345, 1 << 36):
+        for n in (1, 2, 16, 100):
+            for g in (1, 2, 3, 4, 8):
+                prev_end = None
+                S = -(-total // g)
+                for r in range(g):
+                    b, e = ss.shard_range(total, n, g, r)
+                    assert b == min(total, r * S)
+                    assert e == min(total, b + S + n - 1) or (e == total and b + S >= total)
+                    assert b <= e <= total
+                    if prev_end is not None and b < total:
+                        assert prev_end - b == min(n - 1, total - b)      # overlap of n-1 bytes
+                    prev_end = e
+                assert prev_end == total
+    # every window of n bytes lies entirely inside at least one shard
+    total, n, g = 1000, 16, 8
+    ranges = [ss.shard_range(total, n, g, r) for r in range(g)]
+    for i in range(total - n + 1):
+        assert any(b <= i and i + n <= e for b, e in ranges), i
+
+
+def test_host_generator_matches_oracle_restatement():
+    for off, ln in ((0, 100000), (5, 7), (1 << 35, 4099)):
+        a = ss.fill_random_host(ln, 0x5EED0001, off)
+        assert (a == O.fill_random(ln, 0x5EED0001, off)).all()
+        assert not (a == 0xFF).any()
+    # roughly uniform
+    a = ss.fill_random_host(1 << 20, 1)
+    counts = np.bincount(a, minlength=256)
+    assert counts[255] == 0 and counts[1:255].min() > 3500 and counts[0] > 7000
