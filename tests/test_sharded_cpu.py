@@ -1,0 +1,81 @@
+"""world_size-2 gloo test of the range-sharded search: shard ranges with n-1 overlap and
+the single all-reduce(MAX) of the found flag.  The per-shard scan is injected (the CPU oracle) because
+the product has no CPU search path; what is under test is the product's sharding + combine logic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sliceslice_rs_amd as ss
+        from oracle import oracle as O
+        logical = ss.fill_random_host(total, 0x5EED0001).copy()       # same bytes on every rank
+        S = -(-total // world)
+        results = []
+
+        def run(needle, hay):
+            sh = ss.ShardedSearcher(needle, local_search=lambda shard: O.OracleSearcher(needle).search_in(shard))
+            b, e = sh.shard_range(len(hay))
+            got = sh.search_in(hay[b:e])
+            want = O.naive_contains(hay, needle)
+            return (got, want, (b, e))
+
+        n16 = bytes(range(200, 216))
+        cases = []
+        cases.append(("absent", n16, logical))
+        for name, at in (("rank0_only", 10), ("rank1_only", total - 16), ("straddle_mid", S - 8),
+                         ("straddle_1byte_left", S - 1), ("straddle_15_left", S - 15), ("starts_at_boundary", S)):
+            h = logical.copy()
+            h[at:at + 16] = np.frombuffer(n16, dtype=np.uint8)
+            cases.append((name, n16, h))
+        big = bytes((7 * k + 3) % 251 for k in range(S + 10))          # needle longer than a shard's own part
+        h = logical.copy()
+        h[5:5 + len(big)] = np.frombuffer(big, dtype=np.uint8)
+        cases.append(("needle_longer_than_shard", big, h))
+        cases.append(("one_byte_absent", b"\xff", logical))
+        cases.append(("one_byte_present", logical[total - 1:].tobytes(), logical))
+        cases.append(("empty_needle", b"", logical))
+        for name, needle, hay in cases:
+            got, want, rng = run(needle, hay)
+            results.append((name, got, want, rng))
+        q.put((rank, results))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_gloo(world):
+    total = 100_003
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    [p.start() for p in procs]
+    out = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    names = [r[0] for r in out[0]]
+    assert "straddle_mid" in names
+    for rank in range(world):
+        for name, got, want, rng in out[rank]:
+            assert got == want, (rank, name, rng)
+    # every rank returns the same (combined) boolean
+    for i in range(len(names)):
+        assert len({out[r][i][1] for r in range(world)}) == 1

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Kernel-variant / grid sweep on one GPU: prints kernel-only GB/s (hipEvent time on the launch stream)
+for every (needle length, variant, grid) and the plain streaming-read ceiling.  Tuning aid, not a test."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sliceslice_rs_amd as ss  # noqa: E402
+
+
+def absent(n):
+    nd = bytearray(ss.fill_random_host(n, 0x5EED0002).tobytes())
+    nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+    return bytes(nd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gib", type=float, default=8.0)
+    ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--needles", default="16")
+    ap.add_argument("--variants", default="20,21,40,41,80,81")
+    ap.add_argument("--grids", default="0")
+    ap.add_argument("--mis", type=int, default=0)
+    args = ap.parse_args()
+    n_bytes = int(args.gib * (1 << 30))
+    buf = torch.empty(n_bytes + 64, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(buf, 0x5EED0001)
+    hay = buf[args.mis:args.mis + n_bytes]
+    torch.cuda.synchronize()
+    print(json.dumps({"read_ceiling_gbps": round(ss.read_ceiling_gbps(buf[:n_bytes], reps=5), 1)}), flush=True)
+    for n in [int(x) for x in args.needles.split(",")]:
+        nd = absent(n)
+        for v in [int(x) for x in args.variants.split(",")]:
+            for g in [int(x) for x in args.grids.split(",")]:
+                s = ss.DynamicHipSearcher.new(nd)
+                s.set_variant(v)
+                s.set_grid(g)
+                s.set_timing(True)
+                assert s.search_in(hay) is False
+                ms = []
+                for _ in range(args.reps):
+                    s.search_in(hay)
+                    ms.append(s.last_kernel_ms())
+                med = float(np.median(ms))
+                print(json.dumps({"n": n, "variant": v, "grid": g, "ms": round(med, 4),
+                                  "gbps": round(n_bytes / med / 1e6, 1), "min_ms": round(min(ms), 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
