@@ -106,9 +106,12 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_off, const 
 int ss_searcher_set_timing(ss_searcher *s, int enabled);
 int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);
 
-/* Kernel-variant override for tuning/tests: 0 = automatic.  See DESIGN.md "Kernels". */
+/* Kernel-variant override for tuning/tests: variant = 10*U + NTMODE, U in {1,2,4,8} pieces (KiB) per
+ * wave per tile, NTMODE in {0,1,2} (plain / non-temporal first stream / non-temporal both); 0 =
+ * automatic.  See DESIGN.md "Kernels". */
 int ss_searcher_set_variant(ss_searcher *s, int variant);
-/* Grid-size override (blocks); 0 = automatic. */
+/* Grid override: blocks > 0 = that many persistent workgroups (grid-stride over tiles); blocks < 0 =
+ * -blocks tiles per short-lived workgroup; 0 = automatic. */
 int ss_searcher_set_grid(ss_searcher *s, int blocks);
 
 /* Synthetic haystack generator (not part of the reference):
@@ -148,7 +151,7 @@ const char *ss_last_error(void);      /* thread-local, static storage */
 int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *total_mem);
 const char *ss_version(void);
 /* Device self-test of the cross-lane primitives the scan relies on (DPP wave_shl:1, v_alignbyte):
- * fills out[0..192) (host memory); see tests/test_gpu_parity.py::test_cross_lane_primitives. */
+ * fills out[0..320) (host memory); see tests/test_gpu_parity.py::test_cross_lane_primitives. */
 int ss_selftest_dpp(uint32_t *out);
 
 #ifdef __cplusplus

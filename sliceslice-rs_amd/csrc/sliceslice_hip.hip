@@ -139,41 +139,58 @@ void release_slot(const ss_searcher *s, PerDevice *p, int k)
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------
-// variant = 10*U_code + NT, U_code in {2,4,8}; 0 = automatic.
+// variant = 10*U + NTMODE with U in {1,2,4,8} (pieces per wave per tile) and NTMODE in {0,1,2}
+// (scan_kernels.hpp); 0 = automatic.  grid > 0: that many workgroups, grid-stride over tiles;
+// grid < 0: -grid tiles per (short-lived) workgroup; 0 = automatic.
 struct Launch {
     int U;
-    bool NT;
+    int nt;
 };
+
+constexpr int kAutoU = 4;
+constexpr int kAutoNt = 1;
+constexpr int kAutoTilesPerBlock = 64;   // 1 MiB contiguous per workgroup at U = 4 (tools/tune.py sweeps)
 
 Launch pick_variant(int variant)
 {
-    Launch l{4, false};
+    Launch l{kAutoU, kAutoNt};
     if (variant > 0) {
         const int u = variant / 10;
-        if (u == 2 || u == 4 || u == 8) l.U = u;
-        l.NT = (variant % 10) != 0;
+        if (u == 1 || u == 2 || u == 4 || u == 8) l.U = u;
+        l.nt = variant % 10;
+        if (l.nt > 2) l.nt = 2;
     }
     return l;
 }
 
-template <int U, bool NT>
-void launch_scan_un(const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st, int *flag)
+template <int U, int NT>
+void launch_scan_un(const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st, int *flag,
+                    uint64_t tpb)
 {
     using namespace ss;
     dim3 blk(kBlock);
     if (one_byte) {
-        scan_kernel<0, false, true, U, NT><<<grid, blk, 0, st>>>(pr, flag);
+        scan_kernel<0, false, true, U, NT><<<grid, blk, 0, st>>>(pr, flag, tpb);
         return;
     }
 #define SS_CASE(QQ, TT)                                                                            \
     case (QQ) * 2 + (TT ? 1 : 0):                                                                  \
-        scan_kernel<QQ, TT, false, U, NT><<<grid, blk, 0, st>>>(pr, flag);                         \
+        scan_kernel<QQ, TT, false, U, NT><<<grid, blk, 0, st>>>(pr, flag, tpb);                    \
         break;
     switch (q * 2 + (two ? 1 : 0)) {
         SS_CASE(0, false) SS_CASE(0, true) SS_CASE(1, false) SS_CASE(1, true)
         SS_CASE(2, false) SS_CASE(2, true) SS_CASE(3, false) SS_CASE(3, true)
     }
 #undef SS_CASE
+}
+
+template <int U>
+void launch_scan_u(int nt, const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st,
+                   int *flag, uint64_t tpb)
+{
+    if (nt == 0) launch_scan_un<U, 0>(pr, q, two, one_byte, grid, st, flag, tpb);
+    else if (nt == 1) launch_scan_un<U, 1>(pr, q, two, one_byte, grid, st, flag, tpb);
+    else launch_scan_un<U, 2>(pr, q, two, one_byte, grid, st, flag, tpb);
 }
 
 // Builds the Problem for (hay, len) and enqueues the scan; *d_flag is OR-ed (0 -> 1), never cleared.
@@ -191,8 +208,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.end = (uint64_t)len - n + 1;
     pr.nchunks_all = ((uint64_t)pr.mis + len + 15) / 16;
     const bool one_byte = n == 1;
-    const uint64_t stride = one_byte ? 64 : 63;
-    pr.npieces = (((uint64_t)pr.mis + pr.end + 15) / 16 + stride - 1) / stride;
+    pr.npieces = (((uint64_t)pr.mis + pr.end + 15) / 16 + 63) / 64;
     const size_t position = one_byte ? 0 : s->position;
     pr.d = position / 16;
     const uint32_t sh = (uint32_t)(position % 16);
@@ -202,21 +218,40 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
 
     const Launch l = pick_variant(s->variant);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
-    DeviceInfo di;
-    if (int rc = device_info(pd->dev, &di)) return rc;
-    uint64_t blocks = s->grid > 0 ? (uint64_t)s->grid : (uint64_t)di.cus * 8;   // 8 x 256 threads = 32 waves/CU
-    if (blocks > ntiles) blocks = ntiles;
+    uint64_t blocks, tpb;
+    if (s->grid > 0) {
+        blocks = (uint64_t)s->grid;
+        if (blocks > ntiles) blocks = ntiles;
+        tpb = 0;
+    } else {
+        if (s->grid < 0) {
+            tpb = (uint64_t)(-(int64_t)s->grid);
+        } else {
+            // long runs per workgroup, but never fewer than ~16 workgroups per CU's worth of work
+            DeviceInfo di;
+            if (int rc = device_info(pd->dev, &di)) return rc;
+            tpb = ntiles / ((uint64_t)di.cus * 16);
+            if (tpb > (uint64_t)kAutoTilesPerBlock) tpb = kAutoTilesPerBlock;
+            if (tpb < 1) tpb = 1;
+        }
+        blocks = (ntiles + tpb - 1) / tpb;
+        while (blocks > 0x7fffffffull) {        // gridDim.x limit
+            tpb *= 2;
+            blocks = (ntiles + tpb - 1) / tpb;
+        }
+    }
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks);
 
     if (s->timing) HIP_TRY(hipEventRecord(pd->ev0, st));
     const int q = (int)(sh / 4);
     const bool two = pr.d != 0;
-#define SS_U(UU)                                                                                   \
-    if (l.NT) launch_scan_un<UU, true>(pr, q, two, one_byte, grid, st, d_flag);                    \
-    else launch_scan_un<UU, false>(pr, q, two, one_byte, grid, st, d_flag);
-    if (l.U == 2) { SS_U(2) } else if (l.U == 8) { SS_U(8) } else { SS_U(4) }
-#undef SS_U
+    switch (l.U) {
+    case 1: launch_scan_u<1>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
+    case 2: launch_scan_u<2>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
+    case 8: launch_scan_u<8>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
+    default: launch_scan_u<4>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
+    }
     HIP_TRY(hipGetLastError());
     if (s->timing) {
         HIP_TRY(hipEventRecord(pd->ev1, st));
@@ -458,7 +493,7 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_off, const 
         b.position = a.position ? a.position + done : nullptr;
         b.found = a.found + done;
         dim3 grid((unsigned)slices, (unsigned)band);
-        ss::scan_batched_kernel<4, false><<<grid, dim3(ss::kBlock), 0, st>>>(b);
+        ss::scan_batched_kernel<4, 0><<<grid, dim3(ss::kBlock), 0, st>>>(b);
         HIP_TRY(hipGetLastError());
         done += band;
     }
@@ -502,19 +537,20 @@ int ss_read_ceiling(const void *d_src, size_t len, void *hip_stream, int reps, f
     if (!d_src || !ms_per_rep || reps < 1) return fail(SS_ERR_ARGUMENT, "bad argument");
     if (((uintptr_t)d_src & 15) != 0) return fail(SS_ERR_ARGUMENT, "source must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    DeviceInfo di;
-    if (int rc = device_info(dev, &di)) return rc;
     uint32_t *sink = nullptr;
     HIP_TRY(hipMalloc((void **)&sink, 64));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     const uint64_t nvec = len / 16;
-    dim3 grid((unsigned)(di.cus * 8));
+    constexpr int U = 4;
+    const uint64_t tpb = kAutoTilesPerBlock;
+    const uint64_t ntiles = nvec / (64 * ss::kWavesPerBlock * U);
+    uint64_t blocks = (ntiles + tpb - 1) / tpb;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks);
     auto launch = [&]() {
-        ss::read_ceiling_kernel<4, false><<<grid, dim3(ss::kBlock), 0, st>>>(static_cast<const ss::u32x4 *>(d_src), nvec, sink);
+        ss::read_ceiling_kernel<U, true><<<grid, dim3(ss::kBlock), 0, st>>>(static_cast<const ss::u32x4 *>(d_src), nvec, sink, tpb);
     };
     launch();                                                   // warm-up
     HIP_TRY(hipEventRecord(e0, st));
@@ -555,15 +591,15 @@ int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *tota
     return SS_OK;
 }
 
-// DPP / alignbyte self-test used by the GPU tests: out must hold 192 uint32 (host memory).
+// DPP / alignbyte self-test used by the GPU tests: out must hold 320 uint32 (host memory).
 int ss_selftest_dpp(uint32_t *out)
 {
     if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
     uint32_t *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 192 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&d, 320 * sizeof(uint32_t)));
     ss::dpp_probe_kernel<<<1, 64>>>(d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d, 192 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d, 320 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     (void)hipFree(d);
     return SS_OK;
 }

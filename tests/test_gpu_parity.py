@@ -46,13 +46,15 @@ def test_library_is_the_in_tree_hip_build(ss):
 
 def test_cross_lane_primitives(ss):
     import ctypes
-    out = (ctypes.c_uint32 * 192)()
+    out = (ctypes.c_uint32 * 320)()
     rc = ss.lib().ss_selftest_dpp(out)
     assert rc == 0
     out = list(out)
     want = [1000 + l + 1 for l in range(63)] + [0]
-    assert out[0:64] == want            # DPP wave_shl:1 = "value of lane l+1", 0 into lane 63
+    assert out[0:64] == want            # DPP wave_shl:1 = "value of lane l+1"; lane 63 keeps `old` (0)
     assert out[64:128] == want          # the same via __shfl_down
+    assert out[192:256] == [1000 + (l + 1) % 64 for l in range(64)]          # wave_rol:1
+    assert out[256:320] == [1000 + l + 1 for l in range(63)] + [7777]        # lane 63 keeps `old`
     hi, lo = 0x44332211, 0xDDCCBBAA
     for l in range(64):
         r = l & 3
@@ -278,8 +280,8 @@ def test_all_kernel_variants_agree(ss, O):
     cases += [host[ln - n:].tobytes() for n in (1, 2, 16, 20, 200)]
     for nd in cases:
         want = O.OracleSearcher(nd).search_in(host)
-        for variant in (20, 21, 40, 41, 80, 81):
-            for grid in (0, 1, 7, 4096):
+        for variant in (10, 11, 12, 20, 21, 22, 40, 41, 42, 80, 81, 82):
+            for grid in (0, 1, 7, 4096, -1, -3, -1000):
                 s = ss.DynamicHipSearcher.new(nd)
                 s.set_variant(variant)
                 s.set_grid(grid)

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--gib", type=float, default=8.0)
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--needles", default="16")
-    ap.add_argument("--variants", default="20,21,40,41,80,81")
+    ap.add_argument("--variants", default="40,41")
     ap.add_argument("--grids", default="0")
     ap.add_argument("--mis", type=int, default=0)
     args = ap.parse_args()
