@@ -1,0 +1,115 @@
+// sliceslice_hip.hpp - header-only C++ veneer over the C ABI (sliceslice_hip.h) that mirrors the
+// reference's Rust surface name for name, so a C++ caller (and the parity tests in
+// tests/native/) reads like the reference's own tests:
+//
+//   sliceslice::hip::DynamicHipSearcher::new_(needle)                DynamicAvx2Searcher::new            src/x86.rs:454
+//   sliceslice::hip::DynamicHipSearcher::with_position(needle, pos)  DynamicAvx2Searcher::with_position  src/x86.rs:468
+//   searcher.search_in(haystack)                                     DynamicAvx2Searcher::search_in      src/x86.rs:523
+//   searcher.inlined_search_in(haystack)                             ::inlined_search_in                 src/x86.rs:498
+//
+// Contract violations that make the reference panic (src/x86.rs:300,473) throw
+// sliceslice::hip::PositionPanic; HIP / RCCL failures throw sliceslice::hip::Error.  The searcher owns
+// its needle copy (the reference owns `needle: N` by value, src/x86.rs:266-271); haystacks are
+// borrowed for the duration of the call.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+#include "sliceslice_hip.h"
+
+namespace sliceslice {
+namespace hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const char *what) : std::runtime_error(what), code(c) {}
+};
+struct PositionPanic : Error {
+    using Error::Error;
+};
+
+inline void check(int rc)
+{
+    if (rc == SS_OK) return;
+    if (rc == SS_ERR_POSITION) throw PositionPanic(rc, ss_last_error());
+    throw Error(rc, ss_last_error());
+}
+
+// A haystack already resident in device memory (caller-owned hipMalloc memory, any alignment).
+struct DeviceSlice {
+    const void *ptr;
+    size_t len;
+};
+
+class DynamicHipSearcher {
+public:
+    // `new` is a keyword in C++; the reference's `new(needle)` is `new_`.
+    static DynamicHipSearcher new_(const uint8_t *needle, size_t n)
+    {
+        ss_searcher *h = nullptr;
+        check(ss_searcher_new(needle, n, &h));
+        return DynamicHipSearcher(h);
+    }
+    static DynamicHipSearcher new_(const std::string &needle)
+    {
+        return new_(reinterpret_cast<const uint8_t *>(needle.data()), needle.size());
+    }
+    static DynamicHipSearcher with_position(const uint8_t *needle, size_t n, size_t position)
+    {
+        ss_searcher *h = nullptr;
+        check(ss_searcher_with_position(needle, n, position, &h));
+        return DynamicHipSearcher(h);
+    }
+    static DynamicHipSearcher with_position(const std::string &needle, size_t position)
+    {
+        return with_position(reinterpret_cast<const uint8_t *>(needle.data()), needle.size(), position);
+    }
+
+    DynamicHipSearcher(DynamicHipSearcher &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    DynamicHipSearcher &operator=(DynamicHipSearcher &&o) noexcept
+    {
+        if (this != &o) {
+            ss_searcher_free(h_);
+            h_ = std::exchange(o.h_, nullptr);
+        }
+        return *this;
+    }
+    DynamicHipSearcher(const DynamicHipSearcher &) = delete;
+    DynamicHipSearcher &operator=(const DynamicHipSearcher &) = delete;
+    ~DynamicHipSearcher() { ss_searcher_free(h_); }
+
+    // search_in(&[u8]) for a host slice: staged to the device and scanned there (PCIe-bound).
+    bool search_in(const uint8_t *haystack, size_t len) const
+    {
+        int found = 0;
+        check(ss_search_host(h_, haystack, len, &found));
+        return found != 0;
+    }
+    bool search_in(const std::string &haystack) const
+    {
+        return search_in(reinterpret_cast<const uint8_t *>(haystack.data()), haystack.size());
+    }
+    // search_in for a device-resident haystack on a HIP stream (nullptr = default stream).
+    bool search_in(DeviceSlice haystack, void *hip_stream = nullptr) const
+    {
+        int found = 0;
+        check(ss_search_device(h_, haystack.ptr, haystack.len, hip_stream, &found));
+        return found != 0;
+    }
+    template <class H>
+    bool inlined_search_in(H &&haystack) const { return search_in(std::forward<H>(haystack)); }
+
+    size_t position() const { return ss_searcher_position(h_); }
+    size_t needle_len() const { return ss_searcher_needle_len(h_); }
+    ss_searcher *handle() const { return h_; }
+
+private:
+    explicit DynamicHipSearcher(ss_searcher *h) : h_(h) {}
+    ss_searcher *h_;
+};
+
+}  // namespace hip
+}  // namespace sliceslice

@@ -139,8 +139,10 @@ void release_slot(const ss_searcher *s, PerDevice *p, int k)
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------
-// variant = 10*U + NTMODE with U in {1,2,4,8} (pieces per wave per tile) and NTMODE in {0,1,2}
-// (scan_kernels.hpp); 0 = automatic.  grid > 0: that many workgroups, grid-stride over tiles;
+// variant = 10*U + NTMODE with U in {2,4,8} (pieces per wave per tile) and NTMODE in {0,1}
+// (scan_kernels.hpp); 0 = automatic: U = 4; non-temporal loads for the single-stream kernels
+// (position < 16), plain loads for the two-stream kernels, whose second stream re-reads lines of the
+// first and would miss on a non-temporal line (profiles/r01/needle_len_sweep_8gib.jsonl).  grid > 0: that many workgroups, grid-stride over tiles;
 // grid < 0: -grid tiles per (short-lived) workgroup; 0 = automatic.
 struct Launch {
     int U;
@@ -151,14 +153,13 @@ constexpr int kAutoU = 4;
 constexpr int kAutoNt = 1;
 constexpr int kAutoTilesPerBlock = 64;   // 1 MiB contiguous per workgroup at U = 4 (tools/tune.py sweeps)
 
-Launch pick_variant(int variant)
+Launch pick_variant(int variant, bool two)
 {
-    Launch l{kAutoU, kAutoNt};
+    Launch l{kAutoU, two ? 0 : kAutoNt};
     if (variant > 0) {
         const int u = variant / 10;
-        if (u == 1 || u == 2 || u == 4 || u == 8) l.U = u;
-        l.nt = variant % 10;
-        if (l.nt > 2) l.nt = 2;
+        if (u == 2 || u == 4 || u == 8) l.U = u;
+        l.nt = (variant % 10) ? 1 : 0;
     }
     return l;
 }
@@ -189,8 +190,7 @@ void launch_scan_u(int nt, const ss::Problem &pr, int q, bool two, bool one_byte
                    int *flag, uint64_t tpb)
 {
     if (nt == 0) launch_scan_un<U, 0>(pr, q, two, one_byte, grid, st, flag, tpb);
-    else if (nt == 1) launch_scan_un<U, 1>(pr, q, two, one_byte, grid, st, flag, tpb);
-    else launch_scan_un<U, 2>(pr, q, two, one_byte, grid, st, flag, tpb);
+    else launch_scan_un<U, 1>(pr, q, two, one_byte, grid, st, flag, tpb);
 }
 
 // Builds the Problem for (hay, len) and enqueues the scan; *d_flag is OR-ed (0 -> 1), never cleared.
@@ -216,7 +216,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.n0x4 = 0x01010101u * s->needle[0];
     pr.nlx4 = 0x01010101u * s->needle[position];
 
-    const Launch l = pick_variant(s->variant);
+    const Launch l = pick_variant(s->variant, pr.d != 0);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
     uint64_t blocks, tpb;
     if (s->grid > 0) {
@@ -247,7 +247,6 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     const int q = (int)(sh / 4);
     const bool two = pr.d != 0;
     switch (l.U) {
-    case 1: launch_scan_u<1>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
     case 2: launch_scan_u<2>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
     case 8: launch_scan_u<8>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
     default: launch_scan_u<4>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;

@@ -280,7 +280,7 @@ def test_all_kernel_variants_agree(ss, O):
     cases += [host[ln - n:].tobytes() for n in (1, 2, 16, 20, 200)]
     for nd in cases:
         want = O.OracleSearcher(nd).search_in(host)
-        for variant in (10, 11, 12, 20, 21, 22, 40, 41, 42, 80, 81, 82):
+        for variant in (20, 21, 40, 41, 80, 81):
             for grid in (0, 1, 7, 4096, -1, -3, -1000):
                 s = ss.DynamicHipSearcher.new(nd)
                 s.set_variant(variant)
