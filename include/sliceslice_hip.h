@@ -90,15 +90,25 @@ int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t 
  * PCIe-bound by construction; never used for roofline numbers. */
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
 
-/* Batched search, one launch (BASELINE.json config 5): problem i searches needle i
- * (needles + needle_off[i] .. needle_off[i+1]) in haystack i (d_haystacks + hay_off[i] ..
- * hay_off[i+1]); all buffers in device memory; offsets are count+1 uint64 each; position[i]
- * follows the with_position rules (pass NULL for the `new` default n_i - 1).  Writes count int32
- * flags to d_found (device) with the same semantics as ss_search_device per problem.  Validation
- * of positions happens on the host copy `h_needle_off`/`h_position` when given. */
-int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_off, const void *d_needles,
-                      const uint64_t *d_needle_off, const uint64_t *d_position, size_t count,
-                      void *hip_stream, int *d_found);
+/* Batched search, one launch (BASELINE.json config 5): problem i searches the needle
+ * d_needles[needle_begin[i] .. needle_end[i]) in the haystack d_haystacks[hay_begin[i] .. hay_end[i]).
+ * Everything lives in device memory; the four range arrays hold `count` uint64 each.  CSR callers
+ * pass (off, off + 1); ranges may alias, e.g. 4,585 needles against ONE haystack - the loop of
+ * bench/benches/i386.rs:252-256 as a single launch.  position[i] follows the with_position rules
+ * (NULL = the `new` default n_i - 1; out-of-range values are clamped to n_i - 1 on the device since a
+ * device array cannot be validated without a read-back).  Writes `count` int32 flags to d_found
+ * (device), each with the semantics of ss_search_device for its problem.  One workgroup (or more) per
+ * problem: meant for haystacks of KiBs to GiBs. */
+int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                      const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                      const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
+
+/* Same contract, one LANE per problem: the reference's short-haystack workload
+ * (bench/benches/i386.rs:118-129: 10,513,405 word-in-word searches of <= 24 bytes).  Use it when the
+ * haystacks are tens of bytes; any length is correct but long haystacks belong to ss_search_batched. */
+int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                    const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                    const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
 
 /* Kernel timing hook for bench.py's roofline line: when enabled, every scan launched through `s`
  * is bracketed by hipEvents ON THE LAUNCH STREAM; ss_searcher_last_kernel_ms returns the elapsed

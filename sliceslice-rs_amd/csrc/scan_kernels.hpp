@@ -58,6 +58,7 @@ struct Problem {
     uint32_t mis;             // hay - base, 0..15
     uint32_t r;               // (position % 16) % 4: byte part of the shift
     uint32_t n0x4, nlx4;      // needle[0] and needle[position] splatted over a dword
+    uint32_t n1x4, n2x4, n3x4;  // needle[1..3] splatted (second-level filter; valid when n > 1 / 2 / 3)
 };
 
 __device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) { return (x - 0x01010101u) & ~x; }
@@ -83,15 +84,27 @@ __device__ __forceinline__ u32x4 load_chunk(const uint8_t *base, uint64_t chunk)
     return *p;
 }
 
-// Full comparison of the needle with hay[i .. i+n).  Lane-private (divergent) on purpose: on random
-// data almost every candidate dies on the first byte or two.
+// Full comparison of the needle with hay[i .. i+n), four bytes per step (unaligned global dword
+// loads are legal on gfx950; the LDS/global needle side is dword-aligned by construction).
+// Lane-private (divergent) on purpose: on random data almost every candidate dies in the first dword.
+struct __attribute__((packed, aligned(1))) UnalignedU32 {
+    uint32_t v;
+};
+
 __device__ __forceinline__ bool verify_candidate(const Problem &pr, const uint8_t *s_needle, uint64_t i)
 {
     const uint8_t *h = pr.hay + i;
     const uint64_t n_lds = pr.n < (uint64_t)kNeedleLds ? pr.n : (uint64_t)kNeedleLds;
-    for (uint64_t k = 0; k < n_lds; ++k)
+    uint64_t k = 0;
+    for (; k + 4 <= n_lds; k += 4)
+        if (reinterpret_cast<const UnalignedU32 *>(h + k)->v != *reinterpret_cast<const uint32_t *>(s_needle + k))
+            return false;
+    for (; k < n_lds; ++k)
         if (h[k] != s_needle[k]) return false;
-    for (uint64_t k = n_lds; k < pr.n; ++k)
+    for (; k + 4 <= pr.n; k += 4)   // needles longer than the LDS slice continue from the global copy
+        if (reinterpret_cast<const UnalignedU32 *>(h + k)->v != reinterpret_cast<const UnalignedU32 *>(pr.needle + k)->v)
+            return false;
+    for (; k < pr.n; ++k)
         if (h[k] != pr.needle[k]) return false;
     return true;
 }
@@ -130,6 +143,22 @@ __device__ __forceinline__ void filter_piece(const u32x4 &A, const uint32_t w[4]
     g[1] = f1 & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r);
     g[2] = f2 & __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r);
     g[3] = f3 & __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r);
+}
+
+// Second-level filter, run only by waves that have candidates: AND the candidate flags with the flags
+// of needle[K] at byte offset K (K = 1..3), still entirely in registers.  Text-like haystacks pass the
+// two-byte filter at percent rates; every extra byte cuts that by the byte's frequency before any
+// candidate touches memory.  Lane 63 has no neighbour data here and passes conservatively.
+template <int K>
+__device__ __forceinline__ void refine_flags(const u32x4 &A, uint32_t nkx4, uint32_t g[4])
+{
+    const uint32_t e0 = zero_byte_flags(A.x ^ nkx4), e1 = zero_byte_flags(A.y ^ nkx4);
+    const uint32_t e2 = zero_byte_flags(A.z ^ nkx4), e3 = zero_byte_flags(A.w ^ nkx4);
+    const uint32_t e4 = from_next_lane_or(0xFFFFFFFFu, e0);
+    g[0] &= __builtin_amdgcn_alignbyte(e1, e0, K);
+    g[1] &= __builtin_amdgcn_alignbyte(e2, e1, K);
+    g[2] &= __builtin_amdgcn_alignbyte(e3, e2, K);
+    g[3] &= __builtin_amdgcn_alignbyte(e4, e3, K);
 }
 
 // Candidate verification for one lane's flags; returns true when the needle was found.
@@ -238,6 +267,11 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
             const uint32_t any = (g[0] | g[1] | g[2] | g[3]) & 0x80808080u;
             if (__ballot(any != 0) != 0) {              // the wave's "movemask != 0"
+                if (!ONE_BYTE) {                        // second-level filter in registers (wave-uniform)
+                    if (pr.n > 1) refine_flags<1>(A[u], pr.n1x4, g);
+                    if (pr.n > 2) refine_flags<2>(A[u], pr.n2x4, g);
+                    if (pr.n > 3) refine_flags<3>(A[u], pr.n3x4, g);
+                }
                 if (!staged) {
                     stage_needle_wave(s_needle, pr.needle, pr.n, lane);
                     staged = true;
@@ -263,7 +297,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 template <int Q, bool TWO, bool ONE_BYTE, int U, int NTMODE>
 __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, int *found, uint64_t tiles_per_block)
 {
-    __shared__ uint8_t s_needle[kWavesPerBlock * kNeedleLds];
+    __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
     if (tiles_per_block) {
         const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
@@ -276,23 +310,24 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, int *fou
 
 // ---- K4: batched, one grid for many (needle, haystack) problems ----------------------------------
 // blockIdx.y = problem, blockIdx.x = slice of that problem's tiles.  Per-problem flags, no
-// cross-problem early exit.  The problem descriptor is built per workgroup from the CSR offsets.
+// cross-problem early exit.  The problem descriptor is built per workgroup from the range arrays
+// (begin[i], end[i]) - CSR callers pass (off, off + 1); ranges may alias (many needles, one haystack).
 struct BatchArgs {
     const uint8_t *haystacks;
-    const uint64_t *hay_off;
+    const uint64_t *hay_begin, *hay_end;
     const uint8_t *needles;
-    const uint64_t *needle_off;
+    const uint64_t *needle_begin, *needle_end;
     const uint64_t *position;   // may be null: n_i - 1
     int *found;
 };
 
-template <int U, int NTMODE>
+template <int U>
 __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
 {
-    __shared__ uint8_t s_needle[kWavesPerBlock * kNeedleLds];
+    __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     const uint64_t prob = blockIdx.y;
-    const uint64_t h0 = a.hay_off[prob], h1 = a.hay_off[prob + 1];
-    const uint64_t n0 = a.needle_off[prob], n1 = a.needle_off[prob + 1];
+    const uint64_t h0 = a.hay_begin[prob], h1 = a.hay_end[prob];
+    const uint64_t n0 = a.needle_begin[prob], n1 = a.needle_end[prob];
     const uint64_t len = h1 - h0, n = n1 - n0;
     int *found = a.found + prob;
     if (n == 0) {                                   // N0: found everywhere (x86.rs:500)
@@ -317,29 +352,65 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
     pr.r = s % 4;
     pr.n0x4 = 0x01010101u * pr.needle[0];
     pr.nlx4 = 0x01010101u * pr.needle[position];
+    pr.n1x4 = n > 1 ? 0x01010101u * pr.needle[1] : 0;
+    pr.n2x4 = n > 2 ? 0x01010101u * pr.needle[2] : 0;
+    pr.n3x4 = n > 3 ? 0x01010101u * pr.needle[3] : 0;
 
-    const uint64_t t0 = blockIdx.x, ts = gridDim.x;
-    const uint64_t te = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+    // contiguous run of tiles per slice (same launch shape as the single-problem kernel)
+    const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+    const uint64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * per;
+    const uint64_t te = t0 + per < ntiles ? t0 + per : ntiles;
+    if (t0 >= te) return;
     if (n == 1) {
-        scan_tiles<0, false, true, U, NTMODE>(pr, s_needle, t0, ts, te, found);
+        scan_tiles<0, false, true, U, 1>(pr, s_needle, t0, 1, te, found);
         return;
     }
     const int q = (int)(s / 4);
-    if (pr.d == 0) {
+    if (pr.d == 0) {                                // single stream: non-temporal loads
         switch (q) {
-        case 0: scan_tiles<0, false, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
-        case 1: scan_tiles<1, false, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
-        case 2: scan_tiles<2, false, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
-        default: scan_tiles<3, false, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
+        case 0: scan_tiles<0, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        case 1: scan_tiles<1, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        case 2: scan_tiles<2, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        default: scan_tiles<3, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
         }
-    } else {
+    } else {                                        // two streams: plain loads (the re-read must hit)
         switch (q) {
-        case 0: scan_tiles<0, true, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
-        case 1: scan_tiles<1, true, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
-        case 2: scan_tiles<2, true, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
-        default: scan_tiles<3, true, false, U, NTMODE>(pr, s_needle, t0, ts, te, found); break;
+        case 0: scan_tiles<0, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        case 1: scan_tiles<1, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        case 2: scan_tiles<2, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        default: scan_tiles<3, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
         }
     }
+}
+
+// ---- short-haystack pairs: one LANE per (needle, haystack) problem ---------------------------------
+// The shape of the reference's short-haystack loop (bench/benches/i386.rs:118-129, tests/i386.rs:46-59:
+// 10.5 M word-in-word searches of <= 24 bytes each): far too small for a workgroup per problem.  Each
+// lane runs the same two-byte filter + compare sequentially over its few candidate offsets.
+__global__ void __launch_bounds__(kBlock) scan_pairs_kernel(const BatchArgs a, uint64_t count)
+{
+    const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (prob >= count) return;
+    const uint64_t h0 = a.hay_begin[prob], n0 = a.needle_begin[prob];
+    const uint64_t len = a.hay_end[prob] - h0, n = a.needle_end[prob] - n0;
+    int result = 0;
+    if (n == 0) {
+        result = 1;
+    } else if (len >= n) {
+        const uint8_t *h = a.haystacks + h0, *nd = a.needles + n0;
+        uint64_t position = a.position ? a.position[prob] : n - 1;
+        if (position >= n) position = n - 1;
+        const uint8_t first = nd[0], last = nd[position];
+        const uint64_t end = len - n + 1;
+        for (uint64_t i = 0; i < end && !result; ++i) {
+            if (h[i] != first || h[i + position] != last) continue;
+            uint64_t k = 1;
+            while (k < n && h[i + k] == nd[k]) ++k;
+            result = k >= n;
+        }
+    }
+    a.found[prob] = result;
 }
 
 // ---- synthetic haystack generator (not part of the reference) ------------------------

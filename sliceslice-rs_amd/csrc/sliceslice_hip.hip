@@ -215,6 +215,9 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.r = sh % 4;
     pr.n0x4 = 0x01010101u * s->needle[0];
     pr.nlx4 = 0x01010101u * s->needle[position];
+    pr.n1x4 = n > 1 ? 0x01010101u * s->needle[1] : 0;
+    pr.n2x4 = n > 2 ? 0x01010101u * s->needle[2] : 0;
+    pr.n3x4 = n > 3 ? 0x01010101u * s->needle[3] : 0;
 
     const Launch l = pick_variant(s->variant, pr.d != 0);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
@@ -457,45 +460,75 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     return rc;
 }
 
-int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_off, const void *d_needles,
-                      const uint64_t *d_needle_off, const uint64_t *d_position, size_t count,
-                      void *hip_stream, int *d_found)
+static int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint64_t *d_hay_begin,
+                           const uint64_t *d_hay_end, const void *d_needles, const uint64_t *d_needle_begin,
+                           const uint64_t *d_needle_end, const uint64_t *d_position, int *d_found)
+{
+    if (!d_hay_begin || !d_hay_end || !d_needle_begin || !d_needle_end || !d_found)
+        return fail(SS_ERR_ARGUMENT, "NULL argument");
+    a->haystacks = static_cast<const uint8_t *>(d_haystacks);
+    a->hay_begin = d_hay_begin;
+    a->hay_end = d_hay_end;
+    a->needles = static_cast<const uint8_t *>(d_needles);
+    a->needle_begin = d_needle_begin;
+    a->needle_end = d_needle_end;
+    a->position = d_position;
+    a->found = d_found;
+    return SS_OK;
+}
+
+int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                      const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                      const uint64_t *d_position, size_t count, void *hip_stream, int *d_found)
 {
     if (count == 0) return SS_OK;
-    if (!d_hay_off || !d_needle_off || !d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
-    if (count > 65535u * 1024u) return fail(SS_ERR_ARGUMENT, "too many problems");
+    ss::BatchArgs a;
+    if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end,
+                                 d_position, d_found))
+        return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     DeviceInfo di;
     if (int rc = device_info(dev, &di)) return rc;
     HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
-    ss::BatchArgs a;
-    a.haystacks = static_cast<const uint8_t *>(d_haystacks);
-    a.hay_off = d_hay_off;
-    a.needles = static_cast<const uint8_t *>(d_needles);
-    a.needle_off = d_needle_off;
-    a.position = d_position;
-    a.found = d_found;
-    // enough slices per problem to fill the chip even for a handful of problems; a 1 MiB haystack is
-    // 66 tiles of 16 KiB, so 4 slices x 4096 problems keeps every workgroup busy for several tiles.
-    uint64_t slices = ((uint64_t)di.cus * 8 + count - 1) / count;
+    // enough slices per problem to fill the chip even for a handful of problems (>= 16 workgroups per CU
+    // in total); each slice scans a contiguous run of its problem's tiles.
+    uint64_t slices = ((uint64_t)di.cus * 16 + count - 1) / count;
     if (slices < 1) slices = 1;
-    if (slices > 1024) slices = 1024;
-    // gridDim.y is limited to 65535: fold larger counts by launching in bands.
+    if (slices > 4096) slices = 4096;
+    // gridDim.y is limited to 65535: larger counts are launched in bands.
     size_t done = 0;
     while (done < count) {
         const size_t band = count - done < 65535 ? count - done : 65535;
         ss::BatchArgs b = a;
-        b.hay_off = a.hay_off + done;
-        b.needle_off = a.needle_off + done;
-        b.position = a.position ? a.position + done : nullptr;
-        b.found = a.found + done;
+        b.hay_begin += done;
+        b.hay_end += done;
+        b.needle_begin += done;
+        b.needle_end += done;
+        if (b.position) b.position += done;
+        b.found += done;
         dim3 grid((unsigned)slices, (unsigned)band);
-        ss::scan_batched_kernel<4, 0><<<grid, dim3(ss::kBlock), 0, st>>>(b);
+        ss::scan_batched_kernel<4><<<grid, dim3(ss::kBlock), 0, st>>>(b);
         HIP_TRY(hipGetLastError());
         done += band;
     }
+    return SS_OK;
+}
+
+int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                    const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                    const uint64_t *d_position, size_t count, void *hip_stream, int *d_found)
+{
+    if (count == 0) return SS_OK;
+    ss::BatchArgs a;
+    if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end,
+                                 d_position, d_found))
+        return rc;
+    const uint64_t blocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
+    if (blocks > 0x7fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
+    ss::scan_pairs_kernel<<<dim3((unsigned)blocks), dim3(ss::kBlock), 0, static_cast<hipStream_t>(hip_stream)>>>(a, count);
+    HIP_TRY(hipGetLastError());
     return SS_OK;
 }
 

@@ -44,7 +44,8 @@ ABI = {
     "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
     "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
-    "ss_search_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ss_search_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ss_search_pairs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_searcher_set_timing": (_int, [_vp, _int]),
     "ss_searcher_last_kernel_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "ss_searcher_set_variant": (_int, [_vp, _int]),
@@ -280,16 +281,28 @@ class ShardedSearcher:
             self._comm = None
 
 
-def search_batched(haystacks, hay_off, needles, needle_off, position=None, stream=None):
-    """One launch for many (needle_i, haystack_i) problems; all arguments are device tensors
-    (uint8 blobs, uint64-compatible int64 offsets of length count+1).  Returns an int32 device tensor."""
+def _ranges(off, begin, end):
+    """(begin_ptr, end_ptr, count) from either CSR offsets (count+1 int64) or explicit begin/end arrays."""
+    if off is not None:
+        return off.data_ptr(), off.data_ptr() + 8, off.numel() - 1
+    return begin.data_ptr(), end.data_ptr(), begin.numel()
+
+
+def search_batched(haystacks, hay_off, needles, needle_off, position=None, stream=None, hay_ranges=None,
+                   needle_ranges=None, pairs=False):
+    """One launch for many (needle_i, haystack_i) problems; all arguments are device tensors (uint8
+    blobs; int64 CSR offsets of length count+1, or explicit (begin, end) tensor pairs via *_ranges, which
+    may alias).  ``pairs=True`` uses the lane-per-problem kernel for tiny haystacks (ss_search_pairs).
+    Returns an int32 device tensor of flags."""
     import torch
-    count = hay_off.numel() - 1
+    hb, he, count = _ranges(hay_off, *(hay_ranges or (None, None)))
+    nb, ne, ncount = _ranges(needle_off, *(needle_ranges or (None, None)))
+    assert count == ncount
     found = torch.empty(count, dtype=torch.int32, device=haystacks.device)
     st = stream if stream is not None else _current_stream_handle()
-    _check(lib().ss_search_batched(haystacks.data_ptr(), hay_off.data_ptr(), needles.data_ptr(),
-                                   needle_off.data_ptr(), position.data_ptr() if position is not None else None,
-                                   count, st, found.data_ptr()))
+    fn = lib().ss_search_pairs if pairs else lib().ss_search_batched
+    _check(fn(haystacks.data_ptr(), hb, he, needles.data_ptr(), nb, ne,
+              position.data_ptr() if position is not None else None, count, st, found.data_ptr()))
     return found
 
 

@@ -413,3 +413,54 @@ def test_full_size_properties_1gib(ss):
         t[at:at + 16] = saved
         assert sp.search_in(t) == before
     assert s.search_in(t) is False
+
+
+def test_short_haystack_sweep_full_pairs_kernel(ss, corpus, checksums):
+    """tests/i386.rs:46-59 in full: every word searched in every word at or after it in length order -
+    10,513,405 problems through ss_search_pairs, ranges aliasing into ONE copy of the words; the hit count
+    is the committed checksum (39,105)."""
+    words = sorted(corpus["words"], key=len)
+    W = len(words)
+    lens = np.array([len(w) for w in words], dtype=np.int64)
+    starts = np.zeros(W, dtype=np.int64)
+    starts[1:] = np.cumsum(lens)[:-1]
+    blob = torch.from_numpy(np.frombuffer(b"".join(words), dtype=np.uint8).copy()).cuda()
+    ni = np.repeat(np.arange(W, dtype=np.int64), W - np.arange(W))
+    hj = np.concatenate([np.arange(i, W, dtype=np.int64) for i in range(W)])
+    assert ni.size == checksums["short_haystack_pairs"] == 10513405
+    nb, ne = torch.from_numpy(starts[ni]).cuda(), torch.from_numpy(starts[ni] + lens[ni]).cuda()
+    hb, he = torch.from_numpy(starts[hj]).cuda(), torch.from_numpy(starts[hj] + lens[hj]).cuda()
+    found = ss.search_batched(blob, None, blob, None, hay_ranges=(hb, he), needle_ranges=(nb, ne), pairs=True)
+    assert int(found.sum().item()) == checksums["short_haystack_hits"] == 39105
+    # spot-check individual answers (not only the count)
+    got = found.cpu().numpy()
+    rng = random.Random(1)
+    for _ in range(20000):
+        k = rng.randrange(ni.size)
+        assert bool(got[k]) == (words[ni[k]] in words[hj[k]])
+    # and the same answers from the workgroup-per-problem kernel on a slice of the problems
+    sl = slice(0, 50000)
+    f2 = ss.search_batched(blob, None, blob, None, hay_ranges=(hb[sl].contiguous(), he[sl].contiguous()),
+                           needle_ranges=(nb[sl].contiguous(), ne[sl].contiguous()))
+    assert (f2.cpu().numpy() == got[sl]).all()
+
+
+def test_long_haystack_all_needles_one_launch(ss, corpus):
+    """bench/benches/i386.rs:252-256 (`for searcher in &searchers { searcher.search_in(haystack) }`) as ONE
+    launch: 4,585 needles, all ranges aliasing the same 857 kB haystack; plus absent variants."""
+    hay = corpus["i386"]
+    words = list(corpus["words"])
+    absent = [w + b"\x00" for w in words[:500]]
+    needles = words + absent
+    want = [w in hay for w in needles]
+    assert sum(want) == 4585
+    lens = np.array([len(w) for w in needles], dtype=np.int64)
+    nb = np.zeros(len(needles), dtype=np.int64)
+    nb[1:] = np.cumsum(lens)[:-1]
+    nblob = torch.from_numpy(np.frombuffer(b"".join(needles), dtype=np.uint8).copy()).cuda()
+    dh = dev(hay)
+    hb = torch.zeros(len(needles), dtype=torch.int64, device="cuda")
+    he = torch.full((len(needles),), len(hay), dtype=torch.int64, device="cuda")
+    found = ss.search_batched(dh, None, nblob, None, hay_ranges=(hb, he),
+                              needle_ranges=(torch.from_numpy(nb).cuda(), torch.from_numpy(nb + lens).cuda()))
+    assert [bool(x) for x in found.cpu().tolist()] == want
