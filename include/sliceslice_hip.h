@@ -85,6 +85,22 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
 int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t len,
                            void *hip_stream, int *d_found);
 
+/* ---- row f1: position-returning find ------------------------------------------- */
+/* Offset of the LEFTMOST occurrence, or SS_NPOS - the `Option<usize>` shape every competitor in the
+ * reference's benches has (bench/sse4-strstr/src/lib.rs:4-15 `avx2_strstr_v2 -> Option<usize>`,
+ * bench/benches/i386.rs:191-205) and of the reference tests' oracle `find_subsequence`
+ * (tests/i386.rs:6-10).  Not part of DynamicAvx2Searcher itself, which only answers bool.
+ * n == 0 -> 0.  Same kernels as search_in with the flag replaced by an atomicMin'ed uint64; a wave
+ * only skips work that lies to the right of the best match so far. */
+#define SS_NPOS UINT64_MAX
+int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,
+                   uint64_t *position);
+/* Enqueue-only form: atomicMin's base_offset + local offset into *d_best (uint64 in device memory,
+ * caller-initialised to SS_NPOS).  With base_offset = the shard's begin, an all-reduce(MIN) over the
+ * ranks' d_best gives the global leftmost match of a range-sharded haystack. */
+int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t len, uint64_t base_offset,
+                         void *hip_stream, uint64_t *d_best);
+
 /* Drop-in form of search_in(&[u8]) for a HOST haystack: stages the bytes to the device in
  * double-buffered pinned chunks (needle_len-1 bytes of carry between chunks) and scans them there.
  * PCIe-bound by construction; never used for roofline numbers. */

@@ -59,6 +59,7 @@ struct Problem {
     uint32_t r;               // (position % 16) % 4: byte part of the shift
     uint32_t n0x4, nlx4;      // needle[0] and needle[position] splatted over a dword
     uint32_t n1x4, n2x4, n3x4;  // needle[1..3] splatted (second-level filter; valid when n > 1 / 2 / 3)
+    uint64_t find_base;       // FIND kernels: global offset of hay[0] (range shards), added to the match index
 };
 
 __device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) { return (x - 0x01010101u) & ~x; }
@@ -164,7 +165,7 @@ __device__ __forceinline__ void refine_flags(const u32x4 &A, uint32_t nkx4, uint
 // Candidate verification for one lane's flags; returns true when the needle was found.
 template <bool ONE_BYTE>
 __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk, const Problem &pr,
-                                             const uint8_t *s_needle)
+                                             const uint8_t *s_needle, uint64_t &where)
 {
     bool hit = false;
 #pragma unroll
@@ -178,6 +179,7 @@ __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk
             if (i < pr.end) {
                 if (ONE_BYTE) hit = pr.hay[i] == (uint8_t)pr.n0x4;
                 else hit = verify_candidate(pr, s_needle, i);
+                where = i;                              // lowest match of this lane when hit
             }
         }
     }
@@ -195,6 +197,15 @@ __device__ __forceinline__ void publish_found(int *found)
     __hip_atomic_store(found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// FIND kernels keep the leftmost match offset in one uint64 (all-ones = none yet), lowered by atomicMin.
+__device__ __forceinline__ uint64_t poll_best(const uint64_t *best)
+{
+    const uint64_t v = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // Per-wave lazy staging of the needle into the wave's private LDS slice (no workgroup barrier: the DS
 // operations of one wave execute in order).
 __device__ __forceinline__ void stage_needle_wave(uint8_t *s_needle, const uint8_t *needle, uint64_t n, int lane)
@@ -210,10 +221,15 @@ __device__ __forceinline__ void stage_needle_wave(uint8_t *s_needle, const uint8
 // A tile is kWavesPerBlock*U consecutive pieces; wave w owns pieces tile*4U + w*U + u, u = 0..U-1.
 // NTMODE: 0 = plain loads; 1 = non-temporal first-byte stream, plain position-byte stream;
 //         2 = non-temporal for both.  (With a single stream 1 == 2.)
-template <int Q, bool TWO, bool ONE_BYTE, int U, int NTMODE>
+// FIND = false: `sink` is the int found flag (0 -> 1).  FIND = true: `sink` is the uint64 leftmost-match
+// offset (row f1 of SURVEY.md 8f: the `Option<usize>` shape of tests/i386.rs:6-10 and
+// bench/sse4-strstr/src/lib.rs:4-15); a wave only skips work that lies to the RIGHT of the best so far.
+template <int Q, bool TWO, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_block, uint64_t tile0,
-                                           uint64_t tile_step, uint64_t tile_end, int *found)
+                                           uint64_t tile_step, uint64_t tile_end, void *sink)
 {
+    int *found = static_cast<int *>(sink);
+    uint64_t *best = static_cast<uint64_t *>(sink);
     constexpr bool NTA = NTMODE >= 1;
     constexpr bool NTB = TWO ? NTMODE >= 2 : NTMODE >= 1;
     const int lane = threadIdx.x & (kWave - 1);
@@ -224,6 +240,8 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     for (uint64_t tile = tile0; tile < tile_end; tile += tile_step) {
         u32x4 A[U], B[U], H = {0, 0, 0, 0};
         const uint64_t chunk0 = (tile * (kWavesPerBlock * U) + (uint64_t)wave * U) * 64;   // wave-uniform
+        // FIND polls first (oldest load, so waiting for it does not drain the data loads behind it)
+        const uint64_t best_now = FIND ? poll_best(best) : 0;
         const uint64_t halo = chunk0 + 64 * U + pr.d;
         const bool full = halo < pr.nchunks_all;
         if (full) {
@@ -246,7 +264,12 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             }
             if (!ONE_BYTE && lane == kWave - 1 && halo < pr.nchunks_all) H = load_chunk<false>(pr.base, halo);
         }
-        const int stop = poll_found(found);   // issued behind the data loads, consumed after them
+        // issued behind the data loads, consumed after them
+        const int stop = FIND ? 0 : poll_found(found);
+        if (FIND) {
+            const uint64_t first = chunk0 * 16 > pr.mis ? chunk0 * 16 - pr.mis : 0;   // lowest index this wave can report
+            if (best_now <= pr.find_base + first) return;                               // all of it lies right of a match
+        }
 
         bool hit = false;
         uint32_t wcur[4] = {0, 0, 0, 0}, wnext[4] = {0, 0, 0, 0}, wlast[4] = {0, 0, 0, 0};
@@ -276,14 +299,28 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     stage_needle_wave(s_needle, pr.needle, pr.n, lane);
                     staged = true;
                 }
-                hit |= verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, s_needle);
+                uint64_t where = 0;
+                const bool h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, s_needle, where);
+                hit |= h;
+                if (FIND) {
+                    const uint64_t m = __ballot(h);
+                    if (m != 0) {                       // lanes are in address order: lowest lane = leftmost
+                        const int src = __ffsll((unsigned long long)m) - 1;
+                        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)where, src);
+                        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(where >> 32), src);
+                        if (lane == 0)
+                            __hip_atomic_fetch_min(best, pr.find_base + (((uint64_t)hi << 32) | lo), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                        return;                         // the wave's later pieces and tiles are further right
+                    }
+                }
             }
             if (!ONE_BYTE && u + 1 < U) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wcur[j] = wnext[j];
             }
         }
-        if (__ballot(hit) != 0) {
+        if (!FIND && __ballot(hit) != 0) {
             if (hit) publish_found(found);
             return;
         }
@@ -294,17 +331,17 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 // ---- K1/K2/K3: one needle, one haystack ---------------------------------------------------------
 // gridDim.x workgroups; workgroup b scans tiles [b*tiles_per_block, (b+1)*tiles_per_block) when
 // tiles_per_block > 0 (contiguous runs, short-lived workgroups), or b, b+grid, ... when it is 0.
-template <int Q, bool TWO, bool ONE_BYTE, int U, int NTMODE>
-__global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, int *found, uint64_t tiles_per_block)
+template <int Q, bool TWO, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
+__global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *found, uint64_t tiles_per_block)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
     if (tiles_per_block) {
         const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
         const uint64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
-        scan_tiles<Q, TWO, ONE_BYTE, U, NTMODE>(pr, s_needle, t0, 1, t1, found);
+        scan_tiles<Q, TWO, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, t0, 1, t1, found);
     } else {
-        scan_tiles<Q, TWO, ONE_BYTE, U, NTMODE>(pr, s_needle, blockIdx.x, gridDim.x, ntiles, found);
+        scan_tiles<Q, TWO, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, blockIdx.x, gridDim.x, ntiles, found);
     }
 }
 
@@ -355,6 +392,7 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
     pr.n1x4 = n > 1 ? 0x01010101u * pr.needle[1] : 0;
     pr.n2x4 = n > 2 ? 0x01010101u * pr.needle[2] : 0;
     pr.n3x4 = n > 3 ? 0x01010101u * pr.needle[3] : 0;
+    pr.find_base = 0;
 
     // contiguous run of tiles per slice (same launch shape as the single-problem kernel)
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);

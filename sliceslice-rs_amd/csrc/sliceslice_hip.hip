@@ -70,6 +70,8 @@ struct PerDevice {
     uint8_t *d_needle = nullptr;
     int *d_flags = nullptr;     // kSlots ints, zero whenever a slot is free
     int *h_flags = nullptr;     // pinned mirror
+    uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
+    uint64_t *h_best = nullptr; // pinned mirror
     uint64_t free_mask = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed_valid = false;
@@ -108,6 +110,9 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
     HIP_TRY(hipMalloc((void **)&p.d_flags, kSlots * sizeof(int)));
     HIP_TRY(hipMemset(p.d_flags, 0, kSlots * sizeof(int)));
     HIP_TRY(hipHostMalloc((void **)&p.h_flags, kSlots * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t)));
+    HIP_TRY(hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault));
     p.free_mask = ~0ull;
     HIP_TRY(hipEventCreate(&p.ev0));
     HIP_TRY(hipEventCreate(&p.ev1));
@@ -164,19 +169,19 @@ Launch pick_variant(int variant, bool two)
     return l;
 }
 
-template <int U, int NT>
-void launch_scan_un(const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st, int *flag,
+template <int U, int NT, bool FIND = false>
+void launch_scan_un(const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st, void *flag,
                     uint64_t tpb)
 {
     using namespace ss;
     dim3 blk(kBlock);
     if (one_byte) {
-        scan_kernel<0, false, true, U, NT><<<grid, blk, 0, st>>>(pr, flag, tpb);
+        scan_kernel<0, false, true, U, NT, FIND><<<grid, blk, 0, st>>>(pr, flag, tpb);
         return;
     }
 #define SS_CASE(QQ, TT)                                                                            \
     case (QQ) * 2 + (TT ? 1 : 0):                                                                  \
-        scan_kernel<QQ, TT, false, U, NT><<<grid, blk, 0, st>>>(pr, flag, tpb);                    \
+        scan_kernel<QQ, TT, false, U, NT, FIND><<<grid, blk, 0, st>>>(pr, flag, tpb);              \
         break;
     switch (q * 2 + (two ? 1 : 0)) {
         SS_CASE(0, false) SS_CASE(0, true) SS_CASE(1, false) SS_CASE(1, true)
@@ -187,17 +192,19 @@ void launch_scan_un(const ss::Problem &pr, int q, bool two, bool one_byte, dim3 
 
 template <int U>
 void launch_scan_u(int nt, const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st,
-                   int *flag, uint64_t tpb)
+                   void *flag, uint64_t tpb)
 {
     if (nt == 0) launch_scan_un<U, 0>(pr, q, two, one_byte, grid, st, flag, tpb);
     else launch_scan_un<U, 1>(pr, q, two, one_byte, grid, st, flag, tpb);
 }
 
-// Builds the Problem for (hay, len) and enqueues the scan; *d_flag is OR-ed (0 -> 1), never cleared.
-// Preconditions: 1 <= n <= len.
+// Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, OR-ed
+// (0 -> 1), never cleared.  find == true: *d_sink is a uint64, atomicMin'ed with find_base + offset of
+// every match the grid sees (the leftmost one survives).  Preconditions: 1 <= n <= len.
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st,
-                 int *d_flag)
+                 void *d_sink, bool find = false, uint64_t find_base = 0)
 {
+    void *d_flag = d_sink;
     ss::Problem pr;
     const size_t n = s->n;
     pr.hay = static_cast<const uint8_t *>(d_hay);
@@ -218,6 +225,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.n1x4 = n > 1 ? 0x01010101u * s->needle[1] : 0;
     pr.n2x4 = n > 2 ? 0x01010101u * s->needle[2] : 0;
     pr.n3x4 = n > 3 ? 0x01010101u * s->needle[3] : 0;
+    pr.find_base = find_base;
 
     const Launch l = pick_variant(s->variant, pr.d != 0);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
@@ -249,6 +257,11 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     if (s->timing) HIP_TRY(hipEventRecord(pd->ev0, st));
     const int q = (int)(sh / 4);
     const bool two = pr.d != 0;
+    if (find) {   // one tile shape for find(): U = 4, automatic load policy
+        if (l.U != 4) return fail(SS_ERR_ARGUMENT, "find supports the U = 4 kernels only");
+        if (l.nt) launch_scan_un<4, 1, true>(pr, q, two, one_byte, grid, st, d_flag, tpb);
+        else launch_scan_un<4, 0, true>(pr, q, two, one_byte, grid, st, d_flag, tpb);
+    } else
     switch (l.U) {
     case 2: launch_scan_u<2>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
     case 8: launch_scan_u<8>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
@@ -309,6 +322,8 @@ void ss_searcher_free(ss_searcher *s)
         (void)hipFree(p.d_needle);
         (void)hipFree(p.d_flags);
         (void)hipHostFree(p.h_flags);
+        (void)hipFree(p.d_best);
+        (void)hipHostFree(p.h_best);
         if (p.ev0) (void)hipEventDestroy(p.ev0);
         if (p.ev1) (void)hipEventDestroy(p.ev1);
     }
@@ -394,6 +409,55 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     } else {
         (void)hipDeviceSynchronize();
         (void)hipMemset(pd->d_flags + k, 0, sizeof(int));
+    }
+    release_slot(s, pd, k);
+    return rc;
+}
+
+int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t len, uint64_t base_offset,
+                         void *hip_stream, uint64_t *d_best)
+{
+    if (!s || !d_best) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    if (len < s->n) return SS_OK;
+    if (s->n == 0) {        // the empty needle matches at offset 0 of every haystack
+        if (base_offset != 0) return SS_OK;     // only the first shard reports it
+        static const uint64_t zero = 0;
+        HIP_TRY(hipMemcpyAsync(d_best, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+        return SS_OK;
+    }
+    return enqueue_scan(s, pd, d_haystack, len, st, d_best, true, base_offset);
+}
+
+int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, uint64_t *position)
+{
+    if (!s || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    if (s->n == 0) { *position = 0; return SS_OK; }
+    if (len < s->n) { *position = SS_NPOS; return SS_OK; }
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    const int k = acquire_slot(s, pd);
+    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0);
+    if (rc == SS_OK) {
+        hipError_t e = hipMemcpyAsync(pd->h_best + k, pd->d_best + k, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "position read-back: %s", hipGetErrorString(e));
+    }
+    if (rc == SS_OK) {
+        *position = pd->h_best[k];
+        if (*position != SS_NPOS) {                     // slots are all-ones whenever they are free
+            hipError_t e = hipMemsetAsync(pd->d_best + k, 0xFF, sizeof(uint64_t), st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "slot reset: %s", hipGetErrorString(e));
+        }
+    } else {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));
     }
     release_slot(s, pd, k);
     return rc;

@@ -44,6 +44,8 @@ ABI = {
     "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
     "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
+    "ss_find_device": (_int, [_vp, _vp, _sz, _vp, ctypes.POINTER(_u64)]),
+    "ss_find_device_async": (_int, [_vp, _vp, _sz, _u64, _vp, _vp]),
     "ss_search_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_search_pairs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_searcher_set_timing": (_int, [_vp, _int]),
@@ -182,6 +184,29 @@ class DynamicHipSearcher:
 
     inlined_search_in = search_in       # src/x86.rs:498
 
+    def find(self, haystack, stream=None):
+        """Offset of the leftmost occurrence or None (row f1; the shape of tests/i386.rs:6-10
+        `find_subsequence` and of the competitors in bench/benches/i386.rs).  Device tensors only."""
+        pos = _u64(0)
+        if isinstance(haystack, tuple):
+            ptr, length = haystack
+        else:
+            if not (_is_tensor(haystack) and haystack.is_cuda):
+                import torch
+                a = np.frombuffer(haystack, dtype=np.uint8) if not isinstance(haystack, np.ndarray) else haystack
+                haystack = torch.from_numpy(np.ascontiguousarray(a).copy()).cuda() if a.size else \
+                    torch.empty(0, dtype=torch.uint8, device="cuda")
+            ptr, length = haystack.data_ptr(), haystack.numel()
+        st = stream if stream is not None else _current_stream_handle()
+        _check(lib().ss_find_device(self._h, ptr, length, st, ctypes.byref(pos)))
+        return None if pos.value == (1 << 64) - 1 else pos.value
+
+    def find_async(self, haystack, d_best, base_offset=0, stream=None):
+        """Enqueue only: atomicMin base_offset + offset into the uint64 device tensor d_best (init: all ones)."""
+        st = stream if stream is not None else _current_stream_handle()
+        _check(lib().ss_find_device_async(self._h, haystack.data_ptr(), haystack.numel(), base_offset, st,
+                                          d_best.data_ptr()))
+
     def search_in_async(self, haystack, d_flag, stream=None):
         """Enqueue only: OR the result into the int32 device tensor ``d_flag`` (caller-zeroed)."""
         st = stream if stream is not None else _current_stream_handle()
@@ -225,7 +250,7 @@ class ShardedSearcher:
         gloo on CPU - used by the CPU tests with an injected shard searcher).
     """
 
-    def __init__(self, needle, position=None, group=None, backend="torch", local_search=None):
+    def __init__(self, needle, position=None, group=None, backend="torch", local_search=None, local_find=None):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
@@ -234,7 +259,10 @@ class ShardedSearcher:
         self.needle = bytes(needle)
         self.backend = backend
         self._local_search = local_search
-        self._searcher = None if local_search is not None else DynamicHipSearcher(needle, position)
+        self._local_find = local_find
+        self._best = None
+        self._searcher = None if (local_search is not None or local_find is not None) else \
+            DynamicHipSearcher(needle, position)
         self._comm = None
         self._flag = None
         if backend == "rccl":
@@ -274,6 +302,24 @@ class ShardedSearcher:
         self._searcher.search_in_async(shard, self._flag, st)
         self._dist.all_reduce(self._flag, op=self._dist.ReduceOp.MAX, group=self.group)
         return bool(self._flag.item())
+
+    def find(self, shard, shard_begin, stream=None):
+        """Global offset of the leftmost occurrence in the logical haystack, or None: every rank finds its
+        local leftmost match (offset + shard_begin), ONE all-reduce(MIN) combines them."""
+        import torch
+        none = (1 << 63) - 1                                      # int64 stand-in for SS_NPOS in the reduce
+        if self._local_find is not None:                          # CPU tests: injected shard find
+            p = self._local_find(shard)
+            t = torch.tensor([none if p is None else p + shard_begin], dtype=torch.int64)
+        else:
+            if self._best is None:
+                self._best = torch.empty(1, dtype=torch.int64, device=shard.device)
+            self._best.fill_(-1)                                   # all ones = SS_NPOS
+            self._searcher.find_async(shard, self._best, shard_begin, stream)
+            t = torch.where(self._best < 0, torch.full_like(self._best, none), self._best)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
+        v = int(t.item())
+        return None if v == none else v
 
     def close(self):
         if self._comm is not None and _lib is not None:

@@ -464,3 +464,53 @@ def test_long_haystack_all_needles_one_launch(ss, corpus):
     found = ss.search_batched(dh, None, nblob, None, hay_ranges=(hb, he),
                               needle_ranges=(torch.from_numpy(nb).cuda(), torch.from_numpy(nb + lens).cuda()))
     assert [bool(x) for x in found.cpu().tolist()] == want
+
+
+def test_find_leftmost_vs_python(ss, corpus):
+    """Row f1: offset of the leftmost occurrence (tests/i386.rs:6-10 `find_subsequence`), bit-exact vs
+    Python's bytes.find on text, boundaries, repeated matches and random data."""
+    raw = corpus["i386"]
+    dh = dev(raw)
+    rng = random.Random(21)
+    for w in rng.sample(corpus["words"], 400) + [b"", b"\x00\x01\x02", b"zzzzzzzzzzzz"]:
+        want = raw.find(w)
+        assert ss.DynamicHipSearcher.new(w).find(dh) == (None if want < 0 else want), w
+    # many occurrences: the leftmost must win regardless of which workgroup sees which first
+    ln = 8 << 20
+    t = torch.full((ln + 16,), 0x2E, dtype=torch.uint8, device="cuda")
+    for n in (1, 2, 16, 33, 300):
+        needle = bytes((37 * k + 11) % 200 + 50 for k in range(n))
+        nd = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+        for mis in (0, 7):
+            hay = t[mis:mis + ln]
+            s = ss.DynamicHipSearcher.new(needle)
+            assert s.find(hay) is None
+            spots = sorted(rng.sample(range(0, ln - n), 40) + [ln - n])
+            for at in reversed(spots):                 # plant right-to-left; the answer moves left each time
+                hay[at:at + n] = nd
+                got = s.find(hay)
+                assert got is not None and got <= at
+                hb = hay[max(0, got - 1):got + n].cpu().numpy().tobytes()
+                assert needle in hb
+            assert s.find(hay) == hay.cpu().numpy().tobytes().find(needle)
+            hay.fill_(0x2E)
+    # boundary offsets / positions
+    for n in (2, 5, 16, 17, 64):
+        needle = bytes(range(100, 100 + n))
+        nd = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+        hay = t[3:3 + 200000]
+        hay.fill_(0x2E)
+        for at in (0, 1, 15, 16, 1023, 1024, 1025, 16383, 16384, 65535, 65536, 200000 - n):
+            hay[at:at + n] = nd
+            for position in {0, n - 1, n // 2}:
+                assert ss.DynamicHipSearcher.with_position(needle, position).find(hay) == at, (n, at, position)
+            hay[at:at + n] = 0x2E
+    # random data, short needles: first occurrence somewhere in the middle
+    r = torch.empty(4 << 20, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(r, 77)
+    host = r.cpu().numpy().tobytes()
+    for _ in range(60):
+        n = rng.choice([1, 2, 3])
+        nd = bytes(rng.randrange(255) for _ in range(n))
+        want = host.find(nd)
+        assert ss.DynamicHipSearcher.new(nd).find(r) == (None if want < 0 else want), nd

@@ -55,6 +55,16 @@ def _worker(rank, world, port, total, q):
         for name, needle, hay in cases:
             got, want, rng = run(needle, hay)
             results.append((name, got, want, rng))
+            # sharded find: global leftmost offset through one all-reduce(MIN)
+            if len(needle) > 0:
+                def local_find(shard, nd=needle):
+                    p = shard.tobytes().find(nd)
+                    return None if p < 0 else p
+                sh = ss.ShardedSearcher(needle, local_find=local_find)
+                b, e = sh.shard_range(len(hay))
+                gotp = sh.find(hay[b:e], b)
+                wantp = hay.tobytes().find(needle)
+                results.append((name + ":find", gotp, None if wantp < 0 else wantp, (b, e)))
         q.put((rank, results))
     finally:
         dist.destroy_process_group()
