@@ -221,13 +221,30 @@ __device__ __forceinline__ void stage_needle_wave(uint8_t *s_needle, const uint8
 // A tile is kWavesPerBlock*U consecutive pieces; wave w owns pieces tile*4U + w*U + u, u = 0..U-1.
 // NTMODE: 0 = plain loads; 1 = non-temporal first-byte stream, plain position-byte stream;
 //         2 = non-temporal for both.  (With a single stream 1 == 2.)
+// lane l receives `cur` of lane l+k when l+k < 64, else `nxt` of lane l+k-64 (0 <= k <= 64):
+// the value k lanes further along the concatenation {cur, nxt} of two consecutive pieces.
+__device__ __forceinline__ uint32_t from_lane_ahead(uint32_t cur, uint32_t nxt, int lane, int k)
+{
+    const int idx = ((lane + k) & (kWave - 1)) << 2;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)cur);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(idx, (int)nxt);
+    return lane + k < kWave ? a : b;
+}
+
+// MODE selects where the position-byte flags of a candidate come from (position = 16*d + 4*Q + r):
+//   0  d == 0: same chunk / next lane (DPP) - every needle of <= 16 bytes with the default position;
+//   1  d  > 0: a second load stream at +d chunks (plain loads; the re-read hits in L1/L2);
+//   2  0 < d < 64, small: ONE (non-temporal) load stream; the flags computed by the lane that owns chunk
+//      c+d are fetched across lanes with ds_bpermute (the wave loads d+1 halo chunks after its last piece).
 // FIND = false: `sink` is the int found flag (0 -> 1).  FIND = true: `sink` is the uint64 leftmost-match
 // offset (row f1 of SURVEY.md 8f: the `Option<usize>` shape of tests/i386.rs:6-10 and
 // bench/sse4-strstr/src/lib.rs:4-15); a wave only skips work that lies to the RIGHT of the best so far.
-template <int Q, bool TWO, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
+template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_block, uint64_t tile0,
                                            uint64_t tile_step, uint64_t tile_end, void *sink)
 {
+    constexpr bool TWO = MODE == 1;
+    constexpr bool SHIFTED = MODE == 2;
     int *found = static_cast<int *>(sink);
     uint64_t *best = static_cast<uint64_t *>(sink);
     constexpr bool NTA = NTMODE >= 1;
@@ -236,12 +253,14 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
     bool staged = false;
+    const int d = (int)pr.d;                                                // SHIFTED: 1 <= d <= 62
 
     for (uint64_t tile = tile0; tile < tile_end; tile += tile_step) {
         u32x4 A[U], B[U], H = {0, 0, 0, 0};
         const uint64_t chunk0 = (tile * (kWavesPerBlock * U) + (uint64_t)wave * U) * 64;   // wave-uniform
         // FIND polls first (oldest load, so waiting for it does not drain the data loads behind it)
         const uint64_t best_now = FIND ? poll_best(best) : 0;
+        // last chunk this wave touches: the halo chunk (MODE 0/1) or the d+1 halo chunks (MODE 2)
         const uint64_t halo = chunk0 + 64 * U + pr.d;
         const bool full = halo < pr.nchunks_all;
         if (full) {
@@ -250,7 +269,11 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 A[u] = load_chunk<NTA>(pr.base, chunk0 + 64 * u + lane);
                 if (TWO) B[u] = load_chunk<NTB>(pr.base, chunk0 + 64 * u + lane + pr.d);
             }
-            if (!ONE_BYTE && lane == kWave - 1) H = load_chunk<false>(pr.base, halo);
+            if (SHIFTED) {
+                if (lane <= d) H = load_chunk<false>(pr.base, chunk0 + 64 * U + lane);
+            } else if (!ONE_BYTE && lane == kWave - 1) {
+                H = load_chunk<false>(pr.base, halo);
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -262,7 +285,11 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     if (c + pr.d < pr.nchunks_all) B[u] = load_chunk<NTB>(pr.base, c + pr.d);
                 }
             }
-            if (!ONE_BYTE && lane == kWave - 1 && halo < pr.nchunks_all) H = load_chunk<false>(pr.base, halo);
+            if (SHIFTED) {
+                if (lane <= d && chunk0 + 64 * U + lane < pr.nchunks_all) H = load_chunk<false>(pr.base, chunk0 + 64 * U + lane);
+            } else if (!ONE_BYTE && lane == kWave - 1 && halo < pr.nchunks_all) {
+                H = load_chunk<false>(pr.base, halo);
+            }
         }
         // issued behind the data loads, consumed after them
         const int stop = FIND ? 0 : poll_found(found);
@@ -276,18 +303,33 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         if (!ONE_BYTE) position_flags(TWO ? B[0] : A[0], pr.nlx4, wcur);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!ONE_BYTE) {
-                // lane 63's "next lane": lane 0 of the next piece, or the halo chunk after the last piece
-                if (u + 1 < U) {
-                    position_flags(TWO ? B[u + 1] : A[u + 1], pr.nlx4, wnext);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wlast[j] = (j <= Q) ? rotate_from_next_lane(wnext[j]) : 0u;
-                } else {
-                    position_flags(H, pr.nlx4, wlast);
-                }
-            }
             uint32_t g[4];
-            filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
+            if (SHIFTED) {
+                // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
+                position_flags(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
+                uint32_t x[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[j] = (j >= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d) : 0u;
+                    x[4 + j] = (j <= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d + 1) : 0u;
+                }
+                g[0] = zero_byte_flags(A[u].x ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r);
+                g[1] = zero_byte_flags(A[u].y ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r);
+                g[2] = zero_byte_flags(A[u].z ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r);
+                g[3] = zero_byte_flags(A[u].w ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r);
+            } else {
+                if (!ONE_BYTE) {
+                    // lane 63's "next lane": lane 0 of the next piece, or the halo chunk after the last piece
+                    if (u + 1 < U) {
+                        position_flags(TWO ? B[u + 1] : A[u + 1], pr.nlx4, wnext);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wlast[j] = (j <= Q) ? rotate_from_next_lane(wnext[j]) : 0u;
+                    } else {
+                        position_flags(H, pr.nlx4, wlast);
+                    }
+                }
+                filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
+            }
             const uint32_t any = (g[0] | g[1] | g[2] | g[3]) & 0x80808080u;
             if (__ballot(any != 0) != 0) {              // the wave's "movemask != 0"
                 if (!ONE_BYTE) {                        // second-level filter in registers (wave-uniform)
@@ -315,7 +357,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     }
                 }
             }
-            if (!ONE_BYTE && u + 1 < U) {
+            if (!ONE_BYTE && (SHIFTED || u + 1 < U)) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wcur[j] = wnext[j];
             }
@@ -331,7 +373,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 // ---- K1/K2/K3: one needle, one haystack ---------------------------------------------------------
 // gridDim.x workgroups; workgroup b scans tiles [b*tiles_per_block, (b+1)*tiles_per_block) when
 // tiles_per_block > 0 (contiguous runs, short-lived workgroups), or b, b+grid, ... when it is 0.
-template <int Q, bool TWO, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
+template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
 __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *found, uint64_t tiles_per_block)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
@@ -339,11 +381,13 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *fo
     if (tiles_per_block) {
         const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
         const uint64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
-        scan_tiles<Q, TWO, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, t0, 1, t1, found);
+        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, t0, 1, t1, found);
     } else {
-        scan_tiles<Q, TWO, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, blockIdx.x, gridDim.x, ntiles, found);
+        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, blockIdx.x, gridDim.x, ntiles, found);
     }
 }
+
+#ifdef SS_MISC_KERNELS   // only the API translation unit (sliceslice_hip.hip) compiles what follows
 
 // ---- K4: batched, one grid for many (needle, haystack) problems ----------------------------------
 // blockIdx.y = problem, blockIdx.x = slice of that problem's tiles.  Per-problem flags, no
@@ -530,5 +574,7 @@ __global__ void dpp_probe_kernel(uint32_t *out)
     out[192 + threadIdx.x] = rotate_from_next_lane(v);
     out[256 + threadIdx.x] = from_next_lane_or(7777u, v);
 }
+
+#endif  // SS_MISC_KERNELS
 
 }  // namespace ss

@@ -19,7 +19,9 @@
 #include <vector>
 
 #include "../../include/sliceslice_hip.h"
+#define SS_MISC_KERNELS 1
 #include "scan_kernels.hpp"
+#include "scan_launch.hpp"
 
 namespace {
 
@@ -144,58 +146,45 @@ void release_slot(const ss_searcher *s, PerDevice *p, int k)
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------
-// variant = 10*U + NTMODE with U in {2,4,8} (pieces per wave per tile) and NTMODE in {0,1}
-// (scan_kernels.hpp); 0 = automatic: U = 4; non-temporal loads for the single-stream kernels
-// (position < 16), plain loads for the two-stream kernels, whose second stream re-reads lines of the
-// first and would miss on a non-temporal line (profiles/r01/needle_len_sweep_8gib.jsonl).  grid > 0: that many workgroups, grid-stride over tiles;
-// grid < 0: -grid tiles per (short-lived) workgroup; 0 = automatic.
+// variant = 100*MODE + 10*U + NT.  U in {4,8} = pieces (KiB) per wave per tile; NT in {0,1} = plain /
+// non-temporal first-byte stream; MODE (only meaningful for position >= 16, i.e. d > 0): 0 = automatic,
+// 1 = second load stream, 2 = one stream + cross-lane (ds_bpermute) position flags.  variant 0 = automatic:
+// U = 4; d == 0 -> NT; 0 < d <= kShiftMaxD -> MODE 2 with NT; larger d -> MODE 1 with plain loads (a
+// non-temporal line is not kept for the second stream's re-read; profiles/r01/readbench_8gib.txt).
 struct Launch {
     int U;
     int nt;
+    int mode;   // 0: d == 0, 1: two load streams, 2: shifted flags
 };
 
 constexpr int kAutoU = 4;
-constexpr int kAutoNt = 1;
 constexpr int kAutoTilesPerBlock = 64;   // 1 MiB contiguous per workgroup at U = 4 (tools/tune.py sweeps)
+constexpr uint64_t kShiftMaxD = 62;      // d + 1 halo chunks must fit one piece (tools/tune.py: wins up to d = 62)
 
-Launch pick_variant(int variant, bool two)
+Launch pick_variant(int variant, uint64_t d)
 {
-    Launch l{kAutoU, two ? 0 : kAutoNt};
+    Launch l;
+    l.U = kAutoU;
+    l.mode = d == 0 ? 0 : (d <= kShiftMaxD ? 2 : 1);
+    l.nt = l.mode == 1 ? 0 : 1;
     if (variant > 0) {
-        const int u = variant / 10;
-        if (u == 2 || u == 4 || u == 8) l.U = u;
+        const int m = variant / 100, u = (variant / 10) % 10;
+        if (u == 4 || u == 8) l.U = u;
+        if (d != 0 && m == 1) l.mode = 1;
+        if (d != 0 && m == 2 && d <= 62) l.mode = 2;
         l.nt = (variant % 10) ? 1 : 0;
     }
     return l;
 }
 
-template <int U, int NT, bool FIND = false>
-void launch_scan_un(const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st, void *flag,
-                    uint64_t tpb)
-{
-    using namespace ss;
-    dim3 blk(kBlock);
-    if (one_byte) {
-        scan_kernel<0, false, true, U, NT, FIND><<<grid, blk, 0, st>>>(pr, flag, tpb);
-        return;
-    }
-#define SS_CASE(QQ, TT)                                                                            \
-    case (QQ) * 2 + (TT ? 1 : 0):                                                                  \
-        scan_kernel<QQ, TT, false, U, NT, FIND><<<grid, blk, 0, st>>>(pr, flag, tpb);              \
-        break;
-    switch (q * 2 + (two ? 1 : 0)) {
-        SS_CASE(0, false) SS_CASE(0, true) SS_CASE(1, false) SS_CASE(1, true)
-        SS_CASE(2, false) SS_CASE(2, true) SS_CASE(3, false) SS_CASE(3, true)
-    }
-#undef SS_CASE
-}
-
+// launch_scan_un<U, NT, FIND> is defined in scan_launch.hpp and explicitly instantiated in the
+// scan_inst_*.hip translation units, so that the kernel families compile in parallel.
 template <int U>
-void launch_scan_u(int nt, const ss::Problem &pr, int q, bool two, bool one_byte, dim3 grid, hipStream_t st,
+void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st,
                    void *flag, uint64_t tpb)
 {
-    if (nt == 0) launch_scan_un<U, 0>(pr, q, two, one_byte, grid, st, flag, tpb);
-    else launch_scan_un<U, 1>(pr, q, two, one_byte, grid, st, flag, tpb);
+    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, grid, st, flag, tpb);
+    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, grid, st, flag, tpb);
 }
 
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, OR-ed
@@ -227,7 +216,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.n3x4 = n > 3 ? 0x01010101u * s->needle[3] : 0;
     pr.find_base = find_base;
 
-    const Launch l = pick_variant(s->variant, pr.d != 0);
+    const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
     uint64_t blocks, tpb;
     if (s->grid > 0) {
@@ -256,16 +245,14 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
 
     if (s->timing) HIP_TRY(hipEventRecord(pd->ev0, st));
     const int q = (int)(sh / 4);
-    const bool two = pr.d != 0;
-    if (find) {   // one tile shape for find(): U = 4, automatic load policy
+    if (find) {   // one tile shape for find(): U = 4
         if (l.U != 4) return fail(SS_ERR_ARGUMENT, "find supports the U = 4 kernels only");
-        if (l.nt) launch_scan_un<4, 1, true>(pr, q, two, one_byte, grid, st, d_flag, tpb);
-        else launch_scan_un<4, 0, true>(pr, q, two, one_byte, grid, st, d_flag, tpb);
-    } else
-    switch (l.U) {
-    case 2: launch_scan_u<2>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
-    case 8: launch_scan_u<8>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
-    default: launch_scan_u<4>(l.nt, pr, q, two, one_byte, grid, st, d_flag, tpb); break;
+        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
+        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
+    } else if (l.U == 8) {
+        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
+    } else {
+        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
     }
     HIP_TRY(hipGetLastError());
     if (s->timing) {

@@ -276,11 +276,12 @@ def test_all_kernel_variants_agree(ss, O):
     ss.fill_random_device(t, 0xABCDEF)
     t = t[3:3 + ln]
     host = t.cpu().numpy()
-    cases = [absent_needle(ss, n) for n in (1, 2, 16, 20, 200)]
-    cases += [host[ln - n:].tobytes() for n in (1, 2, 16, 20, 200)]
+    cases = [absent_needle(ss, n) for n in (1, 2, 16, 20, 200, 700, 1200)]
+    cases += [host[ln - n:].tobytes() for n in (1, 2, 16, 20, 200, 700, 1200)]
+    cases += [host[12345:12345 + n].tobytes() for n in (33, 100, 257, 1000)]
     for nd in cases:
         want = O.OracleSearcher(nd).search_in(host)
-        for variant in (20, 21, 40, 41, 80, 81):
+        for variant in (40, 41, 80, 81, 140, 141, 181, 240, 241, 280, 281):
             for grid in (0, 1, 7, 4096, -1, -3, -1000):
                 s = ss.DynamicHipSearcher.new(nd)
                 s.set_variant(variant)
