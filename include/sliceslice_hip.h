@@ -106,6 +106,20 @@ int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t le
  * PCIe-bound by construction; never used for roofline numbers. */
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
 
+/* Row f2: the host-file front end of examples/grep.rs:42-56 (`mmap` the file, one
+ * search_in): maps `path` read-only and runs it through ss_search_host's chunked upload + scan. */
+int ss_search_file(const ss_searcher *s, const char *path, int *found);
+
+/* Row f3: data for a `position` policy.  The reference leaves `position` to the caller
+ * and defaults to the last byte (src/x86.rs:252-255, 285).  ss_byte_histogram_device counts byte values
+ * of a device haystack (every ceil(len/sample_bytes)-th 16-byte chunk; sample_bytes = 0 -> all) into
+ * hist[256] (host memory); ss_choose_position returns the index (>= 1) of the needle byte that is rarest
+ * under `hist` - ties to the later byte; hist == NULL -> n-1, the reference default.  The result of a
+ * search never depends on the choice (src/lib.rs:375-378); only the verify load does. */
+int ss_byte_histogram_device(const void *d_haystack, size_t len, size_t sample_bytes, void *hip_stream,
+                             uint64_t hist[256]);
+int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *position);
+
 /* Batched search, one launch (BASELINE.json config 5): problem i searches the needle
  * d_needles[needle_begin[i] .. needle_end[i]) in the haystack d_haystacks[hay_begin[i] .. hay_end[i]).
  * Everything lives in device memory; the four range arrays hold `count` uint64 each.  CSR callers

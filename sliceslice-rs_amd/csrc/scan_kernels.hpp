@@ -563,6 +563,43 @@ __global__ void __launch_bounds__(kBlock) read_ceiling_kernel(const u32x4 *src, 
     if (r == 0x9E3779B9u) sink[0] = r;      // practically never; keeps the loads alive
 }
 
+// ---- byte histogram (row f3 of SURVEY.md 8f: data for a rare-byte `position` policy) ----------------
+// Per-wave private LDS histograms (4 x 256 counters per workgroup), flushed with one global atomic per
+// non-zero counter.  `stride_chunks` > 1 samples every stride-th 16-byte chunk.
+__global__ void __launch_bounds__(kBlock) byte_histogram_kernel(const uint8_t *hay, uint64_t len, uint64_t stride_chunks,
+                                                                unsigned long long *hist)
+{
+    __shared__ uint32_t h[kWavesPerBlock][256];
+    for (int k = threadIdx.x; k < kWavesPerBlock * 256; k += kBlock) (&h[0][0])[k] = 0;
+    __syncthreads();
+    const int wave = threadIdx.x / kWave;
+    const uint64_t nchunks = len / 16;             // the ragged tail (< 16 bytes) is ignored: this is a sample
+    const bool aligned = (((uintptr_t)hay) & 15) == 0;
+    for (uint64_t c = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * stride_chunks; c < nchunks;
+         c += (uint64_t)gridDim.x * kBlock * stride_chunks) {
+        uint32_t w[4];
+        if (aligned) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(hay + c * 16);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = reinterpret_cast<const UnalignedU32 *>(hay + c * 16 + 4 * j)->v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&h[wave][w[j] & 0xFF], 1u);
+            atomicAdd(&h[wave][(w[j] >> 8) & 0xFF], 1u);
+            atomicAdd(&h[wave][(w[j] >> 16) & 0xFF], 1u);
+            atomicAdd(&h[wave][w[j] >> 24], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 256; k += kBlock) {
+        const unsigned long long t = (unsigned long long)h[0][k] + h[1][k] + h[2][k] + h[3][k];
+        if (t) atomicAdd(&hist[k], t);
+    }
+}
+
 // Cross-lane self-test: the DPP controls and v_alignbyte the scan relies on, next to __shfl statements.
 __global__ void dpp_probe_kernel(uint32_t *out)
 {

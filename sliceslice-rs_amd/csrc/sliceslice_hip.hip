@@ -15,6 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <mutex>
 #include <vector>
 
@@ -509,6 +513,81 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     release_slot(s, pd, k);
     if (rc == SS_OK) *found = result;
     return rc;
+}
+
+// ---- row f2: host-file front end (the shape of examples/grep.rs:42-56: mmap the file, one search_in) ----
+int ss_search_file(const ss_searcher *s, const char *path, int *found)
+{
+    if (!s || !path || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(SS_ERR_ARGUMENT, "cannot open %s", path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        return fail(SS_ERR_ARGUMENT, "cannot stat %s", path);
+    }
+    const size_t len = (size_t)sb.st_size;
+    if (len == 0) {
+        close(fd);
+        return ss_search_host(s, nullptr, 0, found);
+    }
+    void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(SS_ERR_ARGUMENT, "cannot mmap %s", path);
+    (void)madvise(map, len, MADV_SEQUENTIAL);
+    const int rc = ss_search_host(s, static_cast<const uint8_t *>(map), len, found);   // chunked upload + scan
+    munmap(map, len);
+    return rc;
+}
+
+// ---- row f3: data for a `position` policy ---------------------------------------------------------------
+int ss_byte_histogram_device(const void *d_haystack, size_t len, size_t sample_bytes, void *hip_stream,
+                             uint64_t hist[256])
+{
+    if (!hist) return fail(SS_ERR_ARGUMENT, "hist is NULL");
+    memset(hist, 0, 256 * sizeof(uint64_t));
+    if (len < 16) return SS_OK;
+    if (!d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo di;
+    if (int rc = device_info(dev, &di)) return rc;
+    unsigned long long *d_hist = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_hist, 256 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), st));
+    uint64_t stride = 1;
+    if (sample_bytes && sample_bytes < len) stride = (len + sample_bytes - 1) / sample_bytes;
+    const uint64_t work = len / 16 / stride;
+    uint64_t blocks = (work + ss::kBlock - 1) / ss::kBlock;
+    if (blocks > (uint64_t)di.cus * 8) blocks = (uint64_t)di.cus * 8;
+    if (blocks < 1) blocks = 1;
+    ss::byte_histogram_kernel<<<dim3((unsigned)blocks), dim3(ss::kBlock), 0, st>>>(
+        static_cast<const uint8_t *>(d_haystack), len, stride, d_hist);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hist, d_hist, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_hist);
+    if (e != hipSuccess) return fail(SS_ERR_HIP, "histogram: %s", hipGetErrorString(e));
+    return SS_OK;
+}
+
+int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *position)
+{
+    if (!position || (n && !needle)) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (n <= 1) {
+        *position = 0;              // with_position demands 0 for one-byte needles (x86.rs:473)
+        return SS_OK;
+    }
+    // rarest byte among needle[1..n); ties go to the later byte (further from the first-byte filter).
+    // Without a histogram: the reference's default, the last byte (x86.rs:285).
+    size_t best = n - 1;
+    if (hist) {
+        for (size_t k = n - 1; k >= 1; --k)
+            if (hist[needle[k]] < hist[needle[best]]) best = k;
+    }
+    *position = best;
+    return SS_OK;
 }
 
 static int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint64_t *d_hay_begin,

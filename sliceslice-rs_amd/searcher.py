@@ -46,6 +46,9 @@ ABI = {
     "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
     "ss_find_device": (_int, [_vp, _vp, _sz, _vp, ctypes.POINTER(_u64)]),
     "ss_find_device_async": (_int, [_vp, _vp, _sz, _u64, _vp, _vp]),
+    "ss_search_file": (_int, [_vp, ctypes.c_char_p, _pint]),
+    "ss_byte_histogram_device": (_int, [_vp, _sz, _sz, _vp, _vp]),
+    "ss_choose_position": (_int, [_vp, _sz, _vp, ctypes.POINTER(_sz)]),
     "ss_search_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_search_pairs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_searcher_set_timing": (_int, [_vp, _int]),
@@ -350,6 +353,30 @@ def search_batched(haystacks, hay_off, needles, needle_off, position=None, strea
     _check(fn(haystacks.data_ptr(), hb, he, needles.data_ptr(), nb, ne,
               position.data_ptr() if position is not None else None, count, st, found.data_ptr()))
     return found
+
+
+def search_file(searcher, path):
+    """examples/grep.rs:42-56: map the file, one search_in (row f2)."""
+    found = ctypes.c_int(0)
+    _check(lib().ss_search_file(searcher._h, os.fsencode(path), ctypes.byref(found)))
+    return bool(found.value)
+
+
+def byte_histogram(haystack, sample_bytes=0, stream=None):
+    """256 byte-value counts of a device haystack (row f3)."""
+    hist = np.zeros(256, dtype=np.uint64)
+    st = stream if stream is not None else _current_stream_handle()
+    _check(lib().ss_byte_histogram_device(haystack.data_ptr(), haystack.numel(), sample_bytes, st, hist.ctypes.data))
+    return hist
+
+
+def choose_position(needle, hist=None):
+    """Index of the rarest needle byte under `hist` (ties: later byte); no histogram -> n-1 (row f3)."""
+    nb = bytes(needle)
+    pos = _sz(0)
+    h = None if hist is None else np.ascontiguousarray(hist, dtype=np.uint64)
+    _check(lib().ss_choose_position(nb, len(nb), None if h is None else h.ctypes.data, ctypes.byref(pos)))
+    return pos.value
 
 
 def fill_random_device(tensor, seed, global_offset=0, stream=None):

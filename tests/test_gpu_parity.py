@@ -515,3 +515,40 @@ def test_find_leftmost_vs_python(ss, corpus):
         nd = bytes(rng.randrange(255) for _ in range(n))
         want = host.find(nd)
         assert ss.DynamicHipSearcher.new(nd).find(r) == (None if want < 0 else want), nd
+
+
+def test_search_file_front_end(ss, corpus, tmp_path):
+    # examples/grep.rs:42-56: "./grep <backend> <needle> <file>" - map the file, one search_in
+    path = tmp_path / "i386.txt"
+    path.write_bytes(corpus["i386"])
+    for w in (b"Zz", b"privilege", b"PREFACE", b"not to be found anywhere in the manual"):
+        assert ss.search_file(ss.DynamicHipSearcher.new(w), str(path)) == (w in corpus["i386"])
+    empty = tmp_path / "empty"
+    empty.write_bytes(b"")
+    assert ss.search_file(ss.DynamicHipSearcher.new(b""), str(empty)) is True
+    assert ss.search_file(ss.DynamicHipSearcher.new(b"x"), str(empty)) is False
+    with pytest.raises(ss.SlicesliceError):
+        ss.search_file(ss.DynamicHipSearcher.new(b"x"), str(tmp_path / "missing"))
+
+
+def test_histogram_and_position_policy(ss, corpus):
+    raw = np.frombuffer(corpus["i386"], dtype=np.uint8)
+    usable = raw[: (raw.size // 16) * 16]
+    hist = ss.byte_histogram(dev(corpus["i386"]))
+    assert (hist == np.bincount(usable, minlength=256).astype(np.uint64)).all()
+    sampled = ss.byte_histogram(dev(corpus["i386"]), sample_bytes=100000)
+    assert 50000 <= int(sampled.sum()) <= 200000
+    # misaligned device pointer
+    t = torch.zeros(raw.size + 8, dtype=torch.uint8, device="cuda")
+    t[3:3 + raw.size] = torch.from_numpy(raw.copy()).cuda()
+    h2 = ss.byte_histogram(t[3:3 + raw.size])
+    assert (h2 == hist).all()
+    needle = b" the quick brown fox "
+    pos = ss.choose_position(needle, hist)
+    assert pos >= 1 and hist[needle[pos]] == min(hist[b] for b in needle[1:])
+    assert needle[pos:pos + 1] in (b"q", b"x", b"k", b"w")
+    assert ss.choose_position(needle) == len(needle) - 1            # reference default (x86.rs:285)
+    assert ss.choose_position(b"a", hist) == 0 and ss.choose_position(b"", hist) == 0
+    # the policy changes speed, never the answer (lib.rs:375-378)
+    dh = dev(corpus["i386"])
+    assert ss.DynamicHipSearcher.with_position(needle, pos).search_in(dh) == (needle in corpus["i386"])
