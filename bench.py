@@ -92,6 +92,12 @@ def cpu_baseline(needle, sample_bytes):
 
 
 def main():
+    # Exactly ONE line may reach stdout.  Libraries (the RCCL banner, for one) print to fd 1, so fd 1 is
+    # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -116,7 +122,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the scan has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("SS_BENCH_FORCE_DIST") == "1"     # exercise the N > 1 code path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -136,7 +143,7 @@ def main():
     torch.cuda.synchronize()
     needle = absent_needle(ss, n)
 
-    if world > 1:
+    if dist is not None:
         searcher = ss.ShardedSearcher(needle, group=None, backend=args.transport)
         inner = searcher._searcher
     else:
@@ -195,7 +202,7 @@ def main():
                             "range-sharded over %d GPU(s) with %d B overlap, one all-reduce(MAX) of the found flag"
                             % (total / (1 << 30), n, n - 1, world, n - 1),
                 "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n,
-                "transport": args.transport if world > 1 else "none", "variant": args.variant,
+                "transport": args.transport if dist is not None else "none", "variant": args.variant,
                 "device": info["name"], "compute_units": info["compute_units"],
             },
             "roofline": {
@@ -210,7 +217,8 @@ def main():
             out["roofline"]["read_ceiling_gbps"] = round(ceiling, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(needle, args.cpu_sample_mib << 20)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         if hasattr(searcher, "close"):
