@@ -58,7 +58,9 @@ struct Problem {
     uint32_t mis;             // hay - base, 0..15
     uint32_t r;               // (position % 16) % 4: byte part of the shift
     uint32_t n0x4, nlx4;      // needle[0] and needle[position] splatted over a dword
-    uint32_t n1x4, n2x4, n3x4;  // needle[1..3] splatted (second-level filter; valid when n > 1 / 2 / 3)
+    uint32_t norder;          // second-level filter: number of extra needle bytes to test (<= 15)
+    uint32_t order_idx[4];    //   their indices K (1 <= K < min(n,16), K != position), rarest byte first, 1 byte each
+    uint32_t order_val[4];    //   needle[K] in the same order, 1 byte each
     uint64_t find_base;       // FIND kernels: global offset of hay[0] (range shards), added to the match index
 };
 
@@ -146,34 +148,135 @@ __device__ __forceinline__ void filter_piece(const u32x4 &A, const uint32_t w[4]
     g[3] = f3 & __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r);
 }
 
-// Second-level filter, run only by waves that have candidates: AND the candidate flags with the flags
-// of needle[K] at byte offset K (K = 1..3), still entirely in registers.  Text-like haystacks pass the
-// two-byte filter at percent rates; every extra byte cuts that by the byte's frequency before any
-// candidate touches memory.  Lane 63 has no neighbour data here and passes conservatively.
-template <int K>
-__device__ __forceinline__ void refine_flags(const u32x4 &A, uint32_t nkx4, uint32_t g[4])
+// ---- second-level filter ------------------------------------------------------------------------------
+// Run only by waves that have candidates: AND the candidate flags with the flags of needle[K] at byte
+// offset K, for up to 15 further needle bytes, still entirely in registers.  Text-like haystacks pass
+// the two-byte filter at percent rates; every extra byte cuts that by the byte's frequency before any
+// candidate touches memory.  The bytes are tried rarest-first (a static, corpus-free rarity guess:
+// build_refine_order) and the wave stops as soon as no lane has a candidate left.
+
+// Smaller = expected to be rarer in typical haystacks (text, logs, source, binaries).  Only the ORDER
+// of the checks depends on this; the result of a search never does.
+__host__ __device__ inline int byte_rarity_rank(uint8_t b)
 {
-    const uint32_t e0 = zero_byte_flags(A.x ^ nkx4), e1 = zero_byte_flags(A.y ^ nkx4);
-    const uint32_t e2 = zero_byte_flags(A.z ^ nkx4), e3 = zero_byte_flags(A.w ^ nkx4);
-    const uint32_t e4 = from_next_lane_or(0xFFFFFFFFu, e0);
-    g[0] &= __builtin_amdgcn_alignbyte(e1, e0, K);
-    g[1] &= __builtin_amdgcn_alignbyte(e2, e1, K);
-    g[2] &= __builtin_amdgcn_alignbyte(e3, e2, K);
-    g[3] &= __builtin_amdgcn_alignbyte(e4, e3, K);
+    if (b == ' ') return 255;
+    if (b >= 'a' && b <= 'z') {
+        // most to least frequent English letters
+        const char *freq = "etaoinshrdlcumwfgypbvkjxqz";
+        for (int k = 0; k < 26; ++k)
+            if (freq[k] == (char)b) return 250 - 4 * k;        // 'e' 250 ... 'z' 150
+        return 150;
+    }
+    if (b == 0) return 200;                                    // zero padding is common in binaries
+    if (b == '\n' || b == '\r' || b == '\t') return 140;
+    if (b >= '0' && b <= '9') return 120;
+    if (b == '.' || b == ',' || b == '-' || b == '_' || b == '/' || b == ':' || b == '"' || b == '=') return 110;
+    if (b >= 'A' && b <= 'Z') return 100;
+    if (b >= 0x21 && b <= 0x7E) return 60;                     // other printable punctuation
+    if (b == 0xFF) return 50;
+    return 20;                                                 // control bytes, 0x80..0xFE
 }
 
-// Candidate verification for one lane's flags; returns true when the needle was found.
+// Indices 1 .. min(n,16)-1 except `position`, sorted rarest-first; packed one byte each.
+__host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, uint64_t n, uint64_t position,
+                                                       uint32_t idx[4], uint32_t val[4])
+{
+    uint8_t ks[15];
+    int rk[15];
+    uint32_t m = 0;
+    const int lim = n < 16 ? (int)n : 16;
+    for (int K = 1; K < lim; ++K) {
+        if ((uint64_t)K == position) continue;                 // already tested by the first-level filter
+        const int r = byte_rarity_rank(needle[K]);
+        int at = (int)m;
+        while (at > 0 && rk[at - 1] > r) {                     // insertion sort, stable
+            rk[at] = rk[at - 1];
+            ks[at] = ks[at - 1];
+            --at;
+        }
+        rk[at] = r;
+        ks[at] = (uint8_t)K;
+        ++m;
+    }
+    for (int j = 0; j < 4; ++j) idx[j] = val[j] = 0;
+    for (uint32_t t = 0; t < m; ++t) {
+        idx[t >> 2] |= (uint32_t)ks[t] << (8 * (t & 3));
+        val[t >> 2] |= (uint32_t)needle[ks[t]] << (8 * (t & 3));
+    }
+    return m;
+}
+
+// Lane 63's next lane is lane 0 of the following piece: `N` is that piece's register (kind 1: lane 0
+// holds the chunk -> wave_rol), or the halo chunk already sitting in lane 63 (kind 0), or unknown
+// (kind 2: lane 63 passes conservatively and is settled by the memory compare).
+struct NextPiece {
+    u32x4 N;
+    int kind;     // wave-uniform
+};
+
+__device__ __forceinline__ uint32_t next_lane_flags(uint32_t own, uint32_t nword, uint32_t nkx4, int kind)
+{
+    uint32_t last = 0xFFFFFFFFu;                                  // what lane 63 will see
+    if (kind != 2) {
+        const uint32_t f = zero_byte_flags(nword ^ nkx4);
+        last = kind == 1 ? rotate_from_next_lane(f) : f;
+    }
+    return from_next_lane_or(last, own);
+}
+
+// One needle byte at run-time offset K (1..15): flags of needle[K], shifted down by K bytes.
+__device__ __forceinline__ void refine_flags_rt(const u32x4 &A, const NextPiece &np, uint32_t nkx4, int K, uint32_t g[4])
+{
+    const int qk = K >> 2, rk = K & 3;          // wave-uniform
+    uint32_t e[8];
+    e[0] = zero_byte_flags(A.x ^ nkx4);
+    e[1] = zero_byte_flags(A.y ^ nkx4);
+    e[2] = zero_byte_flags(A.z ^ nkx4);
+    e[3] = zero_byte_flags(A.w ^ nkx4);
+    e[4] = next_lane_flags(e[0], np.N.x, nkx4, np.kind);
+    e[5] = next_lane_flags(e[1], np.N.y, nkx4, np.kind);
+    e[6] = next_lane_flags(e[2], np.N.z, nkx4, np.kind);
+    e[7] = next_lane_flags(e[3], np.N.w, nkx4, np.kind);
+    uint32_t w[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)                  // w[j] = e[j + qk]
+        w[j] = qk == 0 ? e[j] : (qk == 1 ? e[j + 1] : (qk == 2 ? e[j + 2] : e[j + 3]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] &= __builtin_amdgcn_alignbyte(w[j + 1], w[j], (uint32_t)rk);
+}
+
+// Returns false when no lane of the wave has a candidate left.
+__device__ __forceinline__ bool refine_staged(const u32x4 &A, const NextPiece &np, const Problem &pr, uint32_t g[4])
+{
+    bool any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
+#pragma unroll 1
+    for (uint32_t t = 0; t < pr.norder && any; ++t) {
+        const uint32_t sh = 8 * (t & 3);
+        const int K = (int)((pr.order_idx[t >> 2] >> sh) & 0xFF);
+        const uint32_t v = (pr.order_val[t >> 2] >> sh) & 0xFF;
+        refine_flags_rt(A, np, 0x01010101u * v, K, g);
+        any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
+    }
+    return any;
+}
+
+// Candidate verification for one lane's flags; returns true when the needle was found.  The four flag
+// dwords are walked by a run-time loop so that the compare code exists once per call site.
 template <bool ONE_BYTE>
 __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk, const Problem &pr,
                                              const uint8_t *s_needle, uint64_t &where)
 {
     bool hit = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t m = g[j] & 0x80808080u;
-        while (m != 0 && !hit) {
-            const int bit = __ffs((int)m) - 1;          // lowest flagged byte first (tzcnt, lib.rs:221)
-            m &= m - 1;                                 // clear lowest set bit        (lib.rs:247)
+    // all 16 flags of the lane in one word: flag of byte 4j+t at bit 8t+j (bit 7 of byte t of g[j] >> (7-j))
+    uint32_t m = ((g[0] & 0x80808080u) >> 7) | ((g[1] & 0x80808080u) >> 6) | ((g[2] & 0x80808080u) >> 5) |
+                 ((g[3] & 0x80808080u) >> 4);
+    // address order = j major, t minor: take dword 0's flags first (bits 0, 8, 16, 24), then dword 1's ...
+#pragma unroll 1
+    for (int j = 0; j < 4 && !hit; ++j) {
+        uint32_t mj = (m >> j) & 0x01010101u;
+        while (mj != 0 && !hit) {
+            const int bit = __ffs((int)mj) - 1;         // lowest flagged byte first (tzcnt, lib.rs:221)
+            mj &= mj - 1;                               // clear lowest set bit        (lib.rs:247)
             const uint64_t a = chunk * 16 + (uint64_t)(j * 4 + (bit >> 3));
             const uint64_t i = a - pr.mis;              // wraps for bytes in front of the haystack
             if (i < pr.end) {
@@ -298,12 +401,14 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             if (best_now <= pr.find_base + first) return;                               // all of it lies right of a match
         }
 
-        bool hit = false;
+        // ---- phase 1: the two-byte filter for all U pieces, straight-line (loads are consumed in order) ----
+        uint32_t G[U][4];
+        uint32_t any_tile = 0;
         uint32_t wcur[4] = {0, 0, 0, 0}, wnext[4] = {0, 0, 0, 0}, wlast[4] = {0, 0, 0, 0};
         if (!ONE_BYTE) position_flags(TWO ? B[0] : A[0], pr.nlx4, wcur);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            uint32_t g[4];
+            uint32_t *g = G[u];
             if (SHIFTED) {
                 // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
                 position_flags(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
@@ -330,17 +435,30 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 }
                 filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
             }
-            const uint32_t any = (g[0] | g[1] | g[2] | g[3]) & 0x80808080u;
-            if (__ballot(any != 0) != 0) {              // the wave's "movemask != 0"
-                if (!ONE_BYTE) {                        // second-level filter in registers (wave-uniform)
-                    if (pr.n > 1) refine_flags<1>(A[u], pr.n1x4, g);
-                    if (pr.n > 2) refine_flags<2>(A[u], pr.n2x4, g);
-                    if (pr.n > 3) refine_flags<3>(A[u], pr.n3x4, g);
-                }
-                if (!staged) {
-                    stage_needle_wave(s_needle, pr.needle, pr.n, lane);
-                    staged = true;
-                }
+            any_tile |= g[0] | g[1] | g[2] | g[3];
+            if (!ONE_BYTE && (SHIFTED || u + 1 < U)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wcur[j] = wnext[j];
+            }
+        }
+
+        // ---- phase 2 (rare on random bytes): the wave's "movemask != 0" ---------------------------------
+        if (__ballot((any_tile & 0x80808080u) != 0) != 0) {
+            if (!staged) {
+                stage_needle_wave(s_needle, pr.needle, pr.n, lane);
+                staged = true;
+            }
+            bool hit = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t *g = G[u];
+                // second-level filter in registers (wave-uniform), up to the first 16 needle bytes
+                NextPiece np;
+                np.N = u + 1 < U ? A[u + 1] : H;
+                np.kind = u + 1 < U ? 1 : (MODE == 0 ? 0 : (MODE == 2 ? 1 : 2));
+                const bool left = ONE_BYTE ? (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0)
+                                           : refine_staged(A[u], np, pr, g);
+                if (!left) continue;
                 uint64_t where = 0;
                 const bool h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, s_needle, where);
                 hit |= h;
@@ -357,14 +475,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     }
                 }
             }
-            if (!ONE_BYTE && (SHIFTED || u + 1 < U)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wcur[j] = wnext[j];
+            if (!FIND && __ballot(hit) != 0) {
+                if (hit) publish_found(found);
+                return;
             }
-        }
-        if (!FIND && __ballot(hit) != 0) {
-            if (hit) publish_found(found);
-            return;
         }
         if (stop) return;
     }
@@ -378,13 +492,14 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *fo
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+    // one call site (one copy of the code): contiguous run, or grid-stride when tiles_per_block == 0
+    uint64_t t0 = blockIdx.x, step = gridDim.x, t1 = ntiles;
     if (tiles_per_block) {
-        const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
-        const uint64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
-        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, t0, 1, t1, found);
-    } else {
-        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, blockIdx.x, gridDim.x, ntiles, found);
+        t0 = (uint64_t)blockIdx.x * tiles_per_block;
+        step = 1;
+        t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
     }
+    scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, t0, step, t1, found);
 }
 
 #ifdef SS_MISC_KERNELS   // only the API translation unit (sliceslice_hip.hip) compiles what follows
@@ -433,9 +548,7 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
     pr.r = s % 4;
     pr.n0x4 = 0x01010101u * pr.needle[0];
     pr.nlx4 = 0x01010101u * pr.needle[position];
-    pr.n1x4 = n > 1 ? 0x01010101u * pr.needle[1] : 0;
-    pr.n2x4 = n > 2 ? 0x01010101u * pr.needle[2] : 0;
-    pr.n3x4 = n > 3 ? 0x01010101u * pr.needle[3] : 0;
+    pr.norder = build_refine_order(pr.needle, n, position, pr.order_idx, pr.order_val);
     pr.find_base = 0;
 
     // contiguous run of tiles per slice (same launch shape as the single-problem kernel)

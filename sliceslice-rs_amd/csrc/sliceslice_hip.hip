@@ -215,9 +215,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.r = sh % 4;
     pr.n0x4 = 0x01010101u * s->needle[0];
     pr.nlx4 = 0x01010101u * s->needle[position];
-    pr.n1x4 = n > 1 ? 0x01010101u * s->needle[1] : 0;
-    pr.n2x4 = n > 2 ? 0x01010101u * s->needle[2] : 0;
-    pr.n3x4 = n > 3 ? 0x01010101u * s->needle[3] : 0;
+    pr.norder = ss::build_refine_order(s->needle.data(), n, position, pr.order_idx, pr.order_val);
     pr.find_base = find_base;
 
     const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d);
