@@ -59,8 +59,8 @@ struct Problem {
     uint32_t r;               // (position % 16) % 4: byte part of the shift
     uint32_t n0x4, nlx4;      // needle[0] and needle[position] splatted over a dword
     uint32_t norder;          // second-level filter: number of extra needle bytes to test (<= 15)
-    uint32_t order_idx[4];    //   their indices K (1 <= K < min(n,16), K != position), rarest byte first, 1 byte each
-    uint32_t order_val[4];    //   needle[K] in the same order, 1 byte each
+    uint64_t order_idx[2];    //   their indices K (1 <= K < min(n,16), K != position), rarest byte first, 1 byte each
+    uint64_t order_val[2];    //   needle[K] in the same order, 1 byte each (entry t: word t/8, bits 8(t%8)..)
     uint64_t find_base;       // FIND kernels: global offset of hay[0] (range shards), added to the match index
 };
 
@@ -161,11 +161,12 @@ __host__ __device__ inline int byte_rarity_rank(uint8_t b)
 {
     if (b == ' ') return 255;
     if (b >= 'a' && b <= 'z') {
-        // most to least frequent English letters
-        const char *freq = "etaoinshrdlcumwfgypbvkjxqz";
-        for (int k = 0; k < 26; ++k)
-            if (freq[k] == (char)b) return 250 - 4 * k;        // 'e' 250 ... 'z' 150
-        return 150;
+        // 250 - 4 * (place in "etaoinshrdlcumwfgypbvkjxqz", most to least frequent English letters)
+        constexpr uint8_t kLetter[26] = {/*a*/ 242, /*b*/ 174, /*c*/ 206, /*d*/ 214, /*e*/ 250, /*f*/ 190, /*g*/ 186,
+                                         /*h*/ 222, /*i*/ 234, /*j*/ 162, /*k*/ 166, /*l*/ 210, /*m*/ 198, /*n*/ 230,
+                                         /*o*/ 238, /*p*/ 178, /*q*/ 154, /*r*/ 218, /*s*/ 226, /*t*/ 246, /*u*/ 202,
+                                         /*v*/ 170, /*w*/ 194, /*x*/ 158, /*y*/ 182, /*z*/ 150};
+        return kLetter[b - 'a'];
     }
     if (b == 0) return 200;                                    // zero padding is common in binaries
     if (b == '\n' || b == '\r' || b == '\t') return 140;
@@ -179,7 +180,7 @@ __host__ __device__ inline int byte_rarity_rank(uint8_t b)
 
 // Indices 1 .. min(n,16)-1 except `position`, sorted rarest-first; packed one byte each.
 __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, uint64_t n, uint64_t position,
-                                                       uint32_t idx[4], uint32_t val[4])
+                                                       uint64_t idx[2], uint64_t val[2])
 {
     uint8_t ks[15];
     int rk[15];
@@ -198,11 +199,41 @@ __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, ui
         ks[at] = (uint8_t)K;
         ++m;
     }
-    for (int j = 0; j < 4; ++j) idx[j] = val[j] = 0;
+    idx[0] = idx[1] = val[0] = val[1] = 0;
     for (uint32_t t = 0; t < m; ++t) {
-        idx[t >> 2] |= (uint32_t)ks[t] << (8 * (t & 3));
-        val[t >> 2] |= (uint32_t)needle[ks[t]] << (8 * (t & 3));
+        idx[t >> 3] |= (uint64_t)ks[t] << (8 * (t & 7));
+        val[t >> 3] |= (uint64_t)needle[ks[t]] << (8 * (t & 7));
     }
+    return m;
+}
+
+// Device form for kernels that build the problem descriptor themselves (batched): lane K ranks
+// needle[K]; four rarity classes are emitted in turn from wave ballots.  Coarser than the host sort,
+// which only changes the order of the checks.
+__device__ __forceinline__ uint32_t build_refine_order_wave(const uint8_t *needle, uint64_t n, uint64_t position,
+                                                            int lane, uint64_t idx[2], uint64_t val[2])
+{
+    const int lim = n < 16 ? (int)n : 16;
+    const bool valid = lane >= 1 && lane < lim && (uint64_t)lane != position;
+    const uint32_t b = valid ? needle[lane] : 0u;
+    const int r = byte_rarity_rank((uint8_t)b);
+    const int cls = !valid ? -1 : (r < 64 ? 0 : (r < 128 ? 1 : (r < 192 ? 2 : 3)));
+    uint64_t i0 = 0, i1 = 0, v0 = 0, v1 = 0;
+    uint32_t m = 0;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        uint32_t mask = (uint32_t)__ballot(cls == c) & 0xFFFFu;
+        while (mask) {
+            const int K = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            const uint64_t v = (uint32_t)__builtin_amdgcn_readlane((int)b, K) & 0xFF;
+            const uint32_t sh = 8 * (m & 7);
+            if (m < 8) { i0 |= (uint64_t)K << sh; v0 |= v << sh; }
+            else { i1 |= (uint64_t)K << sh; v1 |= v << sh; }
+            ++m;
+        }
+    }
+    idx[0] = i0; idx[1] = i1; val[0] = v0; val[1] = v1;
     return m;
 }
 
@@ -251,9 +282,9 @@ __device__ __forceinline__ bool refine_staged(const u32x4 &A, const NextPiece &n
     bool any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
 #pragma unroll 1
     for (uint32_t t = 0; t < pr.norder && any; ++t) {
-        const uint32_t sh = 8 * (t & 3);
-        const int K = (int)((pr.order_idx[t >> 2] >> sh) & 0xFF);
-        const uint32_t v = (pr.order_val[t >> 2] >> sh) & 0xFF;
+        const uint32_t sh = 8 * (t & 7);
+        const int K = (int)(((t < 8 ? pr.order_idx[0] : pr.order_idx[1]) >> sh) & 0xFF);
+        const uint32_t v = (uint32_t)(((t < 8 ? pr.order_val[0] : pr.order_val[1]) >> sh) & 0xFF);
         refine_flags_rt(A, np, 0x01010101u * v, K, g);
         any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
     }
@@ -534,21 +565,30 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
     uint64_t position = a.position ? a.position[prob] : n - 1;
     if (position >= n) position = n - 1;            // validated on the host when it can be; never UB here
 
+    // every field below is wave-uniform; readfirstlane tells the compiler so (SGPRs, no scratch)
+    auto uni64 = [](uint64_t x) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    };
     Problem pr;
-    pr.hay = a.haystacks + h0;
+    pr.hay = a.haystacks + uni64(h0);
     pr.mis = (uint32_t)((uintptr_t)pr.hay & 15);
     pr.base = pr.hay - pr.mis;
-    pr.needle = a.needles + n0;
-    pr.n = n;
-    pr.end = len - n + 1;
-    pr.nchunks_all = (pr.mis + len + 15) / 16;
+    pr.needle = a.needles + uni64(n0);
+    pr.n = uni64(n);
+    pr.end = uni64(len - n + 1);
+    pr.nchunks_all = (pr.mis + uni64(len) + 15) / 16;
     pr.npieces = ((pr.mis + pr.end + 15) / 16 + 63) / 64;
+    position = uni64(position);
     pr.d = position / 16;
     const uint32_t s = (uint32_t)(position % 16);
     pr.r = s % 4;
-    pr.n0x4 = 0x01010101u * pr.needle[0];
-    pr.nlx4 = 0x01010101u * pr.needle[position];
-    pr.norder = build_refine_order(pr.needle, n, position, pr.order_idx, pr.order_val);
+    pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[0]);
+    pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[position]);
+    pr.norder = build_refine_order_wave(pr.needle, pr.n, position, threadIdx.x & (kWave - 1), pr.order_idx, pr.order_val);
+    pr.order_idx[0] = uni64(pr.order_idx[0]); pr.order_idx[1] = uni64(pr.order_idx[1]);
+    pr.order_val[0] = uni64(pr.order_val[0]); pr.order_val[1] = uni64(pr.order_val[1]);
+    pr.norder = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.norder);
     pr.find_base = 0;
 
     // contiguous run of tiles per slice (same launch shape as the single-problem kernel)
