@@ -62,6 +62,9 @@ struct Problem {
     uint64_t order_idx[2];    //   their indices K (1 <= K < min(n,16), K != position), rarest byte first, 1 byte each
     uint64_t order_val[2];    //   needle[K] in the same order, 1 byte each (entry t: word t/8, bits 8(t%8)..)
     uint64_t find_base;       // FIND kernels: global offset of hay[0] (range shards), added to the match index
+    int *host_flag;           // optional pinned-host mirror of the found flag (saves the D2H copy); may be null
+    int epoch;                // the value that means "found" in the flag (1 for caller-owned flags; pool slots
+                              // use a fresh value per call, so a slot never has to be cleared)
 };
 
 __device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) { return (x - 0x01010101u) & ~x; }
@@ -320,15 +323,15 @@ __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk
     return hit;
 }
 
-__device__ __forceinline__ int poll_found(const int *found)
+__device__ __forceinline__ int poll_found(const int *found, int epoch)
 {
     return __builtin_amdgcn_readfirstlane(
-        __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+               __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch;
 }
 
-__device__ __forceinline__ void publish_found(int *found)
+__device__ __forceinline__ void publish_found(int *found, int epoch = 1)
 {
-    __hip_atomic_store(found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(found, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // FIND kernels keep the leftmost match offset in one uint64 (all-ones = none yet), lowered by atomicMin.
@@ -426,7 +429,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             }
         }
         // issued behind the data loads, consumed after them
-        const int stop = FIND ? 0 : poll_found(found);
+        const int stop = FIND ? 0 : poll_found(found, pr.epoch);
         if (FIND) {
             const uint64_t first = chunk0 * 16 > pr.mis ? chunk0 * 16 - pr.mis : 0;   // lowest index this wave can report
             if (best_now <= pr.find_base + first) return;                               // all of it lies right of a match
@@ -507,7 +510,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 }
             }
             if (!FIND && __ballot(hit) != 0) {
-                if (hit) publish_found(found);
+                if (hit) {
+                    publish_found(found, pr.epoch);
+                    if (pr.host_flag) __hip_atomic_store(pr.host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 return;
             }
         }
@@ -590,6 +596,8 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
     pr.order_val[0] = uni64(pr.order_val[0]); pr.order_val[1] = uni64(pr.order_val[1]);
     pr.norder = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.norder);
     pr.find_base = 0;
+    pr.host_flag = nullptr;
+    pr.epoch = 1;
 
     // contiguous run of tiles per slice (same launch shape as the single-problem kernel)
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);

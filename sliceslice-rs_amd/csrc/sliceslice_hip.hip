@@ -79,6 +79,7 @@ struct PerDevice {
     uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
     uint64_t *h_best = nullptr; // pinned mirror
     uint64_t free_mask = 0;
+    int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed_valid = false;
 };
@@ -195,7 +196,7 @@ void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte
 // (0 -> 1), never cleared.  find == true: *d_sink is a uint64, atomicMin'ed with find_base + offset of
 // every match the grid sees (the leftmost one survives).  Preconditions: 1 <= n <= len.
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st,
-                 void *d_sink, bool find = false, uint64_t find_base = 0)
+                 void *d_sink, bool find = false, uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1)
 {
     void *d_flag = d_sink;
     ss::Problem pr;
@@ -217,6 +218,8 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.nlx4 = 0x01010101u * s->needle[position];
     pr.norder = ss::build_refine_order(s->needle.data(), n, position, pr.order_idx, pr.order_val);
     pr.find_base = find_base;
+    pr.host_flag = host_flag;
+    pr.epoch = epoch;
 
     const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
@@ -382,23 +385,18 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     const int k = acquire_slot(s, pd);
-    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k);
+    // The wave that finds a match stores the call's epoch to the device flag (polled by the grid for the
+    // early exit) AND to its pinned-host mirror, so the answer needs neither a device-to-host copy nor a
+    // reset of the slot afterwards: launch, wait for the stream, compare.
+    int epoch = ++pd->epoch[k];                         // the slot is owned by this call
+    if (epoch <= 0) epoch = pd->epoch[k] = 1;
+    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch);
     if (rc == SS_OK) {
-        hipError_t e = hipMemcpyAsync(pd->h_flags + k, pd->d_flags + k, sizeof(int), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "stream wait: %s", hipGetErrorString(e));
     }
-    if (rc == SS_OK) {
-        *found = pd->h_flags[k] != 0;
-        if (*found) {                                   // slots are zero whenever they are free
-            hipError_t e = hipMemsetAsync(pd->d_flags + k, 0, sizeof(int), st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag reset: %s", hipGetErrorString(e));
-        }
-    } else {
-        (void)hipDeviceSynchronize();
-        (void)hipMemset(pd->d_flags + k, 0, sizeof(int));
-    }
+    if (rc == SS_OK) *found = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
+    else (void)hipDeviceSynchronize();
     release_slot(s, pd, k);
     return rc;
 }
@@ -468,6 +466,8 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     const int k = acquire_slot(s, pd);
+    int epoch = ++pd->epoch[k];                          // "found" value of this call (see ss_search_device)
+    if (epoch <= 0) epoch = pd->epoch[k] = 1;
     uint8_t *dbuf[2] = {nullptr, nullptr};
     hipStream_t st[2] = {nullptr, nullptr};
     int rc = SS_OK;
@@ -490,23 +490,18 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
         const size_t bytes = (len - off < C ? len - off : C) + lead;
         if (bytes < s->n) break;                         // tail shorter than the needle: nothing new can start here
         hipError_t e = hipStreamSynchronize(st[b]);      // buffer b free again
-        if (e == hipSuccess && idx >= nbuf) {
-            // result of the scan that last used this buffer
-            e = hipMemcpy(pd->h_flags + k, pd->d_flags + k, sizeof(int), hipMemcpyDeviceToHost);
-            if (e == hipSuccess && pd->h_flags[k]) { result = 1; break; }
+        if (e == hipSuccess && idx >= nbuf &&          // result of the scan that last used this buffer
+            __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch) {
+            result = 1;
+            break;
         }
         if (e == hipSuccess) e = hipMemcpyAsync(dbuf[b], haystack + off - lead, bytes, hipMemcpyHostToDevice, st[b]);
         if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
-        rc = enqueue_scan(s, pd, dbuf[b], bytes, st[b], pd->d_flags + k);
+        rc = enqueue_scan(s, pd, dbuf[b], bytes, st[b], pd->d_flags + k, false, 0, pd->h_flags + k, epoch);
     }
     for (size_t b = 0; b < nbuf; ++b)
         if (st[b]) (void)hipStreamSynchronize(st[b]);
-    if (rc == SS_OK && !result) {
-        hipError_t e = hipMemcpy(pd->h_flags + k, pd->d_flags + k, sizeof(int), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
-        else result = pd->h_flags[k] != 0;
-    }
-    (void)hipMemset(pd->d_flags + k, 0, sizeof(int));
+    if (rc == SS_OK && !result) result = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
     cleanup();
     release_slot(s, pd, k);
     if (rc == SS_OK) *found = result;

@@ -93,9 +93,12 @@ def lib():
                 import torch  # noqa: F401
             except Exception:
                 pass
-        path = _build.build()
+        # SLICESLICE_HIP_LIB: load a specific build of the SAME library (A/B timing of two kernel versions)
+        path = os.environ.get("SLICESLICE_HIP_LIB") or _build.build()
         L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in ABI.items():
+            if os.environ.get("SLICESLICE_HIP_LIB") and not hasattr(L, name):
+                continue                   # an older build under A/B test may lack newer entry points
             fn = getattr(L, name)          # AttributeError if the header and the library disagree
             fn.restype = res
             fn.argtypes = args

@@ -552,3 +552,20 @@ def test_histogram_and_position_policy(ss, corpus):
     # the policy changes speed, never the answer (lib.rs:375-378)
     dh = dev(corpus["i386"])
     assert ss.DynamicHipSearcher.with_position(needle, pos).search_in(dh) == (needle in corpus["i386"])
+
+
+def test_flag_slots_are_reusable_without_reset(ss):
+    """One searcher, alternating haystacks that do / do not contain the needle, device and host paths:
+    a stale 'found' value in a reused flag slot would show up as a wrong True."""
+    needle = b"slot-reuse-check"
+    yes = torch.full((300000,), 0x2E, dtype=torch.uint8, device="cuda")
+    no = yes.clone()
+    yes[123456:123456 + 16] = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+    s = ss.DynamicHipSearcher.new(needle)
+    hy, hn = yes.cpu().numpy(), no.cpu().numpy()
+    for k in range(200):
+        assert s.search_in(yes) is True
+        assert s.search_in(no) is False
+        if k % 20 == 0:
+            assert s.search_in(hy) is True and s.search_in(hn) is False
+            assert s.find(yes) == 123456 and s.find(no) is None
