@@ -155,7 +155,7 @@ int ss_searcher_set_variant(ss_searcher *s, int variant);
 int ss_searcher_set_grid(ss_searcher *s, int blocks);
 
 /* Synthetic haystack generator (not part of the reference):
- *   byte(i) = (splitmix64(seed ^ (i >> 3)) >> (8 * (i & 7))) & 0xFF, then 0xFF -> 0x00,
+ *   byte(i) = (splitmix64(splitmix64(seed) ^ (i >> 3)) >> (8 * (i & 7))) & 0xFF, then 0xFF -> 0x00,
  * with i = global_offset + k the GLOBAL byte index, so that range shards on different GPUs hold
  * slices of one logical haystack.  Device and host versions are bit-identical. */
 int ss_fill_random_device(void *d_dst, uint64_t global_offset, size_t len, uint64_t seed,

@@ -102,6 +102,16 @@ public:
     template <class H>
     bool inlined_search_in(H &&haystack) const { return search_in(std::forward<H>(haystack)); }
 
+    // Offset of the leftmost occurrence (the `Option<usize>` of tests/i386.rs:6-10):
+    // returns npos when absent.
+    static constexpr uint64_t npos = UINT64_MAX;
+    uint64_t find(DeviceSlice haystack, void *hip_stream = nullptr) const
+    {
+        uint64_t pos = npos;
+        check(ss_find_device(h_, haystack.ptr, haystack.len, hip_stream, &pos));
+        return pos;
+    }
+
     size_t position() const { return ss_searcher_position(h_); }
     size_t needle_len() const { return ss_searcher_needle_len(h_); }
     ss_searcher *handle() const { return h_; }

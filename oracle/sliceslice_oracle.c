@@ -413,7 +413,8 @@ int oracle_search_in_mt(const oracle_searcher *s, const uint8_t *hay, size_t len
 }
 
 /* ---- independent restatement of the synthetic-haystack generator -- */
-/* byte(i) = (splitmix64(seed ^ (i >> 3)) >> (8 * (i & 7))) & 0xFF, then 0xFF -> 0x00.
+/* byte(i) = (splitmix64(splitmix64(seed) ^ (i >> 3)) >> (8 * (i & 7))) & 0xFF, then 0xFF -> 0x00.
+ * (The seed is hashed so that nearby seeds do not yield word-permuted copies of one stream.)
  * The product has its own host and device versions; tests compare all three. */
 
 static inline uint64_t splitmix64(uint64_t x)
@@ -427,9 +428,10 @@ static inline uint64_t splitmix64(uint64_t x)
 void oracle_fill_random(uint8_t *dst, uint64_t global_offset, size_t len, uint64_t seed)
 {
     size_t k = 0;
+    const uint64_t key = splitmix64(seed);
     while (k < len) {
         const uint64_t i = global_offset + k;
-        uint64_t w = splitmix64(seed ^ (i >> 3)) >> (8 * (i & 7));
+        uint64_t w = splitmix64(key ^ (i >> 3)) >> (8 * (i & 7));
         size_t take = 8 - (size_t)(i & 7);
         if (take > len - k) take = len - k;
         for (size_t j = 0; j < take; ++j, w >>= 8) {

@@ -665,10 +665,12 @@ __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return z ^ (z >> 31);
 }
 
-// 8 generated bytes of global word index w, with 0xFF remapped to 0x00.
+// 8 generated bytes of global word index w, with 0xFF remapped to 0x00.  The seed is hashed first:
+// with a raw `seed ^ w` two seeds that differ in a few low bits would produce the same stream with
+// permuted words (seed 1 and seed 3: word w of one is word w^2 of the other).
 __host__ __device__ __forceinline__ uint64_t synth_word(uint64_t seed, uint64_t w)
 {
-    const uint64_t v = splitmix64(seed ^ w);
+    const uint64_t v = splitmix64(splitmix64(seed) ^ w);
     // bytes equal to 0xFF: ~v has a zero byte there.  Exact per-byte zero detection (no borrow):
     const uint64_t x = ~v;
     const uint64_t zero = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);

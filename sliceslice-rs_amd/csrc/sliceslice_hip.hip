@@ -117,6 +117,7 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
     HIP_TRY(hipMalloc((void **)&p.d_flags, kSlots * sizeof(int)));
     HIP_TRY(hipMemset(p.d_flags, 0, kSlots * sizeof(int)));
     HIP_TRY(hipHostMalloc((void **)&p.h_flags, kSlots * sizeof(int), hipHostMallocDefault));
+    memset(p.h_flags, 0, kSlots * sizeof(int));     // pinned memory is recycled: a stale value must not equal an epoch
     HIP_TRY(hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t)));
     HIP_TRY(hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t)));
     HIP_TRY(hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault));
@@ -142,6 +143,20 @@ int acquire_slot(const ss_searcher *s, PerDevice *p)
         }
         sched_yield();   // > 64 concurrent searches on one handle: wait for a slot
     }
+}
+
+// The value that means "found" for the call that owns slot k: fresh per call, never 0.  On the (2^31
+// calls) wrap-around both copies of the flag are cleared so that no stale value can equal a new epoch.
+int next_epoch(PerDevice *p, int k)
+{
+    int e = ++p->epoch[k];
+    if (e <= 0) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(p->d_flags + k, 0, sizeof(int));
+        p->h_flags[k] = 0;
+        e = p->epoch[k] = 1;
+    }
+    return e;
 }
 
 void release_slot(const ss_searcher *s, PerDevice *p, int k)
@@ -388,8 +403,7 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     // The wave that finds a match stores the call's epoch to the device flag (polled by the grid for the
     // early exit) AND to its pinned-host mirror, so the answer needs neither a device-to-host copy nor a
     // reset of the slot afterwards: launch, wait for the stream, compare.
-    int epoch = ++pd->epoch[k];                         // the slot is owned by this call
-    if (epoch <= 0) epoch = pd->epoch[k] = 1;
+    const int epoch = next_epoch(pd, k);                // the slot is owned by this call
     int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch);
     if (rc == SS_OK) {
         const hipError_t e = hipStreamSynchronize(st);
@@ -466,8 +480,7 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     const int k = acquire_slot(s, pd);
-    int epoch = ++pd->epoch[k];                          // "found" value of this call (see ss_search_device)
-    if (epoch <= 0) epoch = pd->epoch[k] = 1;
+    const int epoch = next_epoch(pd, k);                 // "found" value of this call (see ss_search_device)
     uint8_t *dbuf[2] = {nullptr, nullptr};
     hipStream_t st[2] = {nullptr, nullptr};
     int rc = SS_OK;

@@ -52,6 +52,8 @@ int main()
         CHECK(s.search_in(DeviceSlice{d + 7, len}));
         CHECK(!s.search_in(DeviceSlice{d + 7, len - 1}));
         CHECK(s.inlined_search_in(DeviceSlice{d + 7, len}));
+        CHECK(s.find(DeviceSlice{d + 7, len}) == len - needle.size());
+        CHECK(s.find(DeviceSlice{d + 7, len - 1}) == DynamicHipSearcher::npos);
     }
     (void)hipFree(d);
     std::puts("veneer_test ok");

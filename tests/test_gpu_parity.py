@@ -406,13 +406,13 @@ def test_full_size_properties_1gib(ss):
     assert 0xFF not in present
     sp = ss.DynamicHipSearcher.new(present)
     pn = torch.from_numpy(np.frombuffer(present, dtype=np.uint8).copy()).cuda()
+    assert sp.search_in(t) is False
     for at in (ln - 16, (ln // 2) - 8, 0, 1008 * 12345 - 5):
         saved = t[at:at + 16].clone()
-        before = sp.search_in(t)
         t[at:at + 16] = pn
         assert sp.search_in(t) is True, at
         t[at:at + 16] = saved
-        assert sp.search_in(t) == before
+        assert sp.search_in(t) is False
     assert s.search_in(t) is False
 
 
@@ -569,3 +569,62 @@ def test_flag_slots_are_reusable_without_reset(ss):
         if k % 20 == 0:
             assert s.search_in(hy) is True and s.search_in(hn) is False
             assert s.find(yes) == 123456 and s.find(no) is None
+
+
+def test_offsets_beyond_4gib_and_long_needles(ss):
+    """64-bit offsets: matches planted beyond 2^32 and 2^33 in a 9 GiB haystack (search_in and find), and
+    needles far longer than the 2 KiB LDS slice / longer than a tile (compare continues from global)."""
+    free_b, _ = torch.cuda.mem_get_info()
+    ln = 9 << 30
+    if free_b < ln + (2 << 30):
+        pytest.skip("not enough device memory")
+    t = torch.empty(ln, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0x5EED0001)
+    needle = bytes(ss.fill_random_host(16, 0x5EED0003).tobytes())
+    s = ss.DynamicHipSearcher.new(needle)
+    nd = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+    assert s.search_in(t) is False and s.find(t) is None
+    for at in ((1 << 32) - 8, (1 << 32) + 5, (1 << 33) + 123457, ln - 16):
+        saved = t[at:at + 16].clone()
+        t[at:at + 16] = nd
+        assert s.search_in(t) is True, at
+        assert s.find(t) == at, at
+        t[at:at + 16] = saved
+    # long needles cut from the haystack itself (present) and with one byte flipped (absent)
+    for n in (5000, 70000, 1 << 20):
+        at = (5 << 30) + 777
+        cut = t[at:at + n].cpu().numpy().tobytes()
+        sl = ss.DynamicHipSearcher.new(cut)
+        assert sl.search_in(t) is True and sl.find(t) == at, n
+        bad = bytearray(cut)
+        bad[n - 3] ^= 0x55
+        sb = ss.DynamicHipSearcher.with_position(bytes(bad), n // 2)
+        assert sb.search_in(t) is False, n
+    del t
+
+
+def test_full_size_properties_64gib(ss):
+    """BASELINE.json's target size on one GPU: 64 GiB, 16-byte needle.  Absent by construction -> False;
+    planted at len-16, across the middle, at 0 -> True / exact offset; erased -> False again."""
+    free_b, _ = torch.cuda.mem_get_info()
+    ln = 64 << 30
+    if free_b < ln + (4 << 30):
+        pytest.skip("not enough device memory for the 64 GiB case")
+    t = torch.empty(ln, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0x5EED0001)
+    absent = absent_needle(ss, 16)
+    assert ss.DynamicHipSearcher.new(absent).search_in(t) is False
+    present = bytes(ss.fill_random_host(16, 0x5EED0003).tobytes())
+    sp = ss.DynamicHipSearcher.new(present)
+    pn = torch.from_numpy(np.frombuffer(present, dtype=np.uint8).copy()).cuda()
+    for at in (ln - 16, (ln // 2) - 8, 0):
+        saved = t[at:at + 16].clone()
+        t[at:at + 16] = pn
+        assert sp.search_in(t) is True, at
+        assert sp.find(t) == at, at
+        t[at:at + 16] = saved
+        assert sp.search_in(t) is False
+    # the generator is the same logical haystack whatever the shard: spot-check against the host generator
+    for off in (0, (1 << 35) + 4096 - 8, ln - 4096):
+        assert (t[off:off + 4096].cpu().numpy() == ss.fill_random_host(4096, 0x5EED0001, off)).all()
+    del t
