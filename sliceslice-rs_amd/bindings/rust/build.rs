@@ -1,0 +1,11 @@
+fn main() {
+    let out = std::env::var("OUT_DIR").unwrap();
+    let ok = std::process::Command::new("hipcc")
+        .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o"])
+        .arg(format!("{out}/libsliceslice_hip.so"))
+        .arg("sliceslice-rs_amd/csrc/sliceslice_hip.hip").arg("-ldl")
+        .status().unwrap().success();
+    assert!(ok);
+    println!("cargo:rustc-link-search=native={out}");
+    println!("cargo:rustc-link-lib=dylib=sliceslice_hip");
+}

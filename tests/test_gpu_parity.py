@@ -628,3 +628,41 @@ def test_full_size_properties_64gib(ss):
     for off in (0, (1 << 35) + 4096 - 8, ln - 4096):
         assert (t[off:off + 4096].cpu().numpy() == ss.fill_random_host(4096, 0x5EED0001, off)).all()
     del t
+
+
+def test_fuzz_batched_and_pairs_vs_python(ss):
+    """30,000 random problems (small alphabets, planted and near-miss needles, random `position`s, ragged
+    lengths incl. empty needles/haystacks) through BOTH many-problem kernels in one launch each."""
+    rng = random.Random(777)
+    hays, needles, positions, want = [], [], [], []
+    for _ in range(30000):
+        alpha = rng.choice([b"ab", b"abc", b"\x00\x01", b"the quick brown fox ", bytes(range(256))])
+        n = rng.choice([0, 1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 33, 64, 100])
+        ln = rng.choice([0, 1, max(n - 1, 0), n, n + 1, n + 7, n + 33, 2 * n + 100, 1500, 20000 if rng.random() < 0.05 else 300])
+        hay = bytes(rng.choice(alpha) for _ in range(ln))
+        if n and ln >= n and rng.random() < 0.3:
+            at = rng.randrange(ln - n + 1)
+            nd = bytearray(hay[at:at + n])
+            if rng.random() < 0.3:
+                nd[rng.randrange(n)] ^= 1                # near miss (may still occur elsewhere: Python decides)
+            nd = bytes(nd)
+        else:
+            nd = bytes(rng.choice(alpha) for _ in range(n))
+        hays.append(hay)
+        needles.append(nd)
+        positions.append(rng.randrange(n) if n else 0)
+        want.append(nd in hay)
+    hay_off = np.zeros(len(hays) + 1, dtype=np.int64)
+    hay_off[1:] = np.cumsum([len(h) for h in hays])
+    nd_off = np.zeros(len(needles) + 1, dtype=np.int64)
+    nd_off[1:] = np.cumsum([len(x) for x in needles])
+    blob = torch.from_numpy(np.frombuffer(b"".join(hays) + b"\0", dtype=np.uint8).copy()).cuda()
+    nblob = torch.from_numpy(np.frombuffer(b"".join(needles) + b"\0", dtype=np.uint8).copy()).cuda()
+    ho, no = torch.from_numpy(hay_off).cuda(), torch.from_numpy(nd_off).cuda()
+    pos = torch.from_numpy(np.array(positions, dtype=np.int64)).cuda()
+    for pairs in (False, True):
+        for p in (None, pos):
+            found = ss.search_batched(blob, ho, nblob, no, position=p, pairs=pairs)
+            got = [bool(x) for x in found.cpu().tolist()]
+            bad = [k for k in range(len(want)) if got[k] != want[k]]
+            assert not bad, (pairs, p is not None, bad[:5], [(hays[k][:40], needles[k]) for k in bad[:2]])

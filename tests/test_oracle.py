@@ -125,3 +125,25 @@ def test_generator_has_no_ff_and_is_offset_consistent():
     b = O.fill_random(1000, 0x5EED0001, global_offset=13)
     assert (a[13:1013] == b).all()
     assert O.have_avx2() in (True, False)
+
+
+def test_fuzz_restatement_vs_naive():
+    # 6,000 random (haystack, needle, position) triples over small alphabets (so that matches, near-matches
+    # and dense candidates all occur); the restated AVX2 path must equal windows().any() on every one.
+    rng = random.Random(2024)
+    for case in range(6000):
+        alpha = rng.choice([b"ab", b"abc", b"\x00\x01", bytes(range(256))])
+        n = rng.choice([1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 33, 64])
+        ln = rng.choice([0, 1, n - 1, n, n + 1, n + 2, n + 7, n + 31, n + 32, n + 33, n + 100, 3 * n + 257])
+        ln = max(ln, 0)
+        hay = bytes(rng.choice(alpha) for _ in range(ln))
+        if ln >= n and rng.random() < 0.3:
+            at = rng.randrange(ln - n + 1)
+            needle = hay[at:at + n]
+        else:
+            needle = bytes(rng.choice(alpha) for _ in range(n))
+        want = needle in hay
+        assert O.naive_contains(hay, needle) == want
+        position = rng.randrange(n)
+        assert O.OracleSearcher.with_position(needle, position, force_scalar=bool(case & 1)).search_in(hay) == want, \
+            (case, n, ln, position)

@@ -79,6 +79,33 @@ def main():
             emit(config=3, variant="present_at_end", needle_len=n, found=res2, kernel_ms=round(ms2, 4),
                  note="n<4: the random needle already occurs earlier, early exit")
 
+    if "find" not in skip:
+        nd = absent(16)
+        s = ss.DynamicHipSearcher.new(nd)
+        s.set_timing(True)
+        assert s.find(hay) is None
+        ms = []
+        for _ in range(args.reps):
+            s.find(hay)
+            ms.append(s.last_kernel_ms())
+        med = float(np.median(ms))
+        emit(config="find", variant="absent (full scan)", needle_len=16, haystack_bytes=n_bytes, kernel_ms=round(med, 4),
+             gbps=round(n_bytes / med / 1e6, 1), frac_of_8tbps=round(n_bytes / med / 1e6 / 8000, 4))
+        pres = bytes(ss.fill_random_host(16, 0x5EED0003).tobytes())
+        at = n_bytes // 3
+        saved = hay[at:at + 16].clone()
+        hay[at:at + 16] = torch.from_numpy(np.frombuffer(pres, dtype=np.uint8).copy()).cuda()
+        s2 = ss.DynamicHipSearcher.new(pres)
+        s2.set_timing(True)
+        assert s2.find(hay) == at
+        ms = []
+        for _ in range(args.reps):
+            s2.find(hay)
+            ms.append(s2.last_kernel_ms())
+        hay[at:at + 16] = saved
+        emit(config="find", variant="present at len/3 (work right of the match is skipped)", position=at,
+             kernel_ms=round(float(np.median(ms)), 4))
+
     if "5" not in skip:
         count, each = 4096, 1 << 20
         total = count * each
