@@ -3,7 +3,9 @@ fn main() {
     let ok = std::process::Command::new("hipcc")
         .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o"])
         .arg(format!("{out}/libsliceslice_hip.so"))
-        .arg("sliceslice-rs_amd/csrc/sliceslice_hip.hip").arg("-ldl")
+        .args(["sliceslice_hip.hip", "scan_inst_u4.hip", "scan_inst_u8.hip", "scan_inst_find.hip"]
+              .map(|f| format!("sliceslice-rs_amd/csrc/{f}")))
+        .arg("-ldl")
         .status().unwrap().success();
     assert!(ok);
     println!("cargo:rustc-link-search=native={out}");
