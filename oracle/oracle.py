@@ -52,6 +52,8 @@ def lib():
         L.oracle_sweep_long.restype = ctypes.c_longlong
         L.oracle_bench_long.argtypes = [u8p, sz, u8p, vp, sz, ctypes.c_int]
         L.oracle_bench_long.restype = ctypes.c_longlong
+        L.oracle_bench_short.argtypes = [u8p, vp, sz, ctypes.c_int]
+        L.oracle_bench_short.restype = ctypes.c_longlong
         L.oracle_fill_random.argtypes = [u8p, u64, sz, u64]
         L.oracle_fill_random.restype = None
         L.oracle_have_avx2.argtypes = []
@@ -136,6 +138,11 @@ def bench_long(haystack, words, iters):
     blob, off = pack_words(words)
     k, a, n = _buf(haystack)
     return int(lib().oracle_bench_long(a, n, blob.ctypes.data, off.ctypes.data, len(words), iters))
+
+
+def bench_short(words_sorted, iters):
+    blob, off = pack_words(words_sorted)
+    return int(lib().oracle_bench_short(blob.ctypes.data, off.ctypes.data, len(words_sorted), iters))
 
 
 def fill_random(length, seed, global_offset=0):

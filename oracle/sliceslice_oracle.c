@@ -367,6 +367,23 @@ long long oracle_bench_long(const uint8_t *hay, size_t len, const uint8_t *blob,
     return hits;
 }
 
+/* Timed form of the short sweep (bench/benches/i386.rs:118-129): searchers prebuilt (untimed), then
+ * `iters` passes of: for (i, searcher) in searchers { for haystack in &needles[i..] { search_in } }. */
+long long oracle_bench_short(const uint8_t *blob, const uint64_t *off, size_t count, int iters)
+{
+    oracle_searcher **ss = (oracle_searcher **)calloc(count, sizeof *ss);
+    long long hits = 0;
+    for (size_t i = 0; i < count; ++i)
+        oracle_searcher_init_default(&ss[i], blob + off[i], (size_t)(off[i + 1] - off[i]));
+    for (int it = 0; it < iters; ++it)
+        for (size_t i = 0; i < count; ++i)
+            for (size_t j = i; j < count; ++j)
+                hits += oracle_search_in(ss[i], blob + off[j], (size_t)(off[j + 1] - off[j]));
+    for (size_t i = 0; i < count; ++i) oracle_searcher_free(ss[i]);
+    free(ss);
+    return hits;
+}
+
 /* ---- multi-threaded CPU baseline (NOT in the reference, which is single-threaded) ---------- */
 /* Same range-shard rule the GPU path uses across devices: thread t scans bytes
  * [t*S, (t+1)*S + n-1) clipped to len; OR of the per-thread booleans. */
