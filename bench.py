@@ -60,13 +60,20 @@ def cpu_baseline(needle, sample_bytes):
             assert r is False
         return sample_bytes / b / 1e9
     one = best(1, 3)
-    allc = best(cores, 8) if cores > 1 else one
+    # the reference is single-threaded; the multi-thread figure uses the same range-shard rule as the GPUs.
+    # More threads is not always faster (memory-bound): report the best thread count, and all-threads too.
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128, cores) if 1 < t <= cores}):
+        sweep[th] = best(th, 5)
+    best_th = max(sweep, key=sweep.get) if sweep else 1
     out = {
-        "value": round(allc, 2), "unit": "GB/s", "cores": cores, "kind": "port",
-        "single_thread_value": round(one, 2), "avx2": bool(O.have_avx2()),
+        "value": round(sweep.get(best_th, one), 2), "unit": "GB/s", "cores": best_th, "kind": "port",
+        "single_thread_value": round(one, 2), "hardware_threads": cores,
+        "by_threads": {str(k): round(v, 2) for k, v in sweep.items()}, "avx2": bool(O.have_avx2()),
         "sample": "%d MiB of the same synthetic haystack in host RAM, same 16-byte absent needle; C/AVX2 "
-                  "restatement of DynamicAvx2Searcher (oracle/sliceslice_oracle.c), best of 8 runs on %d threads "
-                  "(range shards, n-1 overlap) and best of 3 on 1 thread" % (sample_bytes >> 20, cores),
+                  "restatement of DynamicAvx2Searcher (oracle/sliceslice_oracle.c): best of 3 runs on 1 thread, best of 5 "
+                  "per thread count in by_threads (range shards, n-1 overlap); value = the fastest thread count"
+                  % (sample_bytes >> 20),
     }
     # BASELINE.json configs[0]: data/i386.txt x data/words.txt, shape of bench/benches/i386.rs:246-256
     try:
