@@ -51,6 +51,7 @@ int fail(int code, const char *fmt, ...)
 struct DeviceInfo {
     int cus = 0;
     bool ok = false;
+    bool gfx950 = false;
 };
 
 int device_info(int dev, DeviceInfo *out)
@@ -63,6 +64,7 @@ int device_info(int dev, DeviceInfo *out)
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cache[dev].cus = prop.multiProcessorCount;
+        cache[dev].gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
         cache[dev].ok = true;
     }
     *out = cache[dev];
@@ -110,6 +112,10 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
             *out = &p;
             return SS_OK;
         }
+    DeviceInfo di;
+    if (int rc = device_info(dev, &di)) return rc;
+    if (!di.gfx950)   // the code objects in this library are gfx950 only; fail here, not at the first launch
+        return fail(SS_ERR_NO_DEVICE, "HIP device %d is not a gfx950 (MI355X-class) device", dev);
     PerDevice p;
     p.dev = dev;
     HIP_TRY(hipMalloc((void **)&p.d_needle, s->n ? s->n : 1));
