@@ -106,8 +106,10 @@ int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t le
  * PCIe-bound by construction; never used for roofline numbers. */
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
 
-/* Row f2: the host-file front end of examples/grep.rs:42-56 (`mmap` the file, one
- * search_in): maps `path` read-only and runs it through ss_search_host's chunked upload + scan. */
+/* Row f2: the host-file front end of examples/grep.rs:42-56 (open the file, one
+ * search_in) as a pipeline: reader threads pread() 64 MiB chunks into pinned buffers while earlier
+ * chunks are uploading and being scanned on their own streams; n-1 bytes are carried across chunk
+ * edges.  Bound by the file read / PCIe, never by the scan. */
 int ss_search_file(const ss_searcher *s, const char *path, int *found);
 
 /* Row f3: data for a `position` policy.  The reference leaves `position` to the caller

@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1) or 1) as pool:
         list(pool.map(compile_one, todo))
     objs = [os.path.join(_CSRC, s[:-4] + ".o") for s in _SOURCES]
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", _SO] + objs + ["-ldl"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", _SO] + objs + ["-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/sliceslice_hip.h"
@@ -527,7 +528,40 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     return rc;
 }
 
-// ---- row f2: host-file front end (the shape of examples/grep.rs:42-56: mmap the file, one search_in) ----
+// ---- row f2: host-file front end (the shape of examples/grep.rs:42-56: open the file, one search_in) ----
+// A three-stage pipeline: reader threads pread() the next chunk into a pinned buffer while the previous
+// chunks are in flight as hipMemcpyAsync + scan on their own streams.  Chunk k carries the last n-1 bytes
+// of chunk k-1 in front, so a match that straddles a chunk edge is seen by the later chunk.
+namespace {
+
+bool parallel_pread(int fd, uint8_t *dst, size_t bytes, off_t off, unsigned threads)
+{
+    if (threads < 1) threads = 1;
+    const size_t part = (bytes + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    std::atomic<bool> ok{true};
+    for (unsigned t = 0; t < threads; ++t) {
+        const size_t b = (size_t)t * part;
+        if (b >= bytes) break;
+        const size_t e = b + part < bytes ? b + part : bytes;
+        pool.emplace_back([=, &ok]() {
+            size_t done = b;
+            while (done < e) {
+                const ssize_t r = pread(fd, dst + done, e - done, off + (off_t)done);
+                if (r <= 0) {
+                    ok = false;
+                    return;
+                }
+                done += (size_t)r;
+            }
+        });
+    }
+    for (auto &th : pool) th.join();
+    return ok;
+}
+
+}  // namespace
+
 int ss_search_file(const ss_searcher *s, const char *path, int *found)
 {
     if (!s || !path || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
@@ -539,16 +573,71 @@ int ss_search_file(const ss_searcher *s, const char *path, int *found)
         return fail(SS_ERR_ARGUMENT, "cannot stat %s", path);
     }
     const size_t len = (size_t)sb.st_size;
-    if (len == 0) {
+    if (s->n == 0 || len < s->n) {                       // answered without reading the file (x86.rs:500, 357-359)
         close(fd);
-        return ss_search_host(s, nullptr, 0, found);
+        *found = s->n == 0;
+        return SS_OK;
     }
-    void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    const size_t carry = s->n - 1;
+    size_t C = (size_t)64 << 20;
+    if (C < 4 * s->n) C = 4 * s->n;
+    if (C > len) C = len;
+    constexpr int kBuf = 3;
+    const int nbuf = len > C ? kBuf : 1;
+    unsigned threads = std::thread::hardware_concurrency();
+    if (threads > 8) threads = 8;
+    if (len < ((size_t)8 << 20)) threads = 1;
+
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) {
+        close(fd);
+        return rc;
+    }
+    const int k = acquire_slot(s, pd);
+    const int epoch = next_epoch(pd, k);
+    uint8_t *hbuf[kBuf] = {nullptr, nullptr, nullptr}, *dbuf[kBuf] = {nullptr, nullptr, nullptr};
+    hipStream_t st[kBuf] = {nullptr, nullptr, nullptr};
+    int rc = SS_OK;
+    for (int b = 0; b < nbuf && rc == SS_OK; ++b) {
+        if (hipHostMalloc((void **)&hbuf[b], C + carry, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&dbuf[b], C + carry) != hipSuccess ||
+            hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess)
+            rc = fail(SS_ERR_HIP, "staging allocation failed");
+    }
+    int result = 0;
+    size_t idx = 0, prev_total = 0;
+    int prev_b = -1;
+    for (size_t off = 0; off < len && rc == SS_OK && !result; off += C, ++idx) {
+        const int b = (int)(idx % (size_t)nbuf);
+        const size_t lead = off == 0 ? 0 : carry;
+        const size_t fresh = len - off < C ? len - off : C;
+        hipError_t e = hipStreamSynchronize(st[b]);      // the copy + scan that last used buffer b are done
+        if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "stream wait: %s", hipGetErrorString(e)); break; }
+        if (__atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch) { result = 1; break; }
+        if (lead) memcpy(hbuf[b], hbuf[prev_b] + prev_total - carry, carry);
+        if (!parallel_pread(fd, hbuf[b] + lead, fresh, (off_t)off, threads)) {
+            rc = fail(SS_ERR_ARGUMENT, "read error on %s", path);
+            break;
+        }
+        const size_t total = lead + fresh;
+        prev_b = b;
+        prev_total = total;
+        if (total < s->n) break;                         // tail shorter than the needle: nothing new can start here
+        e = hipMemcpyAsync(dbuf[b], hbuf[b], total, hipMemcpyHostToDevice, st[b]);
+        if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
+        rc = enqueue_scan(s, pd, dbuf[b], total, st[b], pd->d_flags + k, false, 0, pd->h_flags + k, epoch);
+    }
+    for (int b = 0; b < nbuf; ++b)
+        if (st[b]) (void)hipStreamSynchronize(st[b]);
+    if (rc == SS_OK && !result) result = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
+    for (int b = 0; b < nbuf; ++b) {
+        if (st[b]) (void)hipStreamDestroy(st[b]);
+        if (dbuf[b]) (void)hipFree(dbuf[b]);
+        if (hbuf[b]) (void)hipHostFree(hbuf[b]);
+    }
     close(fd);
-    if (map == MAP_FAILED) return fail(SS_ERR_ARGUMENT, "cannot mmap %s", path);
-    (void)madvise(map, len, MADV_SEQUENTIAL);
-    const int rc = ss_search_host(s, static_cast<const uint8_t *>(map), len, found);   // chunked upload + scan
-    munmap(map, len);
+    release_slot(s, pd, k);
+    if (rc == SS_OK) *found = result;
     return rc;
 }
 

@@ -529,6 +529,22 @@ def test_search_file_front_end(ss, corpus, tmp_path):
     assert ss.search_file(ss.DynamicHipSearcher.new(b"x"), str(empty)) is False
     with pytest.raises(ss.SlicesliceError):
         ss.search_file(ss.DynamicHipSearcher.new(b"x"), str(tmp_path / "missing"))
+    # a file of several 64 MiB chunks: matches straddling chunk edges rely on the n-1 byte carry
+    big = tmp_path / "big.bin"
+    ln = (3 * 64 << 20) + 12345
+    host = np.full(ln, 0x2E, dtype=np.uint8)
+    needle = bytes(range(1, 41))
+    s = ss.DynamicHipSearcher.new(needle)
+    host.tofile(str(big))
+    assert ss.search_file(s, str(big)) is False
+    for at in ((64 << 20) - 17, (128 << 20) - 39, (128 << 20) - 1, (192 << 20), ln - 40, 0):
+        h2 = host.copy()
+        h2[at:at + 40] = np.frombuffer(needle, dtype=np.uint8)
+        h2.tofile(str(big))
+        assert ss.search_file(s, str(big)) is True, at
+    host[ln - 39:] = np.frombuffer(needle[:39], dtype=np.uint8)      # only a 39-byte prefix at the very end
+    host.tofile(str(big))
+    assert ss.search_file(s, str(big)) is False
 
 
 def test_histogram_and_position_policy(ss, corpus):
