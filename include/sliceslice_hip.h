@@ -95,6 +95,9 @@ int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t 
 #define SS_NPOS UINT64_MAX
 int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,
                    uint64_t *position);
+/* The same for a HOST haystack (chunked upload, n-1 byte carry, stops issuing chunks after the first
+ * chunk that reports a match). */
+int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint64_t *position);
 /* Enqueue-only form: atomicMin's base_offset + local offset into *d_best (uint64 in device memory,
  * caller-initialised to SS_NPOS).  With base_offset = the shard's begin, an all-reduce(MIN) over the
  * ranks' d_best gives the global leftmost match of a range-sharded haystack. */

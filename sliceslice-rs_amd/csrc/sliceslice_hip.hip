@@ -528,6 +528,62 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     return rc;
 }
 
+// find() for a host haystack: the chunked upload of ss_search_host with the uint64 best-offset sink.
+// Chunks are issued left to right, so once a finished chunk has reported a match no later chunk can
+// improve on it: stop issuing, drain the (at most one) chunk still in flight, read the minimum.
+int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint64_t *position)
+{
+    if (!s || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    if (s->n == 0) { *position = 0; return SS_OK; }
+    if (len < s->n) { *position = SS_NPOS; return SS_OK; }
+    const size_t carry = s->n - 1;
+    size_t C = (size_t)64 << 20;
+    if (C < 4 * s->n) C = 4 * s->n;
+    if (C > len) C = len;
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    const int k = acquire_slot(s, pd);
+    uint8_t *dbuf[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    int rc = SS_OK;
+    const size_t nbuf = len > C ? 2 : 1;
+    for (size_t b = 0; b < nbuf && rc == SS_OK; ++b) {
+        if (hipMalloc((void **)&dbuf[b], C + carry) != hipSuccess || hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess)
+            rc = fail(SS_ERR_HIP, "staging allocation failed");
+    }
+    size_t idx = 0;
+    bool hit = false;
+    for (size_t off = 0; off < len && rc == SS_OK && !hit; off += C, ++idx) {
+        const int b = (int)(idx % nbuf);
+        const size_t lead = off == 0 ? 0 : carry;
+        const size_t bytes = (len - off < C ? len - off : C) + lead;
+        if (bytes < s->n) break;
+        hipError_t e = hipStreamSynchronize(st[b]);
+        if (e == hipSuccess && idx >= nbuf) {
+            e = hipMemcpy(pd->h_best + k, pd->d_best + k, sizeof(uint64_t), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && pd->h_best[k] != SS_NPOS) { hit = true; break; }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(dbuf[b], haystack + off - lead, bytes, hipMemcpyHostToDevice, st[b]);
+        if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
+        rc = enqueue_scan(s, pd, dbuf[b], bytes, st[b], pd->d_best + k, true, (uint64_t)(off - lead));
+    }
+    for (size_t b = 0; b < nbuf; ++b)
+        if (st[b]) (void)hipStreamSynchronize(st[b]);
+    if (rc == SS_OK) {
+        const hipError_t e = hipMemcpy(pd->h_best + k, pd->d_best + k, sizeof(uint64_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "position read-back: %s", hipGetErrorString(e));
+        else *position = pd->h_best[k];
+    }
+    (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));       // slots are all-ones whenever they are free
+    for (size_t b = 0; b < nbuf; ++b) {
+        if (st[b]) (void)hipStreamDestroy(st[b]);
+        if (dbuf[b]) (void)hipFree(dbuf[b]);
+    }
+    release_slot(s, pd, k);
+    return rc;
+}
+
 // ---- row f2: host-file front end (the shape of examples/grep.rs:42-56: open the file, one search_in) ----
 // A three-stage pipeline: reader threads pread() the next chunk into a pinned buffer while the previous
 // chunks are in flight as hipMemcpyAsync + scan on their own streams.  Chunk k carries the last n-1 bytes

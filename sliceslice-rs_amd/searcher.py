@@ -46,6 +46,7 @@ ABI = {
     "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
     "ss_find_device": (_int, [_vp, _vp, _sz, _vp, ctypes.POINTER(_u64)]),
     "ss_find_device_async": (_int, [_vp, _vp, _sz, _u64, _vp, _vp]),
+    "ss_find_host": (_int, [_vp, _vp, _sz, ctypes.POINTER(_u64)]),
     "ss_search_file": (_int, [_vp, ctypes.c_char_p, _pint]),
     "ss_byte_histogram_device": (_int, [_vp, _sz, _sz, _vp, _vp]),
     "ss_choose_position": (_int, [_vp, _sz, _vp, ctypes.POINTER(_sz)]),
@@ -192,19 +193,18 @@ class DynamicHipSearcher:
 
     def find(self, haystack, stream=None):
         """Offset of the leftmost occurrence or None (row f1; the shape of tests/i386.rs:6-10
-        `find_subsequence` and of the competitors in bench/benches/i386.rs).  Device tensors only."""
+        `find_subsequence` and of the competitors in bench/benches/i386.rs).  Device tensors /
+        (pointer, length) pairs use ss_find_device, host buffers ss_find_host."""
         pos = _u64(0)
-        if isinstance(haystack, tuple):
-            ptr, length = haystack
+        if isinstance(haystack, tuple) or (_is_tensor(haystack) and haystack.is_cuda):
+            ptr, length = haystack if isinstance(haystack, tuple) else (haystack.data_ptr(), haystack.numel())
+            st = stream if stream is not None else _current_stream_handle()
+            _check(lib().ss_find_device(self._h, ptr, length, st, ctypes.byref(pos)))
         else:
-            if not (_is_tensor(haystack) and haystack.is_cuda):
-                import torch
-                a = np.frombuffer(haystack, dtype=np.uint8) if not isinstance(haystack, np.ndarray) else haystack
-                haystack = torch.from_numpy(np.ascontiguousarray(a).copy()).cuda() if a.size else \
-                    torch.empty(0, dtype=torch.uint8, device="cuda")
-            ptr, length = haystack.data_ptr(), haystack.numel()
-        st = stream if stream is not None else _current_stream_handle()
-        _check(lib().ss_find_device(self._h, ptr, length, st, ctypes.byref(pos)))
+            if _is_tensor(haystack):
+                haystack = haystack.numpy()
+            k, addr, n = _host_view(haystack)
+            _check(lib().ss_find_host(self._h, addr, n, ctypes.byref(pos)))
         return None if pos.value == (1 << 64) - 1 else pos.value
 
     def find_async(self, haystack, d_best, base_offset=0, stream=None):

@@ -682,3 +682,19 @@ def test_fuzz_batched_and_pairs_vs_python(ss):
             got = [bool(x) for x in found.cpu().tolist()]
             bad = [k for k in range(len(want)) if got[k] != want[k]]
             assert not bad, (pairs, p is not None, bad[:5], [(hays[k][:40], needles[k]) for k in bad[:2]])
+
+
+def test_find_on_host_buffers(ss, corpus):
+    raw = corpus["i386"]
+    for w in (b"Zz", b"privilege", b"PREFACE", b"", b"not in the manual at all"):
+        want = raw.find(w)
+        assert ss.DynamicHipSearcher.new(w).find(raw) == (None if want < 0 else want), w
+    # several 64 MiB chunks: leftmost of many, straddling a chunk edge
+    ln = (2 * 64 << 20) + 999
+    host = np.full(ln, 0x2E, dtype=np.uint8)
+    needle = bytes(range(1, 41))
+    s = ss.DynamicHipSearcher.new(needle)
+    assert s.find(host) is None
+    for at in (ln - 40, (128 << 20) - 7, (64 << 20) - 17, 12345):          # right to left
+        host[at:at + 40] = np.frombuffer(needle, dtype=np.uint8)
+        assert s.find(host) == at, at
