@@ -77,8 +77,8 @@ int device_info(int dev, DeviceInfo *out)
 struct PerDevice {
     int dev = -1;
     uint8_t *d_needle = nullptr;
-    int *d_flags = nullptr;     // kSlots ints, zero whenever a slot is free
-    int *h_flags = nullptr;     // pinned mirror
+    int *d_flags = nullptr;     // kSlots ints; "found" is the owning call's epoch, so slots are never cleared
+    int *h_flags = nullptr;     // pinned-host mirror written by the finding wave (no D2H copy per call)
     uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
     uint64_t *h_best = nullptr; // pinned mirror
     uint64_t free_mask = 0;
@@ -119,18 +119,33 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         return fail(SS_ERR_NO_DEVICE, "HIP device %d is not a gfx950 (MI355X-class) device", dev);
     PerDevice p;
     p.dev = dev;
-    HIP_TRY(hipMalloc((void **)&p.d_needle, s->n ? s->n : 1));
-    if (s->n) HIP_TRY(hipMemcpy(p.d_needle, s->needle.data(), s->n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&p.d_flags, kSlots * sizeof(int)));
-    HIP_TRY(hipMemset(p.d_flags, 0, kSlots * sizeof(int)));
-    HIP_TRY(hipHostMalloc((void **)&p.h_flags, kSlots * sizeof(int), hipHostMallocDefault));
-    memset(p.h_flags, 0, kSlots * sizeof(int));     // pinned memory is recycled: a stale value must not equal an epoch
-    HIP_TRY(hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t)));
-    HIP_TRY(hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t)));
-    HIP_TRY(hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault));
+    auto alloc = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = hipMalloc((void **)&p.d_needle, s->n ? s->n : 1)) != hipSuccess) return e;
+        if (s->n && (e = hipMemcpy(p.d_needle, s->needle.data(), s->n, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&p.d_flags, kSlots * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMemset(p.d_flags, 0, kSlots * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void **)&p.h_flags, kSlots * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
+        memset(p.h_flags, 0, kSlots * sizeof(int));   // pinned memory is recycled: a stale value must not equal an epoch
+        if ((e = hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
+        if ((e = hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipEventCreate(&p.ev0)) != hipSuccess) return e;
+        return hipEventCreate(&p.ev1);
+    };
+    const hipError_t e = alloc();
+    if (e != hipSuccess) {                             // nothing half-built is left behind
+        (void)hipFree(p.d_needle);
+        (void)hipFree(p.d_flags);
+        (void)hipHostFree(p.h_flags);
+        (void)hipFree(p.d_best);
+        (void)hipHostFree(p.h_best);
+        if (p.ev0) (void)hipEventDestroy(p.ev0);
+        if (p.ev1) (void)hipEventDestroy(p.ev1);
+        return fail(e == hipErrorNoDevice ? SS_ERR_NO_DEVICE : (e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP),
+                    "per-device setup: %s", hipGetErrorString(e));
+    }
     p.free_mask = ~0ull;
-    HIP_TRY(hipEventCreate(&p.ev0));
-    HIP_TRY(hipEventCreate(&p.ev1));
     s->per.reserve(16);              // PerDevice pointers handed out must stay valid
     s->per.push_back(p);
     *out = &s->per.back();
@@ -712,16 +727,18 @@ int ss_byte_histogram_device(const void *d_haystack, size_t len, size_t sample_b
     if (int rc = device_info(dev, &di)) return rc;
     unsigned long long *d_hist = nullptr;
     HIP_TRY(hipMalloc((void **)&d_hist, 256 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), st));
+    hipError_t e = hipMemsetAsync(d_hist, 0, 256 * sizeof(unsigned long long), st);
     uint64_t stride = 1;
     if (sample_bytes && sample_bytes < len) stride = (len + sample_bytes - 1) / sample_bytes;
     const uint64_t work = len / 16 / stride;
     uint64_t blocks = (work + ss::kBlock - 1) / ss::kBlock;
     if (blocks > (uint64_t)di.cus * 8) blocks = (uint64_t)di.cus * 8;
     if (blocks < 1) blocks = 1;
-    ss::byte_histogram_kernel<<<dim3((unsigned)blocks), dim3(ss::kBlock), 0, st>>>(
-        static_cast<const uint8_t *>(d_haystack), len, stride, d_hist);
-    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {
+        ss::byte_histogram_kernel<<<dim3((unsigned)blocks), dim3(ss::kBlock), 0, st>>>(
+            static_cast<const uint8_t *>(d_haystack), len, stride, d_hist);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(hist, d_hist, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_hist);
@@ -857,31 +874,37 @@ int ss_read_ceiling(const void *d_src, size_t len, void *hip_stream, int reps, f
     if (((uintptr_t)d_src & 15) != 0) return fail(SS_ERR_ARGUMENT, "source must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     uint32_t *sink = nullptr;
-    HIP_TRY(hipMalloc((void **)&sink, 64));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
     const uint64_t nvec = len / 16;
     constexpr int U = 4;
     const uint64_t tpb = kAutoTilesPerBlock;
     const uint64_t ntiles = nvec / (64 * ss::kWavesPerBlock * U);
     uint64_t blocks = (ntiles + tpb - 1) / tpb;
     if (blocks < 1) blocks = 1;
-    dim3 grid((unsigned)blocks);
+    const dim3 grid((unsigned)blocks);
     auto launch = [&]() {
         ss::read_ceiling_kernel<U, true><<<grid, dim3(ss::kBlock), 0, st>>>(static_cast<const ss::u32x4 *>(d_src), nvec, sink, tpb);
     };
-    launch();                                                   // warm-up
-    HIP_TRY(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; ++r) launch();
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *ms_per_rep = ms / (float)reps;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    auto run = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = hipMalloc((void **)&sink, 64)) != hipSuccess) return e;
+        if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+        if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
+        launch();                                               // warm-up
+        if ((e = hipEventRecord(e0, st)) != hipSuccess) return e;
+        for (int r = 0; r < reps; ++r) launch();
+        if ((e = hipEventRecord(e1, st)) != hipSuccess) return e;
+        if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return hipEventElapsedTime(&ms, e0, e1);
+    };
+    const hipError_t e = run();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(sink);
+    if (e != hipSuccess) return fail(SS_ERR_HIP, "read ceiling: %s", hipGetErrorString(e));
+    *ms_per_rep = ms / (float)reps;
     return SS_OK;
 }
 
