@@ -269,10 +269,12 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         if (s->grid < 0) {
             tpb = (uint64_t)(-(int64_t)s->grid);
         } else {
-            // long runs per workgroup, but never fewer than ~16 workgroups per CU's worth of work
+            // contiguous runs of up to 64 tiles (1 MiB) per workgroup, but at least ~128 workgroups per CU
+            // overall so that the tail of a short scan stays fine-grained (1 GiB: 2 tiles per workgroup is
+            // 6 % faster than 16; profiles/r01/launch_shape_small.jsonl)
             DeviceInfo di;
             if (int rc = device_info(pd->dev, &di)) return rc;
-            tpb = ntiles / ((uint64_t)di.cus * 16);
+            tpb = ntiles / ((uint64_t)di.cus * 128);
             if (tpb > (uint64_t)kAutoTilesPerBlock) tpb = kAutoTilesPerBlock;
             if (tpb < 1) tpb = 1;
         }
