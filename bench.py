@@ -127,13 +127,21 @@ def main():
         log("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the scan has no CPU path")
+    # SS_BENCH_SHARE_GPU=1 + SS_BENCH_BACKEND=gloo: run the N > 1 code path with every rank on cuda:0 (a
+    # functional check on a one-GPU box; the numbers of such a run mean nothing)
+    if os.environ.get("SS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("SS_BENCH_FORCE_DIST") == "1"     # exercise the N > 1 code path on one GPU
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import sliceslice_rs_amd as ss
     ss.lib()
