@@ -45,6 +45,142 @@ __global__ void __launch_bounds__(256) k_read(const uint8_t* src, uint64_t nbyte
     if (r == 0x9E3779B9u) sink[0] = r;
 }
 
+__device__ __forceinline__ uint32_t zf(uint32_t x) { return (x - 0x01010101u) & ~x; }
+__device__ __forceinline__ uint32_t shl1(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+
+// the same with scan-like VALU work per dword (two zero-byte flag computations, one DPP, one alignbyte, and/or):
+// does the width effect survive next to the filter's instruction stream?
+template <int W, int AUX>
+__global__ void __launch_bounds__(256) k_filter_w(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb,
+                                                  uint32_t n0, uint32_t nl, uint32_t r)
+{
+    constexpr int U = 4;
+    constexpr int L = (U * 1024) / (64 * 4 * W);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_bytes = 4ull * U * 1024;
+    const uint64_t ntiles = nbytes / tile_bytes;
+    uint64_t t0 = (uint64_t)blockIdx.x * tpb;
+    const uint64_t t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+    uint32_t hits = 0;
+    for (; t0 < t1; ++t0) {
+        const uint8_t* base = src + t0 * tile_bytes + (uint64_t)wave * U * 1024;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(U * 1024), 0x00020000);
+        uint32_t v[L][W];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const uint32_t off = (uint32_t)(l * 64 * 4 * W + lane * 4 * W);
+            if (W == 2) { auto t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, AUX); v[l][0] = t[0]; v[l][1 % W] = t[1]; }
+            else { auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, AUX); v[l][0] = t[0]; v[l][1 % W] = t[1]; v[l][2 % W] = t[2]; v[l][3 % W] = t[3]; }
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            uint32_t w[W + 1];
+#pragma unroll
+            for (int k = 0; k < W; ++k) w[k] = zf(v[l][k] ^ nl);
+            w[W] = shl1(w[0]);
+#pragma unroll
+            for (int k = 0; k < W; ++k) any |= zf(v[l][k] ^ n0) & __builtin_amdgcn_alignbyte(w[k + 1], w[k], r);
+        }
+        if (__ballot((any & 0x80808080u) != 0)) hits += 1;
+    }
+    if (hits == 0x9E3779B9u) sink[0] = hits;
+}
+
+// load width: W = 1, 2, 4 dwords per lane per load (uchar4 / 8 B / 16 B); the same bytes per wave-tile
+template <int W, int AUX>
+__global__ void __launch_bounds__(256) k_read_w(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb)
+{
+    constexpr int U = 4;                       // KiB per wave per tile
+    constexpr int L = (U * 1024) / (64 * 4 * W);   // loads per lane per tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_bytes = 4ull * U * 1024;
+    const uint64_t ntiles = nbytes / tile_bytes;
+    uint64_t t0 = (uint64_t)blockIdx.x * tpb;
+    const uint64_t t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+    uint32_t acc = 0;
+    for (; t0 < t1; ++t0) {
+        const uint8_t* base = src + t0 * tile_bytes + (uint64_t)wave * U * 1024;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(U * 1024), 0x00020000);
+        uint32_t v[L][W];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const uint32_t off = (uint32_t)(l * 64 * 4 * W + lane * 4 * W);
+            if (W == 1) v[l][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, AUX);
+            else if (W == 2) { auto t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, AUX); v[l][0] = t[0]; v[l][1 % W] = t[1]; }
+            else { auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, AUX); v[l][0] = t[0]; v[l][1 % W] = t[1]; v[l][2 % W] = t[2]; v[l][3 % W] = t[3]; }
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int w = 0; w < W; ++w) acc ^= v[l][w];
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
+// 16 contiguous bytes per lane fetched as TWO dwordx2 loads (lane stride 16 B, halves at +0 and +8)
+template <int AUX>
+__global__ void __launch_bounds__(256) k_read_split(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb)
+{
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_bytes = 4ull * U * 1024;
+    const uint64_t ntiles = nbytes / tile_bytes;
+    uint64_t t0 = (uint64_t)blockIdx.x * tpb;
+    const uint64_t t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+    uint32_t acc = 0;
+    for (; t0 < t1; ++t0) {
+        const uint8_t* base = src + t0 * tile_bytes + (uint64_t)wave * U * 1024;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(U * 1024), 0x00020000);
+        uint32_t v[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            auto a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (uint32_t)(u * 1024 + lane * 16), 0, AUX);
+            auto b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (uint32_t)(u * 1024 + lane * 16 + 8), 0, AUX);
+            v[u][0] = a[0]; v[u][1] = a[1]; v[u][2] = b[0]; v[u][3] = b[1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
+// 16 B/lane, but each load instruction is issued for HALF the wave (512 B per instruction)
+template <int AUX>
+__global__ void __launch_bounds__(256) k_read_half(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb)
+{
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_bytes = 4ull * U * 1024;
+    const uint64_t ntiles = nbytes / tile_bytes;
+    uint64_t t0 = (uint64_t)blockIdx.x * tpb;
+    const uint64_t t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; t0 < t1; ++t0) {
+        const uint8_t* base = src + t0 * tile_bytes + (uint64_t)wave * U * 1024;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(U * 1024), 0x00020000);
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (lane < 32) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)(u * 1024 + lane * 16), 0, AUX);
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane >= 32) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)(u * 1024 + lane * 16), 0, AUX);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x9E3779B9u) sink[0] = r;
+}
+
 template <typename F>
 static double time_ms(F launch, int reps)
 {
@@ -69,6 +205,16 @@ static void run(const char* name, const uint8_t* d, uint64_t nbytes, uint32_t* s
     fflush(stdout);
 }
 
+template <int W, int AUX>
+static void run_w(const char* name, const uint8_t* d, uint64_t nbytes, uint32_t* sink, uint64_t tpb)
+{
+    const uint64_t ntiles = nbytes / (16ull * 1024);
+    const uint64_t blocks = (ntiles + tpb - 1) / tpb;
+    double ms = time_ms([&]() { k_read_w<W, AUX><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, tpb); }, 7);
+    printf("%-44s W=%d tpb=%-4llu  %8.3f ms  %8.1f GB/s\n", name, W, (unsigned long long)tpb, ms, nbytes / ms / 1e6);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv)
 {
     const double gib = argc > 1 ? atof(argv[1]) : 8.0;
@@ -76,6 +222,28 @@ int main(int argc, char** argv)
     uint8_t* d; uint32_t* sink;
     CK(hipMalloc((void**)&d, nbytes + (1 << 20))); CK(hipMalloc((void**)&sink, 64));
     CK(hipMemset(d, 0x5A, nbytes + (1 << 20)));
+    run_w<1, 2>("4 B/lane  (uchar4, dword) loads, nt", d, nbytes, sink, 64);
+    run_w<2, 2>("8 B/lane  (dwordx2) loads, nt", d, nbytes, sink, 64);
+    run_w<4, 2>("16 B/lane (dwordx4) loads, nt", d, nbytes, sink, 64);
+    {
+        const uint64_t blocks = (nbytes / (16ull * 1024) + 63) / 64;
+        double ms = time_ms([&]() { k_read_split<2><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64); }, 7);
+        printf("%-44s      tpb=64    %8.3f ms  %8.1f GB/s\n", "16 B/lane as two strided dwordx2 loads, nt", ms, nbytes / ms / 1e6);
+    }
+    {
+        const uint64_t blocks = (nbytes / (16ull * 1024) + 63) / 64;
+        double ms = time_ms([&]() { k_read_half<2><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64); }, 7);
+        printf("%-44s      tpb=64    %8.3f ms  %8.1f GB/s\n", "16 B/lane, half-wave (512 B) load instructions, nt", ms, nbytes / ms / 1e6);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        const uint64_t blocks = (nbytes / (16ull * 1024) + 63) / 64;
+        double ms2 = time_ms([&]() { k_filter_w<2, 2><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64, 0x11111111u, 0x22222222u, 3); }, 7);
+        printf("%-44s      tpb=64    %8.3f ms  %8.1f GB/s\n", "filter-like VALU + 8 B/lane loads, nt", ms2, nbytes / ms2 / 1e6);
+        double ms4 = time_ms([&]() { k_filter_w<4, 2><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64, 0x11111111u, 0x22222222u, 3); }, 7);
+        printf("%-44s      tpb=64    %8.3f ms  %8.1f GB/s\n", "filter-like VALU + 16 B/lane loads, nt", ms4, nbytes / ms4 / 1e6);
+    }
+    run_w<1, 0>("4 B/lane  (uchar4, dword) loads, plain", d, nbytes, sink, 64);
+    run_w<4, 0>("16 B/lane (dwordx4) loads, plain", d, nbytes, sink, 64);
     for (uint64_t tpb : {16ull, 64ull}) {
         run<4, 0, 0, 0>("one stream, plain", d, nbytes, sink, tpb);
         run<4, 1, 0, 0>("one stream, sc0", d, nbytes, sink, tpb);
