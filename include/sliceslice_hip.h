@@ -151,7 +151,8 @@ int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const 
 int ss_searcher_set_timing(ss_searcher *s, int enabled);
 int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);
 
-/* Kernel-variant override for tuning/tests: variant = 100*MODE + 10*U + NT; U in {4,8} pieces (KiB)
+/* Kernel-variant override for tuning/tests: variant = 1000*LAYOUT + 100*MODE + 10*U + NT; LAYOUT 0 =
+ * automatic, 1 = 16 bytes per lane, 2 = 8-bytes-per-lane first phase (position < 16 only); U in {4,8} pieces (KiB)
  * per wave per tile; NT in {0,1} (plain / non-temporal loads); MODE 0 = automatic, 1 = second load
  * stream, 2 = cross-lane position flags (position >= 16 only); 0 = automatic.  See DESIGN.md "Kernels". */
 int ss_searcher_set_variant(ss_searcher *s, int variant);

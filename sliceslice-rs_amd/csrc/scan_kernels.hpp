@@ -358,6 +358,59 @@ __device__ __forceinline__ void stage_needle_wave(uint8_t *s_needle, const uint8
 // A tile is kWavesPerBlock*U consecutive pieces; wave w owns pieces tile*4U + w*U + u, u = 0..U-1.
 // NTMODE: 0 = plain loads; 1 = non-temporal first-byte stream, plain position-byte stream;
 //         2 = non-temporal for both.  (With a single stream 1 == 2.)
+// ---- 8-bytes-per-lane first phase (L8) -------------------------------------------------------------------
+// Plain streaming reads run ~2 % faster when a wave instruction covers 512 contiguous bytes (dwordx2 per
+// lane) than 1 KiB (dwordx4) - profiles/r01/readbench_8gib.txt.  The L8 kernels therefore run the two-byte
+// filter on *half-pieces*: 64 lanes x 8 bytes, two dwords per lane; a candidate's position byte lies up to
+// two lanes ahead.  Only tiles in which some candidate survives are transposed (ds_bpermute) into the
+// 16-bytes-per-lane layout and handed to the second phase unchanged; a wave that keeps meeting candidates
+// (text) stays in the 16-byte layout for its following tiles.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ u32x2 load_half(const uint8_t *base, uint64_t half_chunk)
+{
+    const u32x2 *p = reinterpret_cast<const u32x2 *>(base) + half_chunk;
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// a = this lane's 8 bytes; w = their position-byte flags; nw = position-byte flags of the NEXT half-piece
+// (lanes 0 and 1 of it are what lanes 62/63 see two lanes ahead).  position = 4*Q + r < 16.
+template <int Q, bool ONE_BYTE>
+__device__ __forceinline__ uint32_t filter_half(const u32x2 &a, const uint32_t w[2], const uint32_t nw[2], const Problem &pr)
+{
+    const uint32_t f0 = zero_byte_flags(a.x ^ pr.n0x4), f1 = zero_byte_flags(a.y ^ pr.n0x4);
+    if (ONE_BYTE) return f0 | f1;
+    // dword stream relative to this lane: x[0..1] this lane, x[2..3] next lane, x[4..5] the lane after
+    uint32_t x[6] = {w[0], w[1], 0, 0, 0, 0};
+    constexpr bool n2 = Q <= 2, n3 = Q >= 1, n4 = Q >= 2, n5 = Q >= 3;       // stream dwords Q .. Q+2 are used
+    uint32_t r0 = 0, r1 = 0;
+    if (n2 || n4) { r0 = rotate_from_next_lane(nw[0]); x[2] = from_next_lane_or(r0, w[0]); }
+    if (n3 || n5) { r1 = rotate_from_next_lane(nw[1]); x[3] = from_next_lane_or(r1, w[1]); }
+    if (n4) x[4] = from_next_lane_or(rotate_from_next_lane(r0), x[2]);
+    if (n5) x[5] = from_next_lane_or(rotate_from_next_lane(r1), x[3]);
+    return (f0 & __builtin_amdgcn_alignbyte(x[Q + 1], x[Q], pr.r)) | (f1 & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r));
+}
+
+// two half-pieces (lo = bytes 0..511, hi = bytes 512..1023 of a piece, 8 bytes per lane) -> the piece in
+// the 16-bytes-per-lane layout: lane l takes the two half-chunks 2*(l%32), 2*(l%32)+1 of half l/32.
+__device__ __forceinline__ u32x4 transpose_halves(const u32x2 &lo, const u32x2 &hi, int lane)
+{
+    const int i0 = ((lane & 31) * 2) << 2, i1 = i0 + 4;
+    const bool up = lane >= 32;
+    u32x4 A;
+    const uint32_t ax = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)lo.x), bx = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)hi.x);
+    const uint32_t ay = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)lo.y), by = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)hi.y);
+    const uint32_t az = (uint32_t)__builtin_amdgcn_ds_bpermute(i1, (int)lo.x), bz = (uint32_t)__builtin_amdgcn_ds_bpermute(i1, (int)hi.x);
+    const uint32_t aw = (uint32_t)__builtin_amdgcn_ds_bpermute(i1, (int)lo.y), bw = (uint32_t)__builtin_amdgcn_ds_bpermute(i1, (int)hi.y);
+    A.x = up ? bx : ax;
+    A.y = up ? by : ay;
+    A.z = up ? bz : az;
+    A.w = up ? bw : aw;
+    return A;
+}
+
 // lane l receives `cur` of lane l+k when l+k < 64, else `nxt` of lane l+k-64 (0 <= k <= 64):
 // the value k lanes further along the concatenation {cur, nxt} of two consecutive pieces.
 __device__ __forceinline__ uint32_t from_lane_ahead(uint32_t cur, uint32_t nxt, int lane, int k)
@@ -376,10 +429,11 @@ __device__ __forceinline__ uint32_t from_lane_ahead(uint32_t cur, uint32_t nxt, 
 // FIND = false: `sink` is the int found flag (0 -> 1).  FIND = true: `sink` is the uint64 leftmost-match
 // offset (row f1 of SURVEY.md 8f: the `Option<usize>` shape of tests/i386.rs:6-10 and
 // bench/sse4-strstr/src/lib.rs:4-15); a wave only skips work that lies to the RIGHT of the best so far.
-template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
+template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_block, uint64_t tile0,
                                            uint64_t tile_step, uint64_t tile_end, void *sink)
 {
+    static_assert(!L8 || (MODE == 0 && !FIND), "the 8-byte layout covers the single-stream bool kernels");
     constexpr bool TWO = MODE == 1;
     constexpr bool SHIFTED = MODE == 2;
     int *found = static_cast<int *>(sink);
@@ -390,6 +444,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
     bool staged = false;
+    bool dense = false;                                                     // L8: the previous tile had candidates
     const int d = (int)pr.d;                                                // SHIFTED: 1 <= d <= 62
 
     for (uint64_t tile = tile0; tile < tile_end; tile += tile_step) {
@@ -400,7 +455,55 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         // last chunk this wave touches: the halo chunk (MODE 0/1) or the d+1 halo chunks (MODE 2)
         const uint64_t halo = chunk0 + 64 * U + pr.d;
         const bool full = halo < pr.nchunks_all;
-        if (full) {
+        bool have16 = false;
+        if (L8 && !dense) {
+            // ---- 8 bytes per lane: 2U half-pieces + a 16-byte halo in lanes 0 and 1 ----
+            u32x2 Hh[2 * U], halo8 = {0, 0};
+            const uint64_t half0 = chunk0 * 2;
+            if (full) {
+#pragma unroll
+                for (int h = 0; h < 2 * U; ++h) Hh[h] = load_half<NTA>(pr.base, half0 + 64 * h + lane);
+                if (!ONE_BYTE && lane < 2) halo8 = load_half<false>(pr.base, half0 + 128 * U + lane);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2 * U; ++h) {
+                    const uint64_t hc = half0 + 64 * h + lane;
+                    Hh[h] = u32x2{0, 0};
+                    if ((hc >> 1) < pr.nchunks_all) Hh[h] = load_half<NTA>(pr.base, hc);
+                }
+                if (!ONE_BYTE && lane < 2 && halo < pr.nchunks_all) halo8 = load_half<false>(pr.base, half0 + 128 * U + lane);
+            }
+            const int stop8 = poll_found(found, pr.epoch);
+            uint32_t any8 = 0;
+            uint32_t wc[2] = {0, 0}, wn[2] = {0, 0};
+            if (!ONE_BYTE) {
+                wc[0] = zero_byte_flags(Hh[0].x ^ pr.nlx4);
+                wc[1] = zero_byte_flags(Hh[0].y ^ pr.nlx4);
+            }
+#pragma unroll
+            for (int h = 0; h < 2 * U; ++h) {
+                if (!ONE_BYTE) {
+                    const u32x2 nx = h + 1 < 2 * U ? Hh[h + 1] : halo8;
+                    wn[0] = zero_byte_flags(nx.x ^ pr.nlx4);
+                    wn[1] = zero_byte_flags(nx.y ^ pr.nlx4);
+                }
+                any8 |= filter_half<Q, ONE_BYTE>(Hh[h], wc, wn, pr);
+                wc[0] = wn[0];
+                wc[1] = wn[1];
+            }
+            if (__ballot((any8 & 0x80808080u) != 0) == 0) {   // nothing in this tile: the common case
+                if (stop8) return;
+                continue;
+            }
+            // candidates: bring the tile into the 16-bytes-per-lane layout for the second phase
+#pragma unroll
+            for (int u = 0; u < U; ++u) A[u] = transpose_halves(Hh[2 * u], Hh[2 * u + 1], lane);
+            if (!ONE_BYTE && lane == kWave - 1 && halo < pr.nchunks_all) H = load_chunk<false>(pr.base, halo);
+            have16 = true;
+        }
+        if (have16) {
+            // A[] and H are in place
+        } else if (full) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 A[u] = load_chunk<NTA>(pr.base, chunk0 + 64 * u + lane);
@@ -477,7 +580,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         }
 
         // ---- phase 2 (rare on random bytes): the wave's "movemask != 0" ---------------------------------
-        if (__ballot((any_tile & 0x80808080u) != 0) != 0) {
+        const bool cand_tile = __ballot((any_tile & 0x80808080u) != 0) != 0;
+        if (L8) dense = cand_tile;      // stay in the 16-byte layout while tiles keep producing candidates
+        if (cand_tile) {
             if (!staged) {
                 stage_needle_wave(s_needle, pr.needle, pr.n, lane);
                 staged = true;
@@ -524,7 +629,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 // ---- K1/K2/K3: one needle, one haystack ---------------------------------------------------------
 // gridDim.x workgroups; workgroup b scans tiles [b*tiles_per_block, (b+1)*tiles_per_block) when
 // tiles_per_block > 0 (contiguous runs, short-lived workgroups), or b, b+grid, ... when it is 0.
-template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false>
+template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false>
 __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *found, uint64_t tiles_per_block)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
@@ -536,7 +641,7 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *fo
         step = 1;
         t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
     }
-    scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND>(pr, s_needle, t0, step, t1, found);
+    scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
 }
 
 #ifdef SS_MISC_KERNELS   // only the API translation unit (sliceslice_hip.hip) compiles what follows

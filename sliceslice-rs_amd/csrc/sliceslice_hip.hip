@@ -188,7 +188,8 @@ void release_slot(const ss_searcher *s, PerDevice *p, int k)
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------
-// variant = 100*MODE + 10*U + NT.  U in {4,8} = pieces (KiB) per wave per tile; NT in {0,1} = plain /
+// variant = 1000*LAYOUT + 100*MODE + 10*U + NT.  LAYOUT 0 = automatic, 1 = 16 bytes per lane throughout,
+// 2 = 8-bytes-per-lane first phase (single-stream kernels).  U in {4,8} = pieces (KiB) per wave per tile; NT in {0,1} = plain /
 // non-temporal first-byte stream; MODE (only meaningful for position >= 16, i.e. d > 0): 0 = automatic,
 // 1 = second load stream, 2 = one stream + cross-lane (ds_bpermute) position flags.  variant 0 = automatic:
 // U = 4; d == 0 -> NT; 0 < d <= kShiftMaxD -> MODE 2 with NT; larger d -> MODE 1 with plain loads (a
@@ -197,19 +198,27 @@ struct Launch {
     int U;
     int nt;
     int mode;   // 0: d == 0, 1: two load streams, 2: shifted flags
+    bool l8;    // 8-bytes-per-lane first phase (mode 0 / one-byte needles)
 };
+
+// Measured (16 GiB, tools/tune.py): the 8-byte first phase is +1.9 % for one-byte needles (7.09 vs 6.97 TB/s)
+// but -0.5 % for 16-byte needles, whose filter needs position flags from two lanes ahead (16 DPP moves per
+// KiB instead of 8).  Automatic choice: one-byte needles only; 2xxx variants force it for tuning.
 
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 64;   // 1 MiB contiguous per workgroup at U = 4 (tools/tune.py sweeps)
 constexpr uint64_t kShiftMaxD = 62;      // d + 1 halo chunks must fit one piece (tools/tune.py: wins up to d = 62)
 
-Launch pick_variant(int variant, uint64_t d)
+Launch pick_variant(int variant, uint64_t d, bool one_byte)
 {
     Launch l;
     l.U = kAutoU;
     l.mode = d == 0 ? 0 : (d <= kShiftMaxD ? 2 : 1);
     l.nt = l.mode == 1 ? 0 : 1;
+    l.l8 = one_byte;
     if (variant > 0) {
+        if (variant >= 1000) l.l8 = variant / 1000 == 2;       // 1xxx: 16-byte layout, 2xxx: 8-byte first phase
+        variant %= 1000;
         const int m = variant / 100, u = (variant / 10) % 10;
         if (u == 4 || u == 8) l.U = u;
         if (d != 0 && m == 1) l.mode = 1;
@@ -223,10 +232,10 @@ Launch pick_variant(int variant, uint64_t d)
 // scan_inst_*.hip translation units, so that the kernel families compile in parallel.
 template <int U>
 void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st,
-                   void *flag, uint64_t tpb)
+                   void *flag, uint64_t tpb, bool l8)
 {
-    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, grid, st, flag, tpb);
-    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, grid, st, flag, tpb);
+    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8);
+    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8);
 }
 
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, OR-ed
@@ -258,7 +267,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.host_flag = host_flag;
     pr.epoch = epoch;
 
-    const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d);
+    const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d, one_byte);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
     uint64_t blocks, tpb;
     if (s->grid > 0) {
@@ -291,12 +300,12 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     const int q = (int)(sh / 4);
     if (find) {   // one tile shape for find(): U = 4
         if (l.U != 4) return fail(SS_ERR_ARGUMENT, "find supports the U = 4 kernels only");
-        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
-        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
+        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false);
+        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false);
     } else if (l.U == 8) {
-        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
+        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8);
     } else {
-        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb);
+        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8);
     }
     HIP_TRY(hipGetLastError());
     if (s->timing) {
