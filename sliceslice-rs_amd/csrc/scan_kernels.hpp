@@ -258,25 +258,34 @@ __device__ __forceinline__ uint32_t next_lane_flags(uint32_t own, uint32_t nword
     return from_next_lane_or(last, own);
 }
 
-// One needle byte at run-time offset K (1..15): flags of needle[K], shifted down by K bytes.
-__device__ __forceinline__ void refine_flags_rt(const u32x4 &A, const NextPiece &np, uint32_t nkx4, int K, uint32_t g[4])
+// One needle byte at offset K = 4*QK + rk (1..15): flags of needle[K], shifted down by K bytes.  QK is a
+// template parameter so that only the window dwords QK .. QK+4 are built (QK+1 next-lane dwords instead
+// of four, no run-time selects); rk is a run-time byte shift.
+template <int QK>
+__device__ __forceinline__ void refine_flags_q(const u32x4 &A, const NextPiece &np, uint32_t nkx4, uint32_t rk, uint32_t g[4])
 {
-    const int qk = K >> 2, rk = K & 3;          // wave-uniform
     uint32_t e[8];
     e[0] = zero_byte_flags(A.x ^ nkx4);
     e[1] = zero_byte_flags(A.y ^ nkx4);
     e[2] = zero_byte_flags(A.z ^ nkx4);
     e[3] = zero_byte_flags(A.w ^ nkx4);
     e[4] = next_lane_flags(e[0], np.N.x, nkx4, np.kind);
-    e[5] = next_lane_flags(e[1], np.N.y, nkx4, np.kind);
-    e[6] = next_lane_flags(e[2], np.N.z, nkx4, np.kind);
-    e[7] = next_lane_flags(e[3], np.N.w, nkx4, np.kind);
-    uint32_t w[5];
+    e[5] = QK >= 1 ? next_lane_flags(e[1], np.N.y, nkx4, np.kind) : 0u;
+    e[6] = QK >= 2 ? next_lane_flags(e[2], np.N.z, nkx4, np.kind) : 0u;
+    e[7] = QK >= 3 ? next_lane_flags(e[3], np.N.w, nkx4, np.kind) : 0u;
 #pragma unroll
-    for (int j = 0; j < 5; ++j)                  // w[j] = e[j + qk]
-        w[j] = qk == 0 ? e[j] : (qk == 1 ? e[j + 1] : (qk == 2 ? e[j + 2] : e[j + 3]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] &= __builtin_amdgcn_alignbyte(w[j + 1], w[j], (uint32_t)rk);
+    for (int j = 0; j < 4; ++j) g[j] &= __builtin_amdgcn_alignbyte(e[j + QK + 1], e[j + QK], rk);
+}
+
+__device__ __forceinline__ void refine_flags_rt(const u32x4 &A, const NextPiece &np, uint32_t nkx4, int K, uint32_t g[4])
+{
+    const uint32_t rk = (uint32_t)(K & 3);
+    switch (K >> 2) {                            // wave-uniform
+    case 0: refine_flags_q<0>(A, np, nkx4, rk, g); break;
+    case 1: refine_flags_q<1>(A, np, nkx4, rk, g); break;
+    case 2: refine_flags_q<2>(A, np, nkx4, rk, g); break;
+    default: refine_flags_q<3>(A, np, nkx4, rk, g); break;
+    }
 }
 
 // Returns false when no lane of the wave has a candidate left.
