@@ -22,13 +22,19 @@
 //   * lane 63's neighbour is lane 0 of the NEXT piece.  A wave owns U consecutive pieces, so that is a
 //     register of the same wave (one DPP wave_rol:1 feeds it in as the `old` operand of the wave_shl);
 //     after the wave's last piece it is a single 16-byte halo chunk loaded by lane 63 alone.
-//   * `__ballot(any flag)` is the wave's movemask; if it is zero (2^-16 per offset on random bytes) the
-//     wave moves on.  Otherwise every flagged lane walks its flags lowest-first (`__ffs`, clear lowest
-//     set bit - lib.rs:220-247) and compares the needle - staged in LDS by the wave the first time it
-//     gets here - with the haystack bytes; the first equal candidate sets the found flag
-//     (lib.rs:242-244).
+//   * position >= 16 (d > 0): MODE 2 keeps ONE non-temporal load stream and fetches the position-byte
+//     flags from the lane that owns chunk c+d with ds_bpermute (d <= 62); MODE 1 (larger d) issues a
+//     second, plain load stream at +d chunks.
+//   * a tile (U pieces per wave) is filtered in one straight-line phase; `__ballot(any flag)` is the wave's
+//     movemask: zero (2^-16 per offset on random bytes) -> next tile.  Otherwise, per piece, a second-level
+//     filter ANDs in the flags of up to 15 more needle bytes, rarest first, still in registers, with a
+//     ballot after each; what survives is walked lowest-first (`__ffs`, clear lowest set bit -
+//     lib.rs:220-247) and compared with the needle - staged in LDS by the wave the first time it gets
+//     here - four bytes per step; the first equal candidate sets the found flag (lib.rs:242-244).
 //   * the found flag is polled once per tile by every wave, so a hit stops the grid early, which is the
-//     reference's early `return true`.
+//     reference's early `return true`.  FIND kernels keep the leftmost match offset instead (atomicMin).
+//   * L8 kernels run the first phase on 8 bytes per lane (dwordx2 loads, +2 % read rate) and transpose
+//     only tiles with candidates into the 16-byte layout (used for one-byte needles).
 //
 // Nothing here depends on block->XCD placement; all inter-workgroup traffic is one relaxed
 // agent-scope int (monotonic 0 -> 1), read with a relaxed agent-scope load.
@@ -363,10 +369,10 @@ __device__ __forceinline__ void stage_needle_wave(uint8_t *s_needle, const uint8
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Scan tiles tile0, tile0+tile_step, ... (< tile_end) of one problem with the calling workgroup.
-// A tile is kWavesPerBlock*U consecutive pieces; wave w owns pieces tile*4U + w*U + u, u = 0..U-1.
-// NTMODE: 0 = plain loads; 1 = non-temporal first-byte stream, plain position-byte stream;
-//         2 = non-temporal for both.  (With a single stream 1 == 2.)
+// scan_tiles (below): scans tiles tile0, tile0+tile_step, ... (< tile_end) of one problem with the calling
+// workgroup.  A tile is kWavesPerBlock*U consecutive pieces; wave w owns pieces tile*4U + w*U + u, u < U.
+// NTMODE: 0 = plain loads; 1 = non-temporal loads (first-byte stream; the position-byte stream of MODE 1
+// stays plain so that its re-read hits).
 // ---- 8-bytes-per-lane first phase (L8) -------------------------------------------------------------------
 // Plain streaming reads run ~2 % faster when a wave instruction covers 512 contiguous bytes (dwordx2 per
 // lane) than 1 KiB (dwordx4) - profiles/r01/readbench_8gib.txt.  The L8 kernels therefore run the two-byte
