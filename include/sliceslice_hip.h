@@ -187,6 +187,11 @@ int ss_comm_allreduce_flag(ss_comm *c, int *d_flag, void *hip_stream, int *found
 int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, ss_comm *c,
                       void *hip_stream, int *found);
 
+/* The same for the leftmost offset: ss_find_device_async with base_offset = shard_begin, then ONE
+ * ncclAllReduce(uint64, ncclMin); *position = SS_NPOS when no rank has a match. */
+int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, uint64_t shard_begin,
+                    ss_comm *c, void *hip_stream, uint64_t *position);
+
 /* Range partition used by every sharded caller: rank r of G scans bytes
  * [r*S, min(len, (r+1)*S + n-1)) with S = ceil(len/G): an overlap of n-1 bytes, so a match that
  * straddles a boundary is seen by exactly the left rank. */

@@ -998,7 +998,9 @@ Rccl *rccl()
 }
 
 constexpr int kNcclInt32 = 2;   // ncclInt32 / ncclInt  (rccl.h ncclDataType_t)
+constexpr int kNcclUint64 = 5;  // ncclUint64
 constexpr int kNcclMax = 2;     // ncclMax              (rccl.h ncclRedOp_t: sum 0, prod 1, max 2, min 3)
+constexpr int kNcclMin = 3;     // ncclMin
 
 int rccl_fail(Rccl *r, int code, const char *what)
 {
@@ -1012,6 +1014,8 @@ struct ss_comm {
     int nranks = 1, rank = 0;
     int *d_flag = nullptr;      // scratch flag for ss_search_sharded
     int *h_flag = nullptr;
+    uint64_t *d_best = nullptr; // scratch offset for ss_find_sharded
+    uint64_t *h_best = nullptr;
 };
 
 extern "C" {
@@ -1043,6 +1047,8 @@ int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank
     c->rank = rank;
     HIP_TRY(hipMalloc((void **)&c->d_flag, sizeof(int)));
     HIP_TRY(hipHostMalloc((void **)&c->h_flag, sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&c->d_best, sizeof(uint64_t)));
+    HIP_TRY(hipHostMalloc((void **)&c->h_best, sizeof(uint64_t), hipHostMallocDefault));
     *out = c;
     return SS_OK;
 }
@@ -1054,6 +1060,8 @@ void ss_comm_free(ss_comm *c)
     if (r && c->comm) r->CommDestroy(c->comm);
     (void)hipFree(c->d_flag);
     (void)hipHostFree(c->h_flag);
+    (void)hipFree(c->d_best);
+    (void)hipHostFree(c->h_best);
     delete c;
 }
 
@@ -1081,6 +1089,24 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
     HIP_TRY(hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
     if (int rc = ss_search_device_async(s, d_shard, shard_len, hip_stream, c->d_flag)) return rc;
     return ss_comm_allreduce_flag(c, c->d_flag, hip_stream, found);
+}
+
+// Sharded find: every rank lowers its uint64 with shard_begin + local offset of its leftmost match, ONE
+// all-reduce(MIN) over uint64 gives the global leftmost offset (SS_NPOS = all ones = absent everywhere).
+int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, uint64_t shard_begin, ss_comm *c,
+                    void *hip_stream, uint64_t *position)
+{
+    if (!s || !c || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemsetAsync(c->d_best, 0xFF, sizeof(uint64_t), st));
+    if (int rc = ss_find_device_async(s, d_shard, shard_len, shard_begin, hip_stream, c->d_best)) return rc;
+    if (int rc = r->AllReduce(c->d_best, c->d_best, 1, kNcclUint64, kNcclMin, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    HIP_TRY(hipMemcpyAsync(c->h_best, c->d_best, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *position = *c->h_best;
+    return SS_OK;
 }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ ABI = {
     "ss_comm_free": (None, [_vp]),
     "ss_comm_allreduce_flag": (_int, [_vp, _vp, _vp, _pint]),
     "ss_search_sharded": (_int, [_vp, _vp, _sz, _vp, _vp, _pint]),
+    "ss_find_sharded": (_int, [_vp, _vp, _sz, _u64, _vp, _vp, ctypes.POINTER(_u64)]),
     "ss_shard_range": (_int, [_sz, _sz, _int, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_last_error": (ctypes.c_char_p, []),
     "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, ctypes.POINTER(_sz)]),
@@ -317,6 +318,12 @@ class ShardedSearcher:
         if self._local_find is not None:                          # CPU tests: injected shard find
             p = self._local_find(shard)
             t = torch.tensor([none if p is None else p + shard_begin], dtype=torch.int64)
+        elif self.backend == "rccl":                              # native: ncclAllReduce(uint64, ncclMin)
+            pos = _u64(0)
+            st = stream if stream is not None else _current_stream_handle()
+            _check(lib().ss_find_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), shard_begin, self._comm, st,
+                                         ctypes.byref(pos)))
+            return None if pos.value == (1 << 64) - 1 else pos.value
         else:
             if self._best is None:
                 self._best = torch.empty(1, dtype=torch.int64, device=shard.device)
