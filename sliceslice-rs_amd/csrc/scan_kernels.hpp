@@ -737,12 +737,19 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
         case 2: scan_tiles<2, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
         default: scan_tiles<3, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
         }
+    } else if (pr.d <= 62) {                        // one stream + cross-lane position flags (MODE 2)
+        switch (q) {
+        case 0: scan_tiles<0, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        case 1: scan_tiles<1, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        case 2: scan_tiles<2, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        default: scan_tiles<3, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        }
     } else {                                        // two streams: plain loads (the re-read must hit)
         switch (q) {
-        case 0: scan_tiles<0, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
-        case 1: scan_tiles<1, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
-        case 2: scan_tiles<2, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
-        default: scan_tiles<3, true, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        case 0: scan_tiles<0, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        case 1: scan_tiles<1, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        case 2: scan_tiles<2, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        default: scan_tiles<3, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
         }
     }
 }

@@ -653,7 +653,8 @@ def test_fuzz_batched_and_pairs_vs_python(ss):
     hays, needles, positions, want = [], [], [], []
     for _ in range(30000):
         alpha = rng.choice([b"ab", b"abc", b"\x00\x01", b"the quick brown fox ", bytes(range(256))])
-        n = rng.choice([0, 1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 33, 64, 100])
+        n = rng.choice([0, 1, 2, 3, 4, 5, 8, 15, 16, 17, 24, 33, 64, 100, 300 if rng.random() < 0.2 else 40,
+                        1100 if rng.random() < 0.1 else 20])
         ln = rng.choice([0, 1, max(n - 1, 0), n, n + 1, n + 7, n + 33, 2 * n + 100, 1500, 20000 if rng.random() < 0.05 else 300])
         hay = bytes(rng.choice(alpha) for _ in range(ln))
         if n and ln >= n and rng.random() < 0.3:

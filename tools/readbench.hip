@@ -151,6 +151,37 @@ __global__ void __launch_bounds__(256) k_read_split(const uint8_t* src, uint64_t
     if (acc == 0x9E3779B9u) sink[0] = acc;
 }
 
+// block -> address map variants: 0 = block b reads run b (linear); 1 = XCD-partitioned: blocks with the same
+// b % 8 (observed: same XCD) read one contiguous eighth of the buffer; 2 = bit-reversed-ish scatter of runs
+template <int MAP>
+__global__ void __launch_bounds__(256) k_read_map(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb)
+{
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_bytes = 4ull * U * 1024;
+    const uint64_t ntiles = nbytes / tile_bytes;
+    const uint64_t nruns = ntiles / tpb;
+    uint64_t run = blockIdx.x;
+    if (MAP == 1) run = (blockIdx.x % 8) * (nruns / 8) + blockIdx.x / 8;
+    if (MAP == 2) run = (blockIdx.x * 2654435761ull) % nruns;      // nruns is a power of two: odd multiplier = bijection
+    if (run >= nruns) return;
+    uint64_t t0 = run * tpb;
+    const uint64_t t1 = t0 + tpb;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; t0 < t1; ++t0) {
+        const uint8_t* base = src + t0 * tile_bytes + (uint64_t)wave * U * 1024;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(U * 1024), 0x00020000);
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)(u * 1024 + lane * 16), 0, 2);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x9E3779B9u) sink[0] = r;
+}
+
 // 16 B/lane, but each load instruction is issued for HALF the wave (512 B per instruction)
 template <int AUX>
 __global__ void __launch_bounds__(256) k_read_half(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb)
@@ -222,6 +253,14 @@ int main(int argc, char** argv)
     uint8_t* d; uint32_t* sink;
     CK(hipMalloc((void**)&d, nbytes + (1 << 20))); CK(hipMalloc((void**)&sink, 64));
     CK(hipMemset(d, 0x5A, nbytes + (1 << 20)));
+    for (int rep = 0; rep < 2; ++rep) {
+        const uint64_t blocks = nbytes / (16ull * 1024) / 64;
+        double m0 = time_ms([&]() { k_read_map<0><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64); }, 7);
+        double m1 = time_ms([&]() { k_read_map<1><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64); }, 7);
+        double m2 = time_ms([&]() { k_read_map<2><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64); }, 7);
+        printf("block->address map: linear %.1f GB/s | XCD-partitioned %.1f GB/s | scattered runs %.1f GB/s\n",
+               nbytes / m0 / 1e6, nbytes / m1 / 1e6, nbytes / m2 / 1e6);
+    }
     run_w<1, 2>("4 B/lane  (uchar4, dword) loads, nt", d, nbytes, sink, 64);
     run_w<2, 2>("8 B/lane  (dwordx2) loads, nt", d, nbytes, sink, 64);
     run_w<4, 2>("16 B/lane (dwordx4) loads, nt", d, nbytes, sink, 64);
