@@ -506,10 +506,8 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 wc[0] = wn[0];
                 wc[1] = wn[1];
             }
-            if (__ballot((any8 & 0x80808080u) != 0) == 0) {   // nothing in this tile: the common case
-                if (stop8) return;
-                continue;
-            }
+            if (stop8) return;                                // somebody has already found the needle
+            if (__ballot((any8 & 0x80808080u) != 0) == 0) continue;   // nothing in this tile: the common case
             // candidates: bring the tile into the 16-bytes-per-lane layout for the second phase
 #pragma unroll
             for (int u = 0; u < U; ++u) A[u] = transpose_halves(Hh[2 * u], Hh[2 * u + 1], lane);
@@ -597,6 +595,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         // ---- phase 2 (rare on random bytes): the wave's "movemask != 0" ---------------------------------
         const bool cand_tile = __ballot((any_tile & 0x80808080u) != 0) != 0;
         if (L8) dense = cand_tile;      // stay in the 16-byte layout while tiles keep producing candidates
+        if (stop) return;               // somebody has already found the needle: no point in verifying more
         if (cand_tile) {
             if (!staged) {
                 stage_needle_wave(s_needle, pr.needle, pr.n, lane);
@@ -629,15 +628,23 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     }
                 }
             }
-            if (!FIND && __ballot(hit) != 0) {
-                if (hit) {
-                    publish_found(found, pr.epoch);
-                    if (pr.host_flag) __hip_atomic_store(pr.host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!FIND) {
+                const uint64_t hits = __ballot(hit);
+                if (hits != 0) {
+                    // ONE lane of the wave publishes, and only the wave that flips the device flag writes the
+                    // pinned-host mirror: a needle that occurs everywhere would otherwise have every wave of
+                    // the grid queue a system-scope store to the same host address (measured: 14 ms for a
+                    // one-byte needle over 1 GiB instead of 0.02 ms).
+                    if (lane == __ffsll((unsigned long long)hits) - 1 &&
+                        __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.epoch) {
+                        const int old = __hip_atomic_exchange(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old != pr.epoch && pr.host_flag)
+                            __hip_atomic_store(pr.host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    return;
                 }
-                return;
             }
         }
-        if (stop) return;
     }
 }
 
