@@ -621,9 +621,11 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                         const int src = __ffsll((unsigned long long)m) - 1;
                         const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)where, src);
                         const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(where >> 32), src);
-                        if (lane == 0)
-                            __hip_atomic_fetch_min(best, pr.find_base + (((uint64_t)hi << 32) | lo), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
+                        const uint64_t mine = pr.find_base + (((uint64_t)hi << 32) | lo);
+                        // only a wave that can actually lower the minimum touches it (matches everywhere
+                        // would otherwise serialise one atomic per wave on a single address)
+                        if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                            __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         return;                         // the wave's later pieces and tiles are further right
                     }
                 }
