@@ -1,0 +1,32 @@
+"""The JSON line bench.py printed on the MI355X (committed under profiles/) carries every field the driver's
+contract names; guards against an accidental change of the output shape.  CPU only."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    with open(os.path.join(ROOT, "profiles", "r01", "bench64g.json")) as fh:
+        d = json.loads(fh.read())
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
+                     ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert key in d and isinstance(d[key], typ), key
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert d["unit"] == "GB/s" and d["dtype"] == "u8" and d["data"] == "synthetic" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] >= 0.99 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "GB/s" and c["cores"] >= 1 and "sample" in c and c["value"] > 0
+    # whole-job value and kernel-only roofline agree within the launch/sync overhead
+    assert 0.9 * r["achieved"] <= d["value"] <= 1.001 * r["achieved"]
+
+
+def test_bench_source_keeps_exactly_one_stdout_line():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.dup2(2, 1)" in src and src.count("os.write(real_stdout") == 1
+    assert "print(" not in src.split("def main():")[1].replace("print(*a, file=sys.stderr", "")

@@ -151,6 +151,33 @@ __global__ void __launch_bounds__(256) k_read_split(const uint8_t* src, uint64_t
     if (acc == 0x9E3779B9u) sink[0] = acc;
 }
 
+// workgroup size study: WAVES waves per workgroup, each wave U KiB per tile, tpb tiles per workgroup
+template <int WAVES, int U>
+__global__ void __launch_bounds__(WAVES * 64) k_read_bs(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_bytes = (uint64_t)WAVES * U * 1024;
+    const uint64_t ntiles = nbytes / tile_bytes;
+    uint64_t t0 = (uint64_t)blockIdx.x * tpb;
+    const uint64_t t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; t0 < t1; ++t0) {
+        const uint8_t* base = src + t0 * tile_bytes + (uint64_t)wave * U * 1024;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(U * 1024), 0x00020000);
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)(u * 1024 + lane * 16), 0, 2);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x9E3779B9u) sink[0] = r;
+}
+
+template <int WAVES, int U>
+static void run_bs(const uint8_t* d, uint64_t nbytes, uint32_t* sink, uint64_t run_bytes);
+
 // block -> address map variants: 0 = block b reads run b (linear); 1 = XCD-partitioned: blocks with the same
 // b % 8 (observed: same XCD) read one contiguous eighth of the buffer; 2 = bit-reversed-ish scatter of runs
 template <int MAP>
@@ -246,6 +273,18 @@ static void run_w(const char* name, const uint8_t* d, uint64_t nbytes, uint32_t*
     fflush(stdout);
 }
 
+template <int WAVES, int U>
+static void run_bs(const uint8_t* d, uint64_t nbytes, uint32_t* sink, uint64_t run_bytes)
+{
+    const uint64_t tile_bytes = (uint64_t)WAVES * U * 1024;
+    const uint64_t tpb = run_bytes / tile_bytes;
+    const uint64_t blocks = (nbytes / tile_bytes + tpb - 1) / tpb;
+    double ms = time_ms([&]() { k_read_bs<WAVES, U><<<dim3((unsigned)blocks), dim3(WAVES * 64)>>>(d, nbytes, sink, tpb); }, 7);
+    printf("workgroup %4d threads, %d KiB/wave/tile, %4llu KiB runs: %8.1f GB/s\n", WAVES * 64, U,
+           (unsigned long long)(run_bytes >> 10), nbytes / ms / 1e6);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv)
 {
     const double gib = argc > 1 ? atof(argv[1]) : 8.0;
@@ -253,6 +292,17 @@ int main(int argc, char** argv)
     uint8_t* d; uint32_t* sink;
     CK(hipMalloc((void**)&d, nbytes + (1 << 20))); CK(hipMalloc((void**)&sink, 64));
     CK(hipMemset(d, 0x5A, nbytes + (1 << 20)));
+    for (uint64_t run : {256ull << 10, 1024ull << 10}) {
+        run_bs<1, 4>(d, nbytes, sink, run);
+        run_bs<2, 4>(d, nbytes, sink, run);
+        run_bs<4, 4>(d, nbytes, sink, run);
+        run_bs<8, 4>(d, nbytes, sink, run);
+        run_bs<16, 4>(d, nbytes, sink, run);
+        run_bs<4, 2>(d, nbytes, sink, run);
+        run_bs<8, 2>(d, nbytes, sink, run);
+        run_bs<4, 8>(d, nbytes, sink, run);
+        run_bs<2, 8>(d, nbytes, sink, run);
+    }
     for (int rep = 0; rep < 2; ++rep) {
         const uint64_t blocks = nbytes / (16ull * 1024) / 64;
         double m0 = time_ms([&]() { k_read_map<0><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64); }, 7);
