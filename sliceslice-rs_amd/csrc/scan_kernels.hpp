@@ -665,6 +665,14 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *fo
         step = 1;
         t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
     }
+    // Long-lived workgroups (>= 16 tiles each, i.e. haystacks of 8 GiB and more) that are dispatched after the
+    // first few thousand look at the flag BEFORE they load anything: once a match is known the rest of the
+    // grid drains without touching memory (match at offset 0 of 1 GiB: 0.084 -> 0.026 ms in the experiment).
+    // The ~1 us this costs such a workgroup is invisible next to its ~35 us of streaming; short-lived
+    // workgroups (small haystacks) skip it - there it cost 1.5 % of a full scan.
+    if (!FIND && tiles_per_block >= 16 && blockIdx.x >= 4096 &&
+        poll_found(static_cast<const int *>(found), pr.epoch))
+        return;
     scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
 }
 
