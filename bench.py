@@ -117,7 +117,9 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
-    ap.add_argument("--ceiling", action="store_true", help="also measure the plain streaming-read ceiling")
+    ap.add_argument("--no-ceiling", action="store_true",
+                    help="skip the plain streaming-read ceiling (roofline.read_ceiling_gbps; a few launches, untimed)")
+    ap.add_argument("--ceiling", action="store_true", help="(default now) kept for compatibility")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,7 +193,7 @@ def main():
         elapsed = float(t.item())
 
     ceiling = None
-    if args.ceiling and rank == 0:
+    if not args.no_ceiling and rank == 0:
         ceiling = ss.read_ceiling_gbps(shard[: (shard.numel() // 16) * 16], reps=5)
 
     if rank == 0:
