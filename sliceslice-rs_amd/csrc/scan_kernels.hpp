@@ -42,6 +42,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace ss {
 
 constexpr int kWave = 64;
@@ -514,82 +516,92 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             if (!ONE_BYTE && lane == kWave - 1 && halo < pr.nchunks_all) H = load_chunk<false>(pr.base, halo);
             have16 = true;
         }
-        if (have16) {
-            // A[] and H are in place
-        } else if (full) {
+        // Loads + phase 1 are instantiated once per load shape (in place after the L8 transposition /
+        // unconditional / predicated tail) so that the common, unconditional copy gets exact s_waitcnt
+        // vmcnt(k) values: with the shapes merged at a control-flow join the compiler waited for ALL loads
+        // of the tile before the first flag computation.
+        uint32_t G[U][4];
+        uint32_t any_tile = 0;
+        int stop = 0;
+        auto load_and_filter = [&](auto loaded_c, auto full_c) {
+            constexpr bool LOADED = decltype(loaded_c)::value, FULL = decltype(full_c)::value;
+            if constexpr (!LOADED && FULL) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                A[u] = load_chunk<NTA>(pr.base, chunk0 + 64 * u + lane);
-                if (TWO) B[u] = load_chunk<NTB>(pr.base, chunk0 + 64 * u + lane + pr.d);
-            }
-            if (SHIFTED) {
-                if (lane <= d) H = load_chunk<false>(pr.base, chunk0 + 64 * U + lane);
-            } else if (!ONE_BYTE && lane == kWave - 1) {
-                H = load_chunk<false>(pr.base, halo);
-            }
-        } else {
+                for (int u = 0; u < U; ++u) {
+                    A[u] = load_chunk<NTA>(pr.base, chunk0 + 64 * u + lane);
+                    if (TWO) B[u] = load_chunk<NTB>(pr.base, chunk0 + 64 * u + lane + pr.d);
+                }
+                if (SHIFTED) {
+                    if (lane <= d) H = load_chunk<false>(pr.base, chunk0 + 64 * U + lane);
+                } else if (!ONE_BYTE && lane == kWave - 1) {
+                    H = load_chunk<false>(pr.base, halo);
+                }
+            } else if constexpr (!LOADED) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint64_t c = chunk0 + 64 * u + lane;
-                A[u] = u32x4{0, 0, 0, 0};
-                if (c < pr.nchunks_all) A[u] = load_chunk<NTA>(pr.base, c);
-                if (TWO) {
-                    B[u] = u32x4{0, 0, 0, 0};
-                    if (c + pr.d < pr.nchunks_all) B[u] = load_chunk<NTB>(pr.base, c + pr.d);
+                for (int u = 0; u < U; ++u) {
+                    const uint64_t c = chunk0 + 64 * u + lane;
+                    A[u] = u32x4{0, 0, 0, 0};
+                    if (c < pr.nchunks_all) A[u] = load_chunk<NTA>(pr.base, c);
+                    if (TWO) {
+                        B[u] = u32x4{0, 0, 0, 0};
+                        if (c + pr.d < pr.nchunks_all) B[u] = load_chunk<NTB>(pr.base, c + pr.d);
+                    }
+                }
+                if (SHIFTED) {
+                    if (lane <= d && chunk0 + 64 * U + lane < pr.nchunks_all) H = load_chunk<false>(pr.base, chunk0 + 64 * U + lane);
+                } else if (!ONE_BYTE && lane == kWave - 1 && halo < pr.nchunks_all) {
+                    H = load_chunk<false>(pr.base, halo);
                 }
             }
-            if (SHIFTED) {
-                if (lane <= d && chunk0 + 64 * U + lane < pr.nchunks_all) H = load_chunk<false>(pr.base, chunk0 + 64 * U + lane);
-            } else if (!ONE_BYTE && lane == kWave - 1 && halo < pr.nchunks_all) {
-                H = load_chunk<false>(pr.base, halo);
+            // the poll is issued behind the data loads and consumed after them
+            stop = FIND ? 0 : poll_found(found, pr.epoch);
+
+            // ---- phase 1: the two-byte filter for all U pieces, straight-line (loads are consumed in order) ----
+            uint32_t wcur[4] = {0, 0, 0, 0}, wnext[4] = {0, 0, 0, 0}, wlast[4] = {0, 0, 0, 0};
+            if (!ONE_BYTE) position_flags(TWO ? B[0] : A[0], pr.nlx4, wcur);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t *g = G[u];
+                if (SHIFTED) {
+                    // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
+                    position_flags(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
+                    uint32_t x[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        x[j] = (j >= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d) : 0u;
+                        x[4 + j] = (j <= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d + 1) : 0u;
+                    }
+                    g[0] = zero_byte_flags(A[u].x ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r);
+                    g[1] = zero_byte_flags(A[u].y ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r);
+                    g[2] = zero_byte_flags(A[u].z ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r);
+                    g[3] = zero_byte_flags(A[u].w ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r);
+                } else {
+                    if (!ONE_BYTE) {
+                        // lane 63's "next lane": lane 0 of the next piece, or the halo chunk after the last piece
+                        if (u + 1 < U) {
+                            position_flags(TWO ? B[u + 1] : A[u + 1], pr.nlx4, wnext);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) wlast[j] = (j <= Q) ? rotate_from_next_lane(wnext[j]) : 0u;
+                        } else {
+                            position_flags(H, pr.nlx4, wlast);
+                        }
+                    }
+                    filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
+                }
+                any_tile |= g[0] | g[1] | g[2] | g[3];
+                if (!ONE_BYTE && (SHIFTED || u + 1 < U)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wcur[j] = wnext[j];
+                }
             }
-        }
-        // issued behind the data loads, consumed after them
-        const int stop = FIND ? 0 : poll_found(found, pr.epoch);
+
+        };
+        if (have16) load_and_filter(std::true_type{}, std::true_type{});
+        else if (full) load_and_filter(std::false_type{}, std::true_type{});
+        else load_and_filter(std::false_type{}, std::false_type{});
         if (FIND) {
             const uint64_t first = chunk0 * 16 > pr.mis ? chunk0 * 16 - pr.mis : 0;   // lowest index this wave can report
             if (best_now <= pr.find_base + first) return;                               // all of it lies right of a match
-        }
-
-        // ---- phase 1: the two-byte filter for all U pieces, straight-line (loads are consumed in order) ----
-        uint32_t G[U][4];
-        uint32_t any_tile = 0;
-        uint32_t wcur[4] = {0, 0, 0, 0}, wnext[4] = {0, 0, 0, 0}, wlast[4] = {0, 0, 0, 0};
-        if (!ONE_BYTE) position_flags(TWO ? B[0] : A[0], pr.nlx4, wcur);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t *g = G[u];
-            if (SHIFTED) {
-                // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
-                position_flags(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
-                uint32_t x[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    x[j] = (j >= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d) : 0u;
-                    x[4 + j] = (j <= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d + 1) : 0u;
-                }
-                g[0] = zero_byte_flags(A[u].x ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r);
-                g[1] = zero_byte_flags(A[u].y ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r);
-                g[2] = zero_byte_flags(A[u].z ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r);
-                g[3] = zero_byte_flags(A[u].w ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r);
-            } else {
-                if (!ONE_BYTE) {
-                    // lane 63's "next lane": lane 0 of the next piece, or the halo chunk after the last piece
-                    if (u + 1 < U) {
-                        position_flags(TWO ? B[u + 1] : A[u + 1], pr.nlx4, wnext);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) wlast[j] = (j <= Q) ? rotate_from_next_lane(wnext[j]) : 0u;
-                    } else {
-                        position_flags(H, pr.nlx4, wlast);
-                    }
-                }
-                filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
-            }
-            any_tile |= g[0] | g[1] | g[2] | g[3];
-            if (!ONE_BYTE && (SHIFTED || u + 1 < U)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wcur[j] = wnext[j];
-            }
         }
 
         // ---- phase 2 (rare on random bytes): the wave's "movemask != 0" ---------------------------------
