@@ -9,6 +9,21 @@
 #include <algorithm>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename F>
+static double time_ms_fwd(F launch)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    launch(); (void)hipDeviceSynchronize();
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return best;
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 // AUX: cache policy for raw buffer loads on gfx94x/950: bit0 sc0, bit1 nt, bit4 sc1
@@ -89,6 +104,50 @@ __global__ void __launch_bounds__(256) k_filter_w(const uint8_t* src, uint64_t n
         if (__ballot((any & 0x80808080u) != 0)) hits += 1;
     }
     if (hits == 0x9E3779B9u) sink[0] = hits;
+}
+
+// VALU/DPP sensitivity: 16 B/lane loads + NV plain VALU ops and ND wave_shl DPP moves per 16 bytes
+template <int NV, int ND>
+__global__ void __launch_bounds__(256) k_valu(const uint8_t* src, uint64_t nbytes, uint32_t* sink, uint64_t tpb, uint32_t k)
+{
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t tile_bytes = 4ull * U * 1024;
+    const uint64_t ntiles = nbytes / tile_bytes;
+    uint64_t t0 = (uint64_t)blockIdx.x * tpb;
+    const uint64_t t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+    uint32_t acc = 0;
+    for (; t0 < t1; ++t0) {
+        const uint8_t* base = src + t0 * tile_bytes + (uint64_t)wave * U * 1024;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(U * 1024), 0x00020000);
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)(u * 1024 + lane * 16), 0, 2);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t x = v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) x = (x ^ k) + 0x01010101u * (i + 1);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) x = shl1(x) ^ k;
+            acc |= x;
+        }
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
+template <int NV, int ND>
+static void run_valu(const uint8_t* d, uint64_t nbytes, uint32_t* sink)
+{
+    const uint64_t blocks = nbytes / (16ull * 1024) / 64;
+    double best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        double ms = time_ms_fwd([&]() { k_valu<NV, ND><<<dim3((unsigned)blocks), dim3(256)>>>(d, nbytes, sink, 64, 0x5a5a5a5au); });
+        if (ms < best) best = ms;
+    }
+    printf("16 B/lane nt loads + %2d VALU + %2d DPP per 16 B: %8.1f GB/s\n", 2 * NV + 3, ND, nbytes / best / 1e6);
+    fflush(stdout);
 }
 
 // load width: W = 1, 2, 4 dwords per lane per load (uchar4 / 8 B / 16 B); the same bytes per wave-tile
@@ -292,6 +351,16 @@ int main(int argc, char** argv)
     uint8_t* d; uint32_t* sink;
     CK(hipMalloc((void**)&d, nbytes + (1 << 20))); CK(hipMalloc((void**)&sink, 64));
     CK(hipMemset(d, 0x5A, nbytes + (1 << 20)));
+    run_valu<0, 0>(d, nbytes, sink);
+    run_valu<4, 0>(d, nbytes, sink);
+    run_valu<10, 0>(d, nbytes, sink);
+    run_valu<20, 0>(d, nbytes, sink);
+    run_valu<40, 0>(d, nbytes, sink);
+    run_valu<4, 2>(d, nbytes, sink);
+    run_valu<4, 4>(d, nbytes, sink);
+    run_valu<4, 8>(d, nbytes, sink);
+    run_valu<4, 16>(d, nbytes, sink);
+    run_valu<0, 0>(d, nbytes, sink);
     for (uint64_t run : {256ull << 10, 1024ull << 10}) {
         run_bs<1, 4>(d, nbytes, sink, run);
         run_bs<2, 4>(d, nbytes, sink, run);
