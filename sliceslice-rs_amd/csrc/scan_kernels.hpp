@@ -296,15 +296,21 @@ __device__ __forceinline__ void refine_flags_rt(const u32x4 &A, const NextPiece 
     }
 }
 
+// The second-level filter's schedule (Problem::norder / order_idx / order_val), as the wave holds it.
+struct RefineOrder {
+    uint32_t n;
+    uint64_t idx[2], val[2];
+};
+
 // Returns false when no lane of the wave has a candidate left.
-__device__ __forceinline__ bool refine_staged(const u32x4 &A, const NextPiece &np, const Problem &pr, uint32_t g[4])
+__device__ __forceinline__ bool refine_staged(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4])
 {
     bool any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
 #pragma unroll 1
-    for (uint32_t t = 0; t < pr.norder && any; ++t) {
+    for (uint32_t t = 0; t < ro.n && any; ++t) {
         const uint32_t sh = 8 * (t & 7);
-        const int K = (int)(((t < 8 ? pr.order_idx[0] : pr.order_idx[1]) >> sh) & 0xFF);
-        const uint32_t v = (uint32_t)(((t < 8 ? pr.order_val[0] : pr.order_val[1]) >> sh) & 0xFF);
+        const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
+        const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
         refine_flags_rt(A, np, 0x01010101u * v, K, g);
         any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
     }
@@ -338,6 +344,13 @@ __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk
         }
     }
     return hit;
+}
+
+// tells the compiler that a 64-bit value is wave-uniform (SGPR pair)
+__device__ __forceinline__ uint64_t uniform64(uint64_t x)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
 }
 
 __device__ __forceinline__ int poll_found(const int *found, int epoch)
@@ -446,7 +459,9 @@ __device__ __forceinline__ uint32_t from_lane_ahead(uint32_t cur, uint32_t nxt, 
 // FIND = false: `sink` is the int found flag (0 -> 1).  FIND = true: `sink` is the uint64 leftmost-match
 // offset (row f1 of SURVEY.md 8f: the `Option<usize>` shape of tests/i386.rs:6-10 and
 // bench/sse4-strstr/src/lib.rs:4-15); a wave only skips work that lies to the RIGHT of the best so far.
-template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false>
+// LAZY_ORDER (batched kernel): the descriptor arrives without the second-level schedule; a wave builds it
+// when it first meets a candidate, next to staging the needle - not on every workgroup's way in.
+template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_block, uint64_t tile0,
                                            uint64_t tile_step, uint64_t tile_end, void *sink)
 {
@@ -461,6 +476,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
     bool staged = false;
+    RefineOrder ro = {pr.norder, {pr.order_idx[0], pr.order_idx[1]}, {pr.order_val[0], pr.order_val[1]}};
     bool dense = false;                                                     // L8: the previous tile had candidates
     const int d = (int)pr.d;                                                // SHIFTED: 1 <= d <= 62
 
@@ -611,6 +627,15 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         if (cand_tile) {
             if (!staged) {
                 stage_needle_wave(s_needle, pr.needle, pr.n, lane);
+                if (LAZY_ORDER && !ONE_BYTE) {
+                    const uint64_t position = pr.d * 16 + 4 * Q + pr.r;
+                    ro.n = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)build_refine_order_wave(pr.needle, pr.n, position, lane, ro.idx, ro.val));
+                    for (int t = 0; t < 2; ++t) {
+                        ro.idx[t] = uniform64(ro.idx[t]);
+                        ro.val[t] = uniform64(ro.val[t]);
+                    }
+                }
                 staged = true;
             }
             bool hit = false;
@@ -622,7 +647,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 np.N = u + 1 < U ? A[u + 1] : H;
                 np.kind = u + 1 < U ? 1 : (MODE == 0 ? 0 : (MODE == 2 ? 1 : 2));
                 const bool left = ONE_BYTE ? (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0)
-                                           : refine_staged(A[u], np, pr, g);
+                                           : refine_staged(A[u], np, ro, g);
                 if (!left) continue;
                 uint64_t where = 0;
                 const bool h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, s_needle, where);
@@ -691,8 +716,10 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *fo
 #ifdef SS_MISC_KERNELS   // only the API translation unit (sliceslice_hip.hip) compiles what follows
 
 // ---- K4: batched, one grid for many (needle, haystack) problems ----------------------------------
-// blockIdx.y = problem, blockIdx.x = slice of that problem's tiles.  Per-problem flags, no
-// cross-problem early exit.  The problem descriptor is built per workgroup from the range arrays
+// blockIdx.x = problem, blockIdx.y = slice of that problem's tiles: the workgroups of slice 0 of every
+// problem are dispatched before any of slice 1, so when the needles are present early (the reference's
+// i386 loop: every word occurs in the text) the later slices find the flag set on entry and leave - the
+// sequential scan's early exit survives the slicing.  Per-problem flags, no cross-problem early exit.  The problem descriptor is built per workgroup from the range arrays
 // (begin[i], end[i]) - CSR callers pass (off, off + 1); ranges may alias (many needles, one haystack).
 struct BatchArgs {
     const uint8_t *haystacks;
@@ -707,78 +734,77 @@ template <int U>
 __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
-    const uint64_t prob = blockIdx.y;
+    const uint64_t prob = blockIdx.x;
+    const uint32_t slice = blockIdx.y, nslices = gridDim.y;
+    if (slice != 0 && poll_found(a.found + prob, 1)) return;
     const uint64_t h0 = a.hay_begin[prob], h1 = a.hay_end[prob];
     const uint64_t n0 = a.needle_begin[prob], n1 = a.needle_end[prob];
     const uint64_t len = h1 - h0, n = n1 - n0;
     int *found = a.found + prob;
     if (n == 0) {                                   // N0: found everywhere (x86.rs:500)
-        if (blockIdx.x == 0 && threadIdx.x == 0) publish_found(found);
+        if (slice == 0 && threadIdx.x == 0) publish_found(found);
         return;
     }
     if (len < n) return;                            // flag stays 0
     uint64_t position = a.position ? a.position[prob] : n - 1;
     if (position >= n) position = n - 1;            // validated on the host when it can be; never UB here
 
-    // every field below is wave-uniform; readfirstlane tells the compiler so (SGPRs, no scratch)
-    auto uni64 = [](uint64_t x) {
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
-               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
-    };
+    // every field below is wave-uniform; uniform64 tells the compiler so (SGPRs, no scratch)
     Problem pr;
-    pr.hay = a.haystacks + uni64(h0);
+    pr.hay = a.haystacks + uniform64(h0);
     pr.mis = (uint32_t)((uintptr_t)pr.hay & 15);
     pr.base = pr.hay - pr.mis;
-    pr.needle = a.needles + uni64(n0);
-    pr.n = uni64(n);
-    pr.end = uni64(len - n + 1);
-    pr.nchunks_all = (pr.mis + uni64(len) + 15) / 16;
+    pr.n = uniform64(n);
+    pr.end = uniform64(len - n + 1);
+    pr.nchunks_all = (pr.mis + uniform64(len) + 15) / 16;
     pr.npieces = ((pr.mis + pr.end + 15) / 16 + 63) / 64;
-    position = uni64(position);
+    // contiguous run of tiles per slice (same launch shape as the single-problem kernel); surplus slices
+    // of a short haystack leave before anything that depends on the needle is loaded
+    const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+    const uint64_t per = (ntiles + nslices - 1) / nslices;
+    const uint64_t t0 = (uint64_t)slice * per;
+    const uint64_t te = t0 + per < ntiles ? t0 + per : ntiles;
+    if (t0 >= te) return;
+
+    pr.needle = a.needles + uniform64(n0);
+    position = uniform64(position);
     pr.d = position / 16;
     const uint32_t s = (uint32_t)(position % 16);
     pr.r = s % 4;
     pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[0]);
     pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[position]);
-    pr.norder = build_refine_order_wave(pr.needle, pr.n, position, threadIdx.x & (kWave - 1), pr.order_idx, pr.order_val);
-    pr.order_idx[0] = uni64(pr.order_idx[0]); pr.order_idx[1] = uni64(pr.order_idx[1]);
-    pr.order_val[0] = uni64(pr.order_val[0]); pr.order_val[1] = uni64(pr.order_val[1]);
-    pr.norder = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.norder);
+    // the second-level schedule is built lazily by the waves that need it (scan_tiles<..., LAZY_ORDER>)
+    pr.norder = 0;
+    pr.order_idx[0] = pr.order_idx[1] = pr.order_val[0] = pr.order_val[1] = 0;
     pr.find_base = 0;
     pr.host_flag = nullptr;
     pr.epoch = 1;
 
-    // contiguous run of tiles per slice (same launch shape as the single-problem kernel)
-    const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
-    const uint64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * per;
-    const uint64_t te = t0 + per < ntiles ? t0 + per : ntiles;
-    if (t0 >= te) return;
     if (n == 1) {
-        scan_tiles<0, false, true, U, 1>(pr, s_needle, t0, 1, te, found);
+        scan_tiles<0, 0, true, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found);
         return;
     }
     const int q = (int)(s / 4);
     if (pr.d == 0) {                                // single stream: non-temporal loads
         switch (q) {
-        case 0: scan_tiles<0, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
-        case 1: scan_tiles<1, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
-        case 2: scan_tiles<2, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
-        default: scan_tiles<3, false, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
         }
     } else if (pr.d <= 62) {                        // one stream + cross-lane position flags (MODE 2)
         switch (q) {
-        case 0: scan_tiles<0, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
-        case 1: scan_tiles<1, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
-        case 2: scan_tiles<2, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
-        default: scan_tiles<3, 2, false, U, 1>(pr, s_needle, t0, 1, te, found); break;
+        case 0: scan_tiles<0, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        case 1: scan_tiles<1, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        case 2: scan_tiles<2, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        default: scan_tiles<3, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
         }
     } else {                                        // two streams: plain loads (the re-read must hit)
         switch (q) {
-        case 0: scan_tiles<0, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
-        case 1: scan_tiles<1, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
-        case 2: scan_tiles<2, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
-        default: scan_tiles<3, 1, false, U, 0>(pr, s_needle, t0, 1, te, found); break;
+        case 0: scan_tiles<0, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        case 1: scan_tiles<1, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        case 2: scan_tiles<2, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+        default: scan_tiles<3, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
         }
     }
 }

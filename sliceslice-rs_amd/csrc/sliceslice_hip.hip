@@ -807,27 +807,23 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     DeviceInfo di;
     if (int rc = device_info(dev, &di)) return rc;
     HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
-    // enough slices per problem to fill the chip even for a handful of problems (>= 16 workgroups per CU
-    // in total); each slice scans a contiguous run of its problem's tiles.
-    uint64_t slices = ((uint64_t)di.cus * 16 + count - 1) / count;
+    // The haystack lengths live on the device, so the grid is chosen from the problem count alone: about
+    // half as many workgroups in total as the single-problem kernel launches (64 per CU; short-lived workgroups
+    // that each scan a contiguous run of their problem's tiles balance the tail better than one long-lived
+    // workgroup per problem).  Surplus slices of short haystacks exit before touching the needle.
+    // SLICESLICE_BATCH_WGS overrides the total (tuning aid).
+    uint64_t wg_target = (uint64_t)di.cus * 64;
+    if (const char *e = getenv("SLICESLICE_BATCH_WGS")) {
+        const long v = atol(e);
+        if (v > 0) wg_target = (uint64_t)v;
+    }
+    uint64_t slices = (wg_target + count - 1) / count;
     if (slices < 1) slices = 1;
     if (slices > 4096) slices = 4096;
-    // gridDim.y is limited to 65535: larger counts are launched in bands.
-    size_t done = 0;
-    while (done < count) {
-        const size_t band = count - done < 65535 ? count - done : 65535;
-        ss::BatchArgs b = a;
-        b.hay_begin += done;
-        b.hay_end += done;
-        b.needle_begin += done;
-        b.needle_end += done;
-        if (b.position) b.position += done;
-        b.found += done;
-        dim3 grid((unsigned)slices, (unsigned)band);
-        ss::scan_batched_kernel<4><<<grid, dim3(ss::kBlock), 0, st>>>(b);
-        HIP_TRY(hipGetLastError());
-        done += band;
-    }
+    if (count > 0x7fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
+    if (slices > 65535) slices = 65535;
+    ss::scan_batched_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
     return SS_OK;
 }
 
