@@ -365,13 +365,6 @@ __device__ __forceinline__ void publish_found(int *found, int epoch = 1)
 }
 
 // FIND kernels keep the leftmost match offset in one uint64 (all-ones = none yet), lowered by atomicMin.
-__device__ __forceinline__ uint64_t poll_best(const uint64_t *best)
-{
-    const uint64_t v = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
 
 // Per-wave lazy staging of the needle into the wave's private LDS slice (no workgroup barrier: the DS
 // operations of one wave execute in order).
@@ -483,8 +476,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     for (uint64_t tile = tile0; tile < tile_end; tile += tile_step) {
         u32x4 A[U], B[U], H = {0, 0, 0, 0};
         const uint64_t chunk0 = (tile * (kWavesPerBlock * U) + (uint64_t)wave * U) * 64;   // wave-uniform
-        // FIND polls first (oldest load, so waiting for it does not drain the data loads behind it)
-        const uint64_t best_now = FIND ? poll_best(best) : 0;
+        // FIND polls first (oldest load, so waiting for it does not drain the data loads behind it); the value
+        // is only made wave-uniform (readfirstlane = the wait) after the tile's data loads have been issued
+        const uint64_t best_raw = FIND ? __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        uint64_t best_now = 0;
         // last chunk this wave touches: the halo chunk (MODE 0/1) or the d+1 halo chunks (MODE 2)
         const uint64_t halo = chunk0 + 64 * U + pr.d;
         const bool full = halo < pr.nchunks_all;
@@ -571,6 +566,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             }
             // the poll is issued behind the data loads and consumed after them
             stop = FIND ? 0 : poll_found(found, pr.epoch);
+            if (FIND) best_now = uniform64(best_raw);
 
             // ---- phase 1: the two-byte filter for all U pieces, straight-line (loads are consumed in order) ----
             uint32_t wcur[4] = {0, 0, 0, 0}, wnext[4] = {0, 0, 0, 0}, wlast[4] = {0, 0, 0, 0};
