@@ -398,22 +398,30 @@ __device__ __forceinline__ u32x2 load_half(const uint8_t *base, uint64_t half_ch
     return *p;
 }
 
-// a = this lane's 8 bytes; w = their position-byte flags; nw = position-byte flags of the NEXT half-piece
-// (lanes 0 and 1 of it are what lanes 62/63 see two lanes ahead).  position = 4*Q + r < 16.
+// Two-byte filter of one half-piece on raw byte differences.  a = this lane's 8 bytes; t = a ^ needle[position]
+// (zero bytes where the position byte matches); tn = the same of the NEXT half-piece, whose lanes 0 and 1 are
+// what lanes 62/63 see one and two lanes ahead (position = 4*Q + r < 16 reaches at most 15 + 7 bytes on).
+// The position-byte differences are brought `position` bytes down the stream (ds_bpermute for the lanes
+// ahead - the LDS crossbar, not the VALU - and v_alignbyte for the byte part) and OR-ed onto the
+// first-byte differences: a byte of the result is zero exactly where both filter bytes match, so ONE
+// zero-byte test per dword replaces two tests and an AND.  Returns acc | flags (bit 7 of candidate bytes).
 template <int Q, bool ONE_BYTE>
-__device__ __forceinline__ uint32_t filter_half(const u32x2 &a, const uint32_t w[2], const uint32_t nw[2], const Problem &pr)
+__device__ __forceinline__ uint32_t filter_half(const u32x2 &a, const u32x2 &t, const u32x2 &tn, const Problem &pr,
+                                                int lane, uint32_t acc)
 {
-    const uint32_t f0 = zero_byte_flags(a.x ^ pr.n0x4), f1 = zero_byte_flags(a.y ^ pr.n0x4);
-    if (ONE_BYTE) return f0 | f1;
-    // dword stream relative to this lane: x[0..1] this lane, x[2..3] next lane, x[4..5] the lane after
-    uint32_t x[6] = {w[0], w[1], 0, 0, 0, 0};
-    constexpr bool n2 = Q <= 2, n3 = Q >= 1, n4 = Q >= 2, n5 = Q >= 3;       // stream dwords Q .. Q+2 are used
-    uint32_t r0 = 0, r1 = 0;
-    if (n2 || n4) { r0 = rotate_from_next_lane(nw[0]); x[2] = from_next_lane_or(r0, w[0]); }
-    if (n3 || n5) { r1 = rotate_from_next_lane(nw[1]); x[3] = from_next_lane_or(r1, w[1]); }
-    if (n4) x[4] = from_next_lane_or(rotate_from_next_lane(r0), x[2]);
-    if (n5) x[5] = from_next_lane_or(rotate_from_next_lane(r1), x[3]);
-    return (f0 & __builtin_amdgcn_alignbyte(x[Q + 1], x[Q], pr.r)) | (f1 & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r));
+    const uint32_t d0 = a.x ^ pr.n0x4, d1 = a.y ^ pr.n0x4;
+    if (ONE_BYTE) return acc | zero_byte_flags(d0) | zero_byte_flags(d1);
+    // dword stream relative to this lane: x[0..1] this lane, x[2..3] next lane, x[4..5] the lane after;
+    // stream dwords Q .. Q+2 are used
+    uint32_t x[6] = {t.x, t.y, 0, 0, 0, 0};
+    const int i1 = ((lane + 1) & (kWave - 1)) << 2, i2 = ((lane + 2) & (kWave - 1)) << 2;
+    if (Q <= 2) x[2] = (uint32_t)__builtin_amdgcn_ds_bpermute(i1, (int)(lane < 1 ? tn.x : t.x));
+    if (Q >= 1) x[3] = (uint32_t)__builtin_amdgcn_ds_bpermute(i1, (int)(lane < 1 ? tn.y : t.y));
+    if (Q >= 2) x[4] = (uint32_t)__builtin_amdgcn_ds_bpermute(i2, (int)(lane < 2 ? tn.x : t.x));
+    if (Q >= 3) x[5] = (uint32_t)__builtin_amdgcn_ds_bpermute(i2, (int)(lane < 2 ? tn.y : t.y));
+    const uint32_t c0 = d0 | __builtin_amdgcn_alignbyte(x[Q + 1], x[Q], pr.r);
+    const uint32_t c1 = d1 | __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r);
+    return acc | zero_byte_flags(c0) | zero_byte_flags(c1);
 }
 
 // two half-pieces (lo = bytes 0..511, hi = bytes 512..1023 of a piece, 8 bytes per lane) -> the piece in
@@ -503,21 +511,15 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             }
             const int stop8 = poll_found(found, pr.epoch);
             uint32_t any8 = 0;
-            uint32_t wc[2] = {0, 0}, wn[2] = {0, 0};
-            if (!ONE_BYTE) {
-                wc[0] = zero_byte_flags(Hh[0].x ^ pr.nlx4);
-                wc[1] = zero_byte_flags(Hh[0].y ^ pr.nlx4);
-            }
+            u32x2 tc = {Hh[0].x ^ pr.nlx4, Hh[0].y ^ pr.nlx4}, tn = {0, 0};
 #pragma unroll
             for (int h = 0; h < 2 * U; ++h) {
                 if (!ONE_BYTE) {
                     const u32x2 nx = h + 1 < 2 * U ? Hh[h + 1] : halo8;
-                    wn[0] = zero_byte_flags(nx.x ^ pr.nlx4);
-                    wn[1] = zero_byte_flags(nx.y ^ pr.nlx4);
+                    tn = u32x2{nx.x ^ pr.nlx4, nx.y ^ pr.nlx4};
                 }
-                any8 |= filter_half<Q, ONE_BYTE>(Hh[h], wc, wn, pr);
-                wc[0] = wn[0];
-                wc[1] = wn[1];
+                any8 = filter_half<Q, ONE_BYTE>(Hh[h], tc, tn, pr, lane, any8);
+                tc = tn;
             }
             if (stop8) return;                                // somebody has already found the needle
             if (__ballot((any8 & 0x80808080u) != 0) == 0) continue;   // nothing in this tile: the common case

@@ -201,21 +201,23 @@ struct Launch {
     bool l8;    // 8-bytes-per-lane first phase (mode 0 / one-byte needles)
 };
 
-// Measured (16 GiB, tools/tune.py): the 8-byte first phase is +1.9 % for one-byte needles (7.09 vs 6.97 TB/s)
-// but -0.5 % for 16-byte needles, whose filter needs position flags from two lanes ahead (16 DPP moves per
-// KiB instead of 8).  Automatic choice: one-byte needles only; 2xxx variants force it for tuning.
+// Measured (16 GiB, tools/tune.py, profiles/r01/l8_by_position.jsonl): the 8-byte first phase is +2 % for
+// one-byte needles (7.26 vs 7.12 TB/s) and +1 % when the position byte lies in the candidate's own dword
+// (position <= 3: one cross-lane move per half-piece; 7.22 vs 7.14), but costs 0.4 % / 2.5 % at positions
+// 4..7 / 12..15, where two / three values per half-piece come from up to two lanes ahead.  Automatic choice:
+// one-byte needles and position <= 3; 2xxx variants force it for tuning.
 
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 64;   // 1 MiB contiguous per workgroup at U = 4 (tools/tune.py sweeps)
 constexpr uint64_t kShiftMaxD = 62;      // d + 1 halo chunks must fit one piece (tools/tune.py: wins up to d = 62)
 
-Launch pick_variant(int variant, uint64_t d, bool one_byte)
+Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
 {
     Launch l;
     l.U = kAutoU;
     l.mode = d == 0 ? 0 : (d <= kShiftMaxD ? 2 : 1);
     l.nt = l.mode == 1 ? 0 : 1;
-    l.l8 = one_byte;
+    l.l8 = one_byte || (d == 0 && position <= 3);
     if (variant > 0) {
         if (variant >= 1000) l.l8 = variant / 1000 == 2;       // 1xxx: 16-byte layout, 2xxx: 8-byte first phase
         variant %= 1000;
@@ -267,7 +269,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.host_flag = host_flag;
     pr.epoch = epoch;
 
-    const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d, one_byte);
+    const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d, one_byte, one_byte ? 0 : s->position);
     const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
     uint64_t blocks, tpb;
     if (s->grid > 0) {
