@@ -123,27 +123,31 @@ __device__ __forceinline__ bool verify_candidate(const Problem &pr, const uint8_
     return true;
 }
 
-// Position-byte flags of one chunk (4 dwords).
-__device__ __forceinline__ void position_flags(const u32x4 &B, uint32_t nlx4, uint32_t w[4])
+// The filters work on raw byte DIFFERENCES: x ^ splat(b) has a zero byte exactly where the haystack byte
+// equals b.  Differences of two needle bytes are combined with OR after one of them has been moved down
+// the byte stream (cross-lane move + v_alignbyte), and a single zero-byte test then flags the offsets at
+// which both bytes match - one test per dword instead of one per dword and needle byte plus an AND.
+
+// Position-byte differences of one chunk (4 dwords).
+__device__ __forceinline__ void position_diffs(const u32x4 &B, uint32_t nlx4, uint32_t w[4])
 {
-    w[0] = zero_byte_flags(B.x ^ nlx4);
-    w[1] = zero_byte_flags(B.y ^ nlx4);
-    w[2] = zero_byte_flags(B.z ^ nlx4);
-    w[3] = zero_byte_flags(B.w ^ nlx4);
+    w[0] = B.x ^ nlx4;
+    w[1] = B.y ^ nlx4;
+    w[2] = B.z ^ nlx4;
+    w[3] = B.w ^ nlx4;
 }
 
-// Filter one piece.  A = this lane's chunk of the first-byte stream; w = position-byte flags of this
-// lane's chunk of the position-byte stream; wl = what lane 63 must see as "the next lane's" flags
+// Filter one piece.  A = this lane's chunk of the first-byte stream; w = position-byte differences of this
+// lane's chunk of the position-byte stream; wl = what lane 63 must see as "the next lane's" differences
 // (lane 0 of the next piece / the halo chunk; only lane 63's value is used).  Returns per-dword
 // candidate flags (bit 7 of each candidate byte; the other bits are garbage).
 template <int Q, bool ONE_BYTE>
 __device__ __forceinline__ void filter_piece(const u32x4 &A, const uint32_t w[4], const uint32_t wl[4],
                                              const Problem &pr, uint32_t g[4])
 {
-    const uint32_t f0 = zero_byte_flags(A.x ^ pr.n0x4), f1 = zero_byte_flags(A.y ^ pr.n0x4);
-    const uint32_t f2 = zero_byte_flags(A.z ^ pr.n0x4), f3 = zero_byte_flags(A.w ^ pr.n0x4);
+    const uint32_t d0 = A.x ^ pr.n0x4, d1 = A.y ^ pr.n0x4, d2 = A.z ^ pr.n0x4, d3 = A.w ^ pr.n0x4;
     if (ONE_BYTE) {
-        g[0] = f0; g[1] = f1; g[2] = f2; g[3] = f3;
+        g[0] = zero_byte_flags(d0); g[1] = zero_byte_flags(d1); g[2] = zero_byte_flags(d2); g[3] = zero_byte_flags(d3);
         return;
     }
     // 8-dword window {this lane's chunk, next lane's chunk}; dwords Q .. Q+4 are needed.
@@ -153,10 +157,10 @@ __device__ __forceinline__ void filter_piece(const u32x4 &A, const uint32_t w[4]
         x[j] = w[j];
         x[4 + j] = (j <= Q) ? from_next_lane_or(wl[j], w[j]) : 0u;
     }
-    g[0] = f0 & __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r);
-    g[1] = f1 & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r);
-    g[2] = f2 & __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r);
-    g[3] = f3 & __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r);
+    g[0] = zero_byte_flags(d0 | __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r));
+    g[1] = zero_byte_flags(d1 | __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r));
+    g[2] = zero_byte_flags(d2 | __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r));
+    g[3] = zero_byte_flags(d3 | __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r));
 }
 
 // ---- second-level filter ------------------------------------------------------------------------------
@@ -256,33 +260,33 @@ struct NextPiece {
     int kind;     // wave-uniform
 };
 
-__device__ __forceinline__ uint32_t next_lane_flags(uint32_t own, uint32_t nword, uint32_t nkx4, int kind)
+__device__ __forceinline__ uint32_t next_lane_diffs(uint32_t own, uint32_t nword, uint32_t nkx4, int kind)
 {
-    uint32_t last = 0xFFFFFFFFu;                                  // what lane 63 will see
+    uint32_t last = 0u;                                           // what lane 63 will see: "matches" when unknown
     if (kind != 2) {
-        const uint32_t f = zero_byte_flags(nword ^ nkx4);
+        const uint32_t f = nword ^ nkx4;
         last = kind == 1 ? rotate_from_next_lane(f) : f;
     }
     return from_next_lane_or(last, own);
 }
 
-// One needle byte at offset K = 4*QK + rk (1..15): flags of needle[K], shifted down by K bytes.  QK is a
-// template parameter so that only the window dwords QK .. QK+4 are built (QK+1 next-lane dwords instead
-// of four, no run-time selects); rk is a run-time byte shift.
+// One needle byte at offset K = 4*QK + rk (1..15): the differences to needle[K], moved down by K bytes, clear
+// the candidate flags where they are not zero.  QK is a template parameter so that only the window dwords
+// QK .. QK+4 are built (QK+1 next-lane dwords instead of four, no run-time selects); rk is a run-time byte shift.
 template <int QK>
 __device__ __forceinline__ void refine_flags_q(const u32x4 &A, const NextPiece &np, uint32_t nkx4, uint32_t rk, uint32_t g[4])
 {
     uint32_t e[8];
-    e[0] = zero_byte_flags(A.x ^ nkx4);
-    e[1] = zero_byte_flags(A.y ^ nkx4);
-    e[2] = zero_byte_flags(A.z ^ nkx4);
-    e[3] = zero_byte_flags(A.w ^ nkx4);
-    e[4] = next_lane_flags(e[0], np.N.x, nkx4, np.kind);
-    e[5] = QK >= 1 ? next_lane_flags(e[1], np.N.y, nkx4, np.kind) : 0u;
-    e[6] = QK >= 2 ? next_lane_flags(e[2], np.N.z, nkx4, np.kind) : 0u;
-    e[7] = QK >= 3 ? next_lane_flags(e[3], np.N.w, nkx4, np.kind) : 0u;
+    e[0] = A.x ^ nkx4;
+    e[1] = A.y ^ nkx4;
+    e[2] = A.z ^ nkx4;
+    e[3] = A.w ^ nkx4;
+    e[4] = next_lane_diffs(e[0], np.N.x, nkx4, np.kind);
+    e[5] = QK >= 1 ? next_lane_diffs(e[1], np.N.y, nkx4, np.kind) : 0u;
+    e[6] = QK >= 2 ? next_lane_diffs(e[2], np.N.z, nkx4, np.kind) : 0u;
+    e[7] = QK >= 3 ? next_lane_diffs(e[3], np.N.w, nkx4, np.kind) : 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] &= __builtin_amdgcn_alignbyte(e[j + QK + 1], e[j + QK], rk);
+    for (int j = 0; j < 4; ++j) g[j] &= zero_byte_flags(__builtin_amdgcn_alignbyte(e[j + QK + 1], e[j + QK], rk));
 }
 
 __device__ __forceinline__ void refine_flags_rt(const u32x4 &A, const NextPiece &np, uint32_t nkx4, int K, uint32_t g[4])
@@ -572,32 +576,32 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 
             // ---- phase 1: the two-byte filter for all U pieces, straight-line (loads are consumed in order) ----
             uint32_t wcur[4] = {0, 0, 0, 0}, wnext[4] = {0, 0, 0, 0}, wlast[4] = {0, 0, 0, 0};
-            if (!ONE_BYTE) position_flags(TWO ? B[0] : A[0], pr.nlx4, wcur);
+            if (!ONE_BYTE) position_diffs(TWO ? B[0] : A[0], pr.nlx4, wcur);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t *g = G[u];
                 if (SHIFTED) {
                     // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
-                    position_flags(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
+                    position_diffs(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
                     uint32_t x[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         x[j] = (j >= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d) : 0u;
                         x[4 + j] = (j <= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d + 1) : 0u;
                     }
-                    g[0] = zero_byte_flags(A[u].x ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r);
-                    g[1] = zero_byte_flags(A[u].y ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r);
-                    g[2] = zero_byte_flags(A[u].z ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r);
-                    g[3] = zero_byte_flags(A[u].w ^ pr.n0x4) & __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r);
+                    g[0] = zero_byte_flags((A[u].x ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r));
+                    g[1] = zero_byte_flags((A[u].y ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r));
+                    g[2] = zero_byte_flags((A[u].z ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r));
+                    g[3] = zero_byte_flags((A[u].w ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r));
                 } else {
                     if (!ONE_BYTE) {
                         // lane 63's "next lane": lane 0 of the next piece, or the halo chunk after the last piece
                         if (u + 1 < U) {
-                            position_flags(TWO ? B[u + 1] : A[u + 1], pr.nlx4, wnext);
+                            position_diffs(TWO ? B[u + 1] : A[u + 1], pr.nlx4, wnext);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) wlast[j] = (j <= Q) ? rotate_from_next_lane(wnext[j]) : 0u;
                         } else {
-                            position_flags(H, pr.nlx4, wlast);
+                            position_diffs(H, pr.nlx4, wlast);
                         }
                     }
                     filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
