@@ -49,6 +49,7 @@ namespace ss {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;              // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr unsigned kPeekFromBlock = 1024;   // workgroups before this one start with the launch: nothing to see yet
 constexpr int kNeedleLds = 2048;         // needle bytes staged in LDS per wave; longer needles continue from global
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -363,6 +364,28 @@ __device__ __forceinline__ int poll_found(const int *found, int epoch)
                __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch;
 }
 
+// Entry peek of a workgroup at the flag THROUGH THE SCALAR CACHE: a hit costs tens of cycles instead of an
+// L2 round trip, so even one-tile workgroups can afford it before they issue their loads.  The scalar cache
+// is not coherent - a stale "not found" only means the workgroup does its tile as usual.  Staleness is
+// bounded: every tile also polls coherently (free, behind its data loads), and a wave that sees the flag set
+// there invalidates its CU's scalar cache on the way out (forget_scalar_cache), so the workgroups that
+// follow on that CU leave at the peek.
+__device__ __forceinline__ int scalar_peek(const int *p)
+{
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ uint64_t scalar_peek64(const uint64_t *p)
+{
+    uint64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ void forget_scalar_cache() { __builtin_amdgcn_s_dcache_inv(); }
+
 __device__ __forceinline__ void publish_found(int *found, int epoch = 1)
 {
     __hip_atomic_store(found, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -525,7 +548,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 any8 = filter_half<Q, ONE_BYTE>(Hh[h], tc, tn, pr, lane, any8);
                 tc = tn;
             }
-            if (stop8) return;                                // somebody has already found the needle
+            if (stop8) {                                      // somebody has already found the needle
+                forget_scalar_cache();
+                return;
+            }
             if (__ballot((any8 & 0x80808080u) != 0) == 0) continue;   // nothing in this tile: the common case
             // candidates: bring the tile into the 16-bytes-per-lane layout for the second phase
 #pragma unroll
@@ -619,13 +645,19 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         else load_and_filter(std::false_type{}, std::false_type{});
         if (FIND) {
             const uint64_t first = chunk0 * 16 > pr.mis ? chunk0 * 16 - pr.mis : 0;   // lowest index this wave can report
-            if (best_now <= pr.find_base + first) return;                               // all of it lies right of a match
+            if (best_now <= pr.find_base + first) {                                     // all of it lies right of a match
+                forget_scalar_cache();
+                return;
+            }
         }
 
         // ---- phase 2 (rare on random bytes): the wave's "movemask != 0" ---------------------------------
         const bool cand_tile = __ballot((any_tile & 0x80808080u) != 0) != 0;
         if (L8) dense = cand_tile;      // stay in the 16-byte layout while tiles keep producing candidates
-        if (stop) return;               // somebody has already found the needle: no point in verifying more
+        if (stop) {                     // somebody has already found the needle: no point in verifying more
+            forget_scalar_cache();
+            return;
+        }
         if (cand_tile) {
             if (!staged) {
                 stage_needle_wave(s_needle, pr.needle, pr.n, lane);
@@ -665,6 +697,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                         // would otherwise serialise one atomic per wave on a single address)
                         if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                             __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        forget_scalar_cache();
                         return;                         // the wave's later pieces and tiles are further right
                     }
                 }
@@ -682,6 +715,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                         if (old != pr.epoch && pr.host_flag)
                             __hip_atomic_store(pr.host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
+                    forget_scalar_cache();
                     return;
                 }
             }
@@ -692,8 +726,13 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 // ---- K1/K2/K3: one needle, one haystack ---------------------------------------------------------
 // gridDim.x workgroups; workgroup b scans tiles [b*tiles_per_block, (b+1)*tiles_per_block) when
 // tiles_per_block > 0 (contiguous runs, short-lived workgroups), or b, b+grid, ... when it is 0.
+#ifdef SS_WAVES_PER_EU      // occupancy experiments: -DSS_WAVES_PER_EU=5 asks for <= 96 VGPRs (5 waves per SIMD)
+#define SS_SCAN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SS_WAVES_PER_EU, SS_WAVES_PER_EU)))
+#else
+#define SS_SCAN_OCCUPANCY
+#endif
 template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false>
-__global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *found, uint64_t tiles_per_block)
+__global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *found, uint64_t tiles_per_block)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
@@ -704,14 +743,18 @@ __global__ void __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *fo
         step = 1;
         t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
     }
-    // Long-lived workgroups (>= 16 tiles each, i.e. haystacks of 8 GiB and more) that are dispatched after the
-    // first few thousand look at the flag BEFORE they load anything: once a match is known the rest of the
-    // grid drains without touching memory (match at offset 0 of 1 GiB: 0.084 -> 0.026 ms in the experiment).
-    // The ~1 us this costs such a workgroup is invisible next to its ~35 us of streaming; short-lived
-    // workgroups (small haystacks) skip it - there it cost 1.5 % of a full scan.
-    if (!FIND && tiles_per_block >= 16 && blockIdx.x >= 4096 &&
-        poll_found(static_cast<const int *>(found), pr.epoch))
-        return;
+    // Early exit survives short-lived workgroups through the entry peek (scalar cache; see scalar_peek): once
+    // a match is known the rest of the grid drains without touching memory.  The first workgroups of a grid
+    // start before anything can have been found and skip it.
+    if (blockIdx.x >= kPeekFromBlock) {
+        if (FIND) {
+            const uint64_t first_chunk = t0 * (uint64_t)(kWavesPerBlock * U) * 64;
+            const uint64_t first = first_chunk * 16 > pr.mis ? first_chunk * 16 - pr.mis : 0;
+            if (scalar_peek64(static_cast<const uint64_t *>(found)) <= pr.find_base + first) return;
+        } else if (scalar_peek(static_cast<const int *>(found)) == pr.epoch) {
+            return;
+        }
+    }
     scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
 }
 

@@ -7,38 +7,39 @@ namespace ss {
 
 // q = (position % 16) / 4, mode = 0/1/2 (see scan_tiles), `sink` = int flag or uint64 best (FIND).
 // l8 = use the 8-bytes-per-lane first phase (mode 0 / one-byte needles, bool result only).
+// dyn_lds = unused dynamic LDS bytes per workgroup: caps the workgroups resident per CU (occupancy tuning).
 template <int U, int NT, bool FIND>
 void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st, void *sink,
-                    uint64_t tpb, bool l8);
+                    uint64_t tpb, bool l8, uint32_t dyn_lds);
 
 #ifdef SS_DEFINE_LAUNCH
 template <int U, int NT, bool FIND>
 void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st, void *flag,
-                    uint64_t tpb, bool l8)
+                    uint64_t tpb, bool l8, uint32_t dyn_lds)
 {
     dim3 blk(kBlock);
     if constexpr (!FIND) {
         if (l8 && (one_byte || mode == 0)) {
             if (one_byte) {
-                scan_kernel<0, 0, true, U, NT, false, true><<<grid, blk, 0, st>>>(pr, flag, tpb);
+                scan_kernel<0, 0, true, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb);
                 return;
             }
             switch (q) {
-            case 0: scan_kernel<0, 0, false, U, NT, false, true><<<grid, blk, 0, st>>>(pr, flag, tpb); break;
-            case 1: scan_kernel<1, 0, false, U, NT, false, true><<<grid, blk, 0, st>>>(pr, flag, tpb); break;
-            case 2: scan_kernel<2, 0, false, U, NT, false, true><<<grid, blk, 0, st>>>(pr, flag, tpb); break;
-            default: scan_kernel<3, 0, false, U, NT, false, true><<<grid, blk, 0, st>>>(pr, flag, tpb); break;
+            case 0: scan_kernel<0, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
+            case 1: scan_kernel<1, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
+            case 2: scan_kernel<2, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
+            default: scan_kernel<3, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
             }
             return;
         }
     }
     if (one_byte) {
-        scan_kernel<0, 0, true, U, NT, FIND><<<grid, blk, 0, st>>>(pr, flag, tpb);
+        scan_kernel<0, 0, true, U, NT, FIND><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb);
         return;
     }
 #define SS_CASE(QQ, MM)                                                                            \
     case (QQ) * 3 + (MM):                                                                          \
-        scan_kernel<QQ, MM, false, U, NT, FIND><<<grid, blk, 0, st>>>(pr, flag, tpb);              \
+        scan_kernel<QQ, MM, false, U, NT, FIND><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb);              \
         break;
     switch (q * 3 + mode) {
         SS_CASE(0, 0) SS_CASE(0, 1) SS_CASE(0, 2) SS_CASE(1, 0) SS_CASE(1, 1) SS_CASE(1, 2)
@@ -47,12 +48,12 @@ void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, dim3 grid
 #undef SS_CASE
 }
 #else
-extern template void launch_scan_un<4, 0, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool);
-extern template void launch_scan_un<4, 1, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool);
-extern template void launch_scan_un<8, 0, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool);
-extern template void launch_scan_un<8, 1, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool);
-extern template void launch_scan_un<4, 0, true>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool);
-extern template void launch_scan_un<4, 1, true>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool);
+extern template void launch_scan_un<4, 0, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
+extern template void launch_scan_un<4, 1, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
+extern template void launch_scan_un<8, 0, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
+extern template void launch_scan_un<8, 1, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
+extern template void launch_scan_un<4, 0, true>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
+extern template void launch_scan_un<4, 1, true>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
 #endif
 
 }  // namespace ss

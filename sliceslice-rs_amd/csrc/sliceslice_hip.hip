@@ -199,16 +199,17 @@ struct Launch {
     int nt;
     int mode;   // 0: d == 0, 1: two load streams, 2: shifted flags
     bool l8;    // 8-bytes-per-lane first phase (mode 0 / one-byte needles)
+    uint32_t dyn_lds;   // unused dynamic LDS per workgroup (caps workgroups per CU; tuning: variant 10000*OCC)
 };
 
-// Measured (16 GiB, tools/tune.py, profiles/r01/l8_by_position.jsonl): the 8-byte first phase is +2 % for
-// one-byte needles (7.26 vs 7.12 TB/s) and +1 % when the position byte lies in the candidate's own dword
-// (position <= 3: one cross-lane move per half-piece; 7.22 vs 7.14), but costs 0.4 % / 2.5 % at positions
-// 4..7 / 12..15, where two / three values per half-piece come from up to two lanes ahead.  Automatic choice:
-// one-byte needles and position <= 3; 2xxx variants force it for tuning.
+// Measured (tools/tune.py, profiles/r01/l8_short_needles.jsonl, two-tile workgroups): the 8-byte first phase
+// is +5 % for one-byte needles (64 GiB: 7.46 vs 7.08 TB/s) but -5 % for two-byte filters on random bytes
+// (positions 2, 3: 6.95 vs 7.35 TB/s): there one tile in sixteen holds a candidate and pays for the
+// transposition into the 16-byte layout on top of the regular filter.  Automatic choice: one-byte needles
+// only; 2xxx variants force it for tuning.
 
 constexpr int kAutoU = 4;
-constexpr int kAutoTilesPerBlock = 64;   // 1 MiB contiguous per workgroup at U = 4 (tools/tune.py sweeps)
+constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 constexpr uint64_t kShiftMaxD = 62;      // d + 1 halo chunks must fit one piece (tools/tune.py: wins up to d = 62)
 
 Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
@@ -217,8 +218,18 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
     l.U = kAutoU;
     l.mode = d == 0 ? 0 : (d <= kShiftMaxD ? 2 : 1);
     l.nt = l.mode == 1 ? 0 : 1;
-    l.l8 = one_byte || (d == 0 && position <= 3);
+    l.l8 = one_byte;
+    l.dyn_lds = 0;
+    (void)position;
     if (variant > 0) {
+        if (variant >= 10000) {                                 // OCCxxxx: at most OCC workgroups per CU (160 KiB LDS)
+            const int occ = variant / 10000;
+            const uint32_t per = (160u * 1024u) / (uint32_t)occ;
+            const uint32_t fixed = ss::kWavesPerBlock * ss::kNeedleLds;
+            l.dyn_lds = per > fixed + 1024 ? ((per - fixed) & ~1023u) : 0;
+            if (l.dyn_lds > 64u * 1024u - fixed) l.dyn_lds = 64u * 1024u - fixed;
+            variant %= 10000;
+        }
         if (variant >= 1000) l.l8 = variant / 1000 == 2;       // 1xxx: 16-byte layout, 2xxx: 8-byte first phase
         variant %= 1000;
         const int m = variant / 100, u = (variant / 10) % 10;
@@ -234,10 +245,10 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
 // scan_inst_*.hip translation units, so that the kernel families compile in parallel.
 template <int U>
 void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st,
-                   void *flag, uint64_t tpb, bool l8)
+                   void *flag, uint64_t tpb, bool l8, uint32_t dyn_lds)
 {
-    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8);
-    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8);
+    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8, dyn_lds);
+    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8, dyn_lds);
 }
 
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, OR-ed
@@ -280,9 +291,13 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         if (s->grid < 0) {
             tpb = (uint64_t)(-(int64_t)s->grid);
         } else {
-            // contiguous runs of up to 64 tiles (1 MiB) per workgroup, but at least ~128 workgroups per CU
-            // overall so that the tail of a short scan stays fine-grained (1 GiB: 2 tiles per workgroup is
-            // 6 % faster than 16; profiles/r01/launch_shape_small.jsonl)
+            // Short-lived workgroups: two tiles (32 KiB) each from 1 GiB up, one below.  The hardware dispatcher
+            // hands out tiles in address order, so the set of lines in flight stays one narrow, advancing
+            // window, and a fresh workgroup issues its loads the moment a slot frees up.  Measured
+            // (profiles/r01/tiles_per_block_sweep.jsonl, 16-byte needle): 64 GiB 7.40 TB/s at 2 tiles per
+            // workgroup vs 7.28 at 4, 7.21 at 8, 7.11 at 64; 8 GiB 7.08-7.17 vs 6.83-6.98 at 16.  One tile is
+            // another 1 % faster for a full scan of 64 GiB but twice as many workgroups have to be drained
+            // after an early match (the entry peek in scan_kernel); two is the compromise.
             DeviceInfo di;
             if (int rc = device_info(pd->dev, &di)) return rc;
             tpb = ntiles / ((uint64_t)di.cus * 128);
@@ -302,12 +317,12 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     const int q = (int)(sh / 4);
     if (find) {   // one tile shape for find(): U = 4
         if (l.U != 4) return fail(SS_ERR_ARGUMENT, "find supports the U = 4 kernels only");
-        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false);
-        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false);
+        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false, l.dyn_lds);
+        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false, l.dyn_lds);
     } else if (l.U == 8) {
-        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8);
+        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8, l.dyn_lds);
     } else {
-        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8);
+        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8, l.dyn_lds);
     }
     HIP_TRY(hipGetLastError());
     if (s->timing) {

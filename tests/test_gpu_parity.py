@@ -369,6 +369,36 @@ def test_batched_vs_oracle(ss, O):
     assert got == want
 
 
+def test_batched_matches_straddling_slice_boundaries(ss):
+    """Few problems -> many slices each (one tile = 16 KiB per slice): a needle planted across every kind of
+    tile/slice edge of a misaligned haystack must be seen by exactly the slice on its left."""
+    rng = np.random.default_rng(5)
+    hays, needles, want = [], [], []
+    for i in range(12):
+        ln = 200_000 + 4097 * i
+        h = rng.integers(0, 255, size=ln, dtype=np.uint8)          # 0xFF never occurs
+        n = [16, 17, 33, 40, 5, 2][i % 6]
+        nd = rng.integers(0, 255, size=n, dtype=np.uint8)
+        nd[n // 2] = 0xFF                                            # absent unless planted
+        mis = sum(x.size for x in hays) % 16                         # torch allocations are 16-byte aligned
+        if i % 4 != 3:
+            k = 1 + i                                                # tile edge k in aligned coordinates
+            at = 16384 * k - mis - [1, n // 2, n - 1][i % 3]        # straddles the edge
+            h[at:at + n] = nd
+        hays.append(h)
+        needles.append(nd.tobytes())
+        want.append(needles[-1] in h.tobytes())
+    assert want.count(True) == 9
+    hay_off = np.zeros(len(hays) + 1, dtype=np.int64)
+    hay_off[1:] = np.cumsum([h.size for h in hays])
+    nd_off = np.zeros(len(needles) + 1, dtype=np.int64)
+    nd_off[1:] = np.cumsum([len(x) for x in needles])
+    blob = torch.from_numpy(np.concatenate(hays + [np.zeros(1, dtype=np.uint8)])).cuda()
+    nblob = torch.from_numpy(np.frombuffer(b"".join(needles) + b"\0", dtype=np.uint8).copy()).cuda()
+    found = ss.search_batched(blob, torch.from_numpy(hay_off).cuda(), nblob, torch.from_numpy(nd_off).cuda())
+    assert [bool(x) for x in found.cpu().tolist()] == want
+
+
 def test_short_haystack_sweep_sample_batched(ss, O, corpus):
     # tests/i386.rs:46-59 shape (word in word), a 200k-pair sample through the batched entry point
     words = sorted(corpus["words"], key=len)

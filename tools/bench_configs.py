@@ -31,11 +31,18 @@ def absent(n, seed=SEED_NEEDLE):
     return bytes(nd)
 
 
+def warm(fn, seconds=0.05):
+    """Back-to-back launches for ~50 ms: clocks ramp up over the first milliseconds after an idle gap, which
+    is longer than a whole series of sub-millisecond launches."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+
+
 def timed(searcher, hay, reps):
     searcher.set_timing(True)
     res = searcher.search_in(hay)
-    for _ in range(5):                      # warm-up: clocks ramp over the first few sub-millisecond launches
-        searcher.search_in(hay)
+    warm(lambda: searcher.search_in(hay))
     ms = []
     for _ in range(reps):
         searcher.search_in(hay)
@@ -119,8 +126,7 @@ def main():
         nd_off = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
         found = ss.search_batched(blob, hay_off, nblob, nd_off)
         assert int(found.sum().item()) == 0
-        for _ in range(5):
-            ss.search_batched(blob, hay_off, nblob, nd_off)
+        warm(lambda: ss.search_batched(blob, hay_off, nblob, nd_off))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ms = []
         for _ in range(args.reps):
@@ -189,6 +195,7 @@ def main():
         hb = torch.zeros(len(words), dtype=torch.int64, device="cuda")
         he = torch.full((len(words),), len(raw), dtype=torch.int64, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        warm(lambda: ss.search_batched(i386, None, nblob, None, hay_ranges=(hb, he), needle_ranges=(nbt, net)))
         ms = []
         for _ in range(args.reps):
             e0.record()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Early-exit / present-needle scenarios (kernel ms over a 1 GiB haystack): a hunt for pathologies, e.g. a
+"""Early-exit / present-needle scenarios (kernel ms over a 1 GiB haystack, or argv[1] GiB): a hunt for pathologies, e.g. a
 needle that occurs everywhere must not be slower than a full scan."""
 import json
 import os
@@ -23,7 +23,8 @@ def med(fn, s, reps=7):
 
 
 def main():
-    n_bytes = 1 << 30
+    n_bytes = int(float(sys.argv[1]) * (1 << 30)) if len(sys.argv) > 1 else 1 << 30   # [GiB] [grid override]
+    grid = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
     ss.fill_random_device(hay, 0x5EED0001)
     host_head = hay[:4096].cpu().numpy().tobytes()
@@ -32,6 +33,7 @@ def main():
 
     def run(label, needle, h=hay, position=None):
         s = ss.DynamicHipSearcher(needle, position)
+        s.set_grid(grid)
         r, ms = med(lambda: s.search_in(h), s)
         p, msf = med(lambda: s.find(h), s)
         rows.append((label, len(needle), r, round(ms, 4), p, round(msf, 4)))
