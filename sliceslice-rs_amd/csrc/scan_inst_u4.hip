@@ -3,6 +3,6 @@
 #include "scan_launch.hpp"
 
 namespace ss {
-template void launch_scan_un<4, 0, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
-template void launch_scan_un<4, 1, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
+template void launch_scan_un<4, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+template void launch_scan_un<4, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 }  // namespace ss

@@ -47,8 +47,10 @@
 namespace ss {
 
 constexpr int kWave = 64;
-constexpr int kBlock = 256;              // 4 waves
+constexpr int kBlock = 256;              // 4 waves: the batched / auxiliary kernels, and the scan's default
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxBlock = 512;           // scan_kernel takes its workgroup size from the launch (128 / 256 / 512)
+constexpr int kMaxWavesPerBlock = kMaxBlock / kWave;
 constexpr unsigned kPeekFromBlock = 1024;   // workgroups before this one start with the launch: nothing to see yet
 constexpr int kNeedleLds = 2048;         // needle bytes staged in LDS per wave; longer needles continue from global
 
@@ -502,6 +504,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     constexpr bool NTB = TWO ? NTMODE >= 2 : NTMODE >= 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
+    const int wpb = (int)(blockDim.x / kWave);                              // waves per workgroup (launch-time)
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
     bool staged = false;
     RefineOrder ro = {pr.norder, {pr.order_idx[0], pr.order_idx[1]}, {pr.order_val[0], pr.order_val[1]}};
@@ -510,7 +513,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 
     for (uint64_t tile = tile0; tile < tile_end; tile += tile_step) {
         u32x4 A[U], B[U], H = {0, 0, 0, 0};
-        const uint64_t chunk0 = (tile * (kWavesPerBlock * U) + (uint64_t)wave * U) * 64;   // wave-uniform
+        const uint64_t chunk0 = (tile * (uint64_t)(wpb * U) + (uint64_t)wave * U) * 64;   // wave-uniform
         // FIND polls first (oldest load, so waiting for it does not drain the data loads behind it); the value
         // is only made wave-uniform (readfirstlane = the wait) after the tile's data loads have been issued
         const uint64_t best_raw = FIND ? __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -732,10 +735,12 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 #define SS_SCAN_OCCUPANCY
 #endif
 template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false>
-__global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kBlock) scan_kernel(const Problem pr, void *found, uint64_t tiles_per_block)
+__global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const Problem pr, void *found, uint64_t tiles_per_block)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
-    const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+    // one 2 KiB slice per wave; the launch passes (waves per workgroup) * kNeedleLds bytes of dynamic LDS
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_needle[];
+    const uint64_t wpb = blockDim.x / kWave;
+    const uint64_t ntiles = (pr.npieces + wpb * U - 1) / (wpb * U);
     // one call site (one copy of the code): contiguous run, or grid-stride when tiles_per_block == 0
     uint64_t t0 = blockIdx.x, step = gridDim.x, t1 = ntiles;
     if (tiles_per_block) {
@@ -748,7 +753,7 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kBlock) scan_kernel(const Pr
     // start before anything can have been found and skip it.
     if (blockIdx.x >= kPeekFromBlock) {
         if (FIND) {
-            const uint64_t first_chunk = t0 * (uint64_t)(kWavesPerBlock * U) * 64;
+            const uint64_t first_chunk = t0 * (wpb * U) * 64;
             const uint64_t first = first_chunk * 16 > pr.mis ? first_chunk * 16 - pr.mis : 0;
             if (scalar_peek64(static_cast<const uint64_t *>(found)) <= pr.find_base + first) return;
         } else if (scalar_peek(static_cast<const int *>(found)) == pr.epoch) {
@@ -932,17 +937,18 @@ __global__ void __launch_bounds__(kBlock) fill_random_kernel(uint8_t *dst, uint6
 // ---- plain streaming read: the empirical "achievable HBM read" ceiling ------------------------------
 // Same access shape as the scan (workgroup-contiguous 4*U KiB tiles, short-lived workgroups).
 template <int U, bool NT>
-__global__ void __launch_bounds__(kBlock) read_ceiling_kernel(const u32x4 *src, uint64_t nvec, uint32_t *sink,
+__global__ void __launch_bounds__(kMaxBlock) read_ceiling_kernel(const u32x4 *src, uint64_t nvec, uint32_t *sink,
                                                               uint64_t tiles_per_block)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const uint64_t ntiles = nvec / (64 * kWavesPerBlock * U);           // the ragged tail is ignored
+    const uint64_t wpb = blockDim.x / kWave;
+    const uint64_t ntiles = nvec / (64 * wpb * U);                      // the ragged tail is ignored
     uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
     const uint64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
     u32x4 acc = {0, 0, 0, 0};
     for (; t0 < t1; ++t0) {
-        const u32x4 *p = src + (t0 * (kWavesPerBlock * U) + (uint64_t)wave * U) * 64 + lane;
+        const u32x4 *p = src + (t0 * (wpb * U) + (uint64_t)wave * U) * 64 + lane;
         u32x4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + 64 * u) : p[64 * u];

@@ -7,17 +7,26 @@ namespace ss {
 
 // q = (position % 16) / 4, mode = 0/1/2 (see scan_tiles), `sink` = int flag or uint64 best (FIND).
 // l8 = use the 8-bytes-per-lane first phase (mode 0 / one-byte needles, bool result only).
-// dyn_lds = unused dynamic LDS bytes per workgroup: caps the workgroups resident per CU (occupancy tuning).
+// Shape = the launch geometry: workgroups, threads per workgroup (128 / 256 / 512), tiles per workgroup
+// (0 = grid-stride), and unused dynamic LDS per workgroup (caps the workgroups resident per CU; tuning only).
+struct Shape {
+    unsigned blocks;
+    unsigned block;
+    uint64_t tpb;
+    uint32_t lds_pad;
+};
 template <int U, int NT, bool FIND>
-void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st, void *sink,
-                    uint64_t tpb, bool l8, uint32_t dyn_lds);
+void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Shape &sh, hipStream_t st, void *sink,
+                    bool l8);
 
 #ifdef SS_DEFINE_LAUNCH
 template <int U, int NT, bool FIND>
-void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st, void *flag,
-                    uint64_t tpb, bool l8, uint32_t dyn_lds)
+void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Shape &sh, hipStream_t st, void *flag,
+                    bool l8)
 {
-    dim3 blk(kBlock);
+    const dim3 grid(sh.blocks), blk(sh.block);
+    const uint64_t tpb = sh.tpb;
+    const uint32_t dyn_lds = sh.lds_pad + (sh.block / kWave) * kNeedleLds;   // one needle slice per wave
     if constexpr (!FIND) {
         if (l8 && (one_byte || mode == 0)) {
             if (one_byte) {
@@ -48,12 +57,12 @@ void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, dim3 grid
 #undef SS_CASE
 }
 #else
-extern template void launch_scan_un<4, 0, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
-extern template void launch_scan_un<4, 1, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
-extern template void launch_scan_un<8, 0, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
-extern template void launch_scan_un<8, 1, false>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
-extern template void launch_scan_un<4, 0, true>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
-extern template void launch_scan_un<4, 1, true>(const Problem &, int, int, bool, dim3, hipStream_t, void *, uint64_t, bool, uint32_t);
+extern template void launch_scan_un<4, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template void launch_scan_un<4, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template void launch_scan_un<8, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template void launch_scan_un<8, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template void launch_scan_un<4, 0, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template void launch_scan_un<4, 1, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 #endif
 
 }  // namespace ss

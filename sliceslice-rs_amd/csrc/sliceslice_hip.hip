@@ -188,7 +188,9 @@ void release_slot(const ss_searcher *s, PerDevice *p, int k)
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------
-// variant = 1000*LAYOUT + 100*MODE + 10*U + NT.  LAYOUT 0 = automatic, 1 = 16 bytes per lane throughout,
+// variant = 100000*B + 10000*OCC + 1000*LAYOUT + 100*MODE + 10*U + NT.  B: workgroup size (0/2 = 256 threads,
+// 1 = 128, 3 = 512); OCC: at most OCC workgroups per CU through unused dynamic LDS (0 = no cap) - both are
+// tuning aids (profiles/r01/workgroup_size_sweep.jsonl, occupancy_sweep.jsonl).  LAYOUT 0 = automatic, 1 = 16 bytes per lane throughout,
 // 2 = 8-bytes-per-lane first phase (single-stream kernels).  U in {4,8} = pieces (KiB) per wave per tile; NT in {0,1} = plain /
 // non-temporal first-byte stream; MODE (only meaningful for position >= 16, i.e. d > 0): 0 = automatic,
 // 1 = second load stream, 2 = one stream + cross-lane (ds_bpermute) position flags.  variant 0 = automatic:
@@ -200,6 +202,7 @@ struct Launch {
     int mode;   // 0: d == 0, 1: two load streams, 2: shifted flags
     bool l8;    // 8-bytes-per-lane first phase (mode 0 / one-byte needles)
     uint32_t dyn_lds;   // unused dynamic LDS per workgroup (caps workgroups per CU; tuning: variant 10000*OCC)
+    unsigned block;     // threads per workgroup: 128 / 256 / 512 (tuning: variant 100000*B, B = 1 / 2 / 3)
 };
 
 // Measured (tools/tune.py, profiles/r01/l8_short_needles.jsonl, two-tile workgroups): the 8-byte first phase
@@ -220,12 +223,18 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
     l.nt = l.mode == 1 ? 0 : 1;
     l.l8 = one_byte;
     l.dyn_lds = 0;
+    l.block = ss::kBlock;
     (void)position;
     if (variant > 0) {
+        if (variant >= 100000) {                                // Bxxxxx: workgroup size
+            const int b = variant / 100000;
+            l.block = b == 1 ? 128 : (b == 3 ? 512 : 256);
+            variant %= 100000;
+        }
         if (variant >= 10000) {                                 // OCCxxxx: at most OCC workgroups per CU (160 KiB LDS)
             const int occ = variant / 10000;
             const uint32_t per = (160u * 1024u) / (uint32_t)occ;
-            const uint32_t fixed = ss::kWavesPerBlock * ss::kNeedleLds;
+            const uint32_t fixed = (l.block / ss::kWave) * ss::kNeedleLds;
             l.dyn_lds = per > fixed + 1024 ? ((per - fixed) & ~1023u) : 0;
             if (l.dyn_lds > 64u * 1024u - fixed) l.dyn_lds = 64u * 1024u - fixed;
             variant %= 10000;
@@ -244,11 +253,11 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
 // launch_scan_un<U, NT, FIND> is defined in scan_launch.hpp and explicitly instantiated in the
 // scan_inst_*.hip translation units, so that the kernel families compile in parallel.
 template <int U>
-void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte, dim3 grid, hipStream_t st,
-                   void *flag, uint64_t tpb, bool l8, uint32_t dyn_lds)
+void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte, const ss::Shape &shape, hipStream_t st,
+                   void *flag, bool l8)
 {
-    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8, dyn_lds);
-    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, grid, st, flag, tpb, l8, dyn_lds);
+    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, shape, st, flag, l8);
+    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, shape, st, flag, l8);
 }
 
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, OR-ed
@@ -281,7 +290,8 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.epoch = epoch;
 
     const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d, one_byte, one_byte ? 0 : s->position);
-    const uint64_t ntiles = (pr.npieces + ss::kWavesPerBlock * l.U - 1) / (ss::kWavesPerBlock * l.U);
+    const uint64_t wpb = l.block / ss::kWave;
+    const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
     uint64_t blocks, tpb;
     if (s->grid > 0) {
         blocks = (uint64_t)s->grid;
@@ -311,18 +321,18 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         }
     }
     if (blocks < 1) blocks = 1;
-    dim3 grid((unsigned)blocks);
+    const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
 
     if (s->timing) HIP_TRY(hipEventRecord(pd->ev0, st));
     const int q = (int)(sh / 4);
     if (find) {   // one tile shape for find(): U = 4
         if (l.U != 4) return fail(SS_ERR_ARGUMENT, "find supports the U = 4 kernels only");
-        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false, l.dyn_lds);
-        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, grid, st, d_flag, tpb, false, l.dyn_lds);
+        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, shape, st, d_flag, false);
+        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, shape, st, d_flag, false);
     } else if (l.U == 8) {
-        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8, l.dyn_lds);
+        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, shape, st, d_flag, l.l8);
     } else {
-        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, grid, st, d_flag, tpb, l.l8, l.dyn_lds);
+        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, shape, st, d_flag, l.l8);
     }
     HIP_TRY(hipGetLastError());
     if (s->timing) {
