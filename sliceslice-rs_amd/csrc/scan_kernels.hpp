@@ -292,25 +292,59 @@ __device__ __forceinline__ void refine_flags_q(const u32x4 &A, const NextPiece &
     for (int j = 0; j < 4; ++j) g[j] &= zero_byte_flags(__builtin_amdgcn_alignbyte(e[j + QK + 1], e[j + QK], rk));
 }
 
-__device__ __forceinline__ void refine_flags_rt(const u32x4 &A, const NextPiece &np, uint32_t nkx4, int K, uint32_t g[4])
-{
-    const uint32_t rk = (uint32_t)(K & 3);
-    switch (K >> 2) {                            // wave-uniform
-    case 0: refine_flags_q<0>(A, np, nkx4, rk, g); break;
-    case 1: refine_flags_q<1>(A, np, nkx4, rk, g); break;
-    case 2: refine_flags_q<2>(A, np, nkx4, rk, g); break;
-    default: refine_flags_q<3>(A, np, nkx4, rk, g); break;
-    }
-}
-
 // The second-level filter's schedule (Problem::norder / order_idx / order_val), as the wave holds it.
 struct RefineOrder {
     uint32_t n;
     uint64_t idx[2], val[2];
 };
 
-// Returns false when no lane of the wave has a candidate left.
-__device__ __forceinline__ bool refine_staged(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4])
+// Second-level filter for a whole tile (U pieces of one wave): one needle byte at a time, rarest first, applied
+// to all U pieces before the next wave ballot - the scalar bookkeeping (schedule entry, window switch, ballot)
+// is paid once per tile and byte instead of once per piece and byte, and the U independent pieces hide each
+// other's DPP / VALU latencies.  On text nearly every piece of a tile holds candidates, so nothing is wasted;
+// on random bytes the extra pieces cost ~2 VALU per KiB on average.  Returns false when no lane of the wave
+// has a candidate left in any piece.
+template <int U, int MODE>
+__device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H, const RefineOrder &ro, uint32_t (&G)[U][4])
+{
+    auto any_left = [&]() {
+        uint32_t o = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) o |= G[u][0] | G[u][1] | G[u][2] | G[u][3];
+        return __ballot((o & 0x80808080u) != 0) != 0;
+    };
+    auto apply = [&](auto qk_c, uint32_t nkx4, uint32_t rk) {
+        constexpr int QK = decltype(qk_c)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            NextPiece np;
+            np.N = u + 1 < U ? A[u + 1] : H;
+            np.kind = u + 1 < U ? 1 : (MODE == 0 ? 0 : (MODE == 2 ? 1 : 2));
+            refine_flags_q<QK>(A[u], np, nkx4, rk, G[u]);
+        }
+    };
+    bool any = any_left();
+#pragma unroll 1
+    for (uint32_t t = 0; t < ro.n && any; ++t) {
+        const uint32_t sh = 8 * (t & 7);
+        const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
+        const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
+        const uint32_t nkx4 = 0x01010101u * v, rk = (uint32_t)(K & 3);
+        switch (K >> 2) {                            // wave-uniform
+        case 0: apply(std::integral_constant<int, 0>{}, nkx4, rk); break;
+        case 1: apply(std::integral_constant<int, 1>{}, nkx4, rk); break;
+        case 2: apply(std::integral_constant<int, 2>{}, nkx4, rk); break;
+        default: apply(std::integral_constant<int, 3>{}, nkx4, rk); break;
+        }
+        any = any_left();
+    }
+    return any;
+}
+
+// Per-piece form of the same filter (the MODE 2 kernels keep it: with the tile-wide form their first phase,
+// instruction for instruction the same, ran 4-8 % slower on random bytes - profiles/r01/refine_tile_ab.txt).
+// Returns false when no lane of the wave has a candidate left in this piece.
+__device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4])
 {
     bool any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
 #pragma unroll 1
@@ -318,7 +352,13 @@ __device__ __forceinline__ bool refine_staged(const u32x4 &A, const NextPiece &n
         const uint32_t sh = 8 * (t & 7);
         const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
         const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
-        refine_flags_rt(A, np, 0x01010101u * v, K, g);
+        const uint32_t nkx4 = 0x01010101u * v, rk = (uint32_t)(K & 3);
+        switch (K >> 2) {                            // wave-uniform
+        case 0: refine_flags_q<0>(A, np, nkx4, rk, g); break;
+        case 1: refine_flags_q<1>(A, np, nkx4, rk, g); break;
+        case 2: refine_flags_q<2>(A, np, nkx4, rk, g); break;
+        default: refine_flags_q<3>(A, np, nkx4, rk, g); break;
+        }
         any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
     }
     return any;
@@ -675,17 +715,21 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 }
                 staged = true;
             }
+            // second-level filter in registers (wave-uniform), up to the first 16 needle bytes, tile-wide
+            constexpr bool TILE_WIDE = MODE != 2;
+            if (!ONE_BYTE && TILE_WIDE && !refine_tile<U, MODE>(A, H, ro, G)) continue;
             bool hit = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t *g = G[u];
-                // second-level filter in registers (wave-uniform), up to the first 16 needle bytes
-                NextPiece np;
-                np.N = u + 1 < U ? A[u + 1] : H;
-                np.kind = u + 1 < U ? 1 : (MODE == 0 ? 0 : (MODE == 2 ? 1 : 2));
-                const bool left = ONE_BYTE ? (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0)
-                                           : refine_staged(A[u], np, ro, g);
-                if (!left) continue;
+                if (!ONE_BYTE && !TILE_WIDE) {
+                    NextPiece np;
+                    np.N = u + 1 < U ? A[u + 1] : H;
+                    np.kind = 1;                                  // MODE 2: the halo chunks sit in lanes 0..d of H
+                    if (!refine_piece(A[u], np, ro, g)) continue;
+                } else if (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) == 0) {
+                    continue;
+                }
                 uint64_t where = 0;
                 const bool h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, s_needle, where);
                 hit |= h;

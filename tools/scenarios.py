@@ -23,8 +23,9 @@ def med(fn, s, reps=7):
 
 
 def main():
-    n_bytes = int(float(sys.argv[1]) * (1 << 30)) if len(sys.argv) > 1 else 1 << 30   # [GiB] [grid override]
+    n_bytes = int(float(sys.argv[1]) * (1 << 30)) if len(sys.argv) > 1 else 1 << 30   # [GiB] [grid override] [variant]
     grid = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
     ss.fill_random_device(hay, 0x5EED0001)
     host_head = hay[:4096].cpu().numpy().tobytes()
@@ -34,6 +35,7 @@ def main():
     def run(label, needle, h=hay, position=None):
         s = ss.DynamicHipSearcher(needle, position)
         s.set_grid(grid)
+        s.set_variant(variant)
         r, ms = med(lambda: s.search_in(h), s)
         p, msf = med(lambda: s.find(h), s)
         rows.append((label, len(needle), r, round(ms, 4), p, round(msf, 4)))

@@ -13,9 +13,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
 
 
-def absent(n):
+def absent(n, ff_at=-1):
+    """0xFF never occurs in the haystack: at index 0 the first-byte filter never passes (no phase 2 at all)."""
     nd = bytearray(ss.fill_random_host(n, 0x5EED0002).tobytes())
-    nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+    nd[ff_at if ff_at >= 0 else (0 if n == 1 else (1 if n == 2 else n // 2))] = 0xFF
     return bytes(nd)
 
 
@@ -27,6 +28,7 @@ def main():
     ap.add_argument("--variants", default="40,41")
     ap.add_argument("--grids", default="0")
     ap.add_argument("--mis", type=int, default=0)
+    ap.add_argument("--ff-at", type=int, default=-1, help="index of the needle's 0xFF byte (default: the middle)")
     args = ap.parse_args()
     n_bytes = int(args.gib * (1 << 30))
     buf = torch.empty(n_bytes + 64, dtype=torch.uint8, device="cuda")
@@ -35,7 +37,7 @@ def main():
     torch.cuda.synchronize()
     print(json.dumps({"read_ceiling_gbps": round(ss.read_ceiling_gbps(buf[:n_bytes], reps=5), 1)}), flush=True)
     for n in [int(x) for x in args.needles.split(",")]:
-        nd = absent(n)
+        nd = absent(n, args.ff_at)
         for v in [int(x) for x in args.variants.split(",")]:
             for g in [int(x) for x in args.grids.split(",")]:
                 s = ss.DynamicHipSearcher.new(nd)
