@@ -411,7 +411,9 @@ __device__ __forceinline__ int poll_found(const int *found, int epoch)
 // is not coherent - a stale "not found" only means the workgroup does its tile as usual.  Staleness is
 // bounded: every tile also polls coherently (free, behind its data loads), and a wave that sees the flag set
 // there invalidates its CU's scalar cache on the way out (forget_scalar_cache), so the workgroups that
-// follow on that CU leave at the peek.
+// follow on that CU leave at the peek.  A value cached by an EARLIER launch cannot be seen: the acquire at the start
+// of every kernel dispatch invalidates the scalar cache (tests/test_gpu_parity.py::
+// test_caller_owned_flags_are_not_seen_stale pins that for caller-owned flags, which have no epoch).
 __device__ __forceinline__ int scalar_peek(const int *p)
 {
     int v;

@@ -617,6 +617,41 @@ def test_flag_slots_are_reusable_without_reset(ss):
             assert s.find(yes) == 123456 and s.find(no) is None
 
 
+def test_caller_owned_flags_are_not_seen_stale(ss):
+    """Workgroups peek at the flag / best offset through the (non-coherent) scalar cache before they load
+    anything.  A caller-owned flag that held "found" in the previous launch and was reset by the caller must
+    not be seen stale by the next launch, or late workgroups would leave without scanning their tiles."""
+    n_bytes = 192 << 20                                   # 6,144 two-tile workgroups; the peek starts at 1,024
+    hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, 0xABCD01)
+    early = hay[4096:4096 + 16].cpu().numpy().tobytes()
+    late = hay[n_bytes - 5000:n_bytes - 5000 + 16].cpu().numpy().tobytes()
+    absent = bytearray(late)
+    absent[7] = 0xFF
+    s_early, s_late, s_abs = (ss.DynamicHipSearcher.new(x) for x in (early, late, bytes(absent)))
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    best = torch.empty(1, dtype=torch.int64, device="cuda")
+    for _ in range(5):
+        flag.zero_()
+        s_early.search_in_async(hay, flag)
+        assert int(flag.item()) == 1
+        flag.zero_()
+        s_late.search_in_async(hay, flag)                 # same flag address, match in one of the last workgroups
+        assert int(flag.item()) == 1
+        flag.zero_()
+        s_abs.search_in_async(hay, flag)
+        assert int(flag.item()) == 0
+        best.fill_(-1)                                    # all ones = none yet
+        s_early.find_async(hay, best)
+        assert int(best.item()) == 4096
+        best.fill_(-1)
+        s_late.find_async(hay, best)
+        assert int(best.item()) == n_bytes - 5000
+        best.fill_(-1)
+        s_abs.find_async(hay, best)
+        assert int(best.item()) == -1
+
+
 def test_offsets_beyond_4gib_and_long_needles(ss):
     """64-bit offsets: matches planted beyond 2^32 and 2^33 in a 9 GiB haystack (search_in and find), and
     needles far longer than the 2 KiB LDS slice / longer than a tile (compare continues from global)."""
