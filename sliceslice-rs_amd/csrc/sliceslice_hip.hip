@@ -643,6 +643,50 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
 // of chunk k-1 in front, so a match that straddles a chunk edge is seen by the later chunk.
 namespace {
 
+// Staging set of the file front end: pinned host buffers + device buffers + streams.  Pinning 3 x 64 MiB costs
+// ~10 ms, more than reading and scanning a 64 MiB file, so one set per device is kept for the life of the
+// process and lent to one ss_search_file call at a time (a concurrent call builds a private set).
+constexpr int kFileBuf = 3;
+struct FileStaging {
+    uint8_t *h[kFileBuf] = {nullptr, nullptr, nullptr};
+    uint8_t *d[kFileBuf] = {nullptr, nullptr, nullptr};
+    hipStream_t st[kFileBuf] = {nullptr, nullptr, nullptr};
+    size_t cap = 0;      // bytes per buffer
+    int nbuf = 0;
+    void release()
+    {
+        for (int b = 0; b < kFileBuf; ++b) {
+            if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
+            if (d[b]) (void)hipFree(d[b]);
+            if (h[b]) (void)hipHostFree(h[b]);
+            st[b] = nullptr; d[b] = nullptr; h[b] = nullptr;
+        }
+        cap = 0;
+        nbuf = 0;
+    }
+    bool ensure(int want_nbuf, size_t want_cap)     // grow-only
+    {
+        if (nbuf >= want_nbuf && cap >= want_cap) return true;
+        if (want_cap < cap) want_cap = cap;
+        if (want_nbuf < nbuf) want_nbuf = nbuf;
+        release();
+        for (int b = 0; b < want_nbuf; ++b) {
+            if (hipHostMalloc((void **)&h[b], want_cap, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc((void **)&d[b], want_cap) != hipSuccess ||
+                hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess) {
+                release();
+                return false;
+            }
+        }
+        cap = want_cap;
+        nbuf = want_nbuf;
+        return true;
+    }
+};
+constexpr int kMaxDevices = 64;
+std::mutex g_file_staging_mu[kMaxDevices];
+FileStaging g_file_staging[kMaxDevices];
+
 bool parallel_pread(int fd, uint8_t *dst, size_t bytes, off_t off, unsigned threads)
 {
     if (threads < 1) threads = 1;
@@ -688,13 +732,20 @@ int ss_search_file(const ss_searcher *s, const char *path, int *found)
         return SS_OK;
     }
     const size_t carry = s->n - 1;
-    size_t C = (size_t)64 << 20;
+    // chunk: 64 MiB for large files, an eighth of the file (>= 8 MiB) for small ones so that reading, upload
+    // and scan of a few-hundred-MiB file still overlap
+    size_t C = len / 8;
+    if (C > ((size_t)64 << 20)) C = (size_t)64 << 20;
+    if (C < ((size_t)8 << 20)) C = (size_t)8 << 20;
     if (C < 4 * s->n) C = 4 * s->n;
     if (C > len) C = len;
-    constexpr int kBuf = 3;
-    const int nbuf = len > C ? kBuf : 1;
+    const int nbuf = len > C ? kFileBuf : 1;
     unsigned threads = std::thread::hardware_concurrency();
     if (threads > 8) threads = 8;
+    if (const char *e = getenv("SLICESLICE_FILE_THREADS")) {      // tuning aid (tools/host_path_bench.py)
+        const long v = atol(e);
+        if (v > 0 && v <= 256) threads = (unsigned)v;
+    }
     if (len < ((size_t)8 << 20)) threads = 1;
 
     PerDevice *pd = nullptr;
@@ -702,17 +753,22 @@ int ss_search_file(const ss_searcher *s, const char *path, int *found)
         close(fd);
         return rc;
     }
+    // the device's cached staging set when it is free, a private one otherwise
+    FileStaging private_set, *fs = &private_set;
+    std::unique_lock<std::mutex> lease;
+    if (pd->dev >= 0 && pd->dev < kMaxDevices) {
+        lease = std::unique_lock<std::mutex>(g_file_staging_mu[pd->dev], std::try_to_lock);
+        if (lease.owns_lock()) fs = &g_file_staging[pd->dev];
+    }
+    if (!fs->ensure(nbuf, C + carry)) {
+        close(fd);
+        return fail(SS_ERR_HIP, "staging allocation failed");
+    }
+    uint8_t **hbuf = fs->h, **dbuf = fs->d;
+    hipStream_t *st = fs->st;
     const int k = acquire_slot(s, pd);
     const int epoch = next_epoch(pd, k);
-    uint8_t *hbuf[kBuf] = {nullptr, nullptr, nullptr}, *dbuf[kBuf] = {nullptr, nullptr, nullptr};
-    hipStream_t st[kBuf] = {nullptr, nullptr, nullptr};
     int rc = SS_OK;
-    for (int b = 0; b < nbuf && rc == SS_OK; ++b) {
-        if (hipHostMalloc((void **)&hbuf[b], C + carry, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc((void **)&dbuf[b], C + carry) != hipSuccess ||
-            hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess)
-            rc = fail(SS_ERR_HIP, "staging allocation failed");
-    }
     int result = 0;
     size_t idx = 0, prev_total = 0;
     int prev_b = -1;
@@ -736,14 +792,10 @@ int ss_search_file(const ss_searcher *s, const char *path, int *found)
         if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "upload: %s", hipGetErrorString(e)); break; }
         rc = enqueue_scan(s, pd, dbuf[b], total, st[b], pd->d_flags + k, false, 0, pd->h_flags + k, epoch);
     }
-    for (int b = 0; b < nbuf; ++b)
+    for (int b = 0; b < fs->nbuf; ++b)
         if (st[b]) (void)hipStreamSynchronize(st[b]);
     if (rc == SS_OK && !result) result = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
-    for (int b = 0; b < nbuf; ++b) {
-        if (st[b]) (void)hipStreamDestroy(st[b]);
-        if (dbuf[b]) (void)hipFree(dbuf[b]);
-        if (hbuf[b]) (void)hipHostFree(hbuf[b]);
-    }
+    if (fs == &private_set) private_set.release();
     close(fd);
     release_slot(s, pd, k);
     if (rc == SS_OK) *found = result;

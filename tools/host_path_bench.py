@@ -35,15 +35,19 @@ def main():
         d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
         path = os.path.join(d, "ss_host_path_bench.bin")
         host.tofile(path)
-        best = float("inf")
-        for _ in range(3):
-            t = time.perf_counter()
-            r = ss.search_file(s, path)
-            best = min(best, time.perf_counter() - t)
-            assert r is False
+        for threads in [int(x) for x in os.environ.get("SS_FILE_THREADS_SWEEP", "0").split(",")]:
+            if threads:
+                os.environ["SLICESLICE_FILE_THREADS"] = str(threads)
+            best = float("inf")
+            for _ in range(3):
+                t = time.perf_counter()
+                r = ss.search_file(s, path)
+                best = min(best, time.perf_counter() - t)
+                assert r is False
+            print(json.dumps({"entry": "ss_search_file", "source": "file in " + d, "bytes": n_bytes,
+                              "read_threads": threads or "default", "s": round(best, 4),
+                              "gbps": round(n_bytes / best / 1e9, 2)}), flush=True)
         os.unlink(path)
-        print(json.dumps({"entry": "ss_search_file", "source": "file in " + d, "bytes": n_bytes, "s": round(best, 4),
-                          "gbps": round(n_bytes / best / 1e9, 2)}), flush=True)
 
 
 if __name__ == "__main__":
