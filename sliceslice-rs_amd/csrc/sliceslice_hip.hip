@@ -524,6 +524,81 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
     return rc;
 }
 
+// ---- staging sets of the host-buffer and file front ends ---------------------------------------------------
+// Device buffers + streams (+ pinned host buffers for the file reader).  Creating them per call costs ~0.3 ms
+// (hipMalloc, stream create/destroy) and pinning 3 x 64 MiB ~10 ms - more than uploading and scanning a small
+// haystack - so one set per device is kept for the life of the process and lent to one call at a time; a
+// concurrent call builds a private set.
+namespace {
+
+constexpr int kStageBuf = 3;
+struct Staging {
+    uint8_t *h[kStageBuf] = {nullptr, nullptr, nullptr};
+    uint8_t *d[kStageBuf] = {nullptr, nullptr, nullptr};
+    hipStream_t st[kStageBuf] = {nullptr, nullptr, nullptr};
+    size_t cap_d = 0, cap_h = 0;      // bytes per device / pinned buffer
+    int nbuf = 0;
+    void release()
+    {
+        for (int b = 0; b < kStageBuf; ++b) {
+            if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
+            if (d[b]) (void)hipFree(d[b]);
+            if (h[b]) (void)hipHostFree(h[b]);
+            st[b] = nullptr; d[b] = nullptr; h[b] = nullptr;
+        }
+        cap_d = cap_h = 0;
+        nbuf = 0;
+    }
+    bool ensure(int want_nbuf, size_t want_cap, bool pinned)     // grow-only
+    {
+        if (want_cap < ((size_t)1 << 20)) want_cap = (size_t)1 << 20;      // do not regrow for every small call
+        if (nbuf >= want_nbuf && cap_d >= want_cap && (!pinned || cap_h >= want_cap)) return true;
+        if (want_cap < cap_d) want_cap = cap_d;
+        if (want_nbuf < nbuf) want_nbuf = nbuf;
+        const bool want_pinned = pinned || cap_h > 0;
+        release();
+        for (int b = 0; b < want_nbuf; ++b) {
+            if ((want_pinned && hipHostMalloc((void **)&h[b], want_cap, hipHostMallocDefault) != hipSuccess) ||
+                hipMalloc((void **)&d[b], want_cap) != hipSuccess ||
+                hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess) {
+                release();
+                return false;
+            }
+        }
+        cap_d = want_cap;
+        cap_h = want_pinned ? want_cap : 0;
+        nbuf = want_nbuf;
+        return true;
+    }
+};
+constexpr int kMaxDevices = 64;
+std::mutex g_staging_mu[kMaxDevices];
+Staging g_staging[kMaxDevices];
+
+// Lends the device's cached set when it is free, `mine` otherwise; `mine` is released by its destructor-like
+// call site (Lease::done).
+struct Lease {
+    Staging mine, *set = &mine;
+    std::unique_lock<std::mutex> lock;
+    explicit Lease(int dev)
+    {
+        if (dev >= 0 && dev < kMaxDevices) {
+            lock = std::unique_lock<std::mutex>(g_staging_mu[dev], std::try_to_lock);
+            if (lock.owns_lock()) set = &g_staging[dev];
+        }
+    }
+    ~Lease()
+    {
+        if (set == &mine) {
+            mine.release();
+        } else {
+            for (int b = 0; b < set->nbuf; ++b) (void)hipStreamSynchronize(set->st[b]);   // nothing of this call in flight
+        }
+    }
+};
+
+}  // namespace
+
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found)
 {
     if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
@@ -539,22 +614,14 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     if (C > len) C = len;
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
+    const size_t nbuf = len > C ? 2 : 1;
+    Lease lease(pd->dev);
+    if (!lease.set->ensure((int)nbuf, C + carry, false)) return fail(SS_ERR_HIP, "staging allocation failed");
+    uint8_t **dbuf = lease.set->d;
+    hipStream_t *st = lease.set->st;
     const int k = acquire_slot(s, pd);
     const int epoch = next_epoch(pd, k);                 // "found" value of this call (see ss_search_device)
-    uint8_t *dbuf[2] = {nullptr, nullptr};
-    hipStream_t st[2] = {nullptr, nullptr};
     int rc = SS_OK;
-    auto cleanup = [&]() {
-        for (int b = 0; b < 2; ++b) {
-            if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
-            if (dbuf[b]) (void)hipFree(dbuf[b]);
-        }
-    };
-    const size_t nbuf = len > C ? 2 : 1;
-    for (size_t b = 0; b < nbuf && rc == SS_OK; ++b) {
-        if (hipMalloc((void **)&dbuf[b], C + carry) != hipSuccess || hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess)
-            rc = fail(SS_ERR_HIP, "staging allocation failed");
-    }
     int result = 0;
     size_t idx = 0;
     for (size_t off = 0; off < len && rc == SS_OK && !result; off += C, ++idx) {
@@ -575,7 +642,6 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     for (size_t b = 0; b < nbuf; ++b)
         if (st[b]) (void)hipStreamSynchronize(st[b]);
     if (rc == SS_OK && !result) result = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
-    cleanup();
     release_slot(s, pd, k);
     if (rc == SS_OK) *found = result;
     return rc;
@@ -596,15 +662,13 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
     if (C > len) C = len;
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
-    const int k = acquire_slot(s, pd);
-    uint8_t *dbuf[2] = {nullptr, nullptr};
-    hipStream_t st[2] = {nullptr, nullptr};
-    int rc = SS_OK;
     const size_t nbuf = len > C ? 2 : 1;
-    for (size_t b = 0; b < nbuf && rc == SS_OK; ++b) {
-        if (hipMalloc((void **)&dbuf[b], C + carry) != hipSuccess || hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess)
-            rc = fail(SS_ERR_HIP, "staging allocation failed");
-    }
+    Lease lease(pd->dev);
+    if (!lease.set->ensure((int)nbuf, C + carry, false)) return fail(SS_ERR_HIP, "staging allocation failed");
+    uint8_t **dbuf = lease.set->d;
+    hipStream_t *st = lease.set->st;
+    const int k = acquire_slot(s, pd);
+    int rc = SS_OK;
     size_t idx = 0;
     bool hit = false;
     for (size_t off = 0; off < len && rc == SS_OK && !hit; off += C, ++idx) {
@@ -629,10 +693,6 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
         else *position = pd->h_best[k];
     }
     (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));       // slots are all-ones whenever they are free
-    for (size_t b = 0; b < nbuf; ++b) {
-        if (st[b]) (void)hipStreamDestroy(st[b]);
-        if (dbuf[b]) (void)hipFree(dbuf[b]);
-    }
     release_slot(s, pd, k);
     return rc;
 }
@@ -642,50 +702,6 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
 // chunks are in flight as hipMemcpyAsync + scan on their own streams.  Chunk k carries the last n-1 bytes
 // of chunk k-1 in front, so a match that straddles a chunk edge is seen by the later chunk.
 namespace {
-
-// Staging set of the file front end: pinned host buffers + device buffers + streams.  Pinning 3 x 64 MiB costs
-// ~10 ms, more than reading and scanning a 64 MiB file, so one set per device is kept for the life of the
-// process and lent to one ss_search_file call at a time (a concurrent call builds a private set).
-constexpr int kFileBuf = 3;
-struct FileStaging {
-    uint8_t *h[kFileBuf] = {nullptr, nullptr, nullptr};
-    uint8_t *d[kFileBuf] = {nullptr, nullptr, nullptr};
-    hipStream_t st[kFileBuf] = {nullptr, nullptr, nullptr};
-    size_t cap = 0;      // bytes per buffer
-    int nbuf = 0;
-    void release()
-    {
-        for (int b = 0; b < kFileBuf; ++b) {
-            if (st[b]) { (void)hipStreamSynchronize(st[b]); (void)hipStreamDestroy(st[b]); }
-            if (d[b]) (void)hipFree(d[b]);
-            if (h[b]) (void)hipHostFree(h[b]);
-            st[b] = nullptr; d[b] = nullptr; h[b] = nullptr;
-        }
-        cap = 0;
-        nbuf = 0;
-    }
-    bool ensure(int want_nbuf, size_t want_cap)     // grow-only
-    {
-        if (nbuf >= want_nbuf && cap >= want_cap) return true;
-        if (want_cap < cap) want_cap = cap;
-        if (want_nbuf < nbuf) want_nbuf = nbuf;
-        release();
-        for (int b = 0; b < want_nbuf; ++b) {
-            if (hipHostMalloc((void **)&h[b], want_cap, hipHostMallocDefault) != hipSuccess ||
-                hipMalloc((void **)&d[b], want_cap) != hipSuccess ||
-                hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess) {
-                release();
-                return false;
-            }
-        }
-        cap = want_cap;
-        nbuf = want_nbuf;
-        return true;
-    }
-};
-constexpr int kMaxDevices = 64;
-std::mutex g_file_staging_mu[kMaxDevices];
-FileStaging g_file_staging[kMaxDevices];
 
 bool parallel_pread(int fd, uint8_t *dst, size_t bytes, off_t off, unsigned threads)
 {
@@ -739,7 +755,7 @@ int ss_search_file(const ss_searcher *s, const char *path, int *found)
     if (C < ((size_t)8 << 20)) C = (size_t)8 << 20;
     if (C < 4 * s->n) C = 4 * s->n;
     if (C > len) C = len;
-    const int nbuf = len > C ? kFileBuf : 1;
+    const int nbuf = len > C ? kStageBuf : 1;
     unsigned threads = std::thread::hardware_concurrency();
     if (threads > 8) threads = 8;
     if (const char *e = getenv("SLICESLICE_FILE_THREADS")) {      // tuning aid (tools/host_path_bench.py)
@@ -754,13 +770,9 @@ int ss_search_file(const ss_searcher *s, const char *path, int *found)
         return rc;
     }
     // the device's cached staging set when it is free, a private one otherwise
-    FileStaging private_set, *fs = &private_set;
-    std::unique_lock<std::mutex> lease;
-    if (pd->dev >= 0 && pd->dev < kMaxDevices) {
-        lease = std::unique_lock<std::mutex>(g_file_staging_mu[pd->dev], std::try_to_lock);
-        if (lease.owns_lock()) fs = &g_file_staging[pd->dev];
-    }
-    if (!fs->ensure(nbuf, C + carry)) {
+    Lease lease(pd->dev);
+    Staging *fs = lease.set;
+    if (!fs->ensure(nbuf, C + carry, true)) {
         close(fd);
         return fail(SS_ERR_HIP, "staging allocation failed");
     }
@@ -795,7 +807,6 @@ int ss_search_file(const ss_searcher *s, const char *path, int *found)
     for (int b = 0; b < fs->nbuf; ++b)
         if (st[b]) (void)hipStreamSynchronize(st[b]);
     if (rc == SS_OK && !result) result = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
-    if (fs == &private_set) private_set.release();
     close(fd);
     release_slot(s, pd, k);
     if (rc == SS_OK) *found = result;
