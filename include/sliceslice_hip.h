@@ -104,15 +104,18 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
 int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t len, uint64_t base_offset,
                          void *hip_stream, uint64_t *d_best);
 
-/* Drop-in form of search_in(&[u8]) for a HOST haystack: stages the bytes to the device in
- * double-buffered pinned chunks (needle_len-1 bytes of carry between chunks) and scans them there.
- * PCIe-bound by construction; never used for roofline numbers. */
+/* Drop-in form of search_in(&[u8]) for a HOST haystack: uploads the bytes in double-buffered chunks of up
+ * to 64 MiB (needle_len-1 bytes of carry between chunks) and scans them on the device.  PCIe-bound by
+ * construction; never used for roofline numbers.  The device buffers and streams come from a per-device
+ * set that lives for the rest of the process and is lent to one call at a time (a concurrent call on the
+ * same device builds and frees a private set), so a small haystack costs tens of microseconds per call. */
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
 
 /* Row f2: the host-file front end of examples/grep.rs:42-56 (open the file, one
  * search_in) as a pipeline: reader threads pread() 64 MiB chunks into pinned buffers while earlier
  * chunks are uploading and being scanned on their own streams; n-1 bytes are carried across chunk
- * edges.  Bound by the file read / PCIe, never by the scan. */
+ * edges.  Bound by the file read / PCIe, never by the scan.  Uses the same cached per-device staging set
+ * (plus pinned host buffers) as ss_search_host. */
 int ss_search_file(const ss_searcher *s, const char *path, int *found);
 
 /* Row f3: data for a `position` policy.  The reference leaves `position` to the caller
