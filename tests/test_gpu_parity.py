@@ -344,6 +344,37 @@ def test_concurrent_search_on_one_searcher(ss):
     assert not errs, errs
 
 
+def test_concurrent_host_and_file_searches(ss, tmp_path):
+    """The host/file front ends borrow ONE cached staging set per device; concurrent callers must fall back
+    to private sets and still answer correctly (ctypes releases the GIL during the calls)."""
+    rng = np.random.default_rng(9)
+    hay = rng.integers(0, 255, size=(3 << 20) + 77, dtype=np.uint8)
+    yes = hay[-40:-8].tobytes()
+    no = bytearray(yes)
+    no[5] = 0xFF
+    path = tmp_path / "hay.bin"
+    hay.tofile(path)
+    s_yes, s_no = ss.DynamicHipSearcher.new(yes), ss.DynamicHipSearcher.new(bytes(no))
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                if i % 2:
+                    assert s_yes.search_in(hay) is True
+                    assert s_no.search_in(hay) is False
+                    assert s_yes.find(hay) == hay.size - 40
+                else:
+                    assert ss.search_file(s_yes, str(path)) is True
+                    assert ss.search_file(s_no, str(path)) is False
+        except Exception as e:     # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+
+
 def test_batched_vs_oracle(ss, O):
     rng = random.Random(11)
     hays, needles, want = [], [], []
