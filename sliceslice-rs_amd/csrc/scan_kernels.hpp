@@ -980,28 +980,32 @@ __global__ void __launch_bounds__(kBlock) fill_random_kernel(uint8_t *dst, uint6
     }
 }
 
-// ---- plain streaming read: the empirical "achievable HBM read" ceiling ------------------------------
-// Same access shape as the scan (workgroup-contiguous 4*U KiB tiles, short-lived workgroups).
-template <int U, bool NT>
-__global__ void __launch_bounds__(kMaxBlock) read_ceiling_kernel(const u32x4 *src, uint64_t nvec, uint32_t *sink,
-                                                              uint64_t tiles_per_block)
+// ---- plain streaming read: the empirical "achievable HBM read" reference ------------------------------
+// Same access shape as the scan (workgroup-contiguous tiles of 4*U KiB per 4 waves, short-lived workgroups).
+// V = u32x4 (16 bytes per lane, 1 KiB per wave instruction) or u32x2 (8 bytes per lane, the L8 shape).
+template <int U, typename V>
+__global__ void __launch_bounds__(kMaxBlock) read_ceiling_kernel(const V *src, uint64_t nvec, uint32_t *sink,
+                                                                 uint64_t tiles_per_block)
 {
+    constexpr int kPerKiB = 1024 / (64 * (int)sizeof(V));              // wave instructions per KiB piece: 1 or 2
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint64_t wpb = blockDim.x / kWave;
-    const uint64_t ntiles = nvec / (64 * wpb * U);                      // the ragged tail is ignored
+    const uint64_t ntiles = nvec / (64 * kPerKiB * wpb * U);            // the ragged tail is ignored
     uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
     const uint64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
-    u32x4 acc = {0, 0, 0, 0};
+    V acc = {};
     for (; t0 < t1; ++t0) {
-        const u32x4 *p = src + (t0 * (wpb * U) + (uint64_t)wave * U) * 64 + lane;
-        u32x4 v[U];
+        const V *p = src + (t0 * (wpb * U) + (uint64_t)wave * U) * (64 * kPerKiB) + lane;
+        V v[U * kPerKiB];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + 64 * u) : p[64 * u];
+        for (int u = 0; u < U * kPerKiB; ++u) v[u] = __builtin_nontemporal_load(p + 64 * u);
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc ^= v[u];
+        for (int u = 0; u < U * kPerKiB; ++u) acc ^= v[u];
     }
-    const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(V) / 4); ++k) r ^= acc[k];
     if (r == 0x9E3779B9u) sink[0] = r;      // practically never; keeps the loads alive
 }
 

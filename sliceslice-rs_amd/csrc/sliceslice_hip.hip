@@ -973,28 +973,43 @@ int ss_read_ceiling(const void *d_src, size_t len, void *hip_stream, int reps, f
     uint32_t *sink = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0;
-    const uint64_t nvec = len / 16;
     constexpr int U = 4;
-    const uint64_t tpb = kAutoTilesPerBlock;
-    const uint64_t ntiles = nvec / (64 * ss::kWavesPerBlock * U);
-    uint64_t blocks = (ntiles + tpb - 1) / tpb;
-    if (blocks < 1) blocks = 1;
-    const dim3 grid((unsigned)blocks);
-    auto launch = [&]() {
-        ss::read_ceiling_kernel<U, true><<<grid, dim3(ss::kBlock), 0, st>>>(static_cast<const ss::u32x4 *>(d_src), nvec, sink, tpb);
+    // A handful of launch shapes (bytes per lane, tiles per workgroup, workgroups per CU through unused LDS);
+    // the fastest is reported.  The 16-byte / two-tile shape is the scan's own.
+    struct Shape { int lane_bytes; uint64_t tpb; uint32_t lds; };
+    const Shape shapes[] = {{16, 2, 0}, {16, 2, 32 << 10}, {16, 1, 32 << 10}, {8, 2, 0}, {8, 2, 32 << 10}, {8, 1, 32 << 10}};
+    auto launch = [&](const Shape &sh) {
+        const uint64_t ntiles = (len / 1024) / (ss::kWavesPerBlock * U);
+        uint64_t blocks = (ntiles + sh.tpb - 1) / sh.tpb;
+        if (blocks < 1) blocks = 1;
+        const dim3 grid((unsigned)blocks);
+        if (sh.lane_bytes == 16)
+            ss::read_ceiling_kernel<U, ss::u32x4><<<grid, dim3(ss::kBlock), sh.lds, st>>>(static_cast<const ss::u32x4 *>(d_src), len / 16, sink, sh.tpb);
+        else
+            ss::read_ceiling_kernel<U, ss::u32x2><<<grid, dim3(ss::kBlock), sh.lds, st>>>(static_cast<const ss::u32x2 *>(d_src), len / 8, sink, sh.tpb);
     };
     auto run = [&]() -> hipError_t {
         hipError_t e;
         if ((e = hipMalloc((void **)&sink, 64)) != hipSuccess) return e;
         if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
         if ((e = hipEventCreate(&e1)) != hipSuccess) return e;
-        launch();                                               // warm-up
-        if ((e = hipEventRecord(e0, st)) != hipSuccess) return e;
-        for (int r = 0; r < reps; ++r) launch();
-        if ((e = hipEventRecord(e1, st)) != hipSuccess) return e;
-        if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        return hipEventElapsedTime(&ms, e0, e1);
+        float best = 0;
+        for (const Shape &sh : shapes) {
+            launch(sh);                                             // warm-up
+            if ((e = hipEventRecord(e0, st)) != hipSuccess) return e;
+            for (int r = 0; r < reps; ++r) launch(sh);
+            if ((e = hipEventRecord(e1, st)) != hipSuccess) return e;
+            if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            float t = 0;
+            if ((e = hipEventElapsedTime(&t, e0, e1)) != hipSuccess) return e;
+            if (getenv("SLICESLICE_CEILING_VERBOSE"))
+                fprintf(stderr, "read ceiling: %2d B/lane, %llu tile(s)/workgroup, %2u KiB LDS pad: %.1f GB/s\n", sh.lane_bytes,
+                        (unsigned long long)sh.tpb, sh.lds >> 10, (double)len * reps / (t * 1e6));
+            if (best == 0 || t < best) best = t;
+        }
+        ms = best;
+        return hipSuccess;
     };
     const hipError_t e = run();
     if (e0) (void)hipEventDestroy(e0);
