@@ -10,34 +10,38 @@
 //     into an unmapped page (the guarantee the reference gets from its overlapped tail chunk,
 //     lib.rs:276-284).  Pieces do not overlap: HBM traffic == haystack bytes (+16 B per wave-tile).
 //   * the "first byte" filter (hay[i] == needle[0]) and the "position byte" filter
-//     (hay[i+position] == needle[position]) are evaluated on 4 bytes per VALU op with the zero-byte
-//     trick  z(x) = (x - 0x01010101) & ~x  (bit 7 of every byte of x that is zero is set; it can also
-//     flag a 0x01 byte sitting above a zero byte - a false POSITIVE only, and candidates are
-//     verified, so the boolean is unaffected).
-//   * position = 16*d + 4*Q + r.  The position-byte flags of lane l's candidates live in the flag
-//     dwords of chunk c+d (and c+d+1): d is folded into the load address of a second stream (d == 0,
-//     i.e. position < 16 - every needle of <= 16 bytes - needs no second load at all), the chunk
-//     c+d+1 part comes from the neighbouring lane with one DPP wave_shl:1 per dword, Q selects the
-//     dword window at compile time and r is a v_alignbyte_b32.
+//     (hay[i+position] == needle[position]) work on byte DIFFERENCES, 4 bytes per VALU op:
+//     A ^ splat(needle[0]) has a zero byte where the first byte matches, B ^ splat(needle[position]) where
+//     the position byte matches; the latter is moved `position` bytes down the stream and OR-ed onto the
+//     former, and ONE zero-byte test  z(x) = (x - 0x01010101) & ~x  per dword flags the offsets at which
+//     both match (bit 7 of every zero byte of x is set; it can also flag a 0x01 byte sitting above a zero
+//     byte - a false POSITIVE only, and candidates are verified, so the boolean is unaffected).
+//   * position = 16*d + 4*Q + r.  The position-byte differences of lane l's candidates live in the
+//     dwords of chunk c+d (and c+d+1): for d == 0 (position < 16 - every needle of <= 16 bytes) that is the
+//     lane's own chunk, the chunk c+1 part comes from the neighbouring lane with one DPP wave_shl:1 per
+//     dword, Q selects the dword window at compile time and r is a v_alignbyte_b32.
 //   * lane 63's neighbour is lane 0 of the NEXT piece.  A wave owns U consecutive pieces, so that is a
 //     register of the same wave (one DPP wave_rol:1 feeds it in as the `old` operand of the wave_shl);
 //     after the wave's last piece it is a single 16-byte halo chunk loaded by lane 63 alone.
 //   * position >= 16 (d > 0): MODE 2 keeps ONE non-temporal load stream and fetches the position-byte
-//     flags from the lane that owns chunk c+d with ds_bpermute (d <= 62); MODE 1 (larger d) issues a
+//     differences from the lane that owns chunk c+d with ds_bpermute (d <= 62); MODE 1 (larger d) issues a
 //     second, plain load stream at +d chunks.
 //   * a tile (U pieces per wave) is filtered in one straight-line phase; `__ballot(any flag)` is the wave's
-//     movemask: zero (2^-16 per offset on random bytes) -> next tile.  Otherwise, per piece, a second-level
-//     filter ANDs in the flags of up to 15 more needle bytes, rarest first, still in registers, with a
-//     ballot after each; what survives is walked lowest-first (`__ffs`, clear lowest set bit -
-//     lib.rs:220-247) and compared with the needle - staged in LDS by the wave the first time it gets
-//     here - four bytes per step; the first equal candidate sets the found flag (lib.rs:242-244).
-//   * the found flag is polled once per tile by every wave, so a hit stops the grid early, which is the
-//     reference's early `return true`.  FIND kernels keep the leftmost match offset instead (atomicMin).
-//   * L8 kernels run the first phase on 8 bytes per lane (dwordx2 loads, +2 % read rate) and transpose
-//     only tiles with candidates into the 16-byte layout (used for one-byte needles).
+//     movemask: zero (2^-16 per offset on random bytes) -> next tile.  Otherwise a second-level filter
+//     clears the flags where one of up to 15 more needle bytes differs, rarest byte first, still in
+//     registers, with a ballot after each byte; what survives is walked lowest-first (`__ffs`, clear lowest
+//     set bit - lib.rs:220-247) and compared with the needle - staged in LDS by the wave the first time it
+//     gets here - four bytes per step; the first equal candidate sets the found flag (lib.rs:242-244).
+//   * workgroups are short-lived (one or two tiles each): the hardware dispatcher hands out tiles in address
+//     order.  Every workgroup but the first few peeks at the found flag through the scalar cache before it
+//     loads anything, and every tile polls it coherently behind its data loads, so a hit stops the grid
+//     early - the reference's early `return true`.  FIND kernels keep the leftmost match offset instead
+//     (atomicMin) and skip only work that lies to the right of it.
+//   * L8 kernels run the first phase on 8 bytes per lane (dwordx2 loads) and transpose only tiles with
+//     candidates into the 16-byte layout (used for one-byte needles).
 //
-// Nothing here depends on block->XCD placement; all inter-workgroup traffic is one relaxed
-// agent-scope int (monotonic 0 -> 1), read with a relaxed agent-scope load.
+// Nothing here depends on block->XCD placement; all inter-workgroup traffic is one relaxed agent-scope int
+// (or uint64 minimum), read with relaxed agent-scope loads and scalar-cache peeks.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
