@@ -789,26 +789,28 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
 {
     // one 2 KiB slice per wave; the launch passes (waves per workgroup) * kNeedleLds bytes of dynamic LDS
     extern __shared__ __attribute__((aligned(16))) uint8_t s_needle[];
-    const uint64_t wpb = blockDim.x / kWave;
-    const uint64_t ntiles = (pr.npieces + wpb * U - 1) / (wpb * U);
-    // one call site (one copy of the code): contiguous run, or grid-stride when tiles_per_block == 0
-    uint64_t t0 = blockIdx.x, step = gridDim.x, t1 = ntiles;
-    if (tiles_per_block) {
-        t0 = (uint64_t)blockIdx.x * tiles_per_block;
-        step = 1;
-        t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
-    }
     // Early exit survives short-lived workgroups through the entry peek (scalar cache; see scalar_peek): once
-    // a match is known the rest of the grid drains without touching memory.  The first workgroups of a grid
-    // start before anything can have been found and skip it.
+    // a match is known the rest of the grid drains without touching memory, so the peek comes before anything
+    // else.  The first workgroups of a grid start before anything can have been found and skip it.
+    // Pieces per tile = waves per workgroup (2, 4 or 8) * U: a power of two, so no division anywhere.
+    static_assert((U & (U - 1)) == 0, "U is a power of two");
+    const unsigned tile_shift = (unsigned)__builtin_ctz(blockDim.x / kWave) + (unsigned)__builtin_ctz(U);
+    uint64_t t0 = tiles_per_block ? (uint64_t)blockIdx.x * tiles_per_block : blockIdx.x;
     if (blockIdx.x >= kPeekFromBlock) {
         if (FIND) {
-            const uint64_t first_chunk = t0 * (wpb * U) * 64;
+            const uint64_t first_chunk = (t0 << tile_shift) * 64;
             const uint64_t first = first_chunk * 16 > pr.mis ? first_chunk * 16 - pr.mis : 0;
             if (scalar_peek64(static_cast<const uint64_t *>(found)) <= pr.find_base + first) return;
         } else if (scalar_peek(static_cast<const int *>(found)) == pr.epoch) {
             return;
         }
+    }
+    const uint64_t ntiles = (pr.npieces + ((uint64_t)1 << tile_shift) - 1) >> tile_shift;
+    // one call site (one copy of the code): contiguous run, or grid-stride when tiles_per_block == 0
+    uint64_t step = gridDim.x, t1 = ntiles;
+    if (tiles_per_block) {
+        step = 1;
+        t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
     }
     scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
 }
@@ -995,7 +997,7 @@ __global__ void __launch_bounds__(kMaxBlock) read_ceiling_kernel(const V *src, u
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const uint64_t wpb = blockDim.x / kWave;
-    const uint64_t ntiles = nvec / (64 * kPerKiB * wpb * U);            // the ragged tail is ignored
+    const uint64_t ntiles = nvec >> (__builtin_ctz(64 * kPerKiB * U) + __builtin_ctz((unsigned)wpb));   // ragged tail ignored
     uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_block;
     const uint64_t t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
     V acc = {};
