@@ -301,16 +301,17 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         if (s->grid < 0) {
             tpb = (uint64_t)(-(int64_t)s->grid);
         } else {
-            // Short-lived workgroups: two tiles (32 KiB) each from 1 GiB up, one below.  The hardware dispatcher
-            // hands out tiles in address order, so the set of lines in flight stays one narrow, advancing
-            // window, and a fresh workgroup issues its loads the moment a slot frees up.  Measured
-            // (profiles/r01/tiles_per_block_sweep.jsonl, 16-byte needle): 64 GiB 7.40 TB/s at 2 tiles per
-            // workgroup vs 7.28 at 4, 7.21 at 8, 7.11 at 64; 8 GiB 7.08-7.17 vs 6.83-6.98 at 16.  One tile is
-            // another 1 % faster for a full scan of 64 GiB but twice as many workgroups have to be drained
-            // after an early match (the entry peek in scan_kernel); two is the compromise.
+            // Short-lived workgroups: two tiles (32 KiB) each from 2 GiB up (from 1 GiB for position >= 16), one
+            // below.  The hardware dispatcher hands out tiles in address order, so the set of lines in flight
+            // stays one narrow, advancing window, and a fresh workgroup issues its loads the moment a slot
+            // frees up.  Measured (profiles/r01/tiles_per_block_sweep.jsonl, tiles_1_vs_2.txt; 16-byte needle):
+            // 64 GiB 7.40-7.43 TB/s at 2 tiles per workgroup vs 7.28 at 4, 7.21 at 8, 7.11 at 64.  One tile is
+            // +2 % at 1 GiB, within +-0.7 % from 4 GiB up (and +1.5 % for one-byte needles), but twice as many
+            // workgroups have to be drained after an early match (the entry peek in scan_kernel), and the
+            // cross-lane kernels (position >= 16) lose 5 % with it: each wave re-loads its halo chunks per tile.
             DeviceInfo di;
             if (int rc = device_info(pd->dev, &di)) return rc;
-            tpb = ntiles / ((uint64_t)di.cus * 128);
+            tpb = ntiles / ((uint64_t)di.cus * (l.mode == 0 ? 256 : 128));
             if (tpb > (uint64_t)kAutoTilesPerBlock) tpb = kAutoTilesPerBlock;
             if (tpb < 1) tpb = 1;
         }

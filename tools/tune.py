@@ -5,6 +5,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -36,6 +37,11 @@ def main():
     hay = buf[args.mis:args.mis + n_bytes]
     torch.cuda.synchronize()
     print(json.dumps({"read_ceiling_gbps": round(ss.read_ceiling_gbps(buf[:n_bytes], reps=5), 1)}), flush=True)
+    # settle: the first ~0.1 s of sustained load after the start of a process runs a few percent slow
+    warm = ss.DynamicHipSearcher.new(absent(16))
+    t_end = time.perf_counter() + 0.25
+    while time.perf_counter() < t_end:
+        warm.search_in(hay)
     for n in [int(x) for x in args.needles.split(",")]:
         nd = absent(n, args.ff_at)
         for v in [int(x) for x in args.variants.split(",")]:
