@@ -98,6 +98,61 @@ def cpu_baseline(needle, sample_bytes):
     return out
 
 
+def cpu_report(out):
+    """The extended CPU-side report (`--cpu-report`, no GPU needed): BASELINE.md section 3 timed on THIS host with
+    the C/AVX2 restatement - config 1 long + short loops (beside README's 35.181 / 79.416 ms), the needle-length
+    sweep {1,2,4,8,16,32,128} at 1 thread and the 16-byte needle at 1 / 8 / 64 / all threads.  JSON lines."""
+    from oracle import oracle as O
+
+    def emit(**kw):
+        out.write((json.dumps(kw) + "\n").encode())
+
+    def absent(n):
+        nd = bytearray(O.fill_random(n, SEED_NEEDLE).tobytes())
+        nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+        return bytes(nd)
+    cores = len(os.sched_getaffinity(0))
+    model = "?"
+    with open("/proc/cpuinfo") as fh:
+        for l in fh:
+            if l.startswith("model name"):
+                model = l.split(":", 1)[1].strip()
+                break
+    emit(cpu_model=model, hardware_threads=cores, avx2=bool(O.have_avx2()), note="C restatement of the reference AVX2 path")
+    gd = os.path.join(ROOT, "tests", "golden", "data")
+    i386 = open(os.path.join(gd, "i386.txt"), "rb").read()
+    words = [w for w in open(os.path.join(gd, "words.txt"), "rb").read().split(b"\n") if w]
+    O.bench_long(i386, words, 1)
+    t = time.perf_counter()
+    hits = O.bench_long(i386, words, 10)
+    emit(config=1, loop="long (bench/benches/i386.rs:246-256)", threads=1, ms_per_iteration=round((time.perf_counter() - t) * 100, 3),
+         hits=hits // 10, readme_ms=35.181)
+    ws = sorted(words, key=len)
+    t = time.perf_counter()
+    hits = O.bench_short(ws, 2)
+    emit(config=1, loop="short (bench/benches/i386.rs:118-129)", threads=1, ms_per_iteration=round((time.perf_counter() - t) * 500, 3),
+         hits=hits // 2, readme_ms=79.416)
+    n_bytes = 1 << 30
+    hay = O.fill_random(n_bytes, SEED_HAY)
+    for n in (1, 2, 4, 8, 16, 32, 128):
+        s = O.OracleSearcher(absent(n))
+        best = float("inf")
+        for _ in range(3):
+            t = time.perf_counter()
+            r = s.search_in(hay)
+            best = min(best, time.perf_counter() - t)
+        assert r is False
+        emit(config=3, needle_len=n, threads=1, haystack_bytes=n_bytes, gbps=round(n_bytes / best / 1e9, 2))
+    s = O.OracleSearcher(absent(16))
+    for th in sorted({1, 8, 64, cores}):
+        best = float("inf")
+        for _ in range(5):
+            t = time.perf_counter()
+            r = s.search_in(hay, threads=th)
+            best = min(best, time.perf_counter() - t)
+        emit(config=2, needle_len=16, threads=th, haystack_bytes=n_bytes, gbps=round(n_bytes / best / 1e9, 2))
+
+
 def main():
     # Exactly ONE line may reach stdout.  Libraries (the RCCL banner, for one) print to fd 1, so fd 1 is
     # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
@@ -120,7 +175,13 @@ def main():
     ap.add_argument("--no-ceiling", action="store_true",
                     help="skip the plain streaming-read ceiling (roofline.read_ceiling_gbps; a few launches, untimed)")
     ap.add_argument("--ceiling", action="store_true", help="(default now) kept for compatibility")
+    ap.add_argument("--cpu-report", action="store_true",
+                    help="print the extended CPU-side report (JSON lines; no GPU needed) and exit")
     args = ap.parse_args()
+    if args.cpu_report:
+        with os.fdopen(real_stdout, "wb", closefd=False) as out:
+            cpu_report(out)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
