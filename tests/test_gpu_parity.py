@@ -281,7 +281,9 @@ def test_all_kernel_variants_agree(ss, O):
     cases += [host[12345:12345 + n].tobytes() for n in (33, 100, 257, 1000)]
     for nd in cases:
         want = O.OracleSearcher(nd).search_in(host)
-        for variant in (40, 41, 80, 81, 140, 141, 181, 240, 241, 280, 281, 1040, 1041, 1081, 2040, 2041, 2080, 2081):
+        # + launch-shape digits: 1xxxxx / 3xxxxx = 128- / 512-thread workgroups, x4xxxx = occupancy cap
+        for variant in (40, 41, 80, 81, 140, 141, 181, 240, 241, 280, 281, 1040, 1041, 1081, 2040, 2041, 2080, 2081,
+                        100041, 300041, 100241, 300141, 302041, 40041, 130081):
             for grid in (0, 1, 7, 4096, -1, -3, -1000):
                 s = ss.DynamicHipSearcher.new(nd)
                 s.set_variant(variant)
