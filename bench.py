@@ -60,21 +60,35 @@ def cpu_baseline(needle, sample_bytes):
             assert r is False
         return sample_bytes / b / 1e9
     one = best(1, 3)
-    # the reference is single-threaded; the multi-thread figure uses the same range-shard rule as the GPUs.
-    # More threads is not always faster (memory-bound): report the best thread count, and all-threads too.
+    # The reference is single-threaded; the multi-thread figure uses the same range-shard rule as the GPUs, on a
+    # LARGER sample (4x, so that creating the threads does not dominate a few-millisecond scan) that the same
+    # number of NUMA-confined threads first touched.  More threads is not always faster (memory-bound): report
+    # the best thread count, and every count tried.
     sweep = {}
-    for th in sorted({t for t in (8, 16, 32, 64, 128, cores) if 1 < t <= cores}):
-        sweep[th] = best(th, 5)
+    counts = sorted({t for t in (8, 16, 32, 64, 128, cores) if 1 < t <= cores})
+    mt_bytes = sample_bytes * 4 if counts else 0
+    if counts:
+        del hay
+        t0 = time.perf_counter()
+        hay = O.fill_random(mt_bytes, SEED_HAY, threads=cores)
+        gen_mt_s = time.perf_counter() - t0
+        sample_bytes_1t, sample_bytes = sample_bytes, mt_bytes
+        for th in counts:
+            sweep[th] = best(th, 5)
+        sample_bytes = sample_bytes_1t
     best_th = max(sweep, key=sweep.get) if sweep else 1
     out = {
         "value": round(sweep.get(best_th, one), 2), "unit": "GB/s", "cores": best_th, "kind": "port",
         "single_thread_value": round(one, 2), "hardware_threads": cores,
         "by_threads": {str(k): round(v, 2) for k, v in sweep.items()}, "avx2": bool(O.have_avx2()),
-        "sample": "%d MiB of the same synthetic haystack in host RAM, same 16-byte absent needle; C/AVX2 "
-                  "restatement of DynamicAvx2Searcher (oracle/sliceslice_oracle.c): best of 3 runs on 1 thread, best of 5 "
-                  "per thread count in by_threads (range shards, n-1 overlap); value = the fastest thread count"
-                  % (sample_bytes >> 20),
+        "sample": "the same synthetic haystack in host RAM, same 16-byte absent needle; C/AVX2 restatement of "
+                  "DynamicAvx2Searcher (oracle/sliceslice_oracle.c): %d MiB, best of 3 runs on 1 thread; %d MiB "
+                  "(first touched by %d NUMA-confined threads), best of 5 per thread count in by_threads (range "
+                  "shards, n-1 overlap, threads confined to the NUMA node of their share); value = the fastest "
+                  "thread count" % (sample_bytes >> 20, mt_bytes >> 20, cores),
     }
+    if counts:
+        out["host_generate_mt_s"] = round(gen_mt_s, 2)
     # BASELINE.json configs[0]: data/i386.txt x data/words.txt, shape of bench/benches/i386.rs:246-256
     try:
         gd = os.path.join(ROOT, "tests", "golden", "data")
@@ -144,13 +158,18 @@ def cpu_report(out):
         assert r is False
         emit(config=3, needle_len=n, threads=1, haystack_bytes=n_bytes, gbps=round(n_bytes / best / 1e9, 2))
     s = O.OracleSearcher(absent(16))
-    for th in sorted({1, 8, 64, cores}):
+    del hay
+    mt_bytes = 4 * n_bytes                      # larger sample, first touched by NUMA-confined threads (see cpu_baseline)
+    hay = O.fill_random(mt_bytes, SEED_HAY, threads=cores)
+    for th in sorted({1, 8, 16, 32, 64, 128, cores}):
+        if th > cores:
+            continue
         best = float("inf")
-        for _ in range(5):
+        for _ in range(5 if th > 1 else 2):
             t = time.perf_counter()
             r = s.search_in(hay, threads=th)
             best = min(best, time.perf_counter() - t)
-        emit(config=2, needle_len=16, threads=th, haystack_bytes=n_bytes, gbps=round(n_bytes / best / 1e9, 2))
+        emit(config=2, needle_len=16, threads=th, haystack_bytes=mt_bytes, gbps=round(mt_bytes / best / 1e9, 2))
 
 
 def main():

@@ -56,6 +56,8 @@ def lib():
         L.oracle_bench_short.restype = ctypes.c_longlong
         L.oracle_fill_random.argtypes = [u8p, u64, sz, u64]
         L.oracle_fill_random.restype = None
+        L.oracle_fill_random_mt.argtypes = [u8p, u64, sz, u64, ctypes.c_int]
+        L.oracle_fill_random_mt.restype = None
         L.oracle_have_avx2.argtypes = []
         L.oracle_have_avx2.restype = ctypes.c_int
         _lib = L
@@ -145,9 +147,14 @@ def bench_short(words_sorted, iters):
     return int(lib().oracle_bench_short(blob.ctypes.data, off.ctypes.data, len(words_sorted), iters))
 
 
-def fill_random(length, seed, global_offset=0):
+def fill_random(length, seed, global_offset=0, threads=1):
+    """threads > 1: written by that many pinned threads over a block partition (first touch = local memory
+    for the multi-threaded baseline)."""
     out = np.empty(length, dtype=np.uint8)
-    lib().oracle_fill_random(out.ctypes.data, global_offset, length, seed)
+    if threads > 1:
+        lib().oracle_fill_random_mt(out.ctypes.data, global_offset, length, seed, threads)
+    else:
+        lib().oracle_fill_random(out.ctypes.data, global_offset, length, seed)
     return out
 
 

@@ -43,11 +43,15 @@
  * always compiled and is used at run time when the host CPU lacks AVX2; tests
  * check that both builders agree.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE            /* sched_getaffinity / pthread_setaffinity_np for the multi-threaded baseline */
+#endif
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <sched.h>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -393,11 +397,60 @@ typedef struct {
     const uint8_t *hay;
     size_t len;
     int found;
+    int t, threads;
 } mt_arg;
+
+/* Thread t of T is confined to the CPUs of the NUMA node that holds the same relative share of the machine
+ * (node floor(t/T * nodes), from /sys/devices/system/node/node<k>/cpulist, intersected with the process'
+ * affinity mask); inside the node the scheduler spreads the threads over cores as usual.  The generator below
+ * uses the same rule, so with a block partition of the buffer a thread scans memory that a thread of the same
+ * node first touched, whatever the two thread counts are.  Best effort: on any failure nothing is pinned. */
+#include <stdio.h>
+
+static int node_cpus(int node, cpu_set_t *out)
+{
+    char path[96], buf[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *fh = fopen(path, "r");
+    if (!fh) return 0;
+    const size_t got = fread(buf, 1, sizeof buf - 1, fh);
+    fclose(fh);
+    buf[got] = 0;
+    CPU_ZERO(out);
+    int n = 0;
+    for (char *p = buf; *p;) {                       /* "0-63,128-191" */
+        char *end;
+        long lo = strtol(p, &end, 10);
+        if (end == p) break;
+        long hi = lo;
+        if (*end == '-') hi = strtol(end + 1, &end, 10);
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) {
+            CPU_SET((int)c, out);
+            ++n;
+        }
+        p = *end == ',' ? end + 1 : end;
+        if (*p == '\n') break;
+    }
+    return n;
+}
+
+static void pin_to_share(int t, int threads)
+{
+    cpu_set_t allowed, node, both;
+    if (threads <= 0 || sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    int nodes = 0;
+    while (nodes < 64 && node_cpus(nodes, &node) > 0) ++nodes;
+    if (nodes < 2) return;                           /* one node (or no sysfs): nothing to gain */
+    const int k = (int)(((long long)t * nodes) / threads);
+    if (node_cpus(k, &node) <= 0) return;
+    CPU_AND(&both, &node, &allowed);
+    if (CPU_COUNT(&both) > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof both, &both);
+}
 
 static void *mt_worker(void *p)
 {
     mt_arg *a = (mt_arg *)p;
+    pin_to_share(a->t, a->threads);
     a->found = oracle_search_in(a->s, a->hay, a->len);
     return NULL;
 }
@@ -418,6 +471,8 @@ int oracle_search_in_mt(const oracle_searcher *s, const uint8_t *hay, size_t len
         arg[t].s = s;
         arg[t].hay = hay + b;
         arg[t].len = e - b;
+        arg[t].t = t;
+        arg[t].threads = threads;
         pthread_create(&tid[t], NULL, mt_worker, &arg[t]);
     }
     for (int t = 0; t < threads; ++t) {
@@ -457,6 +512,50 @@ void oracle_fill_random(uint8_t *dst, uint64_t global_offset, size_t len, uint64
         }
         k += take;
     }
+}
+
+/* The same bytes, written by `threads` pinned threads over a block partition (first touch = local memory for
+ * the multi-threaded baseline; see pin_to_share). */
+typedef struct {
+    uint8_t *dst;
+    uint64_t off;
+    size_t len;
+    uint64_t seed;
+    int t, threads;
+} fill_arg;
+
+static void *fill_worker(void *p)
+{
+    fill_arg *a = (fill_arg *)p;
+    pin_to_share(a->t, a->threads);
+    oracle_fill_random(a->dst, a->off, a->len, a->seed);
+    return NULL;
+}
+
+void oracle_fill_random_mt(uint8_t *dst, uint64_t global_offset, size_t len, uint64_t seed, int threads)
+{
+    if (threads <= 1 || len < (size_t)threads * 4096) {
+        oracle_fill_random(dst, global_offset, len, seed);
+        return;
+    }
+    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof *tid);
+    fill_arg *arg = (fill_arg *)calloc((size_t)threads, sizeof *arg);
+    const size_t shard = (len + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; ++t) {
+        size_t b = (size_t)t * shard, e = b + shard;
+        if (b > len) b = len;
+        if (e > len) e = len;
+        arg[t].dst = dst + b;
+        arg[t].off = global_offset + b;
+        arg[t].len = e - b;
+        arg[t].seed = seed;
+        arg[t].t = t;
+        arg[t].threads = threads;
+        pthread_create(&tid[t], NULL, fill_worker, &arg[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+    free(tid);
+    free(arg);
 }
 
 int oracle_have_avx2(void) { return have_avx2(); }
