@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--no-ceiling", action="store_true",
                     help="skip the plain streaming-read ceiling (roofline.read_ceiling_gbps; a few launches, untimed)")
     ap.add_argument("--ceiling", action="store_true", help="(default now) kept for compatibility")
+    ap.add_argument("--settle-seconds", type=float, default=20.0,
+                    help="upper bound on the wait for a previous process' VRAM to be reclaimed before allocating")
     ap.add_argument("--cpu-report", action="store_true",
                     help="print the extended CPU-side report (JSON lines; no GPU needed) and exit")
     args = ap.parse_args()
@@ -231,7 +233,30 @@ def main():
 
     n = args.needle_len
     total = int(args.haystack_gib * (1 << 30))
-    free_b, _ = torch.cuda.mem_get_info()
+    # Device hygiene (untimed): the driver reclaims the VRAM of a process that has just exited lazily, and a scan
+    # that runs while another process' tens of GiB are still being reclaimed is 3-4 % slower (ten back-to-back
+    # runs: 7.34-7.38 TB/s with 69 GB of VRAM in use afterwards, 7.05-7.13 with 138 GB).  Wait (bounded) until the
+    # device's memory is free again before allocating.
+    t_wait = time.perf_counter()
+    vram_used_file = None
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        cand = "/sys/bus/pci/devices/%04x:%02x:%02x.0/mem_info_vram_used" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        if os.path.exists(cand):
+            vram_used_file = cand
+    except Exception:
+        vram_used_file = None
+
+    def vram_used():
+        try:
+            return int(open(vram_used_file).read())
+        except Exception:
+            return 0
+    used_at_start = vram_used() if vram_used_file else None
+    while vram_used_file and vram_used() > (8 << 30) and time.perf_counter() - t_wait < args.settle_seconds:
+        time.sleep(0.05)
+    free_b, total_b = torch.cuda.mem_get_info()
+    waited_s = time.perf_counter() - t_wait
     while (total + world - 1) // world + n > 0.92 * free_b and total > (1 << 28):
         total //= 2                                            # a smaller device: say so in config
     begin, end = ss.shard_range(total, n, world, rank)
@@ -301,6 +326,7 @@ def main():
                 "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n,
                 "transport": args.transport if dist is not None else "none", "variant": args.variant,
                 "device": info["name"], "compute_units": info["compute_units"],
+                "waited_for_free_vram_s": round(waited_s, 2), "vram_used_at_start": used_at_start,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
