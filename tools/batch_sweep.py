@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
+from settle import wait_for_vram_reclaim  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -33,6 +34,7 @@ def timed(fn, reps):
 
 
 def main():
+    wait_for_vram_reclaim()
     targets = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,4096,8192,16384,32768,65536").split(",")]
     count, each = 4096, 1 << 20
     blob = torch.empty(count * each, dtype=torch.uint8, device="cuda")

@@ -21,6 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import sliceslice_rs_amd as ss  # noqa: E402
+from settle import wait_for_vram_reclaim  # noqa: E402
 
 SEED_HAY, SEED_NEEDLE = 0x5EED0001, 0x5EED0002
 
@@ -55,6 +56,7 @@ def emit(**kw):
 
 
 def main():
+    wait_for_vram_reclaim()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=10)

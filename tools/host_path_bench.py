@@ -12,9 +12,11 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
+from settle import wait_for_vram_reclaim  # noqa: E402
 
 
 def main():
+    wait_for_vram_reclaim()
     gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
     n_bytes = int(gib * (1 << 30))
     host = ss.fill_random_host(n_bytes, 0x5EED0001)

@@ -12,6 +12,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
+from settle import wait_for_vram_reclaim  # noqa: E402
+
+wait_for_vram_reclaim()
 
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 64.0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 3

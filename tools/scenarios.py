@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
+from settle import wait_for_vram_reclaim  # noqa: E402
 
 
 def med(fn, s, reps=7):
@@ -23,6 +24,7 @@ def med(fn, s, reps=7):
 
 
 def main():
+    wait_for_vram_reclaim()
     n_bytes = int(float(sys.argv[1]) * (1 << 30)) if len(sys.argv) > 1 else 1 << 30   # [GiB] [grid override] [variant]
     grid = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0

@@ -12,6 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
+from settle import wait_for_vram_reclaim  # noqa: E402
 
 
 def absent(n, ff_at=-1):
@@ -22,6 +23,7 @@ def absent(n, ff_at=-1):
 
 
 def main():
+    wait_for_vram_reclaim()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=8.0)
     ap.add_argument("--reps", type=int, default=6)
@@ -37,7 +39,7 @@ def main():
     hay = buf[args.mis:args.mis + n_bytes]
     torch.cuda.synchronize()
     print(json.dumps({"read_ceiling_gbps": round(ss.read_ceiling_gbps(buf[:n_bytes], reps=5), 1)}), flush=True)
-    # settle: the first ~0.1 s of sustained load after the start of a process runs a few percent slow
+    # settle (on top of wait_for_vram_reclaim above): a short run-in before the first measured series
     warm = ss.DynamicHipSearcher.new(absent(16))
     t_end = time.perf_counter() + 0.25
     while time.perf_counter() < t_end:
@@ -51,7 +53,7 @@ def main():
                 s.set_grid(g)
                 s.set_timing(True)
                 assert s.search_in(hay) is False
-                for _ in range(8):                 # settle: the first launches of a series run up to 5 % slow
+                for _ in range(8):                 # run-in of the series
                     s.search_in(hay)
                 ms = []
                 for _ in range(args.reps):
