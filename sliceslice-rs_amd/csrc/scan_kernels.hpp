@@ -345,8 +345,9 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
     return any;
 }
 
-// Per-piece form of the same filter (the MODE 2 kernels keep it: with the tile-wide form their first phase,
-// instruction for instruction the same, ran 4-8 % slower on random bytes - profiles/r01/refine_tile_ab.txt).
+// Per-piece form of the same filter.  The MODE 2 kernels keep it: they need 95 VGPRs with it (96 allocated: 5
+// waves per SIMD) and 97 with the tile-wide form (104 allocated: 4 waves), and with 4 waves they run 2-7 %
+// slower on random bytes (profiles/r01/refine_tile_ab.txt).
 // Returns false when no lane of the wave has a candidate left in this piece.
 __device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4])
 {
