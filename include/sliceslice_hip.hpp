@@ -6,6 +6,8 @@
 //   sliceslice::hip::DynamicHipSearcher::with_position(needle, pos)  DynamicAvx2Searcher::with_position  src/x86.rs:468
 //   searcher.search_in(haystack)                                     DynamicAvx2Searcher::search_in      src/x86.rs:523
 //   searcher.inlined_search_in(haystack)                             ::inlined_search_in                 src/x86.rs:498
+//   searcher.find(haystack)            leftmost offset, the Option<usize> of find_subsequence     tests/i386.rs:6-10
+//   searcher.search_in_file(path)      open the file + one search_in                              examples/grep.rs:42-56
 //
 // Contract violations that make the reference panic (src/x86.rs:300,473) throw
 // sliceslice::hip::PositionPanic; HIP / RCCL failures throw sliceslice::hip::Error.  The searcher owns
@@ -110,6 +112,25 @@ public:
         uint64_t pos = npos;
         check(ss_find_device(h_, haystack.ptr, haystack.len, hip_stream, &pos));
         return pos;
+    }
+
+    // ... and for a host slice (uploaded in chunks like search_in).
+    uint64_t find(const uint8_t *haystack, size_t len) const
+    {
+        uint64_t pos = npos;
+        check(ss_find_host(h_, haystack, len, &pos));
+        return pos;
+    }
+    uint64_t find(const std::string &haystack) const
+    {
+        return find(reinterpret_cast<const uint8_t *>(haystack.data()), haystack.size());
+    }
+    // examples/grep.rs:42-56: open the file, one search_in (read -> upload -> scan pipeline).
+    bool search_in_file(const std::string &path) const
+    {
+        int found = 0;
+        check(ss_search_file(h_, path.c_str(), &found));
+        return found != 0;
     }
 
     size_t position() const { return ss_searcher_position(h_); }

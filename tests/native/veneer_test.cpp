@@ -56,6 +56,21 @@ int main()
         CHECK(s.find(DeviceSlice{d + 7, len - 1}) == DynamicHipSearcher::npos);
     }
     (void)hipFree(d);
+
+    // host slice: find; file front end (examples/grep.rs shape)
+    {
+        auto s = DynamicHipSearcher::new_(needle);
+        CHECK(s.find(host.data(), len) == len - needle.size());
+        CHECK(s.find(host.data(), len - 1) == DynamicHipSearcher::npos);
+        const std::string path = "/tmp/veneer_test_haystack.bin";
+        std::FILE *fh = std::fopen(path.c_str(), "wb");
+        CHECK(fh != nullptr);
+        CHECK(std::fwrite(host.data(), 1, len, fh) == len);
+        std::fclose(fh);
+        CHECK(s.search_in_file(path));
+        CHECK(!DynamicHipSearcher::new_("not in the file at all").search_in_file(path));
+        std::remove(path.c_str());
+    }
     std::puts("veneer_test ok");
     return 0;
 }
