@@ -82,6 +82,7 @@ struct PerDevice {
     uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
     uint64_t *h_best = nullptr; // pinned mirror
     uint64_t free_mask = 0;
+    uint64_t best_dirty = 0;    // find(): slots whose d_best holds a result and must be re-armed before their next use
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed_valid = false;
@@ -165,6 +166,16 @@ int acquire_slot(const ss_searcher *s, PerDevice *p)
         }
         sched_yield();   // > 64 concurrent searches on one handle: wait for a slot
     }
+}
+
+// find(): true when slot k still holds an earlier result and has to be re-armed (all ones) before use;
+// clears the mark.
+bool take_best_dirty(const ss_searcher *s, PerDevice *p, int k)
+{
+    std::lock_guard<std::mutex> lock(s->mu);
+    const bool dirty = (p->best_dirty >> k) & 1;
+    p->best_dirty &= ~(1ull << k);
+    return dirty;
 }
 
 // The value that means "found" for the call that owns slot k: fresh per call, never 0.  On the (2^31
@@ -504,7 +515,14 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     const int k = acquire_slot(s, pd);
-    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0);
+    // A slot that still holds the result of an earlier find() is re-armed (all ones) here, stream-ordered in
+    // front of this call's kernel: the earlier call has synchronised, so nothing else touches the slot, and the
+    // call that found something does not pay a second synchronisation for the reset.
+    int rc = SS_OK;
+    const bool dirty = take_best_dirty(s, pd, k);
+    if (dirty && hipMemsetAsync(pd->d_best + k, 0xFF, sizeof(uint64_t), st) != hipSuccess)
+        rc = fail(SS_ERR_HIP, "slot reset failed");
+    if (rc == SS_OK) rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0);
     if (rc == SS_OK) {
         hipError_t e = hipMemcpyAsync(pd->h_best + k, pd->d_best + k, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -512,10 +530,9 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
     }
     if (rc == SS_OK) {
         *position = pd->h_best[k];
-        if (*position != SS_NPOS) {                     // slots are all-ones whenever they are free
-            hipError_t e = hipMemsetAsync(pd->d_best + k, 0xFF, sizeof(uint64_t), st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "slot reset: %s", hipGetErrorString(e));
+        if (*position != SS_NPOS) {
+            std::lock_guard<std::mutex> lk(s->mu);
+            pd->best_dirty |= 1ull << k;
         }
     } else {
         (void)hipDeviceSynchronize();
@@ -669,6 +686,7 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
     uint8_t **dbuf = lease.set->d;
     hipStream_t *st = lease.set->st;
     const int k = acquire_slot(s, pd);
+    if (take_best_dirty(s, pd, k)) (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));   // left by ss_find_device
     int rc = SS_OK;
     size_t idx = 0;
     bool hit = false;
