@@ -272,6 +272,7 @@ class ShardedSearcher:
             DynamicHipSearcher(needle, position)
         self._comm = None
         self._flag = None
+        self._flag_next = 0
         if backend == "rccl":
             self._init_rccl()
 
@@ -303,12 +304,18 @@ class ShardedSearcher:
             _check(lib().ss_search_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), self._comm, st,
                                            ctypes.byref(found)))
             return bool(found.value)
-        if self._flag is None:
-            self._flag = torch.zeros(1, dtype=torch.int32, device=shard.device)
-        self._flag.zero_()
-        self._searcher.search_in_async(shard, self._flag, st)
-        self._dist.all_reduce(self._flag, op=self._dist.ReduceOp.MAX, group=self.group)
-        return bool(self._flag.item())
+        # a ring of pre-zeroed flags: one fresh zero per call, one zero_() launch per 256 calls instead of per call
+        if self._flag is None or self._flag_next == self._flag.numel():
+            if self._flag is None:
+                self._flag = torch.zeros(256, dtype=torch.int32, device=shard.device)
+            else:
+                self._flag.zero_()
+            self._flag_next = 0
+        flag = self._flag[self._flag_next:self._flag_next + 1]
+        self._flag_next += 1
+        self._searcher.search_in_async(shard, flag, st)
+        self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX, group=self.group)
+        return bool(flag.item())
 
     def find(self, shard, shard_begin, stream=None):
         """Global offset of the leftmost occurrence in the logical haystack, or None: every rank finds its
