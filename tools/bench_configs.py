@@ -163,6 +163,14 @@ def main():
             res, ms = timed(s, text, args.reps)
             emit(config="text", needle=nd.decode("latin1"), label=label, haystack_bytes=text.numel(), found=res,
                  kernel_ms=round(ms, 3), gbps=round(text.numel() / ms / 1e6, 1))
+            # row f3: the same needle with the position chosen from a byte histogram of (a sample of) the haystack
+            hist = ss.byte_histogram(text, sample_bytes=64 << 20)
+            pos = ss.choose_position(nd, hist)
+            s = ss.DynamicHipSearcher.with_position(nd, pos)
+            res, ms = timed(s, text, args.reps)
+            emit(config="text", needle=nd.decode("latin1"), label=label + "; position chosen by ss_choose_position",
+                 position=pos, position_byte=chr(nd[pos]), haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
+                 gbps=round(text.numel() / ms / 1e6, 1))
         del text
         a = torch.full((n_bytes,), 0x61, dtype=torch.uint8, device="cuda")
         for nd, pos, label in ((b"a" * 15 + b"b", None, "adversarial: every offset passes both filters"),
