@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU: search_in / find through the C ABI against Python's bytes.find over
+random (haystack kind, length, misalignment, needle, position, kernel variant, launch shape).  Runs for
+argv[1] seconds (default 60) with seed argv[2]; prints a JSON summary, exits non-zero on the first mismatch."""
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sliceslice_rs_amd as ss  # noqa: E402
+
+VARIANTS = [0, 40, 41, 80, 81, 141, 241, 281, 1041, 2041, 2081, 100041, 300041, 100241, 40041]
+GRIDS = [0, 0, 0, 1, 3, 64, 4096, -1, -2, -3, -7, -64]
+
+
+def make_haystack(rng, n_bytes):
+    kind = rng.choice(["random", "random", "abcd", "ab", "text", "zeros"])
+    if kind == "random":
+        a = np.frombuffer(rng.randbytes(n_bytes), dtype=np.uint8).copy()
+    elif kind == "abcd":
+        a = np.frombuffer(bytes(rng.choice(b"abcd") for _ in range(min(n_bytes, 4096))), dtype=np.uint8)
+        a = np.resize(a, n_bytes).copy()
+        idx = np.array([rng.randrange(n_bytes) for _ in range(max(1, n_bytes // 997))], dtype=np.int64)
+        a[idx] = ord("e")
+    elif kind == "ab":
+        a = np.full(n_bytes, ord("a"), dtype=np.uint8)
+        idx = np.array([rng.randrange(n_bytes) for _ in range(max(1, n_bytes // 257))], dtype=np.int64)
+        a[idx] = ord("b")
+    elif kind == "text":
+        t = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "data", "i386.txt"), "rb").read()
+        a = np.resize(np.frombuffer(t, dtype=np.uint8), n_bytes).copy()
+    else:
+        a = np.zeros(n_bytes, dtype=np.uint8)
+        a[rng.randrange(n_bytes)] = 1
+    return kind, a
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = random.Random(seed)
+    t_end = time.time() + seconds
+    cases = searches = 0
+    while time.time() < t_end:
+        n_bytes = rng.choice([1, 15, 16, 17, 63, 1000, 4097, 70000, 1 << 20, (3 << 20) + 5, (20 << 20) + 123])
+        kind, host = make_haystack(rng, n_bytes)
+        mis = rng.randrange(16)
+        dev = torch.empty(n_bytes + 32, dtype=torch.uint8, device="cuda")
+        dev[mis:mis + n_bytes] = torch.from_numpy(host).cuda()
+        hay = dev[mis:mis + n_bytes]
+        hb = host.tobytes()
+        cases += 1
+        for _ in range(12):
+            n = rng.choice([1, 1, 2, 3, 4, 8, 15, 16, 17, 31, 33, 64, 100, 257, 1000, 1100, 3000])
+            if n > n_bytes and rng.random() < 0.8:
+                n = rng.randrange(1, n_bytes + 1)
+            if n <= n_bytes and rng.random() < 0.6:
+                at = rng.choice([0, n_bytes - n, rng.randrange(n_bytes - n + 1)])
+                nd = bytearray(hb[at:at + n])
+                if rng.random() < 0.4:                               # near miss: one byte changed
+                    k = rng.randrange(n)
+                    nd[k] = (nd[k] + 1 + rng.randrange(254)) & 0xFF
+            else:
+                nd = bytearray(rng.randbytes(n))
+            nd = bytes(nd)
+            pos = None if rng.random() < 0.5 else (0 if n == 1 else rng.randrange(n))
+            want = hb.find(nd)
+            s = ss.DynamicHipSearcher(nd, pos)
+            s.set_variant(rng.choice(VARIANTS))
+            s.set_grid(rng.choice(GRIDS))
+            got_b = s.search_in(hay)
+            s.set_variant(rng.choice([0, 40, 41, 141, 241]))         # find() supports the U = 4 kernels
+            got_p = s.find(hay)
+            searches += 2
+            if got_b != (want >= 0) or got_p != (want if want >= 0 else None):
+                print(json.dumps({"MISMATCH": True, "kind": kind, "len": n_bytes, "mis": mis, "needle_len": n, "position": pos,
+                                  "want": want, "search_in": got_b, "find": got_p, "seed": seed, "case": cases}))
+                sys.exit(1)
+    print(json.dumps({"fuzz": "ok", "seconds": seconds, "seed": seed, "haystacks": cases, "searches": searches}))
+
+
+if __name__ == "__main__":
+    main()
