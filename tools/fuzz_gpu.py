@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test on the GPU: search_in / find through the C ABI against Python's bytes.find over
 random (haystack kind, length, misalignment, needle, position, kernel variant, launch shape).  Runs for
-argv[1] seconds (default 60) with seed argv[2]; prints a JSON summary, exits non-zero on the first mismatch."""
+argv[1] seconds (default 60) with seed argv[2]; a third argument (GiB) selects the large-haystack mode.  Prints a
+JSON summary, exits non-zero on the first mismatch."""
 import json
 import os
 import random
@@ -40,9 +41,51 @@ def make_haystack(rng, n_bytes):
     return kind, a
 
 
+def big(seconds, seed, gib):
+    """Large haystacks (two-tile workgroups, entry peek, early exit): the same needle planted at several random
+    offsets of a random haystack; find must return the leftmost, search_in true; then every copy is destroyed
+    again and both must say absent."""
+    rng = random.Random(seed)
+    n_bytes = int(gib * (1 << 30))
+    hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, 0xF00D + seed)
+    t_end = time.time() + seconds
+    rounds = 0
+    while time.time() < t_end:
+        n = rng.choice([1, 2, 5, 16, 17, 40, 300, 1100])
+        nd = bytearray(rng.randbytes(n))
+        nd[rng.randrange(n)] = 0xFF                                   # 0xFF never occurs in the haystack
+        nd = bytes(nd)
+        t = torch.from_numpy(np.frombuffer(nd, dtype=np.uint8).copy()).cuda()
+        offs = sorted(rng.randrange(n_bytes - n + 1) for _ in range(rng.choice([1, 2, 5])))
+        if rng.random() < 0.3:
+            offs[0] = rng.choice([0, n_bytes - n, 32768 * 1024 - 3, (1 << 30) - 1])   # edges: start, end, peek threshold ...
+            offs.sort()
+        saved = [hay[o:o + n].clone() for o in offs]
+        for o in offs:
+            hay[o:o + n] = t
+        pos = None if rng.random() < 0.5 else (0 if n == 1 else rng.randrange(n))
+        s = ss.DynamicHipSearcher(nd, pos)
+        s.set_variant(rng.choice([0, 0, 41, 141, 241, 1041]))
+        s.set_grid(rng.choice([0, 0, 0, -1, -2, -5, 8192]))
+        got_b, got_p = s.search_in(hay), s.find(hay)
+        for o, sv in zip(reversed(offs), reversed(saved)):            # restore (overlapping plants: reverse order)
+            hay[o:o + n] = sv
+        absent_b, absent_p = s.search_in(hay), s.find(hay)
+        rounds += 1
+        if got_b is not True or got_p != offs[0] or absent_b is not False or absent_p is not None:
+            print(json.dumps({"MISMATCH": True, "mode": "big", "needle_len": n, "position": pos, "planted": offs,
+                              "search_in": got_b, "find": got_p, "after_restore": [absent_b, absent_p], "seed": seed}))
+            sys.exit(1)
+    print(json.dumps({"fuzz": "ok", "mode": "big", "gib": gib, "seconds": seconds, "seed": seed, "rounds": rounds,
+                      "searches": 4 * rounds}))
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3:                                             # fuzz_gpu.py SECONDS SEED GIB: the large-haystack mode
+        return big(seconds, seed, float(sys.argv[3]))
     rng = random.Random(seed)
     t_end = time.time() + seconds
     cases = searches = 0
