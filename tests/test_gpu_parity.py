@@ -685,6 +685,39 @@ def test_caller_owned_flags_are_not_seen_stale(ss):
         assert int(best.item()) == -1
 
 
+def test_async_entry_points_capture_into_a_graph(ss):
+    """ss_search_device_async / ss_find_device_async only enqueue, so a launch-bound loop of searches can be
+    captured once into a hipGraph and replayed."""
+    hay = torch.empty(48 << 20, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, 0x77)
+    at = hay.numel() - 1000
+    yes = hay[at:at + 16].cpu().numpy().tobytes()
+    no = bytearray(yes)
+    no[3] = 0xFF
+    s_yes, s_no = ss.DynamicHipSearcher.new(yes), ss.DynamicHipSearcher.new(bytes(no))
+    flags = torch.zeros(2, dtype=torch.int32, device="cuda")
+    best = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                           # first use outside the capture
+        s_yes.search_in_async(hay, flags[0:1])
+        s_no.search_in_async(hay, flags[1:2])
+        s_yes.find_async(hay, best)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        flags.zero_()
+        best.fill_(-1)
+        s_yes.search_in_async(hay, flags[0:1])
+        s_no.search_in_async(hay, flags[1:2])
+        s_yes.find_async(hay, best)
+    for _ in range(3):
+        flags.fill_(7)
+        best.fill_(5)
+        g.replay()
+        torch.cuda.synchronize()
+        assert flags.tolist() == [1, 0] and int(best.item()) == at
+
+
 def test_offsets_beyond_4gib_and_long_needles(ss):
     """64-bit offsets: matches planted beyond 2^32 and 2^33 in a 9 GiB haystack (search_in and find), and
     needles far longer than the 2 KiB LDS slice / longer than a tile (compare continues from global)."""
