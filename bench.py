@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py - haystack GB/s of the MI355X substring scan (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher around it (WORLD_SIZE unset): bench.py starts the N ranks itself
+(`torch.distributed.run --nproc-per-node N`, rendezvous on 127.0.0.1) and refuses - non-zero exit, nothing on
+stdout - when fewer than N GPUs are visible or when --gpus disagrees with an existing WORLD_SIZE: a line that
+says n_gpus N always comes from N ranks on N devices.
 
 One *step* = one complete `search_in` of the whole logical haystack for a 16-byte ABSENT needle
 (position = 15, the `new` default): every rank scans its range shard (shards overlap by n-1 bytes),
@@ -38,6 +43,21 @@ def absent_needle(ss, n):
     nd = bytearray(ss.fill_random_host(n, SEED_NEEDLE).tobytes())
     nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
     return bytes(nd)
+
+
+def physical_cores():
+    """Physical cores of this host: distinct (physical id, core id) pairs of /proc/cpuinfo."""
+    try:
+        seen, phys = set(), None
+        with open("/proc/cpuinfo") as fh:
+            for l in fh:
+                if l.startswith("physical id"):
+                    phys = l.split(":", 1)[1].strip()
+                elif l.startswith("core id"):
+                    seen.add((phys, l.split(":", 1)[1].strip()))
+        return len(seen) or None
+    except Exception:
+        return None
 
 
 def cpu_baseline(needle, sample_bytes):
@@ -79,6 +99,7 @@ def cpu_baseline(needle, sample_bytes):
     best_th = max(sweep, key=sweep.get) if sweep else 1
     out = {
         "value": round(sweep.get(best_th, one), 2), "unit": "GB/s", "cores": best_th, "kind": "port",
+        "threads_used": best_th, "host_physical_cores": physical_cores(), "host_hardware_threads": cores,
         "single_thread_value": round(one, 2), "hardware_threads": cores,
         "by_threads": {str(k): round(v, 2) for k, v in sweep.items()}, "avx2": bool(O.have_avx2()),
         "sample": "the same synthetic haystack in host RAM, same 16-byte absent needle; C/AVX2 restatement of "
@@ -172,21 +193,122 @@ def cpu_report(out):
         emit(config=2, needle_len=16, threads=th, haystack_bytes=mt_bytes, gbps=round(mt_bytes / best / 1e9, 2))
 
 
-def main():
-    # Exactly ONE line may reach stdout.  Libraries (the RCCL banner, for one) print to fd 1, so fd 1 is
-    # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def fail(msg):
+    """Refuse loudly: message on stderr, NOTHING on stdout, non-zero exit."""
+    sys.stderr.write("bench.py: " + msg + "\n")
+    sys.stderr.flush()
+    raise SystemExit(2)
 
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here."""
+    import subprocess
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    share = os.environ.get("SS_BENCH_SHARE_GPU") == "1"
+    if visible < args.gpus and not (share and visible >= 1):
+        fail("--gpus %d but only %d HIP device(s) visible; refusing to run a smaller job under that label" % (args.gpus, visible))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    env = dict(os.environ, SS_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def median_kernel_ms(searcher, hay, reps):
+    searcher.set_timing(True)
+    res = searcher.search_in(hay)
+    t_end = time.perf_counter() + 0.05                     # clocks ramp up over the first milliseconds after an idle gap
+    while time.perf_counter() < t_end:
+        searcher.search_in(hay)
+    ms = []
+    for _ in range(reps):
+        searcher.search_in(hay)
+        ms.append(searcher.last_kernel_ms())
+    return res, float(np.median(ms))
+
+
+def other_configs(ss, shard, reps=10):
+    """BASELINE.json configs 3 and 5 at their full shape (1 GPU), kernel time by hipEvents on the launch stream:
+    config 3 = 1 GiB haystack x needle lengths {1,2,4,8,16,32,128} (absent: every byte scanned);
+    config 5 = 4096 x 1 MiB haystacks x 4096 distinct 16-byte needles in ONE launch."""
+    out = {}
+    gib = 1 << 30
+    if shard.numel() >= gib:
+        hay = shard[:gib]
+        rows = []
+        for n in (1, 2, 4, 8, 16, 32, 128):
+            s = ss.DynamicHipSearcher.new(absent_needle(ss, n))
+            res, ms = median_kernel_ms(s, hay, reps)
+            assert res is False
+            rows.append({"needle_len": n, "kernel_ms": round(ms, 4), "gbps": round(gib / ms / 1e6, 1),
+                         "frac": round(gib / ms / 1e6 / HBM_PEAK_GBPS, 4), "filter_bytes": list(s.filter)})
+        out["3"] = {"workload": "1 GiB synthetic haystack (the first GiB of the headline haystack), absent needles of "
+                                "{1,2,4,8,16,32,128} bytes, ss_search_device", "rows": rows}
+    count, each = 4096, 1 << 20
+    if shard.numel() >= count * each:
+        blob = shard[:count * each]
+        nd = bytearray(ss.fill_random_host(16 * count, SEED_NEEDLE + 1).tobytes())
+        for i in range(count):
+            nd[16 * i + 8] = 0xFF                          # absent: 0xFF never occurs in the haystack
+        nblob = torch.from_numpy(np.frombuffer(bytes(nd), dtype=np.uint8).copy()).cuda()
+        hay_off = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
+        nd_off = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
+        found = ss.search_batched(blob, hay_off, nblob, nd_off)
+        assert int(found.sum().item()) == 0
+        t_end = time.perf_counter() + 0.05
+        while time.perf_counter() < t_end:
+            ss.search_batched(blob, hay_off, nblob, nd_off)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        for _ in range(reps):
+            e0.record()
+            ss.search_batched(blob, hay_off, nblob, nd_off)
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        med = float(np.median(ms))
+        out["5"] = {"workload": "4096 x 1 MiB haystacks, 4096 distinct absent 16-byte needles, ONE ss_search_batched launch "
+                                "(incl. the flag memset)", "launch_ms": round(med, 4),
+                    "gbps": round(count * each / med / 1e6, 1), "frac": round(count * each / med / 1e6 / HBM_PEAK_GBPS, 4)}
+    return out
+
+
+def native_measurements(ss):
+    """tools/native_bench (C ABI + HIP runtime only): per-call latencies and the config-1 per-needle loop."""
+    import subprocess
+    out = {}
+    try:
+        exe = sys.modules["sliceslice_rs_amd._build"].build_native_bench()
+        gd = os.path.join(ROOT, "tests", "golden", "data")
+        for key, cmd in (("latency_us", [exe, "latency", "1000"]),
+                         ("1", [exe, "config1", os.path.join(gd, "i386.txt"), os.path.join(gd, "words.txt"), "3"])):
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out[key] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
+    except Exception as e:      # pragma: no cover
+        out["error"] = repr(e)
+    return out
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--haystack-gib", type=float, default=64.0, help="TOTAL logical haystack size")
     ap.add_argument("--needle-len", type=int, default=16)
-    ap.add_argument("--transport", choices=["torch", "rccl"], default="torch",
-                    help="flag all-reduce: torch.distributed (RCCL backend) or native RCCL via the C ABI")
+    ap.add_argument("--transport", choices=["torch", "rccl"], default="rccl",
+                    help="N > 1, flag all-reduce: native RCCL via the C ABI (ss_search_sharded: scan + ncclAllReduce + "
+                         "read-back on one HIP stream; the default) or torch.distributed (RCCL backend)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,30 +316,45 @@ def main():
     ap.add_argument("--no-ceiling", action="store_true",
                     help="skip the plain streaming-read ceiling (roofline.read_ceiling_gbps; a few launches, untimed)")
     ap.add_argument("--ceiling", action="store_true", help="(default now) kept for compatibility")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/5 + latency block (N = 1 only, untimed)")
     ap.add_argument("--settle-seconds", type=float, default=20.0,
                     help="upper bound on the wait for a previous process' VRAM to be reclaimed before allocating")
     ap.add_argument("--cpu-report", action="store_true",
                     help="print the extended CPU-side report (JSON lines; no GPU needed) and exit")
     args = ap.parse_args()
+    if args.gpus < 1:
+        fail("--gpus must be >= 1")
     if args.cpu_report:
-        with os.fdopen(real_stdout, "wb", closefd=False) as out:
+        with os.fdopen(os.dup(1), "wb") as out:
             cpu_report(out)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                      # does not return
+
+    # Exactly ONE line may reach stdout.  Libraries (the RCCL banner, for one) print to fd 1, so fd 1 is
+    # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+        fail("WORLD_SIZE=%d but --gpus %d: refusing to label a %d-rank run as %d GPUs" % (world, args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the scan has no CPU path")
+        fail("needs a GPU: the scan has no CPU path")
     # SS_BENCH_SHARE_GPU=1 + SS_BENCH_BACKEND=gloo: run the N > 1 code path with every rank on cuda:0 (a
-    # functional check on a one-GPU box; the numbers of such a run mean nothing)
-    if os.environ.get("SS_BENCH_SHARE_GPU") == "1":
+    # functional check on a one-GPU box; the numbers of such a run mean nothing and the line says so)
+    share = os.environ.get("SS_BENCH_SHARE_GPU") == "1"
+    if share:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        fail("%d ranks but only %d HIP device(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("SS_BENCH_FORCE_DIST") == "1"     # exercise the N > 1 code path on one GPU
+    backend = "none"
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -226,6 +363,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    transport = args.transport
+    if share and world > 1 and transport == "rccl":
+        transport = "torch"                                    # RCCL refuses two ranks on one device
 
     import sliceslice_rs_amd as ss
     ss.lib()
@@ -253,10 +393,17 @@ def main():
         except Exception:
             return 0
     used_at_start = vram_used() if vram_used_file else None
-    while vram_used_file and vram_used() > (8 << 30) and time.perf_counter() - t_wait < args.settle_seconds:
+    while vram_used_file and not share and vram_used() > (8 << 30) and time.perf_counter() - t_wait < args.settle_seconds:
         time.sleep(0.05)
     free_b, total_b = torch.cuda.mem_get_info()
     waited_s = time.perf_counter() - t_wait
+    if share:
+        free_b //= world
+    if dist is not None:
+        # every rank must partition the SAME logical haystack: agree on the smallest free VRAM first
+        fb = torch.tensor([free_b], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(fb, op=dist.ReduceOp.MIN)
+        free_b = int(fb.item())
     while (total + world - 1) // world + n > 0.92 * free_b and total > (1 << 28):
         total //= 2                                            # a smaller device: say so in config
     begin, end = ss.shard_range(total, n, world, rank)
@@ -265,9 +412,13 @@ def main():
     torch.cuda.synchronize()
     needle = absent_needle(ss, n)
 
+    rccl_ranks = None
     if dist is not None:
-        searcher = ss.ShardedSearcher(needle, group=None, backend=args.transport)
+        searcher = ss.ShardedSearcher(needle, group=None, backend=transport)
         inner = searcher._searcher
+        rccl_ranks = searcher.rccl_ranks()                     # ncclCommCount of the native communicator
+        if transport == "rccl" and rccl_ranks != world:
+            fail("RCCL reports %r ranks, expected %d" % (rccl_ranks, world))
     else:
         searcher = ss.DynamicHipSearcher.new(needle)
         inner = searcher
@@ -293,7 +444,7 @@ def main():
     elapsed = time.perf_counter() - t0
     assert found is False
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -306,31 +457,40 @@ def main():
         value = total * args.steps / elapsed / 1e9
         k_ms = float(np.mean(kernel_ms))
         achieved = shard.numel() / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_source = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
                 pj = json.load(open(tj))
                 traffic = pj["hbm_read_bytes_per_haystack_byte"] * shard.numel()
+                traffic_source = ("stored ratio, NOT measured in this run: FETCH_SIZE of this kernel from an earlier "
+                                  "`rocprofv3 --pmc FETCH_SIZE` pass of the same command (profiles/pmc_traffic.json: %s) "
+                                  "x this run's bytes per launch" % pj.get("source", "?"))
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
+        fa, fb = inner.filter
         out = {
             "metric": "haystack GB/s scanned (and % HBM roofline), 16-byte needle, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {
-                "workload": "%.4g GiB synthetic random-byte haystack (0xFF-free), %d-byte absent needle, position %d; "
-                            "range-sharded over %d GPU(s) with %d B overlap, one all-reduce(MAX) of the found flag"
-                            % (total / (1 << 30), n, n - 1, world, n - 1),
-                "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n,
-                "transport": args.transport if dist is not None else "none", "variant": args.variant,
+                "workload": "%.4g GiB synthetic random-byte haystack (0xFF-free), %d-byte absent needle, `new` (API position %d; "
+                            "device filter bytes %d and %d); range-sharded over %d GPU(s) with %d B overlap, one "
+                            "all-reduce(MAX) of the found flag"
+                            % (total / (1 << 30), n, n - 1, fa, fb, world, n - 1),
+                "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n, "filter_bytes": [fa, fb],
+                "ranks": dist.get_world_size() if dist is not None else 1, "rccl_ranks": rccl_ranks,
+                "transport": (transport if backend == "nccl" or transport == "rccl" else transport + " over " + backend) if dist is not None else "none",
+                "launcher": os.environ.get("SS_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
+                "devices_visible": torch.cuda.device_count(), "ranks_share_one_gpu": bool(share and world > 1),
+                "variant": args.variant,
                 "device": info["name"], "compute_units": info["compute_units"],
                 "waited_for_free_vram_s": round(waited_s, 2), "vram_used_at_start": used_at_start,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "ss::scan_kernel", "kernel_ms_avg": round(k_ms, 4),
                 "algorithmic_bytes_per_launch": shard.numel(),
                 "frac_of_whole_job_value": round(value / world / HBM_PEAK_GBPS, 4),
@@ -338,7 +498,15 @@ def main():
         }
         if ceiling is not None:
             out["roofline"]["read_ceiling_gbps"] = round(ceiling, 2)
+        if world == 1 and not args.no_configs:
+            cfg = other_configs(ss, shard)
+            cfg.update(native_measurements(ss))
+            cfg["note"] = ("untimed extras of the N = 1 run; the headline fields above are config 2/4's shape.  3 and 5: kernel "
+                           "GB/s by hipEvents; 1 and latency_us: tools/native_bench (C ABI only, no Python in the loop)")
+            out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:
+            del shard
+            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(needle, args.cpu_sample_mib << 20)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -72,6 +72,20 @@ void ss_searcher_free(ss_searcher *s);
 size_t ss_searcher_needle_len(const ss_searcher *s);
 size_t ss_searcher_position(const ss_searcher *s);
 
+/* The two needle bytes the device filter tests, needle[first] and needle[second] (first <= second < n).
+ * The reference tests needle[0] and needle[position] (src/x86.rs:297-316) and proves with its own tests that
+ * the result does not depend on `position` (src/lib.rs:375-378).  ss_searcher_with_position keeps the
+ * reference's pair (0, position).  ss_searcher_new - whose caller did not choose - picks both bytes by a
+ * static rarity ranking of the needle's bytes, at most 15 apart, so that text-like haystacks rarely pass the
+ * filter and long needles stay on the single-stream kernels; ss_searcher_position() still reports n-1.
+ * SLICESLICE_AUTO_FILTER=0 in the environment keeps (0, n-1) for ss_searcher_new as well.
+ * ss_searcher_set_filter overrides the pair (tests, tuning, a caller with corpus statistics - see
+ * ss_byte_histogram_device); SS_ERR_POSITION if out of range.  Not thread-safe against running searches. */
+int ss_searcher_filter(const ss_searcher *s, size_t *first, size_t *second);
+int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second);
+/* The pair ss_searcher_new would pick for this needle (pure host function, no device needed). */
+int ss_choose_filter_pair(const uint8_t *needle, size_t n, size_t *first, size_t *second);
+
 /* DynamicAvx2Searcher::search_in (src/x86.rs:523-525) on a haystack ALREADY RESIDENT in device
  * memory (any alignment, any length up to the device's memory).  Enqueues on `hip_stream`
  * (a hipStream_t; NULL = the default stream), waits for that stream, writes 0/1 to *found. */
@@ -133,10 +147,12 @@ int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256]
  * Everything lives in device memory; the four range arrays hold `count` uint64 each.  CSR callers
  * pass (off, off + 1); ranges may alias, e.g. 4,585 needles against ONE haystack - the loop of
  * bench/benches/i386.rs:252-256 as a single launch.  position[i] follows the with_position rules
- * (NULL = the `new` default n_i - 1; out-of-range values are clamped to n_i - 1 on the device since a
- * device array cannot be validated without a read-back).  Writes `count` int32 flags to d_found
- * (device), each with the semantics of ss_search_device for its problem.  One workgroup (or more) per
+ * (NULL = the `new` default n_i - 1).  Writes `count` int32 flags to d_found (device), each with the
+ * semantics of ss_search_device for its problem; a problem whose position breaks those rules - where the
+ * reference panics while building the searcher, src/x86.rs:300,473 - gets SS_BATCH_BAD_POSITION instead
+ * (a device array cannot be validated on the host without a read-back).  One workgroup (or more) per
  * problem: meant for haystacks of KiBs to GiBs. */
+#define SS_BATCH_BAD_POSITION (-1)
 int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
                       const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
                       const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
@@ -152,7 +168,7 @@ int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const 
  * is bracketed by hipEvents ON THE LAUNCH STREAM; ss_searcher_last_kernel_ms returns the elapsed
  * time of the most recent completed scan kernel (milliseconds). */
 int ss_searcher_set_timing(ss_searcher *s, int enabled);
-int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);
+int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);   /* of the CALLING THREAD's latest scan through s */
 
 /* Kernel-variant override for tuning/tests: variant = 1000*LAYOUT + 100*MODE + 10*U + NT; LAYOUT 0 =
  * automatic, 1 = 16 bytes per lane, 2 = 8-bytes-per-lane first phase (position < 16 only); U in {4,8} pieces (KiB)
@@ -185,10 +201,13 @@ typedef struct ss_comm ss_comm;
 int ss_comm_unique_id(uint8_t id[SS_UNIQUE_ID_BYTES]);                       /* rank 0, then broadcast */
 int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank, ss_comm **out);
 void ss_comm_free(ss_comm *c);
+int ss_comm_count(const ss_comm *c, int *nranks);                            /* ncclCommCount: what RCCL itself sees */
 /* In-place all-reduce(MAX) of one int32 device flag on `hip_stream`, then (if found != NULL)
  * stream-synchronise and copy the combined flag to *found. */
 int ss_comm_allreduce_flag(ss_comm *c, int *d_flag, void *hip_stream, int *found);
-/* ss_search_device_async + ss_comm_allreduce_flag on one stream: the whole sharded search_in. */
+/* Scan + all-reduce + read-back on one stream: the whole sharded search_in.  The communicator's flag is
+ * never cleared - "found" is the call's epoch (every rank makes the same sequence of calls on a communicator,
+ * so the epochs agree) - which saves the memset launch per search.  Collective: every rank must call it. */
 int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, ss_comm *c,
                       void *hip_stream, int *found);
 
@@ -196,6 +215,30 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
  * ncclAllReduce(uint64, ncclMin); *position = SS_NPOS when no rank has a match. */
 int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, uint64_t shard_begin,
                     ss_comm *c, void *hip_stream, uint64_t *position);
+
+/* ---- multi-GPU inside ONE process (ncclCommInitAll) --------------------------------------------------- */
+/* The form a drop-in `search_in(&self, haystack) -> bool` (src/x86.rs:523) over all GPUs of a node needs: no
+ * launcher, no rendezvous.  ss_comm_init_all creates one communicator, one stream, one flag and one pinned
+ * mirror per device (devs == NULL: devices 0 .. ndev-1).  ss_search_sharded_all scans shard g (resident on
+ * device g of the set, ranges from ss_shard_range) on device g's stream, combines the flags with the G
+ * ncclAllReduce(int32, ncclMax) calls inside ONE ncclGroupStart/End, reads the result back from device 0,
+ * drains every stream and restores the caller's current device.  ss_find_sharded_all does the same for the
+ * leftmost offset (uint64, ncclMin; shard_begins[g] = global offset of shard g).
+ * SS_COMBINE_HOST skips the collective: the host ORs the G pinned mirrors (possible only in this
+ * single-process form; the difference between the two is the cost of the collective).
+ * One search at a time per set (the set's streams and flags are its scratch). */
+typedef struct ss_comm_set ss_comm_set;
+#define SS_COMBINE_RCCL 0
+#define SS_COMBINE_HOST 1
+int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out);
+void ss_comm_set_free(ss_comm_set *set);
+int ss_comm_set_size(const ss_comm_set *set);
+int ss_comm_set_device(const ss_comm_set *set, int index, int *device);
+int ss_comm_set_combine(ss_comm_set *set, int combine);
+int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
+                          ss_comm_set *set, int *found);
+int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
+                        const uint64_t *shard_begins, ss_comm_set *set, uint64_t *position);
 
 /* Range partition used by every sharded caller: rank r of G scans bytes
  * [r*S, min(len, (r+1)*S + n-1)) with S = ceil(len/G): an overlap of n-1 bytes, so a match that
@@ -209,6 +252,10 @@ const char *ss_version(void);
 /* Device self-test of the cross-lane primitives the scan relies on (DPP wave_shl:1, v_alignbyte):
  * fills out[0..320) (host memory); see tests/test_gpu_parity.py::test_cross_lane_primitives. */
 int ss_selftest_dpp(uint32_t *out);
+/* Test hooks: set the "found"-epoch counters (of every flag slot of `s` on the current device / of a
+ * communicator or communicator set) so that a test can cross the 2^31 wrap. */
+int ss_debug_set_epochs(ss_searcher *s, int value);
+int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
 
 #ifdef __cplusplus
 }

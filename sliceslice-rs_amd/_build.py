@@ -1,5 +1,11 @@
 """Builds csrc/ into the in-tree C-ABI library with hipcc for gfx950 (cross-compiles without a GPU).
-The kernel families are separate translation units and are compiled in parallel."""
+The kernel families are separate translation units and are compiled in parallel.
+
+Concurrency: every rank of a `torch.distributed.run` job may call build() at once on a fresh clone.  The
+whole build runs under an exclusive fcntl lock, objects and the library are written to temporary names
+and os.replace()d into place, so no process can ever CDLL a half-written file, and the up-to-date check
+compares the library with its objects (a failed link leaves an old .so behind newer .o files)."""
+import fcntl
 import os
 import shutil
 import subprocess
@@ -7,14 +13,24 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
+_ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_CSRC, "libsliceslice_hip.so")
 _SOURCES = ["sliceslice_hip.hip", "scan_inst_u4.hip", "scan_inst_u8.hip", "scan_inst_find.hip"]
 _HEADERS = ["scan_kernels.hpp", "scan_launch.hpp", os.path.join("..", "..", "include", "sliceslice_hip.h")]
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
+# Host-side sanitizer build (the reference's guard on its unsafe code is its ASAN CI job,
+# .github/workflows/check.yml:42-58): ASan + UBSan on the HOST code of the same sources, device code untouched.
+_SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"]
+_NATIVE_BENCH_SRC = os.path.join(_ROOT, "tools", "native_bench.cpp")
+_NATIVE_BENCH = os.path.join(_ROOT, "tools", "native_bench")
 
 
 def library_path():
     return _SO
+
+
+def native_bench_path():
+    return _NATIVE_BENCH
 
 
 def _mtime(rel):
@@ -28,30 +44,83 @@ def _hipcc():
     return hipcc
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> csrc/libsliceslice_hip.so.  Returns the path."""
-    newest_header = max(_mtime(h) for h in _HEADERS)
-    todo = []
-    for src in _SOURCES:
-        obj = os.path.join(_CSRC, src[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(_mtime(src), newest_header):
-            todo.append((src, obj))
-    if not todo and os.path.exists(_SO) and not force:
-        return _SO
-    hipcc = _hipcc()
+class _Lock:
+    def __init__(self, name):
+        self._path = os.path.join(_CSRC, name)
 
-    def compile_one(job):
-        src, obj = job
-        cmd = [hipcc] + _FLAGS + ["-c", os.path.join(_CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    def __enter__(self):
+        self._fh = open(self._path, "w")
+        fcntl.flock(self._fh, fcntl.LOCK_EX)
+        return self
 
-    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1) or 1) as pool:
-        list(pool.map(compile_one, todo))
-    objs = [os.path.join(_CSRC, s[:-4] + ".o") for s in _SOURCES]
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", _SO] + objs + ["-ldl", "-pthread"]
+    def __exit__(self, *a):
+        fcntl.flock(self._fh, fcntl.LOCK_UN)
+        self._fh.close()
+        return False
+
+
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return _SO
+
+
+def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose):
+    newest_header = max(_mtime(h) for h in _HEADERS)
+    objs = [os.path.join(_CSRC, s[:-4] + obj_suffix) for s in _SOURCES]
+    todo = []
+    for src, obj in zip(_SOURCES, objs):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(_mtime(src), newest_header):
+            todo.append((src, obj))
+    if not todo and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(o) for o in objs):
+        return so
+    hipcc = _hipcc()
+    tag = ".tmp%d" % os.getpid()
+
+    def compile_one(job):
+        src, obj = job
+        _run([hipcc] + _FLAGS + extra_flags + ["-c", os.path.join(_CSRC, src), "-o", obj + tag], verbose)
+        os.replace(obj + tag, obj)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1) or 1) as pool:
+            list(pool.map(compile_one, todo))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", so + tag] + link_flags + objs +
+         ["-ldl", "-pthread"], verbose)
+    os.replace(so + tag, so)
+    return so
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> csrc/libsliceslice_hip.so.  Returns the path."""
+    with _Lock(".build.lock"):
+        return _build_variant(_SO, ".o", [], [], force, verbose)
+
+
+def build_sanitized(force=False, verbose=False):
+    """The same sources with ASan + UBSan on the host code -> csrc/libsliceslice_hip_asan.so (test builds only:
+    load it with SLICESLICE_HIP_LIB=<path> and the ASan runtime preloaded; see tests/test_gpu_sanitizer.py)."""
+    so = os.path.join(_CSRC, "libsliceslice_hip_asan.so")
+    with _Lock(".build_asan.lock"):
+        return _build_variant(so, ".asan.o", _SAN_FLAGS, ["-fsanitize=address,undefined", "-shared-libsan"], force, verbose)
+
+
+def asan_runtime():
+    """Path of the clang ASan runtime that build_sanitized() links against (to LD_PRELOAD into python)."""
+    out = subprocess.check_output([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+def build_native_bench(force=False, verbose=False):
+    """tools/native_bench.cpp -> tools/native_bench: the measurements that must not have Python or torch in the
+    loop (per-call latencies, the config-1 per-needle loop), linked against the in-tree library."""
+    so = build(verbose=verbose)
+    with _Lock(".build_tools.lock"):
+        if (not force and os.path.exists(_NATIVE_BENCH) and
+                os.path.getmtime(_NATIVE_BENCH) >= max(os.path.getmtime(_NATIVE_BENCH_SRC), os.path.getmtime(so))):
+            return _NATIVE_BENCH
+        tmp = _NATIVE_BENCH + ".tmp%d" % os.getpid()
+        _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(_ROOT, "include"), _NATIVE_BENCH_SRC, "-o", tmp,
+              "-L", _CSRC, "-lsliceslice_hip", "-Wl,-rpath,$ORIGIN/../sliceslice-rs_amd/csrc", "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
+        os.replace(tmp, _NATIVE_BENCH)
+        return _NATIVE_BENCH

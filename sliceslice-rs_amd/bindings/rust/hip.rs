@@ -1,22 +1,100 @@
-// src/hip.rs  (source only: this image has no rustc; the C ABI below is the tested contract)
+// src/hip.rs - the backend module a maintainer of cloudflare/sliceslice-rs would add next to src/x86.rs,
+// gated like the others in src/lib.rs:11-24 (`#[cfg(feature = "hip")] pub mod hip;`).
+//
+// SOURCE ONLY: this image has no rustc, so the file has never been compiled.  The `extern "C"` block is
+// checked mechanically against include/sliceslice_hip.h (names, arity, pointer / integer widths) by
+// tests/test_bindings_cpu.py; the C ABI itself is what the GPU tests exercise.
+//
+// Mirrors `x86::DynamicAvx2Searcher<N>` member for member (src/x86.rs:405-525): the searcher owns
+// `needle: N` by value for any `N: Needle` - `&[u8]`, `[u8; K]`, `Box<[u8]>`, `Vec<u8>`, `Rc<[u8]>`,
+// `Arc<[u8]>` (src/lib.rs:43-104) - while the library keeps its own host + device copy of the bytes, the
+// way `DynamicAvx2Searcher` keeps a private `[u8; n]` for n in 2..=16 (src/x86.rs:476-490).
+#![allow(non_camel_case_types, dead_code)]
 use crate::Needle;
-use std::os::raw::{c_int, c_void};
+use std::os::raw::{c_char, c_float, c_int, c_void};
 
 #[repr(C)] pub struct ss_searcher { _private: [u8; 0] }
+#[repr(C)] pub struct ss_comm { _private: [u8; 0] }
+#[repr(C)] pub struct ss_comm_set { _private: [u8; 0] }
+
+pub const SS_OK: c_int = 0;
+pub const SS_ERR_POSITION: c_int = 1;
+pub const SS_ERR_ARGUMENT: c_int = 2;
+pub const SS_ERR_NO_DEVICE: c_int = 3;
+pub const SS_ERR_HIP: c_int = 4;
+pub const SS_ERR_RCCL: c_int = 5;
+pub const SS_ERR_NOMEM: c_int = 6;
+pub const SS_NPOS: u64 = u64::MAX;
+pub const SS_UNIQUE_ID_BYTES: usize = 128;
+pub const SS_COMBINE_RCCL: c_int = 0;
+pub const SS_COMBINE_HOST: c_int = 1;
+pub const SS_BATCH_BAD_POSITION: c_int = -1;
 
 #[link(name = "sliceslice_hip")]
 extern "C" {
-    fn ss_searcher_new(needle: *const u8, n: usize, out: *mut *mut ss_searcher) -> c_int;
-    fn ss_searcher_with_position(needle: *const u8, n: usize, position: usize,
-                                 out: *mut *mut ss_searcher) -> c_int;
-    fn ss_searcher_free(s: *mut ss_searcher);
-    fn ss_search_host(s: *const ss_searcher, hay: *const u8, len: usize, found: *mut c_int) -> c_int;
-    fn ss_search_device(s: *const ss_searcher, d_hay: *const c_void, len: usize,
-                        hip_stream: *mut c_void, found: *mut c_int) -> c_int;
-    fn ss_last_error() -> *const std::os::raw::c_char;
+    // construction (src/x86.rs:454-493)
+    pub fn ss_searcher_new(needle: *const u8, n: usize, out: *mut *mut ss_searcher) -> c_int;
+    pub fn ss_searcher_with_position(needle: *const u8, n: usize, position: usize, out: *mut *mut ss_searcher) -> c_int;
+    pub fn ss_searcher_free(s: *mut ss_searcher);
+    pub fn ss_searcher_needle_len(s: *const ss_searcher) -> usize;
+    pub fn ss_searcher_position(s: *const ss_searcher) -> usize;
+    pub fn ss_searcher_filter(s: *const ss_searcher, first: *mut usize, second: *mut usize) -> c_int;
+    pub fn ss_searcher_set_filter(s: *mut ss_searcher, first: usize, second: usize) -> c_int;
+    pub fn ss_choose_filter_pair(needle: *const u8, n: usize, first: *mut usize, second: *mut usize) -> c_int;
+    // search_in (src/x86.rs:498-525)
+    pub fn ss_search_device(s: *const ss_searcher, d_haystack: *const c_void, len: usize, hip_stream: *mut c_void, found: *mut c_int) -> c_int;
+    pub fn ss_search_device_async(s: *const ss_searcher, d_haystack: *const c_void, len: usize, hip_stream: *mut c_void, d_found: *mut c_int) -> c_int;
+    pub fn ss_search_host(s: *const ss_searcher, haystack: *const u8, len: usize, found: *mut c_int) -> c_int;
+    pub fn ss_search_file(s: *const ss_searcher, path: *const c_char, found: *mut c_int) -> c_int;
+    // find: the Option<usize> shape of the bench competitors (bench/sse4-strstr/src/lib.rs:4-15)
+    pub fn ss_find_device(s: *const ss_searcher, d_haystack: *const c_void, len: usize, hip_stream: *mut c_void, position: *mut u64) -> c_int;
+    pub fn ss_find_host(s: *const ss_searcher, haystack: *const u8, len: usize, position: *mut u64) -> c_int;
+    pub fn ss_find_device_async(s: *const ss_searcher, d_haystack: *const c_void, len: usize, base_offset: u64, hip_stream: *mut c_void, d_best: *mut u64) -> c_int;
+    // position policy data
+    pub fn ss_byte_histogram_device(d_haystack: *const c_void, len: usize, sample_bytes: usize, hip_stream: *mut c_void, hist: *mut u64) -> c_int;
+    pub fn ss_choose_position(needle: *const u8, n: usize, hist: *const u64, position: *mut usize) -> c_int;
+    // many problems, one launch
+    pub fn ss_search_batched(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
+                             d_needle_begin: *const u64, d_needle_end: *const u64, d_position: *const u64, count: usize,
+                             hip_stream: *mut c_void, d_found: *mut c_int) -> c_int;
+    pub fn ss_search_pairs(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
+                           d_needle_begin: *const u64, d_needle_end: *const u64, d_position: *const u64, count: usize,
+                           hip_stream: *mut c_void, d_found: *mut c_int) -> c_int;
+    // measurement / tuning hooks
+    pub fn ss_searcher_set_timing(s: *mut ss_searcher, enabled: c_int) -> c_int;
+    pub fn ss_searcher_last_kernel_ms(s: *const ss_searcher, ms: *mut c_float) -> c_int;
+    pub fn ss_searcher_set_variant(s: *mut ss_searcher, variant: c_int) -> c_int;
+    pub fn ss_searcher_set_grid(s: *mut ss_searcher, blocks: c_int) -> c_int;
+    pub fn ss_fill_random_device(d_dst: *mut c_void, global_offset: u64, len: usize, seed: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn ss_fill_random_host(dst: *mut u8, global_offset: u64, len: usize, seed: u64) -> c_int;
+    pub fn ss_read_ceiling(d_src: *const c_void, len: usize, hip_stream: *mut c_void, reps: c_int, ms_per_rep: *mut c_float) -> c_int;
+    // multi-GPU, one process per GPU
+    pub fn ss_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn ss_comm_init_rank(id: *const u8, nranks: c_int, rank: c_int, out: *mut *mut ss_comm) -> c_int;
+    pub fn ss_comm_free(c: *mut ss_comm);
+    pub fn ss_comm_count(c: *const ss_comm, nranks: *mut c_int) -> c_int;
+    pub fn ss_comm_allreduce_flag(c: *mut ss_comm, d_flag: *mut c_int, hip_stream: *mut c_void, found: *mut c_int) -> c_int;
+    pub fn ss_search_sharded(s: *const ss_searcher, d_shard: *const c_void, shard_len: usize, c: *mut ss_comm, hip_stream: *mut c_void, found: *mut c_int) -> c_int;
+    pub fn ss_find_sharded(s: *const ss_searcher, d_shard: *const c_void, shard_len: usize, shard_begin: u64, c: *mut ss_comm,
+                           hip_stream: *mut c_void, position: *mut u64) -> c_int;
+    // multi-GPU inside one process
+    pub fn ss_comm_init_all(ndev: c_int, devs: *const c_int, out: *mut *mut ss_comm_set) -> c_int;
+    pub fn ss_comm_set_free(set: *mut ss_comm_set);
+    pub fn ss_comm_set_size(set: *const ss_comm_set) -> c_int;
+    pub fn ss_comm_set_device(set: *const ss_comm_set, index: c_int, device: *mut c_int) -> c_int;
+    pub fn ss_comm_set_combine(set: *mut ss_comm_set, combine: c_int) -> c_int;
+    pub fn ss_search_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, set: *mut ss_comm_set, found: *mut c_int) -> c_int;
+    pub fn ss_find_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, shard_begins: *const u64,
+                               set: *mut ss_comm_set, position: *mut u64) -> c_int;
+    pub fn ss_shard_range(len: usize, needle_len: usize, nranks: c_int, rank: c_int, begin: *mut usize, end: *mut usize) -> c_int;
+    // diagnostics
+    pub fn ss_last_error() -> *const c_char;
+    pub fn ss_device_info(name: *mut c_char, name_cap: usize, compute_units: *mut c_int, total_mem: *mut usize) -> c_int;
+    pub fn ss_version() -> *const c_char;
+    pub fn ss_selftest_dpp(out: *mut u32) -> c_int;
+    pub fn ss_debug_set_epochs(s: *mut ss_searcher, value: c_int) -> c_int;
+    pub fn ss_debug_set_comm_epoch(c: *mut ss_comm, set: *mut ss_comm_set, value: c_int) -> c_int;
 }
-
-const SS_ERR_POSITION: c_int = 1;
 
 /// Haystack already resident in device memory (caller-owned `hipMalloc` memory).
 #[derive(Clone, Copy)]
@@ -29,18 +107,22 @@ unsafe impl<N: Needle + Send> Send for DynamicHipSearcher<N> {}
 unsafe impl<N: Needle + Sync> Sync for DynamicHipSearcher<N> {}   // ss_search_* is re-entrant per handle
 
 fn check(rc: c_int) {
-    if rc == 0 { return; }
+    if rc == SS_OK { return; }
     let msg = unsafe { std::ffi::CStr::from_ptr(ss_last_error()) }.to_string_lossy().into_owned();
     // contract violations panic exactly where the reference does (x86.rs:300, :473)
     if rc == SS_ERR_POSITION { panic!("{}", msg) } else { panic!("sliceslice_hip error {}: {}", rc, msg) }
 }
 
 impl<N: Needle> DynamicHipSearcher<N> {
-    /// `position` defaults to the last byte (x86.rs:454-459).
+    /// x86.rs:454-459.  `ss_searcher_new` (not `with_position(len - 1)`): the caller did not choose a
+    /// position, so the library may pick both filter bytes; `position()` still reports `len - 1`.
     pub fn new(needle: N) -> Self {
-        let position = needle.as_bytes().len().wrapping_sub(1);
-        Self::with_position(needle, position)
+        let b = needle.as_bytes();
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ss_searcher_new(b.as_ptr(), b.len(), &mut handle) });
+        Self { handle, needle }
     }
+    /// x86.rs:468-493; panics like the reference for `position >= len` (and `position != 0` for one byte).
     pub fn with_position(needle: N, position: usize) -> Self {
         let b = needle.as_bytes();
         let mut handle = std::ptr::null_mut();
@@ -60,13 +142,91 @@ impl<N: Needle> DynamicHipSearcher<N> {
         check(unsafe { ss_search_device(self.handle, haystack.ptr, haystack.len, stream, &mut found) });
         found != 0
     }
+    /// Leftmost occurrence - the `Option<usize>` of `find_subsequence` (tests/i386.rs:6-10).
+    pub fn find(&self, haystack: &[u8]) -> Option<usize> {
+        let mut pos = SS_NPOS;
+        check(unsafe { ss_find_host(self.handle, haystack.as_ptr(), haystack.len(), &mut pos) });
+        if pos == SS_NPOS { None } else { Some(pos as usize) }
+    }
+    pub fn find_device(&self, haystack: DeviceSlice, stream: *mut c_void) -> Option<usize> {
+        let mut pos = SS_NPOS;
+        check(unsafe { ss_find_device(self.handle, haystack.ptr, haystack.len, stream, &mut pos) });
+        if pos == SS_NPOS { None } else { Some(pos as usize) }
+    }
+    pub fn position(&self) -> usize { unsafe { ss_searcher_position(self.handle) } }
     pub fn needle(&self) -> &N { &self.needle }
+    pub fn handle(&self) -> *const ss_searcher { self.handle }
 }
 
 impl<N: Needle> Drop for DynamicHipSearcher<N> {
     fn drop(&mut self) { unsafe { ss_searcher_free(self.handle) } }
 }
 
-// and in the crate's generic test suite (src/lib.rs:383-420):
-//   impl crate::tests::TestSearcher for DynamicHipSearcher<&[u8]> { ... }
-//   crate::generate_tests!(dynamic_hip_searcher, DynamicHipSearcher);
+/// All GPUs of the node behind ONE `search_in`: the haystack is range-partitioned into one shard per
+/// device (n-1 bytes of overlap, `ss_shard_range`), resident in that device's HBM; a search is one scan per
+/// device plus one grouped all-reduce(MAX) of the found flag (`ss_search_sharded_all`).
+pub struct NodeHaystack { pub shards: Vec<DeviceSlice>, pub begins: Vec<u64> }
+
+pub struct NodeSearcher<N: Needle> { inner: DynamicHipSearcher<N>, set: *mut ss_comm_set, ndev: usize }
+
+impl<N: Needle> NodeSearcher<N> {
+    pub fn new(needle: N, ndev: usize) -> Self {
+        let mut set = std::ptr::null_mut();
+        check(unsafe { ss_comm_init_all(ndev as c_int, std::ptr::null(), &mut set) });
+        Self { inner: DynamicHipSearcher::new(needle), set, ndev }
+    }
+    /// Byte range of shard `g` of a haystack of `len` bytes.
+    pub fn shard_range(&self, len: usize, g: usize) -> (usize, usize) {
+        let (mut b, mut e) = (0usize, 0usize);
+        let n = self.inner.needle().as_bytes().len();
+        check(unsafe { ss_shard_range(len, n, self.ndev as c_int, g as c_int, &mut b, &mut e) });
+        (b, e)
+    }
+    pub fn search_in(&self, haystack: &NodeHaystack) -> bool {
+        assert_eq!(haystack.shards.len(), self.ndev);
+        let ptrs: Vec<*const c_void> = haystack.shards.iter().map(|s| s.ptr).collect();
+        let lens: Vec<usize> = haystack.shards.iter().map(|s| s.len).collect();
+        let mut found = 0;
+        check(unsafe { ss_search_sharded_all(self.inner.handle(), ptrs.as_ptr(), lens.as_ptr(), self.set, &mut found) });
+        found != 0
+    }
+    pub fn find(&self, haystack: &NodeHaystack) -> Option<usize> {
+        let ptrs: Vec<*const c_void> = haystack.shards.iter().map(|s| s.ptr).collect();
+        let lens: Vec<usize> = haystack.shards.iter().map(|s| s.len).collect();
+        let mut pos = SS_NPOS;
+        check(unsafe { ss_find_sharded_all(self.inner.handle(), ptrs.as_ptr(), lens.as_ptr(), haystack.begins.as_ptr(), self.set, &mut pos) });
+        if pos == SS_NPOS { None } else { Some(pos as usize) }
+    }
+}
+
+impl<N: Needle> Drop for NodeSearcher<N> {
+    fn drop(&mut self) { unsafe { ss_comm_set_free(self.set) } }
+}
+
+// Hook-up to the crate's generic test suite (src/lib.rs:383-420; the x86 back end does the same at
+// src/x86.rs:589-611): every KAT of src/lib.rs:422-544 runs for every `position`.
+#[cfg(test)]
+mod tests {
+    use super::DynamicHipSearcher;
+    use crate::tests::TestSearcher;
+
+    impl TestSearcher for DynamicHipSearcher<&[u8]> {
+        fn with_position(needle: &'static [u8], position: usize) -> Self { DynamicHipSearcher::with_position(needle, position) }
+        fn search_in(&self, haystack: &[u8]) -> bool { DynamicHipSearcher::search_in(self, haystack) }
+    }
+
+    crate::generate_tests!(dynamic_hip_searcher, DynamicHipSearcher);
+
+    #[test]
+    #[should_panic]
+    fn dynamic_hip_invalid_position() { let _ = DynamicHipSearcher::with_position(b"foo".as_ref(), 3); }   // x86.rs:533-537
+
+    #[test]
+    fn owns_any_needle_form() {                                       // src/lib.rs:43-104
+        let hay = b"Lorem ipsum dolor sit amet";
+        assert!(DynamicHipSearcher::new(Box::<[u8]>::from(&b"ipsum"[..])).search_in(hay));
+        assert!(DynamicHipSearcher::new(b"ipsum".to_vec()).search_in(hay));
+        assert!(DynamicHipSearcher::new(std::sync::Arc::<[u8]>::from(&b"ipsum"[..])).search_in(hay));
+        assert!(DynamicHipSearcher::new(*b"ipsum").search_in(hay));
+    }
+}

@@ -416,9 +416,9 @@ __device__ __forceinline__ int poll_found(const int *found, int epoch)
 // is not coherent - a stale "not found" only means the workgroup does its tile as usual.  Staleness is
 // bounded: every tile also polls coherently (free, behind its data loads), and a wave that sees the flag set
 // there invalidates its CU's scalar cache on the way out (forget_scalar_cache), so the workgroups that
-// follow on that CU leave at the peek.  A value cached by an EARLIER launch cannot be seen: the acquire at the start
-// of every kernel dispatch invalidates the scalar cache (tests/test_gpu_parity.py::
-// test_caller_owned_flags_are_not_seen_stale pins that for caller-owned flags, which have no epoch).
+// follow on that CU leave at the peek.  A peek HIT is always confirmed with a coherent load before the workgroup
+// leaves (scan_kernel), so correctness never rests on the dispatch-time invalidation of the scalar cache
+// (which tests/test_gpu_parity.py::test_caller_owned_flags_are_not_seen_stale observes on the current ROCm).
 __device__ __forceinline__ int scalar_peek(const int *p)
 {
     int v;
@@ -801,8 +801,14 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         if (FIND) {
             const uint64_t first_chunk = (t0 << tile_shift) * 64;
             const uint64_t first = first_chunk * 16 > pr.mis ? first_chunk * 16 - pr.mis : 0;
-            if (scalar_peek64(static_cast<const uint64_t *>(found)) <= pr.find_base + first) return;
-        } else if (scalar_peek(static_cast<const int *>(found)) == pr.epoch) {
+            // a peek hit is confirmed with one coherent load before the workgroup leaves: the scalar cache is not
+            // coherent, and a caller-owned sink (re-armed by the caller, e.g. on every hipGraph replay) has no
+            // epoch that would make a line cached by an earlier launch harmless
+            if (scalar_peek64(static_cast<const uint64_t *>(found)) <= pr.find_base + first &&
+                uniform64(__hip_atomic_load(static_cast<const uint64_t *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <=
+                    pr.find_base + first)
+                return;
+        } else if (scalar_peek(static_cast<const int *>(found)) == pr.epoch && poll_found(static_cast<const int *>(found), pr.epoch)) {
             return;
         }
     }
@@ -832,6 +838,7 @@ struct BatchArgs {
     const uint64_t *position;   // may be null: n_i - 1
     int *found;
 };
+constexpr int kBadPosition = -1;   // SS_BATCH_BAD_POSITION: flag of a problem whose position breaks the with_position rules
 
 template <int U>
 __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
@@ -848,9 +855,12 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
         if (slice == 0 && threadIdx.x == 0) publish_found(found);
         return;
     }
-    if (len < n) return;                            // flag stays 0
     uint64_t position = a.position ? a.position[prob] : n - 1;
-    if (position >= n) position = n - 1;            // validated on the host when it can be; never UB here
+    if (n == 1 ? position != 0 : position >= n) {   // the reference panics building this searcher (x86.rs:300, 473)
+        if (slice == 0 && threadIdx.x == 0) publish_found(found, kBadPosition);
+        return;
+    }
+    if (len < n) return;                            // flag stays 0
 
     // every field below is wave-uniform; uniform64 tells the compiler so (SGPRs, no scratch)
     Problem pr;
@@ -923,12 +933,13 @@ __global__ void __launch_bounds__(kBlock) scan_pairs_kernel(const BatchArgs a, u
     const uint64_t h0 = a.hay_begin[prob], n0 = a.needle_begin[prob];
     const uint64_t len = a.hay_end[prob] - h0, n = a.needle_end[prob] - n0;
     int result = 0;
+    uint64_t position = (a.position && n) ? a.position[prob] : n - 1;
     if (n == 0) {
         result = 1;
+    } else if (n == 1 ? position != 0 : position >= n) {              // x86.rs:300, 473
+        result = kBadPosition;
     } else if (len >= n) {
         const uint8_t *h = a.haystacks + h0, *nd = a.needles + n0;
-        uint64_t position = a.position ? a.position[prob] : n - 1;
-        if (position >= n) position = n - 1;
         const uint8_t first = nd[0], last = nd[position];
         const uint64_t end = len - n + 1;
         for (uint64_t i = 0; i < end && !result; ++i) {
@@ -1051,6 +1062,14 @@ __global__ void __launch_bounds__(kBlock) byte_histogram_kernel(const uint8_t *h
         const unsigned long long t = (unsigned long long)h[0][k] + h[1][k] + h[2][k] + h[3][k];
         if (t) atomicAdd(&hist[k], t);
     }
+}
+
+// find(): hands the final minimum to the host through its pinned mirror (one system-scope store), stream-ordered
+// behind the scan - the read-back of ss_find_device without a device-to-host copy command.
+__global__ void publish_best_kernel(const uint64_t *d_best, uint64_t *h_best)
+{
+    __hip_atomic_store(h_best, __hip_atomic_load(d_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Cross-lane self-test: the DPP controls and v_alignbyte the scan relies on, next to __shfl statements.

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <climits>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +21,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -84,22 +87,44 @@ struct PerDevice {
     uint64_t free_mask = 0;
     uint64_t best_dirty = 0;    // find(): slots whose d_best holds a result and must be re-armed before their next use
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed_valid = false;
 };
 constexpr int kSlots = 64;
+constexpr int kMaxDevices = 64;
+
+// Kernel timing (ss_searcher_set_timing): the hipEvent pair that brackets a scan belongs to the CALLING
+// THREAD (one pair per thread and device, created on first use), so concurrent calls on one handle never
+// share events; ss_searcher_last_kernel_ms reports the calling thread's most recent timed scan.
+struct ThreadTimer {
+    hipEvent_t ev0[kMaxDevices] = {nullptr}, ev1[kMaxDevices] = {nullptr};
+    const void *owner = nullptr;      // the searcher of the most recent timed scan
+    int dev = -1;
+    ~ThreadTimer()
+    {
+        for (int d = 0; d < kMaxDevices; ++d) {
+            if (ev0[d]) (void)hipEventDestroy(ev0[d]);
+            if (ev1[d]) (void)hipEventDestroy(ev1[d]);
+        }
+    }
+};
+thread_local ThreadTimer g_timer;
 
 }  // namespace
 
 struct ss_searcher {
     std::vector<uint8_t> needle;
     size_t n = 0;
-    size_t position = 0;
+    size_t position = 0;      // the API position (what ss_searcher_position reports; x86.rs:468)
+    // The two needle bytes the device filter actually tests: needle[fa] and needle[fb], fa < fb (fa == fb == 0
+    // for one-byte needles and for with_position(.., 0)).  with_position callers get (0, position) - the
+    // reference's filter; `new` callers get a pair chosen by choose_filter_pair.  The result of a search never
+    // depends on the pair (src/lib.rs:375-378 asserts that for every position).
+    size_t fa = 0, fb = 0;
     int variant = 0;
     int grid = 0;
     bool timing = false;
     mutable std::mutex mu;
-    mutable std::vector<PerDevice> per;
+    mutable std::condition_variable slot_cv;    // signalled when a flag slot is released
+    mutable std::deque<PerDevice> per;          // deque: PerDevice pointers handed out stay valid as devices are added
 };
 
 namespace {
@@ -130,9 +155,7 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         memset(p.h_flags, 0, kSlots * sizeof(int));   // pinned memory is recycled: a stale value must not equal an epoch
         if ((e = hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
         if ((e = hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
-        if ((e = hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipEventCreate(&p.ev0)) != hipSuccess) return e;
-        return hipEventCreate(&p.ev1);
+        return hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault);
     };
     const hipError_t e = alloc();
     if (e != hipSuccess) {                             // nothing half-built is left behind
@@ -141,13 +164,10 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         (void)hipHostFree(p.h_flags);
         (void)hipFree(p.d_best);
         (void)hipHostFree(p.h_best);
-        if (p.ev0) (void)hipEventDestroy(p.ev0);
-        if (p.ev1) (void)hipEventDestroy(p.ev1);
         return fail(e == hipErrorNoDevice ? SS_ERR_NO_DEVICE : (e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP),
                     "per-device setup: %s", hipGetErrorString(e));
     }
     p.free_mask = ~0ull;
-    s->per.reserve(16);              // PerDevice pointers handed out must stay valid
     s->per.push_back(p);
     *out = &s->per.back();
     return SS_OK;
@@ -155,17 +175,11 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
 
 int acquire_slot(const ss_searcher *s, PerDevice *p)
 {
-    for (;;) {
-        {
-            std::lock_guard<std::mutex> lock(s->mu);
-            if (p->free_mask) {
-                const int k = __builtin_ctzll(p->free_mask);
-                p->free_mask &= p->free_mask - 1;
-                return k;
-            }
-        }
-        sched_yield();   // > 64 concurrent searches on one handle: wait for a slot
-    }
+    std::unique_lock<std::mutex> lock(s->mu);
+    s->slot_cv.wait(lock, [p]() { return p->free_mask != 0; });   // > 64 concurrent searches on one handle and device wait here
+    const int k = __builtin_ctzll(p->free_mask);
+    p->free_mask &= p->free_mask - 1;
+    return k;
 }
 
 // find(): true when slot k still holds an earlier result and has to be re-armed (all ones) before use;
@@ -182,20 +196,22 @@ bool take_best_dirty(const ss_searcher *s, PerDevice *p, int k)
 // calls) wrap-around both copies of the flag are cleared so that no stale value can equal a new epoch.
 int next_epoch(PerDevice *p, int k)
 {
-    int e = ++p->epoch[k];
-    if (e <= 0) {
+    if (p->epoch[k] >= INT_MAX - 1 || p->epoch[k] < 0) {
         (void)hipDeviceSynchronize();
         (void)hipMemset(p->d_flags + k, 0, sizeof(int));
         p->h_flags[k] = 0;
-        e = p->epoch[k] = 1;
+        p->epoch[k] = 0;
     }
-    return e;
+    return ++p->epoch[k];
 }
 
 void release_slot(const ss_searcher *s, PerDevice *p, int k)
 {
-    std::lock_guard<std::mutex> lock(s->mu);
-    p->free_mask |= 1ull << k;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        p->free_mask |= 1ull << k;
+    }
+    s->slot_cv.notify_one();
 }
 
 // ---- kernel selection -------------------------------------------------------------------------------
@@ -280,27 +296,34 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     void *d_flag = d_sink;
     ss::Problem pr;
     const size_t n = s->n;
+    const bool one_byte = n == 1;
+    // The filter stream starts at the FIRST filter byte: candidate i is tested through hay[fa + i] == needle[fa]
+    // and hay[fb + i] == needle[fb], so the kernel's aligned coordinates are those of hay + fa, while matches
+    // are verified (and reported) at hay + i.  Bytes in front of hay + fa are never candidates (their index
+    // wraps and fails `i < end`), and the last byte either stream touches is hay[len - n + fb] <= hay[len - 1].
+    const size_t fa = one_byte ? 0 : s->fa, fb = one_byte ? 0 : s->fb;
+    const uint8_t *hf = static_cast<const uint8_t *>(d_hay) + fa;
     pr.hay = static_cast<const uint8_t *>(d_hay);
-    pr.mis = (uint32_t)((uintptr_t)d_hay & 15);
-    pr.base = pr.hay - pr.mis;
+    pr.mis = (uint32_t)((uintptr_t)hf & 15);
+    pr.base = hf - pr.mis;
     pr.needle = pd->d_needle;
     pr.n = n;
     pr.end = (uint64_t)len - n + 1;
-    pr.nchunks_all = ((uint64_t)pr.mis + len + 15) / 16;
-    const bool one_byte = n == 1;
+    pr.nchunks_all = ((uint64_t)pr.mis + (len - fa) + 15) / 16;
     pr.npieces = (((uint64_t)pr.mis + pr.end + 15) / 16 + 63) / 64;
-    const size_t position = one_byte ? 0 : s->position;
+    const size_t position = fb - fa;                    // distance between the two filter bytes
     pr.d = position / 16;
     const uint32_t sh = (uint32_t)(position % 16);
     pr.r = sh % 4;
-    pr.n0x4 = 0x01010101u * s->needle[0];
-    pr.nlx4 = 0x01010101u * s->needle[position];
-    pr.norder = ss::build_refine_order(s->needle.data(), n, position, pr.order_idx, pr.order_val);
+    pr.n0x4 = 0x01010101u * s->needle[fa];
+    pr.nlx4 = 0x01010101u * s->needle[fb];
+    // second-level filter: up to 15 further needle bytes behind the first filter byte
+    pr.norder = ss::build_refine_order(s->needle.data() + fa, n - fa, position, pr.order_idx, pr.order_val);
     pr.find_base = find_base;
     pr.host_flag = host_flag;
     pr.epoch = epoch;
 
-    const Launch l = pick_variant(s->variant, one_byte ? 0 : pr.d, one_byte, one_byte ? 0 : s->position);
+    const Launch l = pick_variant(s->variant, pr.d, one_byte, position);
     const uint64_t wpb = l.block / ss::kWave;
     const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
     uint64_t blocks, tpb;
@@ -335,7 +358,15 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     if (blocks < 1) blocks = 1;
     const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
 
-    if (s->timing) HIP_TRY(hipEventRecord(pd->ev0, st));
+    ThreadTimer &tm = g_timer;
+    const bool timed = s->timing && pd->dev >= 0 && pd->dev < kMaxDevices;
+    if (timed) {
+        if (!tm.ev0[pd->dev]) {
+            HIP_TRY(hipEventCreate(&tm.ev0[pd->dev]));
+            HIP_TRY(hipEventCreate(&tm.ev1[pd->dev]));
+        }
+        HIP_TRY(hipEventRecord(tm.ev0[pd->dev], st));
+    }
     const int q = (int)(sh / 4);
     if (find) {   // one tile shape for find(): U = 4
         if (l.U != 4) return fail(SS_ERR_ARGUMENT, "find supports the U = 4 kernels only");
@@ -347,21 +378,58 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, shape, st, d_flag, l.l8);
     }
     HIP_TRY(hipGetLastError());
-    if (s->timing) {
-        HIP_TRY(hipEventRecord(pd->ev1, st));
-        pd->timed_valid = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(tm.ev1[pd->dev], st));
+        tm.owner = s;
+        tm.dev = pd->dev;
     }
     return SS_OK;
 }
 
-}  // namespace
+// ---- filter-pair choice for `new` callers ---------------------------------------------------------------
+// The reference tests needle[0] and needle[position] and leaves `position` to the caller, defaulting to the last
+// byte (x86.rs:252-255, 285); the result never depends on it (lib.rs:375-378).  On the GPU the pair decides how
+// often the second phase runs (text passes a {' ', ' '} filter at percent rates) and, through the distance
+// between the two bytes, which kernel runs (a distance >= 16 needs cross-lane traffic or a second load stream).
+// For `new` callers the library therefore picks BOTH bytes: the pair (a, b), a < b <= a + 15, among the first
+// kFilterWindow needle bytes with the lowest summed rarity rank (ss::byte_rarity_rank: a static, corpus-free
+// guess; bytes outside text are all "rare" alike).  Ties go to the reference's own pair (0, n-1) when it is
+// among the best, else to the widest pair (neighbouring text bytes are correlated), else to the earliest.
+// with_position callers keep (0, position).
+constexpr size_t kFilterWindow = 1024;
 
-extern "C" {
+inline int rarity_class(uint8_t b)
+{
+    const int r = ss::byte_rarity_rank(b);
+    return r < 64 ? 0 : r;          // everything that is not text-like counts as equally rare
+}
 
-const char *ss_last_error(void) { return g_err; }
-const char *ss_version(void) { return "sliceslice-hip 0.1 (gfx950)"; }
+void choose_filter_pair(const uint8_t *needle, size_t n, size_t *fa, size_t *fb)
+{
+    *fa = 0;
+    *fb = n ? n - 1 : 0;
+    if (n < 2) { *fb = 0; return; }
+    const size_t w = n < kFilterWindow ? n : kFilterWindow;
+    int best = INT_MAX;
+    size_t ba = 0, bb = 1;
+    for (size_t a = 0; a + 1 < w; ++a) {
+        const int ca = rarity_class(needle[a]);
+        if (ca > best) continue;
+        for (size_t b = a + 1; b < w && b <= a + 15; ++b) {
+            const int c = ca + rarity_class(needle[b]);
+            if (c < best || (c == best && b - a > bb - ba)) {
+                best = c;
+                ba = a;
+                bb = b;
+            }
+        }
+    }
+    if (n <= 16 && rarity_class(needle[0]) + rarity_class(needle[n - 1]) == best) return;   // the reference's pair is as good
+    *fa = ba;
+    *fb = bb;
+}
 
-int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out)
+int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_filter, ss_searcher **out)
 {
     if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -377,6 +445,9 @@ int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, 
     s->needle.assign(needle, needle + n);
     s->n = n;
     s->position = position;
+    s->fa = 0;
+    s->fb = n >= 2 ? position : 0;
+    if (auto_filter) choose_filter_pair(s->needle.data(), n, &s->fa, &s->fb);
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) {      // uploads the needle to the current device now
         delete s;
@@ -386,9 +457,52 @@ int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, 
     return SS_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+const char *ss_last_error(void) { return g_err; }
+const char *ss_version(void) { return "sliceslice-hip 0.1 (gfx950)"; }
+
+int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out)
+{
+    return make_searcher(needle, n, position, false, out);
+}
+
 int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out)
 {
-    return ss_searcher_with_position(needle, n, n - 1 /* wrapping_sub(1), x86.rs:457 */, out);
+    // x86.rs:457: position = n.wrapping_sub(1) - what ss_searcher_position keeps reporting.  The filter bytes
+    // the device tests are chosen by choose_filter_pair (SLICESLICE_AUTO_FILTER=0: the reference's pair (0, n-1)).
+    const char *e = getenv("SLICESLICE_AUTO_FILTER");
+    return make_searcher(needle, n, n - 1, !(e && e[0] == '0'), out);
+}
+
+int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second)
+{
+    if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
+    if (s->n < 2) {
+        if (first != 0 || second != 0) return fail(SS_ERR_POSITION, "needles shorter than two bytes have no filter pair");
+        return SS_OK;
+    }
+    if (first > second || second >= s->n) return fail(SS_ERR_POSITION, "filter pair (%zu, %zu) out of range for a needle of %zu bytes", first, second, s->n);
+    s->fa = first;
+    s->fb = second;
+    return SS_OK;
+}
+
+int ss_choose_filter_pair(const uint8_t *needle, size_t n, size_t *first, size_t *second)
+{
+    if (!first || !second || (n && !needle)) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    choose_filter_pair(needle, n, first, second);
+    return SS_OK;
+}
+
+int ss_searcher_filter(const ss_searcher *s, size_t *first, size_t *second)
+{
+    if (!s || !first || !second) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    *first = s->fa;
+    *second = s->fb;
+    return SS_OK;
 }
 
 void ss_searcher_free(ss_searcher *s)
@@ -403,10 +517,9 @@ void ss_searcher_free(ss_searcher *s)
         (void)hipHostFree(p.h_flags);
         (void)hipFree(p.d_best);
         (void)hipHostFree(p.h_best);
-        if (p.ev0) (void)hipEventDestroy(p.ev0);
-        if (p.ev1) (void)hipEventDestroy(p.ev1);
     }
     (void)hipSetDevice(cur);
+    if (g_timer.owner == s) g_timer.owner = nullptr;
     delete s;
 }
 
@@ -423,11 +536,22 @@ int ss_searcher_set_timing(ss_searcher *s, int enabled)
 int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms)
 {
     if (!s || !ms) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    ThreadTimer &tm = g_timer;
+    if (tm.owner != s || tm.dev < 0) return fail(SS_ERR_ARGUMENT, "no timed scan has been launched through this searcher by the calling thread");
+    HIP_TRY(hipEventSynchronize(tm.ev1[tm.dev]));
+    HIP_TRY(hipEventElapsedTime(ms, tm.ev0[tm.dev], tm.ev1[tm.dev]));
+    return SS_OK;
+}
+
+// Test hooks: move the epoch counters close to the 2^31 wrap so that tests can cross it.
+int ss_debug_set_epochs(ss_searcher *s, int value)
+{
+    if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
-    if (!pd->timed_valid) return fail(SS_ERR_ARGUMENT, "no timed scan has been launched");
-    HIP_TRY(hipEventSynchronize(pd->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, pd->ev0, pd->ev1));
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (pd->free_mask != ~0ull) return fail(SS_ERR_ARGUMENT, "searches in flight");
+    for (int k = 0; k < kSlots; ++k) pd->epoch[k] = value;
     return SS_OK;
 }
 
@@ -524,12 +648,21 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
         rc = fail(SS_ERR_HIP, "slot reset failed");
     if (rc == SS_OK) rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0);
     if (rc == SS_OK) {
-        hipError_t e = hipMemcpyAsync(pd->h_best + k, pd->d_best + k, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        // read-back through the pinned mirror: a one-lane kernel behind the scan stores the minimum to host memory
+        // (SLICESLICE_FIND_READBACK=memcpy: a device-to-host copy command instead; tools/native_bench latency compares)
+        static const bool by_copy = []() { const char *v = getenv("SLICESLICE_FIND_READBACK"); return v && !strcmp(v, "memcpy"); }();
+        hipError_t e;
+        if (by_copy) {
+            e = hipMemcpyAsync(pd->h_best + k, pd->d_best + k, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        } else {
+            ss::publish_best_kernel<<<1, 1, 0, st>>>(pd->d_best + k, pd->h_best + k);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(SS_ERR_HIP, "position read-back: %s", hipGetErrorString(e));
     }
     if (rc == SS_OK) {
-        *position = pd->h_best[k];
+        *position = __atomic_load_n(pd->h_best + k, __ATOMIC_ACQUIRE);
         if (*position != SS_NPOS) {
             std::lock_guard<std::mutex> lk(s->mu);
             pd->best_dirty |= 1ull << k;
@@ -589,7 +722,6 @@ struct Staging {
         return true;
     }
 };
-constexpr int kMaxDevices = 64;
 std::mutex g_staging_mu[kMaxDevices];
 Staging g_staging[kMaxDevices];
 
@@ -1091,7 +1223,11 @@ struct Rccl {
     void *h = nullptr;
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, Id128 /* ncclUniqueId, by value */, int) = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -1109,11 +1245,17 @@ Rccl *rccl()
         if (!r.h) return;
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.h, "ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.h, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.h, "ncclGroupEnd");
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
     });
-    if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) return nullptr;
+    if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.CommCount || !r.GroupStart ||
+        !r.GroupEnd || !r.AllReduce)
+        return nullptr;
     return &r;
 }
 
@@ -1127,16 +1269,97 @@ int rccl_fail(Rccl *r, int code, const char *what)
     return fail(SS_ERR_RCCL, "%s: %s", what, r && r->GetErrorString ? r->GetErrorString(code) : "rccl error");
 }
 
+// restores the calling thread's current device on scope exit
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
 }  // namespace
 
+// One rank's end of a communicator (one process per GPU).  The found flag of a sharded search is never
+// cleared: "found" is the call's epoch - every rank makes the same sequence of collective calls on a
+// communicator, so the ranks' epochs agree - and since a rank's flag only ever holds epochs of earlier
+// calls or of this one, max over the ranks == epoch exactly when some rank found the needle in THIS call.
 struct ss_comm {
     void *comm = nullptr;
     int nranks = 1, rank = 0;
-    int *d_flag = nullptr;      // scratch flag for ss_search_sharded
-    int *h_flag = nullptr;
+    int dev = 0;
+    int epoch = 0;
+    int *d_flag = nullptr;      // this rank's found flag (epoch-valued, never cleared)
+    int *d_recv = nullptr;      // all-reduce(MAX) result
+    int *h_flag = nullptr;      // pinned read-back
     uint64_t *d_best = nullptr; // scratch offset for ss_find_sharded
     uint64_t *h_best = nullptr;
 };
+
+// All ranks of a communicator inside ONE process (ncclCommInitAll): one stream, flag and read-back per device.
+struct ss_comm_set {
+    int ndev = 0;
+    int combine = 0;            // SS_COMBINE_RCCL / SS_COMBINE_HOST
+    int epoch = 0;
+    std::vector<int> devs;
+    std::vector<void *> comms;
+    std::vector<hipStream_t> streams;
+    std::vector<int *> d_flag, d_recv, h_flag;          // h_flag[g]: pinned mirror written by device g's finding wave
+    std::vector<uint64_t *> d_best, d_best_recv;
+    int *h_recv = nullptr;                              // pinned: device 0's all-reduce result
+    uint64_t *h_best = nullptr;                         // pinned: ndev offsets (host combine) / [0] = all-reduce result
+};
+
+namespace {
+
+int next_comm_epoch(int *epoch, int *const *d_flags, const int *devs, int ndev, int *const *h_flags = nullptr)
+{
+    if (*epoch >= INT_MAX - 1 || *epoch < 0) {          // 2^31 calls: clear the flags so that no stale value equals a new epoch
+        DeviceGuard guard;
+        for (int g = 0; g < ndev; ++g) {
+            (void)hipSetDevice(devs[g]);
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(d_flags[g], 0, sizeof(int));
+            if (h_flags) *h_flags[g] = 0;
+        }
+        *epoch = 0;
+    }
+    return ++*epoch;
+}
+
+void free_comm(ss_comm *c)
+{
+    Rccl *r = rccl();
+    if (r && c->comm) r->CommDestroy(c->comm);
+    (void)hipFree(c->d_flag);
+    (void)hipFree(c->d_recv);
+    (void)hipHostFree(c->h_flag);
+    (void)hipFree(c->d_best);
+    (void)hipHostFree(c->h_best);
+    delete c;
+}
+
+void free_comm_set(ss_comm_set *set)
+{
+    Rccl *r = rccl();
+    DeviceGuard guard;
+    for (int g = 0; g < set->ndev; ++g) {
+        (void)hipSetDevice(set->devs[g]);
+        if (g < (int)set->streams.size() && set->streams[g]) {
+            (void)hipStreamSynchronize(set->streams[g]);
+            (void)hipStreamDestroy(set->streams[g]);
+        }
+        if (r && g < (int)set->comms.size() && set->comms[g]) r->CommDestroy(set->comms[g]);
+        if (g < (int)set->d_flag.size()) (void)hipFree(set->d_flag[g]);
+        if (g < (int)set->d_recv.size()) (void)hipFree(set->d_recv[g]);
+        if (g < (int)set->h_flag.size()) (void)hipHostFree(set->h_flag[g]);
+        if (g < (int)set->d_best.size()) (void)hipFree(set->d_best[g]);
+        if (g < (int)set->d_best_recv.size()) (void)hipFree(set->d_best_recv[g]);
+    }
+    (void)hipHostFree(set->h_recv);
+    (void)hipHostFree(set->h_best);
+    delete set;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1153,6 +1376,7 @@ int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank
 {
     if (!out || !id) return fail(SS_ERR_ARGUMENT, "NULL argument");
     *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SS_ERR_ARGUMENT, "bad rank %d of %d", rank, nranks);
     Rccl *r = rccl();
     if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
     ss_comm *c = new (std::nothrow) ss_comm;
@@ -1160,29 +1384,46 @@ int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank
     Id128 uid;
     memcpy(uid.b, id, sizeof uid);
     if (int rc = r->CommInitRank(&c->comm, nranks, uid, rank)) {
-        delete c;
+        c->comm = nullptr;
+        free_comm(c);
         return rccl_fail(r, rc, "ncclCommInitRank");
     }
     c->nranks = nranks;
     c->rank = rank;
-    HIP_TRY(hipMalloc((void **)&c->d_flag, sizeof(int)));
-    HIP_TRY(hipHostMalloc((void **)&c->h_flag, sizeof(int), hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&c->d_best, sizeof(uint64_t)));
-    HIP_TRY(hipHostMalloc((void **)&c->h_best, sizeof(uint64_t), hipHostMallocDefault));
+    hipError_t e = hipGetDevice(&c->dev);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_recv, sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_best, sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_best, sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) {                               // nothing half-built is left behind (communicator included)
+        free_comm(c);
+        return fail(SS_ERR_HIP, "communicator scratch: %s", hipGetErrorString(e));
+    }
     *out = c;
     return SS_OK;
 }
 
 void ss_comm_free(ss_comm *c)
 {
-    if (!c) return;
+    if (c) free_comm(c);
+}
+
+int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value)
+{
+    if (c) c->epoch = value;
+    if (set) set->epoch = value;
+    return SS_OK;
+}
+
+int ss_comm_count(const ss_comm *c, int *nranks)
+{
+    if (!c || !nranks) return fail(SS_ERR_ARGUMENT, "NULL argument");
     Rccl *r = rccl();
-    if (r && c->comm) r->CommDestroy(c->comm);
-    (void)hipFree(c->d_flag);
-    (void)hipHostFree(c->h_flag);
-    (void)hipFree(c->d_best);
-    (void)hipHostFree(c->h_best);
-    delete c;
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    if (int rc = r->CommCount(c->comm, nranks)) return rccl_fail(r, rc, "ncclCommCount");   // what RCCL itself says
+    return SS_OK;
 }
 
 int ss_comm_allreduce_flag(ss_comm *c, int *d_flag, void *hip_stream, int *found)
@@ -1205,10 +1446,22 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
                       void *hip_stream, int *found)
 {
     if (!s || !c || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (shard_len && !d_shard) return fail(SS_ERR_ARGUMENT, "shard is NULL");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    if (s->n == 0) { *found = 1; return SS_OK; }            // N0 (x86.rs:500): the same on every rank, nothing to combine
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    HIP_TRY(hipMemsetAsync(c->d_flag, 0, sizeof(int), st));
-    if (int rc = ss_search_device_async(s, d_shard, shard_len, hip_stream, c->d_flag)) return rc;
-    return ss_comm_allreduce_flag(c, c->d_flag, hip_stream, found);
+    const int epoch = next_comm_epoch(&c->epoch, &c->d_flag, &c->dev, 1);
+    if (shard_len >= s->n) {                                // a shard shorter than the needle holds no candidate
+        PerDevice *pd = nullptr;
+        if (int rc = get_per_device(s, &pd)) return rc;
+        if (int rc = enqueue_scan(s, pd, d_shard, shard_len, st, c->d_flag, false, 0, nullptr, epoch)) return rc;
+    }
+    if (int rc = r->AllReduce(c->d_flag, c->d_recv, 1, kNcclInt32, kNcclMax, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    HIP_TRY(hipMemcpyAsync(c->h_flag, c->d_recv, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *found = *c->h_flag == epoch;
+    return SS_OK;
 }
 
 // Sharded find: every rank lowers its uint64 with shard_begin + local offset of its leftmost match, ONE
@@ -1226,6 +1479,191 @@ int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len,
     HIP_TRY(hipMemcpyAsync(c->h_best, c->d_best, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *position = *c->h_best;
+    return SS_OK;
+}
+
+// ---- multi-GPU inside ONE process ---------------------------------------------------------------------
+// What a drop-in `search_in(&self, &[u8]) -> bool` over the 8 GPUs of a node calls (x86.rs:523 has no
+// launcher to lean on): ncclCommInitAll once, then per search one scan per device on that device's stream,
+// the G all-reduces inside ONE ncclGroupStart/End, one read-back.
+int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
+{
+    if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int visible = 0;
+    HIP_TRY(hipGetDeviceCount(&visible));
+    if (ndev < 1 || ndev > visible) return fail(SS_ERR_ARGUMENT, "%d devices requested, %d visible", ndev, visible);
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    ss_comm_set *set = new (std::nothrow) ss_comm_set;
+    if (!set) return fail(SS_ERR_NOMEM, "out of memory");
+    set->ndev = ndev;
+    for (int g = 0; g < ndev; ++g) {
+        const int d = devs ? devs[g] : g;
+        if (d < 0 || d >= visible) {
+            delete set;
+            return fail(SS_ERR_ARGUMENT, "device %d out of range (%d visible)", d, visible);
+        }
+        for (int k = 0; k < g; ++k)
+            if (set->devs[k] == d) {
+                delete set;
+                return fail(SS_ERR_ARGUMENT, "device %d listed twice", d);
+            }
+        set->devs.push_back(d);
+    }
+    set->comms.assign(ndev, nullptr);
+    set->streams.assign(ndev, nullptr);
+    set->d_flag.assign(ndev, nullptr);
+    set->d_recv.assign(ndev, nullptr);
+    set->h_flag.assign(ndev, nullptr);
+    set->d_best.assign(ndev, nullptr);
+    set->d_best_recv.assign(ndev, nullptr);
+    DeviceGuard guard;
+    if (int rc = r->CommInitAll(set->comms.data(), ndev, set->devs.data())) {
+        set->comms.assign(ndev, nullptr);
+        free_comm_set(set);
+        return rccl_fail(r, rc, "ncclCommInitAll");
+    }
+    hipError_t e = hipSuccess;
+    for (int g = 0; g < ndev && e == hipSuccess; ++g) {
+        e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&set->streams[g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_flag[g], sizeof(int));
+        if (e == hipSuccess) e = hipMemset(set->d_flag[g], 0, sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_recv[g], sizeof(int));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_flag[g], sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+        if (e == hipSuccess) *set->h_flag[g] = 0;
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_best[g], sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_best_recv[g], sizeof(uint64_t));
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_recv, sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_best, (size_t)ndev * sizeof(uint64_t), hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        free_comm_set(set);
+        return fail(SS_ERR_HIP, "communicator set scratch: %s", hipGetErrorString(e));
+    }
+    *out = set;
+    return SS_OK;
+}
+
+void ss_comm_set_free(ss_comm_set *set)
+{
+    if (set) free_comm_set(set);
+}
+
+int ss_comm_set_size(const ss_comm_set *set) { return set ? set->ndev : 0; }
+
+int ss_comm_set_device(const ss_comm_set *set, int index, int *device)
+{
+    if (!set || !device || index < 0 || index >= set->ndev) return fail(SS_ERR_ARGUMENT, "bad communicator-set index");
+    *device = set->devs[index];
+    return SS_OK;
+}
+
+int ss_comm_set_combine(ss_comm_set *set, int combine)
+{
+    if (!set || (combine != SS_COMBINE_RCCL && combine != SS_COMBINE_HOST)) return fail(SS_ERR_ARGUMENT, "bad combine mode");
+    set->combine = combine;
+    return SS_OK;
+}
+
+int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens, ss_comm_set *set,
+                          int *found)
+{
+    if (!s || !d_shards || !shard_lens || !set || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (s->n == 0) { *found = 1; return SS_OK; }            // N0 (x86.rs:500)
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    const int G = set->ndev;
+    for (int g = 0; g < G; ++g)
+        if (shard_lens[g] && !d_shards[g]) return fail(SS_ERR_ARGUMENT, "shard %d is NULL", g);
+    DeviceGuard guard;
+    const int epoch = next_comm_epoch(&set->epoch, set->d_flag.data(), set->devs.data(), G, set->h_flag.data());
+    int rc = SS_OK;
+    // 1. one scan per device, each on its device's stream; the finding wave also writes the epoch to that device's
+    //    pinned-host mirror
+    for (int g = 0; g < G && rc == SS_OK; ++g) {
+        if (shard_lens[g] < s->n) continue;                 // shorter than the needle: no candidate, flag stays old
+        if (hipSetDevice(set->devs[g]) != hipSuccess) { rc = fail(SS_ERR_HIP, "hipSetDevice(%d) failed", set->devs[g]); break; }
+        PerDevice *pd = nullptr;
+        rc = get_per_device(s, &pd);
+        if (rc == SS_OK) rc = enqueue_scan(s, pd, d_shards[g], shard_lens[g], set->streams[g], set->d_flag[g], false, 0, set->h_flag[g], epoch);
+    }
+    // 2. combine: G all-reduce(MAX) calls as ONE group (the default), or no collective at all - the host ORs the
+    //    G pinned mirrors (possible only because all ranks live in this process)
+    if (rc == SS_OK && set->combine == SS_COMBINE_RCCL) {
+        int nrc = r->GroupStart();
+        for (int g = 0; g < G && nrc == 0; ++g)
+            nrc = r->AllReduce(set->d_flag[g], set->d_recv[g], 1, kNcclInt32, kNcclMax, set->comms[g], set->streams[g]);
+        const int erc = r->GroupEnd();
+        if (nrc == 0) nrc = erc;
+        if (nrc != 0) rc = rccl_fail(r, nrc, "grouped ncclAllReduce");
+        if (rc == SS_OK) {
+            hipError_t e = hipSetDevice(set->devs[0]);
+            if (e == hipSuccess) e = hipMemcpyAsync(set->h_recv, set->d_recv[0], sizeof(int), hipMemcpyDeviceToHost, set->streams[0]);
+            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
+        }
+    }
+    // 3. every stream is drained before the call returns: the haystacks are only borrowed for the call
+    for (int g = 0; g < G; ++g) {
+        hipError_t e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipStreamSynchronize(set->streams[g]);
+        if (e != hipSuccess && rc == SS_OK) rc = fail(SS_ERR_HIP, "stream wait on device %d: %s", set->devs[g], hipGetErrorString(e));
+    }
+    if (rc != SS_OK) return rc;
+    int any = 0;
+    if (set->combine == SS_COMBINE_RCCL) {
+        any = *set->h_recv == epoch;
+    } else {
+        for (int g = 0; g < G; ++g) any |= __atomic_load_n(set->h_flag[g], __ATOMIC_ACQUIRE) == epoch;
+    }
+    *found = any;
+    return SS_OK;
+}
+
+int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
+                        const uint64_t *shard_begins, ss_comm_set *set, uint64_t *position)
+{
+    if (!s || !d_shards || !shard_lens || !shard_begins || !set || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    const int G = set->ndev;
+    DeviceGuard guard;
+    int rc = SS_OK;
+    for (int g = 0; g < G && rc == SS_OK; ++g) {
+        hipError_t e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipMemsetAsync(set->d_best[g], 0xFF, sizeof(uint64_t), set->streams[g]);
+        if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "device %d: %s", set->devs[g], hipGetErrorString(e)); break; }
+        rc = ss_find_device_async(s, d_shards[g], shard_lens[g], shard_begins[g], set->streams[g], set->d_best[g]);
+    }
+    if (rc == SS_OK && set->combine == SS_COMBINE_RCCL) {
+        int nrc = r->GroupStart();
+        for (int g = 0; g < G && nrc == 0; ++g)
+            nrc = r->AllReduce(set->d_best[g], set->d_best_recv[g], 1, kNcclUint64, kNcclMin, set->comms[g], set->streams[g]);
+        const int erc = r->GroupEnd();
+        if (nrc == 0) nrc = erc;
+        if (nrc != 0) rc = rccl_fail(r, nrc, "grouped ncclAllReduce");
+    }
+    if (rc == SS_OK) {                                       // read-back: the reduced value from device 0, or all G minima
+        const int nread = set->combine == SS_COMBINE_RCCL ? 1 : G;
+        for (int g = 0; g < nread && rc == SS_OK; ++g) {
+            hipError_t e = hipSetDevice(set->devs[g]);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(set->h_best + g, set->combine == SS_COMBINE_RCCL ? set->d_best_recv[g] : set->d_best[g],
+                                   sizeof(uint64_t), hipMemcpyDeviceToHost, set->streams[g]);
+            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "offset read-back: %s", hipGetErrorString(e));
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+        hipError_t e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipStreamSynchronize(set->streams[g]);
+        if (e != hipSuccess && rc == SS_OK) rc = fail(SS_ERR_HIP, "stream wait on device %d: %s", set->devs[g], hipGetErrorString(e));
+    }
+    if (rc != SS_OK) return rc;
+    uint64_t best = set->h_best[0];
+    if (set->combine != SS_COMBINE_RCCL)
+        for (int g = 1; g < G; ++g) best = set->h_best[g] < best ? set->h_best[g] : best;
+    *position = best;
     return SS_OK;
 }
 

@@ -41,6 +41,9 @@ ABI = {
     "ss_searcher_free": (None, [_vp]),
     "ss_searcher_needle_len": (_sz, [_vp]),
     "ss_searcher_position": (_sz, [_vp]),
+    "ss_searcher_filter": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_searcher_set_filter": (_int, [_vp, _sz, _sz]),
+    "ss_choose_filter_pair": (_int, [_vp, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
     "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
@@ -62,6 +65,14 @@ ABI = {
     "ss_comm_unique_id": (_int, [_vp]),
     "ss_comm_init_rank": (_int, [_vp, _int, _int, _pvp]),
     "ss_comm_free": (None, [_vp]),
+    "ss_comm_count": (_int, [_vp, _pint]),
+    "ss_comm_init_all": (_int, [_int, _pint, _pvp]),
+    "ss_comm_set_free": (None, [_vp]),
+    "ss_comm_set_size": (_int, [_vp]),
+    "ss_comm_set_device": (_int, [_vp, _int, _pint]),
+    "ss_comm_set_combine": (_int, [_vp, _int]),
+    "ss_search_sharded_all": (_int, [_vp, _pvp, ctypes.POINTER(_sz), _vp, _pint]),
+    "ss_find_sharded_all": (_int, [_vp, _pvp, ctypes.POINTER(_sz), ctypes.POINTER(_u64), _vp, ctypes.POINTER(_u64)]),
     "ss_comm_allreduce_flag": (_int, [_vp, _vp, _vp, _pint]),
     "ss_search_sharded": (_int, [_vp, _vp, _sz, _vp, _vp, _pint]),
     "ss_find_sharded": (_int, [_vp, _vp, _sz, _u64, _vp, _vp, ctypes.POINTER(_u64)]),
@@ -70,6 +81,8 @@ ABI = {
     "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, ctypes.POINTER(_sz)]),
     "ss_version": (ctypes.c_char_p, []),
     "ss_selftest_dpp": (_int, [_vp]),
+    "ss_debug_set_epochs": (_int, [_vp, _int]),
+    "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
 }
 
 
@@ -140,6 +153,29 @@ def _current_stream_handle():
     return 0
 
 
+class _on_device_of:
+    """The C side launches on the CURRENT device (its needle copy, its flag slots) and, by default, on torch's
+    current stream OF THAT DEVICE: make the tensor's device current for the duration of the call, so that a
+    haystack on cuda:1 is never scanned by a kernel launched on cuda:0."""
+
+    def __init__(self, t):
+        self._ctx = None
+        if _is_tensor(t) and t.is_cuda:
+            import torch
+            if t.device.index != torch.cuda.current_device():
+                self._ctx = torch.cuda.device(t.device)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
+        return False
+
+
 class DynamicHipSearcher:
     """GPU counterpart of ``sliceslice::x86::DynamicAvx2Searcher`` (src/x86.rs:405-525)."""
 
@@ -179,8 +215,9 @@ class DynamicHipSearcher:
                 return self.search_in(haystack.numpy())
             if haystack.dtype.itemsize != 1 or not haystack.is_contiguous():
                 raise TypeError("device haystack must be a contiguous 1-byte tensor")
-            st = stream if stream is not None else _current_stream_handle()
-            _check(lib().ss_search_device(self._h, haystack.data_ptr(), haystack.numel(), st, ctypes.byref(found)))
+            with _on_device_of(haystack):
+                st = stream if stream is not None else _current_stream_handle()
+                _check(lib().ss_search_device(self._h, haystack.data_ptr(), haystack.numel(), st, ctypes.byref(found)))
         elif isinstance(haystack, tuple):
             ptr, length = haystack
             st = stream if stream is not None else _current_stream_handle()
@@ -199,8 +236,9 @@ class DynamicHipSearcher:
         pos = _u64(0)
         if isinstance(haystack, tuple) or (_is_tensor(haystack) and haystack.is_cuda):
             ptr, length = haystack if isinstance(haystack, tuple) else (haystack.data_ptr(), haystack.numel())
-            st = stream if stream is not None else _current_stream_handle()
-            _check(lib().ss_find_device(self._h, ptr, length, st, ctypes.byref(pos)))
+            with _on_device_of(haystack):
+                st = stream if stream is not None else _current_stream_handle()
+                _check(lib().ss_find_device(self._h, ptr, length, st, ctypes.byref(pos)))
         else:
             if _is_tensor(haystack):
                 haystack = haystack.numpy()
@@ -210,16 +248,28 @@ class DynamicHipSearcher:
 
     def find_async(self, haystack, d_best, base_offset=0, stream=None):
         """Enqueue only: atomicMin base_offset + offset into the uint64 device tensor d_best (init: all ones)."""
-        st = stream if stream is not None else _current_stream_handle()
-        _check(lib().ss_find_device_async(self._h, haystack.data_ptr(), haystack.numel(), base_offset, st,
-                                          d_best.data_ptr()))
+        with _on_device_of(haystack):
+            st = stream if stream is not None else _current_stream_handle()
+            _check(lib().ss_find_device_async(self._h, haystack.data_ptr(), haystack.numel(), base_offset, st,
+                                              d_best.data_ptr()))
 
     def search_in_async(self, haystack, d_flag, stream=None):
         """Enqueue only: OR the result into the int32 device tensor ``d_flag`` (caller-zeroed)."""
-        st = stream if stream is not None else _current_stream_handle()
-        _check(lib().ss_search_device_async(self._h, haystack.data_ptr(), haystack.numel(), st, d_flag.data_ptr()))
+        with _on_device_of(haystack):
+            st = stream if stream is not None else _current_stream_handle()
+            _check(lib().ss_search_device_async(self._h, haystack.data_ptr(), haystack.numel(), st, d_flag.data_ptr()))
 
     # -- tuning / measurement hooks ------------------------------------------------------------------
+    @property
+    def filter(self):
+        """(first, second): indices of the two needle bytes the device filter tests."""
+        a, b = _sz(0), _sz(0)
+        _check(lib().ss_searcher_filter(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def set_filter(self, first, second):
+        _check(lib().ss_searcher_set_filter(self._h, first, second))
+
     def set_timing(self, on=True):
         _check(lib().ss_searcher_set_timing(self._h, int(on)))
 
@@ -298,24 +348,38 @@ class ShardedSearcher:
             flag = torch.tensor([1 if self._local_search(shard) else 0], dtype=torch.int32)
             self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX, group=self.group)
             return bool(flag.item())
-        st = stream if stream is not None else _current_stream_handle()
         if self.backend == "rccl":
             found = ctypes.c_int(0)
-            _check(lib().ss_search_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), self._comm, st,
-                                           ctypes.byref(found)))
+            with _on_device_of(shard):
+                st = stream if stream is not None else _current_stream_handle()
+                _check(lib().ss_search_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), self._comm, st,
+                                               ctypes.byref(found)))
             return bool(found.value)
-        # a ring of pre-zeroed flags: one fresh zero per call, one zero_() launch per 256 calls instead of per call
-        if self._flag is None or self._flag_next == self._flag.numel():
-            if self._flag is None:
-                self._flag = torch.zeros(256, dtype=torch.int32, device=shard.device)
-            else:
-                self._flag.zero_()
-            self._flag_next = 0
-        flag = self._flag[self._flag_next:self._flag_next + 1]
-        self._flag_next += 1
-        self._searcher.search_in_async(shard, flag, st)
-        self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX, group=self.group)
-        return bool(flag.item())
+        # torch transport: the scan, the flag housekeeping and the all-reduce must all be ordered on ONE stream -
+        # torch's current stream.  A caller-supplied stream (object or raw handle) is made current for the duration.
+        with _on_device_of(shard), self._as_current(stream):
+            # a ring of pre-zeroed flags: one fresh zero per call, one zero_() launch per 256 calls instead of per call
+            if self._flag is None or self._flag_next == self._flag.numel():
+                if self._flag is None:
+                    self._flag = torch.zeros(256, dtype=torch.int32, device=shard.device)
+                else:
+                    self._flag.zero_()
+                self._flag_next = 0
+            flag = self._flag[self._flag_next:self._flag_next + 1]
+            self._flag_next += 1
+            self._searcher.search_in_async(shard, flag)
+            self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX, group=self.group)
+            return bool(flag.item())
+
+    @staticmethod
+    def _as_current(stream):
+        import contextlib
+        import torch
+        if stream is None:
+            return contextlib.nullcontext()
+        if isinstance(stream, int):
+            stream = torch.cuda.ExternalStream(stream)
+        return torch.cuda.stream(stream)
 
     def find(self, shard, shard_begin, stream=None):
         """Global offset of the leftmost occurrence in the logical haystack, or None: every rank finds its
@@ -327,24 +391,96 @@ class ShardedSearcher:
             t = torch.tensor([none if p is None else p + shard_begin], dtype=torch.int64)
         elif self.backend == "rccl":                              # native: ncclAllReduce(uint64, ncclMin)
             pos = _u64(0)
-            st = stream if stream is not None else _current_stream_handle()
-            _check(lib().ss_find_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), shard_begin, self._comm, st,
-                                         ctypes.byref(pos)))
+            with _on_device_of(shard):
+                st = stream if stream is not None else _current_stream_handle()
+                _check(lib().ss_find_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), shard_begin, self._comm, st,
+                                             ctypes.byref(pos)))
             return None if pos.value == (1 << 64) - 1 else pos.value
         else:
-            if self._best is None:
-                self._best = torch.empty(1, dtype=torch.int64, device=shard.device)
-            self._best.fill_(-1)                                   # all ones = SS_NPOS
-            self._searcher.find_async(shard, self._best, shard_begin, stream)
-            t = torch.where(self._best < 0, torch.full_like(self._best, none), self._best)
+            with _on_device_of(shard), self._as_current(stream):   # everything ordered on one (the current) stream
+                if self._best is None:
+                    self._best = torch.empty(1, dtype=torch.int64, device=shard.device)
+                self._best.fill_(-1)                               # all ones = SS_NPOS
+                self._searcher.find_async(shard, self._best, shard_begin)
+                t = torch.where(self._best < 0, torch.full_like(self._best, none), self._best)
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
+                v = int(t.item())
+            return None if v == none else v
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
         v = int(t.item())
         return None if v == none else v
+
+    def rccl_ranks(self):
+        """Number of ranks RCCL itself reports for the native communicator (ncclCommCount), or None."""
+        if self._comm is None:
+            return None
+        n = ctypes.c_int(0)
+        _check(lib().ss_comm_count(self._comm, ctypes.byref(n)))
+        return n.value
 
     def close(self):
         if self._comm is not None and _lib is not None:
             _lib.ss_comm_free(self._comm)
             self._comm = None
+
+
+class NodeSearcher:
+    """Range-sharded search over several GPUs from ONE process (ss_comm_init_all / ss_search_sharded_all):
+    what a drop-in ``search_in(&self, haystack) -> bool`` (src/x86.rs:523) over the GPUs of a node calls - no
+    launcher, no rendezvous.  ``shards`` is a list of uint8 tensors, shard g resident on device g of the set
+    (ranges from ``shard_range``)."""
+
+    COMBINE_RCCL, COMBINE_HOST = 0, 1
+
+    def __init__(self, needle, position=None, devices=None, ndev=None):
+        import torch
+        if devices is None:
+            devices = list(range(ndev if ndev is not None else torch.cuda.device_count()))
+        self.devices = list(devices)
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        self._set = ctypes.c_void_p()
+        _check(lib().ss_comm_init_all(len(self.devices), arr, ctypes.byref(self._set)))
+        self._searcher = DynamicHipSearcher(needle, position)
+        self.needle = bytes(needle)
+
+    def set_combine(self, mode):
+        _check(lib().ss_comm_set_combine(self._set, mode))
+
+    def shard_range(self, total_len, g):
+        return shard_range(total_len, len(self.needle), len(self.devices), g)
+
+    def _args(self, shards):
+        G = len(self.devices)
+        assert len(shards) == G
+        for g, t in enumerate(shards):
+            assert t.is_cuda and t.device.index == self.devices[g] and t.dtype.itemsize == 1 and t.is_contiguous()
+        ptrs = (ctypes.c_void_p * G)(*[t.data_ptr() if t.numel() else None for t in shards])
+        lens = (_sz * G)(*[t.numel() for t in shards])
+        return ptrs, lens
+
+    def search_in(self, shards):
+        ptrs, lens = self._args(shards)
+        found = ctypes.c_int(0)
+        _check(lib().ss_search_sharded_all(self._searcher._h, ptrs, lens, self._set, ctypes.byref(found)))
+        return bool(found.value)
+
+    def find(self, shards, begins):
+        ptrs, lens = self._args(shards)
+        b = (_u64 * len(begins))(*begins)
+        pos = _u64(0)
+        _check(lib().ss_find_sharded_all(self._searcher._h, ptrs, lens, b, self._set, ctypes.byref(pos)))
+        return None if pos.value == (1 << 64) - 1 else pos.value
+
+    def close(self):
+        if getattr(self, "_set", None) and _lib is not None:
+            _lib.ss_comm_set_free(self._set)
+            self._set = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _ranges(off, begin, end):
@@ -394,6 +530,14 @@ def choose_position(needle, hist=None):
     h = None if hist is None else np.ascontiguousarray(hist, dtype=np.uint64)
     _check(lib().ss_choose_position(nb, len(nb), None if h is None else h.ctypes.data, ctypes.byref(pos)))
     return pos.value
+
+
+def choose_filter_pair(needle):
+    """(first, second): the two needle bytes `DynamicHipSearcher.new(needle)` lets the device filter test."""
+    nb = bytes(needle)
+    a, b = _sz(0), _sz(0)
+    _check(lib().ss_choose_filter_pair(nb, len(nb), ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 def fill_random_device(tensor, seed, global_offset=0, stream=None):

@@ -1,0 +1,192 @@
+// Stress of the HOST side of the C-ABI library: the flag-slot pool under more concurrent callers than slots,
+// the epoch wrap, the staging leases of the host / file front ends under contention, the communicator
+// objects (one rank; all visible devices in one process) and the error paths.  Built twice by
+// tests/test_gpu_native.py: plainly, and with -fsanitize=address,undefined against the sanitized build of the
+// library - the counterpart of the reference's ASAN job (.github/workflows/check.yml:42-58) for the part of
+// this build that is ordinary C++.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sliceslice_hip.h"
+
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            std::fprintf(stderr, "FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #cond, ss_last_error()); \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+static std::atomic<int> g_failures{0};
+#define TCHECK(cond)                                                                 \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            std::fprintf(stderr, "FAILED %s:%d: %s (%s)\n", __FILE__, __LINE__, #cond, ss_last_error()); \
+            ++g_failures;                                                            \
+            return;                                                                  \
+        }                                                                            \
+    } while (0)
+
+int main(int argc, char **argv)
+{
+    const int nthreads = argc > 1 ? std::atoi(argv[1]) : 128;
+    const size_t len = 2u << 20;
+    const uint8_t needle[7] = {9, 8, 7, 6, 5, 4, 3};
+    std::vector<uint8_t> h_no(len, 0), h_yes(len, 0);
+    std::memcpy(h_yes.data() + len - 7, needle, 7);
+    uint8_t *d_no = nullptr, *d_yes = nullptr;
+    CHECK(hipMalloc((void **)&d_no, len) == hipSuccess && hipMalloc((void **)&d_yes, len) == hipSuccess);
+    CHECK(hipMemcpy(d_no, h_no.data(), len, hipMemcpyHostToDevice) == hipSuccess);
+    CHECK(hipMemcpy(d_yes, h_yes.data(), len, hipMemcpyHostToDevice) == hipSuccess);
+    const std::string path = "/tmp/host_stress_haystack.bin";
+    {
+        std::FILE *fh = std::fopen(path.c_str(), "wb");
+        CHECK(fh != nullptr);
+        CHECK(std::fwrite(h_yes.data(), 1, len, fh) == len);
+        std::fclose(fh);
+    }
+
+    // ---- error paths ----
+    ss_searcher *bad = nullptr;
+    CHECK(ss_searcher_with_position(needle, 7, 7, &bad) == SS_ERR_POSITION && bad == nullptr);
+    CHECK(ss_searcher_with_position(needle, 1, 1, &bad) == SS_ERR_POSITION);
+    CHECK(ss_searcher_new(nullptr, 3, &bad) == SS_ERR_ARGUMENT);
+    CHECK(ss_searcher_new(needle, 7, nullptr) == SS_ERR_ARGUMENT);
+    ss_comm *badc = nullptr;
+    uint8_t id[SS_UNIQUE_ID_BYTES] = {0};
+    CHECK(ss_comm_init_rank(id, 0, 0, &badc) == SS_ERR_ARGUMENT && badc == nullptr);
+    CHECK(ss_comm_init_rank(id, 2, 2, &badc) == SS_ERR_ARGUMENT);
+    ss_comm_set *bads = nullptr;
+    CHECK(ss_comm_init_all(0, nullptr, &bads) == SS_ERR_ARGUMENT);
+    CHECK(ss_comm_init_all(4096, nullptr, &bads) == SS_ERR_ARGUMENT);
+    ss_searcher_free(nullptr);
+    ss_comm_free(nullptr);
+    ss_comm_set_free(nullptr);
+
+    ss_searcher *s = nullptr;
+    CHECK(ss_searcher_new(needle, 7, &s) == SS_OK);
+    CHECK(ss_searcher_set_filter(s, 3, 2) == SS_ERR_POSITION && ss_searcher_set_filter(s, 0, 7) == SS_ERR_POSITION);
+    size_t fa = 9, fb = 9;
+    CHECK(ss_searcher_filter(s, &fa, &fb) == SS_OK && fa <= fb && fb < 7);
+    CHECK(ss_searcher_set_timing(s, 1) == SS_OK);
+
+    // ---- more concurrent callers than flag slots, all entry points mixed ----
+    std::vector<std::thread> pool;
+    for (int k = 0; k < nthreads; ++k)
+        pool.emplace_back([&, k]() {
+            hipStream_t st = nullptr;
+            TCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+            for (int it = 0; it < 16; ++it) {
+                int found = -1;
+                uint64_t pos = 1;
+                switch ((k + it) % 6) {
+                case 0:
+                    TCHECK(ss_search_device(s, d_yes, len, st, &found) == SS_OK && found == 1);
+                    break;
+                case 1: {
+                    TCHECK(ss_search_device(s, d_no, len, st, &found) == SS_OK && found == 0);
+                    float ms = -1;
+                    TCHECK(ss_searcher_last_kernel_ms(s, &ms) == SS_OK && ms >= 0);
+                    break;
+                }
+                case 2:
+                    TCHECK(ss_find_device(s, d_yes, len, st, &pos) == SS_OK && pos == len - 7);
+                    TCHECK(ss_find_device(s, d_no, len, st, &pos) == SS_OK && pos == SS_NPOS);
+                    break;
+                case 3:
+                    TCHECK(ss_search_host(s, h_yes.data(), len, &found) == SS_OK && found == 1);
+                    TCHECK(ss_search_host(s, h_no.data(), len, &found) == SS_OK && found == 0);
+                    break;
+                case 4:
+                    TCHECK(ss_find_host(s, h_yes.data(), len, &pos) == SS_OK && pos == len - 7);
+                    break;
+                default:
+                    TCHECK(ss_search_file(s, path.c_str(), &found) == SS_OK && found == 1);
+                    break;
+                }
+            }
+            (void)hipStreamDestroy(st);
+        });
+    for (auto &t : pool) t.join();
+    CHECK(g_failures == 0);
+
+    // ---- epoch wrap of the flag slots ----
+    CHECK(ss_debug_set_epochs(s, INT_MAX - 3) == SS_OK);
+    for (int it = 0; it < 8; ++it) {
+        int found = -1;
+        CHECK(ss_search_device(s, d_yes, len, nullptr, &found) == SS_OK && found == 1);
+        CHECK(ss_search_device(s, d_no, len, nullptr, &found) == SS_OK && found == 0);
+        CHECK(ss_search_host(s, h_yes.data(), len, &found) == SS_OK && found == 1);
+    }
+
+    // ---- communicators: one rank; every visible device from this process ----
+    {
+        ss_comm *c = nullptr;
+        CHECK(ss_comm_unique_id(id) == SS_OK);
+        CHECK(ss_comm_init_rank(id, 1, 0, &c) == SS_OK);
+        int nr = 0;
+        CHECK(ss_comm_count(c, &nr) == SS_OK && nr == 1);
+        CHECK(ss_debug_set_comm_epoch(c, nullptr, INT_MAX - 2) == SS_OK);
+        for (int it = 0; it < 5; ++it) {
+            int found = -1;
+            uint64_t pos = 1;
+            CHECK(ss_search_sharded(s, d_yes, len, c, nullptr, &found) == SS_OK && found == 1);
+            CHECK(ss_search_sharded(s, d_no, len, c, nullptr, &found) == SS_OK && found == 0);
+            CHECK(ss_find_sharded(s, d_yes, len, 1000, c, nullptr, &pos) == SS_OK && pos == 1000 + len - 7);
+        }
+        ss_comm_free(c);
+    }
+    {
+        int ndev = 0;
+        CHECK(hipGetDeviceCount(&ndev) == hipSuccess && ndev >= 1);
+        if (ndev > 8) ndev = 8;
+        ss_comm_set *set = nullptr;
+        CHECK(ss_comm_init_all(ndev, nullptr, &set) == SS_OK && ss_comm_set_size(set) == ndev);
+        std::vector<uint8_t *> bufs(ndev, nullptr);
+        std::vector<const void *> shards(ndev);
+        std::vector<size_t> lens(ndev, len);
+        std::vector<uint64_t> begins(ndev);
+        for (int g = 0; g < ndev; ++g) {
+            int d = -1;
+            CHECK(ss_comm_set_device(set, g, &d) == SS_OK && d == g);
+            CHECK(hipSetDevice(g) == hipSuccess && hipMalloc((void **)&bufs[g], len) == hipSuccess);
+            CHECK(hipMemcpy(bufs[g], g == ndev - 1 ? h_yes.data() : h_no.data(), len, hipMemcpyHostToDevice) == hipSuccess);
+            shards[g] = bufs[g];
+            begins[g] = (uint64_t)g * len;
+        }
+        CHECK(hipSetDevice(0) == hipSuccess);
+        for (int mode : {SS_COMBINE_RCCL, SS_COMBINE_HOST}) {
+            CHECK(ss_comm_set_combine(set, mode) == SS_OK);
+            for (int it = 0; it < 4; ++it) {
+                int found = -1;
+                uint64_t pos = 1;
+                CHECK(ss_search_sharded_all(s, shards.data(), lens.data(), set, &found) == SS_OK && found == 1);
+                CHECK(ss_find_sharded_all(s, shards.data(), lens.data(), begins.data(), set, &pos) == SS_OK &&
+                      pos == (uint64_t)(ndev - 1) * len + len - 7);
+                int cur = -1;
+                CHECK(hipGetDevice(&cur) == hipSuccess && cur == 0);
+            }
+        }
+        for (int g = 0; g < ndev; ++g) {
+            CHECK(hipSetDevice(g) == hipSuccess);
+            (void)hipFree(bufs[g]);
+        }
+        CHECK(hipSetDevice(0) == hipSuccess);
+        ss_comm_set_free(set);
+    }
+
+    ss_searcher_free(s);
+    (void)hipFree(d_no);
+    (void)hipFree(d_yes);
+    std::remove(path.c_str());
+    std::puts("host_stress_test ok");
+    return 0;
+}

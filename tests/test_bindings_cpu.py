@@ -1,0 +1,179 @@
+"""CPU-only checks of the bindings around the C ABI and of bench.py's launch contract.
+
+* the Rust `extern "C"` block (sliceslice-rs_amd/bindings/rust/hip.rs - source only, there is no rustc in this
+  image) is compared mechanically with include/sliceslice_hip.h: same names, same arity, same pointer /
+  integer widths per argument and for the return value;
+* the ctypes table of the Python mirror gets the same treatment;
+* `python bench.py --gpus N` never prints a line it cannot back with N ranks on N devices."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import sliceslice_rs_amd as ss
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _strip_c_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def _c_class(t):
+    """pointer / integer width class of a C type as spelled in the header."""
+    t = t.strip()
+    if "*" in t or "[" in t:
+        return "ptr"
+    t = re.sub(r"\bconst\b", "", t).strip()
+    return {"int": "i32", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "float": "f32", "void": "void"}[t]
+
+
+def header_prototypes():
+    text = _strip_c_comments(open(os.path.join(ROOT, "include", "sliceslice_hip.h")).read())
+    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#"))
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(ss_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        arglist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                arr = "[" in a
+                a = re.sub(r"\[.*?\]", "", a)
+                mm = re.match(r"(.*?)([A-Za-z_][A-Za-z0-9_]*)$", a.strip())      # type + parameter name
+                typ = mm.group(1).strip()
+                arglist.append("ptr" if arr else _c_class(typ))
+        protos[name] = (_c_class(ret), arglist)
+    return protos
+
+
+def _rust_class(t):
+    t = t.strip()
+    if t.startswith("*"):
+        return "ptr"
+    return {"c_int": "i32", "usize": "usize", "u64": "u64", "u32": "u32", "c_float": "f32"}[t]
+
+
+def rust_prototypes():
+    text = open(os.path.join(ROOT, "sliceslice-rs_amd", "bindings", "rust", "hip.rs")).read()
+    block = re.search(r'extern "C" \{(.*?)\n\}', text, flags=re.S).group(1)
+    block = re.sub(r"//[^\n]*", "", block)
+    protos = {}
+    for m in re.finditer(r"fn\s+(ss_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        name, args, ret = m.group(1), m.group(2).strip(), (m.group(3) or "").strip()
+        arglist = [_rust_class(a.split(":", 1)[1]) for a in args.split(",") if a.strip()] if args else []
+        protos[name] = ("void" if not ret else _rust_class(ret), arglist)
+    return protos
+
+
+def test_header_parser_sees_every_symbol():
+    protos = header_prototypes()
+    assert sorted(protos) == sorted(ss.searcher.ABI)                 # the same set tests/test_host_logic.py checks in the .so
+    assert protos["ss_searcher_new"] == ("i32", ["ptr", "usize", "ptr"])
+    assert protos["ss_find_sharded"] == ("i32", ["ptr", "ptr", "usize", "u64", "ptr", "ptr", "ptr"])
+    assert protos["ss_searcher_free"] == ("void", ["ptr"])
+    assert protos["ss_last_error"] == ("ptr", [])
+
+
+def test_rust_extern_block_matches_the_header():
+    c, r = header_prototypes(), rust_prototypes()
+    assert sorted(r) == sorted(c), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name in c:
+        assert r[name] == c[name], (name, r[name], c[name])
+    text = open(os.path.join(ROOT, "sliceslice-rs_amd", "bindings", "rust", "hip.rs")).read()
+    # constants the Rust side restates
+    hdr = open(os.path.join(ROOT, "include", "sliceslice_hip.h")).read()
+    for cname, cval in re.findall(r"^\s*(SS_(?:OK|ERR_[A-Z_]+))\s*=\s*(\d+)", hdr, flags=re.M):
+        assert re.search(r"pub const %s: c_int = %s;" % (cname, cval), text), cname
+    assert "pub const SS_UNIQUE_ID_BYTES: usize = 128;" in text and "#define SS_UNIQUE_ID_BYTES 128" in hdr
+    # `new` must not degrade to with_position(len - 1): the caller of `new` did not choose a position
+    new_body = text.split("pub fn new(needle: N) -> Self {", 1)[1].split("}", 1)[0]
+    assert "ss_searcher_new(" in new_body and "with_position" not in new_body
+    # the copy shown in INTEGRATION.md is this file's extern block, not an older one
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "bindings/rust/hip.rs" in integ and "ss_search_sharded_all" in integ
+
+
+def test_ctypes_table_matches_the_header():
+    c = header_prototypes()
+
+    def cls(t):
+        if t is None:
+            return "void"
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or isinstance(t, type(ctypes.POINTER(ctypes.c_int))):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_size_t: "usize", ctypes.c_uint64: "u64", ctypes.c_float: "f32"}[t]
+    for name, (res, args) in ss.searcher.ABI.items():
+        got = (cls(res), [cls(a) for a in args])
+        want = c[name]
+        # size_t and uint64_t are the same width on this ABI; the table may spell either
+        norm = lambda p: (p[0].replace("usize", "u64"), [a.replace("usize", "u64") for a in p[1]])   # noqa: E731
+        assert norm(got) == norm(want), (name, got, want)
+
+
+def _bench(args, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if not env_extra or k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300,
+                          env=env, cwd=ROOT)
+
+
+def test_bench_refuses_to_mislabel_a_run():
+    """No GPU here: `--gpus 2` must exit non-zero with NOTHING on stdout (the driver parses stdout), and say why.
+    The same for a launcher whose WORLD_SIZE disagrees with --gpus, and for N = 1 without a device."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible: the refusal branch is covered by tests/test_gpu_sharded.py")
+    out = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "--gpus 2 but only" in out.stderr and "refusing" in out.stderr
+    out = _bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "WORLD_SIZE=2 but --gpus 4" in out.stderr
+    if not torch.cuda.is_available():
+        out = _bench(["--steps", "1", "--warmup", "0"])
+        assert out.returncode != 0 and out.stdout.strip() == "" and "no CPU path" in out.stderr
+
+
+def test_filter_pair_choice_properties():
+    """ss_choose_filter_pair (pure host code): a pair inside the needle, at most 15 apart, the reference's own
+    pair (0, n-1) whenever nothing in the needle is rarer, rare bytes when there are some."""
+    import random
+    rng = random.Random(1)
+    for _ in range(2000):
+        n = rng.choice([2, 3, 5, 16, 17, 40, 200, 1500, 3000])
+        alpha = rng.choice([bytes(range(256)), b"etaoin shrdlu", b"ab", b"the quick brown fox jumps over the lazy dog.,;!"])
+        nd = bytes(rng.choice(alpha) for _ in range(n))
+        a, b = ss.choose_filter_pair(nd)
+        assert 0 <= a < b < n and b - a <= 15 or (n <= 16 and (a, b) == (0, n - 1)), (nd[:20], a, b)
+        assert b < 1024
+    assert ss.choose_filter_pair(b"") == (0, 0) and ss.choose_filter_pair(b"x") == (0, 0)
+    assert ss.choose_filter_pair(b"ab") == (0, 1)
+    assert ss.choose_filter_pair(bytes(range(200, 216))) == (0, 15)          # nothing to choose between: the reference's pair
+    assert ss.choose_filter_pair(b" the quick brown fox ") == (5, 19)        # 'q' and 'x' instead of ' ' and ' '
+    assert ss.choose_filter_pair(b"a" * 15 + b"b") == (0, 15)
+    assert ss.choose_filter_pair(b"ab" + b"a" * 14) == (1, 15)              # 'b' is in the pair wherever it sits
+    a, b = ss.choose_filter_pair(b"e" * 2000 + b"\x07\x08")                  # only the first 1024 bytes are looked at
+    assert b < 1024
+
+
+def test_bench_line_fields_of_the_committed_round2_capture():
+    """Shape of the round-2 bench line (committed under profiles/r02 once captured on the GPU box)."""
+    path = os.path.join(ROOT, "profiles", "r02", "bench64g.json")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("no round-2 capture committed yet")
+    d = json.loads(open(path).read())
+    assert d["n_gpus"] == 1 and d["config"]["ranks"] == 1 and d["config"]["filter_bytes"] == [0, 15]
+    assert d["roofline"]["traffic_source"].startswith("stored ratio")
+    assert set(d["configs"]) >= {"1", "3", "5", "latency_us"}
+    assert [r["needle_len"] for r in d["configs"]["3"]["rows"]] == [1, 2, 4, 8, 16, 32, 128]
+    c = d["cpu_baseline"]
+    assert c["cores"] == c["threads_used"] and c["host_physical_cores"] >= 1

@@ -1,0 +1,304 @@
+"""GPU parity of what round 2 added: the filter-pair choice of `new` (results must not depend on the pair -
+the reference's own claim for `position`, src/lib.rs:375-378), BASELINE.json configs 3 and 5 at their FULL
+shape, the batched position contract, slot exhaustion and the epoch wrap.  Bit-exact booleans / offsets.
+Reference citations are paths under /root/reference."""
+import ctypes
+import os
+import random
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import sliceslice_rs_amd as m
+    assert torch.cuda.is_available(), "these tests must run on the GPU box"
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def dev(b):
+    a = np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else np.asarray(b, dtype=np.uint8)
+    if a.size == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda")
+    return torch.from_numpy(a.copy()).cuda()
+
+
+def absent_needle(ss, n, seed=0x5EED0002):
+    nd = bytearray(ss.fill_random_host(n, seed).tobytes())
+    nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+    return bytes(nd)
+
+
+# ---- filter pair ------------------------------------------------------------------------------------------
+
+def test_every_filter_pair_gives_the_reference_answer_on_the_kats(ss, kat):
+    """src/lib.rs:375-378 runs every KAT for every `position`; here for every (first, second) pair."""
+    for row in kat["generic"]:
+        hay, needle = row["haystack"].encode(), row["needle"].encode()
+        dh = dev(hay)
+        s = ss.DynamicHipSearcher.new(needle)
+        assert s.position == (len(needle) - 1) % (1 << 64)
+        n = len(needle)
+        for a in range(n):
+            for b in range(a, n):
+                if n < 2 and (a, b) != (0, 0):
+                    continue
+                s.set_filter(a, b)
+                assert s.filter == (a, b)
+                assert s.search_in(dh) == row["expected"], (row, a, b)
+                assert s.search_in(hay) == row["expected"], (row, a, b)           # host path
+                p = s.find(dh)
+                want = hay.find(needle)
+                assert p == (None if want < 0 else want), (row, a, b)
+
+
+def test_filter_pair_bounds_are_checked(ss):
+    s = ss.DynamicHipSearcher.new(b"abcdef")
+    for a, b in ((1, 0), (0, 6), (6, 6), (5, 7)):
+        with pytest.raises(ss.PositionError):
+            s.set_filter(a, b)
+    s1 = ss.DynamicHipSearcher.new(b"a")
+    s1.set_filter(0, 0)
+    with pytest.raises(ss.PositionError):
+        s1.set_filter(0, 1)
+
+
+def test_new_picks_rare_bytes_and_with_position_keeps_the_reference_pair(ss):
+    s = ss.DynamicHipSearcher.new(b" the quick brown fox ")
+    assert s.position == 20 and s.filter == ss.choose_filter_pair(b" the quick brown fox ") == (5, 19)   # 'q', 'x'
+    for p in (0, 7, 20):
+        assert ss.DynamicHipSearcher.with_position(b" the quick brown fox ", p).filter == (0, p)
+    # a 2000-byte needle: the default position 1999 would need two load streams; `new` stays within 15 bytes
+    long_needle = (b"lorem ipsum dolor sit amet, " * 80)[:2000]
+    a, b = ss.DynamicHipSearcher.new(long_needle).filter
+    assert a < b <= a + 15
+    os.environ["SLICESLICE_AUTO_FILTER"] = "0"
+    try:
+        assert ss.DynamicHipSearcher.new(long_needle).filter == (0, 1999)
+    finally:
+        del os.environ["SLICESLICE_AUTO_FILTER"]
+
+
+def test_filter_pairs_on_text_and_random_haystacks_vs_oracle(ss, O, corpus):
+    """Random pairs - near, 16..1008 apart (cross-lane kernels), further (two streams), close to the needle's
+    end (no second-level bytes left) - on a text haystack and a random one, misaligned, against the oracle."""
+    rng = random.Random(2024)
+    text = corpus["i386"]
+    buf = torch.empty(len(text) + 64, dtype=torch.uint8, device="cuda")
+    rnd_host = np.asarray(ss.fill_random_host(3 << 20, 77))
+    rbuf = torch.empty(rnd_host.size + 64, dtype=torch.uint8, device="cuda")
+    for mis in (0, 3, 13):
+        tview = buf[mis:mis + len(text)]
+        tview.copy_(torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()))
+        rview = rbuf[mis:mis + rnd_host.size]
+        rview.copy_(torch.from_numpy(rnd_host))
+        cases = []
+        for n in (2, 3, 9, 16, 17, 40, 300, 1100, 2500):
+            at = rng.randrange(len(text) - n)
+            cases.append((tview, text, text[at:at + n]))                               # present in the text
+            bad = bytearray(text[at:at + n])
+            bad[rng.randrange(n)] ^= 0x15
+            cases.append((tview, text, bytes(bad)))                                    # (almost surely) absent
+            at = rng.randrange(rnd_host.size - n)
+            cases.append((rview, rnd_host.tobytes(), rnd_host[at:at + n].tobytes()))
+            cases.append((rview, rnd_host.tobytes(), absent_needle(ss, n)))
+        for view, host, needle in cases:
+            n = len(needle)
+            want = O.OracleSearcher(needle).search_in(np.frombuffer(host, dtype=np.uint8))
+            wantp = host.find(needle)
+            assert want == (wantp >= 0)
+            s = ss.DynamicHipSearcher.new(needle)
+            pairs = {s.filter, (0, n - 1), (n - 2, n - 1), (0, 1)}
+            for _ in range(6):
+                a = rng.randrange(n - 1)
+                pairs.add((a, rng.randrange(a + 1, min(n, a + 16))))                   # near
+                pairs.add((a, rng.randrange(a, n)))                                    # anywhere
+            for a, b in sorted(pairs):
+                s.set_filter(a, b)
+                assert s.search_in(view) == want, (n, mis, a, b)
+                assert s.find(view) == (None if wantp < 0 else wantp), (n, mis, a, b)
+
+
+def test_filter_stream_never_reads_outside_the_haystack(ss):
+    """hay + first is the start of the filter stream: with the haystack flush against BOTH ends of an allocation
+    no pair may fault or report the needle copies that sit just outside."""
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    size = 1 << 16
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(size)) == 0
+    try:
+        assert hip.hipMemset(p, 0x2E, ctypes.c_size_t(size)) == 0
+        needle = bytes([0x30 + k for k in range(40)])
+        s = ss.DynamicHipSearcher.new(needle)
+        for a, b in ((0, 39), (38, 39), (20, 35), (0, 1), (3, 3), (39, 39)):
+            s.set_filter(a, b)
+            for ln in (40, 41, 4097, size):
+                assert s.search_in((p.value + size - ln, ln)) is False, (a, b, ln)
+                assert s.search_in((p.value, ln)) is False, (a, b, ln)
+    finally:
+        hip.hipFree(p)
+
+
+# ---- BASELINE.json config 3 at full shape -------------------------------------------------------------------
+
+def test_config3_one_gib_needle_length_sweep_full_shape(ss):
+    """1 GiB synthetic haystack x needle lengths {1,2,4,8,32,128}: absent by construction -> False / None;
+    planted at 0, mid (straddling 2^29) and len-n -> True and find() returns the plant (or an earlier natural
+    occurrence, only possible for n <= 4 - checked against the planted bytes)."""
+    ln = 1 << 30
+    t = torch.empty(ln, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0x5EED0001)
+    for n in (1, 2, 4, 8, 32, 128):
+        nd = absent_needle(ss, n)
+        s = ss.DynamicHipSearcher.new(nd)
+        assert s.search_in(t) is False, n
+        assert s.find(t) is None, n
+        present = bytes(ss.fill_random_host(n, 0x5EED0003).tobytes())
+        assert 0xFF not in present
+        sp = ss.DynamicHipSearcher.new(present)
+        pn = dev(present)
+        naturally = sp.find(t)                             # n <= 4: a random needle occurs somewhere already
+        assert naturally is None or n <= 4, n
+        for at in (ln - n, (ln // 2) - n // 2, 0):
+            saved = t[at:at + n].clone()
+            t[at:at + n] = pn
+            assert sp.search_in(t) is True, (n, at)
+            got = sp.find(t)
+            assert got is not None and got <= at, (n, at, got)
+            if naturally is None:
+                assert got == at, (n, at, got)
+            else:
+                assert t[got:got + n].cpu().numpy().tobytes() == present
+            t[at:at + n] = saved
+        assert sp.find(t) == naturally, n
+    del t
+
+
+# ---- BASELINE.json config 5 at full shape -------------------------------------------------------------------
+
+def test_config5_batched_4096_x_1mib_full_shape_with_plants(ss):
+    """4096 problems x 1 MiB haystacks x 16-byte needles, ONE launch.  ~200 problems get their needle planted -
+    at 0, at len-16, and straddling the edges between the slices a problem is cut into - the flags must equal
+    the plant list exactly."""
+    count, each = 4096, 1 << 20
+    blob = torch.empty(count * each, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(blob, 0x5EED0001)
+    nd = bytearray(ss.fill_random_host(16 * count, 0x5EED0077).tobytes())       # 0xFF-free needles
+    # unplanted problems must be absent: give them one 0xFF byte; planted ones stay 0xFF-free
+    rng = random.Random(5)
+    planted = sorted(rng.sample(range(count), 200))
+    plant_set = set(planted)
+    for i in range(count):
+        if i not in plant_set:
+            nd[16 * i + 8] = 0xFF
+    nblob = dev(bytes(nd))
+    # a problem of 1 MiB = 64 tiles of 16 KiB; the launch cuts it into 1..8 contiguous slices: plant at every
+    # multiple of 1/8 of the haystack (minus 1, 8, 15 bytes), at 0 and at len-16
+    spots = [0, each - 16] + [k * (each // 8) - d for k in range(1, 8) for d in (1, 8, 15)] + [k * (each // 8) for k in range(1, 8)]
+    where = {}
+    for j, i in enumerate(planted):
+        at = spots[j % len(spots)]
+        where[i] = at
+        blob[i * each + at:i * each + at + 16] = nblob[16 * i:16 * i + 16]
+    hay_off = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
+    nd_off = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
+    found = ss.search_batched(blob, hay_off, nblob, nd_off).cpu().numpy()
+    assert sorted(np.nonzero(found)[0].tolist()) == planted
+    assert set(np.unique(found).tolist()) <= {0, 1}
+    # spot-check with the single-problem entry point (search + find) on a few planted and unplanted problems
+    for i in planted[:6] + [k for k in range(count) if k not in plant_set][:3]:
+        s = ss.DynamicHipSearcher.new(bytes(nd[16 * i:16 * i + 16]))
+        view = blob[i * each:(i + 1) * each]
+        assert s.search_in(view) is (i in plant_set)
+        assert s.find(view) == where.get(i)
+    del blob
+
+
+def test_batched_position_contract(ss):
+    """position[i] follows the with_position rules (x86.rs:300, 473); a violation is reported as
+    SS_BATCH_BAD_POSITION for that problem by both many-problem kernels instead of being clamped."""
+    hays = [b"hello world", b"hello world", b"x", b"", b"hello world", b"ab"]
+    needles = [b"world", b"world", b"x", b"", b"o", b"abc"]
+    pos = [4, 5, 1, 99, 0, 3]          # ok, == n (bad), one-byte needle with position 1 (bad), N0 any, ok, bad even though len < n
+    want = [1, -1, -1, 1, 1, -1]
+    hay_off = np.zeros(len(hays) + 1, dtype=np.int64)
+    hay_off[1:] = np.cumsum([len(h) for h in hays])
+    nd_off = np.zeros(len(needles) + 1, dtype=np.int64)
+    nd_off[1:] = np.cumsum([len(x) for x in needles])
+    blob, nblob = dev(b"".join(hays) + b"\0"), dev(b"".join(needles) + b"\0")
+    p = torch.tensor(pos, dtype=torch.int64, device="cuda")
+    for pairs in (False, True):
+        got = ss.search_batched(blob, torch.from_numpy(hay_off).cuda(), nblob, torch.from_numpy(nd_off).cuda(), position=p,
+                                pairs=pairs).cpu().tolist()
+        assert got == want, (pairs, got)
+
+
+# ---- host library: slot exhaustion, epoch wrap ---------------------------------------------------------------
+
+def test_128_concurrent_calls_on_one_handle(ss):
+    """More callers than flag slots (64) on ONE handle and device: the surplus waits on a condition variable;
+    every call gets its own answer (search and find, device and host haystacks mixed)."""
+    ln = 2 << 20
+    yes = torch.zeros(ln, dtype=torch.uint8, device="cuda")
+    no = torch.zeros(ln, dtype=torch.uint8, device="cuda")
+    needle = bytes([9, 8, 7, 6, 5, 4, 3])
+    yes[ln - 7:] = dev(needle)
+    host_yes = yes.cpu().numpy()
+    host_no = no.cpu().numpy()
+    s = ss.DynamicHipSearcher.new(needle)
+    streams = [torch.cuda.Stream() for _ in range(128)]
+    errors = []
+    barrier = threading.Barrier(128)
+
+    def worker(k):
+        try:
+            barrier.wait()
+            for it in range(12):
+                kind = (k + it) % 4
+                st = streams[k].cuda_stream
+                if kind == 0:
+                    assert s.search_in(yes, stream=st) is True
+                elif kind == 1:
+                    assert s.search_in(no, stream=st) is False
+                elif kind == 2:
+                    assert s.find(yes, stream=st) == ln - 7
+                    assert s.find(no, stream=st) is None
+                else:
+                    assert s.search_in(host_yes if it % 2 else host_no) is bool(it % 2)
+        except Exception as e:                      # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(128)]
+    [t.start() for t in threads]
+    [t.join(timeout=300) for t in threads]
+    assert not any(t.is_alive() for t in threads)
+    assert not errors, errors[:3]
+
+
+def test_epoch_wrap_of_the_flag_slots(ss):
+    """"found" is a per-call epoch, never cleared; at 2^31 calls the counters wrap and both copies of the flag
+    are reset.  The test hook moves the counters to the edge; answers must stay right across it."""
+    ln = 1 << 20
+    yes = torch.zeros(ln, dtype=torch.uint8, device="cuda")
+    yes[1000:1003] = torch.tensor([7, 7, 9], dtype=torch.uint8)
+    no = torch.zeros(ln, dtype=torch.uint8, device="cuda")
+    s = ss.DynamicHipSearcher.new(bytes([7, 7, 9]))
+    assert s.search_in(yes) is True and s.search_in(no) is False
+    assert ss.lib().ss_debug_set_epochs(s._h, 2**31 - 3) == 0
+    for it in range(8):                               # slot 0 is reused by every sequential call: crosses the wrap
+        assert s.search_in(yes) is True, it
+        assert s.search_in(no) is False, it
+        assert s.search_in(yes.cpu().numpy()) is True, it

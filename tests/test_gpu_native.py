@@ -32,3 +32,62 @@ def test_c_grep_example(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("true"), out.stdout + out.stderr
     out = subprocess.run([exe, "no such phrase in the manual", data], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("false"), out.stdout + out.stderr
+
+
+def _build_native(src, exe, so, extra=()):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", os.path.dirname(so), "-l" + os.path.basename(so)[3:-3], "-Wl,-rpath," + os.path.dirname(so)] + list(extra))
+
+
+def test_host_library_stress(tmp_path):
+    """128 threads on one handle (64 flag slots), the epoch wrap, staging-lease contention, communicators."""
+    import sliceslice_rs_amd as ss
+    so = ss.build()
+    exe = str(tmp_path / "host_stress_test")
+    _build_native(os.path.join(ROOT, "tests", "native", "host_stress_test.cpp"), exe, so)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "host_stress_test ok" in out.stdout
+
+
+def test_host_library_stress_under_asan_ubsan(tmp_path):
+    """The same stress against the ASan + UBSan build of the library's host code (device code untouched) - the
+    reference's guard on its unsafe code is its ASAN CI job (.github/workflows/check.yml:42-58).  Leak checking is
+    off (the HIP runtime keeps process-lifetime allocations); every other report is fatal."""
+    import sys
+    import sliceslice_rs_amd as ss
+    b = sys.modules["sliceslice_rs_amd._build"]
+    so = b.build_sanitized()
+    rt = b.asan_runtime()
+    assert rt, "clang ASan runtime not found"
+    exe = str(tmp_path / "host_stress_test_asan")
+    _build_native(os.path.join(ROOT, "tests", "native", "host_stress_test.cpp"), exe, so,
+                  ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-g", "-Wl,-rpath," + os.path.dirname(rt)])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:protect_shadow_gap=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([exe, "96"], capture_output=True, text=True, timeout=1800, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
+    assert "host_stress_test ok" in out.stdout
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-6000:]
+
+
+def test_native_bench_modes():
+    """tools/native_bench (what bench.py embeds as configs.1 and configs.latency_us): C ABI + HIP runtime only."""
+    import json
+    import sys
+    import sliceslice_rs_amd as ss
+    exe = sys.modules["sliceslice_rs_amd._build"].build_native_bench()
+    gd = os.path.join(ROOT, "tests", "golden", "data")
+    out = subprocess.run([exe, "config1", os.path.join(gd, "i386.txt"), os.path.join(gd, "words.txt"), "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["needles"] == d["hits"] == d["batched_hits"] == 4585          # tests/i386.rs:61-70
+    out = subprocess.run([exe, "latency", "200"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert [r["haystack_bytes"] for r in d["rows"]] == [1 << 10, 64 << 10, 1 << 20, 16 << 20]
+    assert all(r["search_device_absent"] > 0 for r in d["rows"])
+    out = subprocess.run([exe, "headline", "1", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert json.loads(out.stdout.strip().splitlines()[-1])["found"] == 0

@@ -31,3 +31,108 @@ def test_sharded_kernels_with_several_ranks_on_one_gpu(world):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "sharded gpu worker ok" in out.stdout
+
+
+def test_single_process_multi_gpu_entry():
+    """ss_comm_init_all / ss_search_sharded_all / ss_find_sharded_all: every visible GPU (1 on the test box, 8 on a
+    node) driven from THIS process, ncclCommInitAll + one grouped all-reduce per search.  Matches are planted at
+    0, at the very end and across every shard edge; both combine modes (RCCL all-reduce, host OR) must agree."""
+    import numpy as np
+    import torch
+    import sliceslice_rs_amd as ss
+    G = max(1, min(torch.cuda.device_count(), 8))
+    needle = bytes(range(200, 216))
+    total = (48 << 20) + 12345
+    node = ss.NodeSearcher(needle, devices=list(range(G)))
+    ranges = [node.shard_range(total, g) for g in range(G)]
+    S = -(-total // G)
+    shards = []
+    for g, (b, e) in enumerate(ranges):
+        assert b == g * S and e == min(total, b + S + 15)
+        t = torch.empty(e - b, dtype=torch.uint8, device="cuda:%d" % g)
+        with torch.cuda.device(g):
+            ss.fill_random_device(t, 0x5EED0001, b)
+            torch.cuda.synchronize()
+        shards.append(t)
+    begins = [b for b, _ in ranges]
+    pn = np.frombuffer(needle, dtype=np.uint8)
+    cur = torch.cuda.current_device()
+    for mode in (ss.NodeSearcher.COMBINE_RCCL, ss.NodeSearcher.COMBINE_HOST):
+        node.set_combine(mode)
+        assert node.search_in(shards) is False and node.find(shards, begins) is None
+        spots = [0, total - 16, total // 2] + [r * S - k for r in range(1, G) for k in (1, 8, 15)] + [r * S for r in range(1, G)]
+        for at in spots:
+            saved = []
+            for g, (b, e) in enumerate(ranges):
+                lo, hi = max(at, b), min(at + 16, e)
+                if lo < hi:                                  # shard g holds (part of) the planted bytes
+                    saved.append((g, lo - b, hi - b, shards[g][lo - b:hi - b].clone()))
+                    shards[g][lo - b:hi - b] = torch.from_numpy(pn[lo - at:hi - at].copy()).to(shards[g].device)
+            for g in range(G):
+                torch.cuda.synchronize(g)
+            assert node.search_in(shards) is True, (mode, at)
+            assert node.find(shards, begins) == at, (mode, at)
+            for g, lo, hi, old in saved:
+                shards[g][lo:hi] = old
+            for g in range(G):
+                torch.cuda.synchronize(g)
+            assert node.search_in(shards) is False, (mode, at)
+        assert torch.cuda.current_device() == cur            # the caller's current device is restored
+    # the empty needle, and shards shorter than the needle
+    empty = ss.NodeSearcher(b"", devices=list(range(G)))
+    assert empty.search_in(shards) is True and empty.find(shards, begins) == 0
+    tiny = [s[:5] for s in shards]
+    assert node.search_in(tiny) is False and node.find(tiny, begins) is None
+    # epoch wrap of the set's flags
+    assert ss.lib().ss_debug_set_comm_epoch(None, node._set, 2**31 - 3) == 0
+    for mode in (ss.NodeSearcher.COMBINE_RCCL, ss.NodeSearcher.COMBINE_HOST):
+        node.set_combine(mode)
+        for it in range(4):
+            assert node.search_in(shards) is False
+            shards[-1][-16:] = torch.from_numpy(pn.copy()).to(shards[-1].device)
+            torch.cuda.synchronize(G - 1)
+            assert node.search_in(shards) is True
+            with torch.cuda.device(G - 1):
+                ss.fill_random_device(shards[-1], 0x5EED0001, begins[-1])
+                torch.cuda.synchronize()
+    node.close()
+    empty.close()
+
+
+def _run_bench(args, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` must never print an n_gpus-1 line under an N-GPU label."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = _run_bench(["--gpus", str(n), "--steps", "2", "--warmup", "1"], {})
+    assert out.returncode != 0
+    assert out.stdout.strip() == "", out.stdout
+    assert "only %d HIP device(s) visible" % (n - 1) in out.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts 2 ranks itself.  On a one-GPU box the two
+    ranks share cuda:0 and the flag travels over gloo (SS_BENCH_SHARE_GPU / SS_BENCH_BACKEND); on a multi-GPU
+    box it is the real thing: native RCCL, one rank per device."""
+    import json
+    import torch
+    multi = torch.cuda.device_count() >= 2
+    extra = {} if multi else {"SS_BENCH_SHARE_GPU": "1", "SS_BENCH_BACKEND": "gloo"}
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--haystack-gib", "0.5", "--no-ceiling"], extra)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["launcher"] == "self"
+    assert d["config"]["ranks_share_one_gpu"] is (not multi)
+    if multi:
+        assert d["config"]["rccl_ranks"] == 2 and d["config"]["transport"] == "rccl"
+    assert d["config"]["haystack_bytes"] == 1 << 29 and d["config"]["shard_bytes"] == (1 << 28) + 15
+    assert d["value"] > 0 and "cpu_baseline" not in d

@@ -158,11 +158,19 @@ def main():
         text = torch.from_numpy(i386.copy()).cuda().repeat(reps_t)
         for nd, label in ((b"privilege level zero!", "absent phrase, last byte '!'"),
                           (b" the quick brown fox ", "absent, first/last byte ' ' (27% of the text)"),
-                          (b"e" + b"\x00" * 14 + b"e", "absent, first/last byte 'e'")):
+                          (b"e" + b"\x00" * 14 + b"e", "absent, first/last byte 'e'"),
+                          (b"segment descriptor table entries are", "absent, lower-case letters and spaces only"),
+                          (b"the interrupt", "absent? common words only (13 bytes)")):
             s = ss.DynamicHipSearcher.new(nd)
             res, ms = timed(s, text, args.reps)
-            emit(config="text", needle=nd.decode("latin1"), label=label, haystack_bytes=text.numel(), found=res,
+            emit(config="text", needle=nd.decode("latin1"), label=label + "; new() - filter bytes chosen by the library",
+                 filter_bytes=list(s.filter), filter_chars=[chr(nd[k]) for k in s.filter], haystack_bytes=text.numel(), found=res,
                  kernel_ms=round(ms, 3), gbps=round(text.numel() / ms / 1e6, 1))
+            s = ss.DynamicHipSearcher.with_position(nd, len(nd) - 1)
+            res, ms = timed(s, text, args.reps)
+            emit(config="text", needle=nd.decode("latin1"), label=label + "; with_position(n-1): the reference's pair (0, n-1)",
+                 filter_bytes=list(s.filter), haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
+                 gbps=round(text.numel() / ms / 1e6, 1))
             # row f3: the same needle with the position chosen from a byte histogram of (a sample of) the haystack
             hist = ss.byte_histogram(text, sample_bytes=64 << 20)
             pos = ss.choose_position(nd, hist)
@@ -173,14 +181,23 @@ def main():
                  gbps=round(text.numel() / ms / 1e6, 1))
         del text
         a = torch.full((n_bytes,), 0x61, dtype=torch.uint8, device="cuda")
-        for nd, pos, label in ((b"a" * 15 + b"b", None, "adversarial: every offset passes both filters"),
+        for nd, pos, label in ((b"a" * 15 + b"b", None, "adversarial: every offset passes the first-byte filter"),
+                               (b"a" * 15 + b"b", 15, "same needle, with_position(15)"),
                                (b"a" * 15 + b"b", 0, "same needle, position 0"),
                                (b"ab" + b"a" * 14, None, "first byte common, last byte common, fails at byte 1")):
             s = ss.DynamicHipSearcher(nd, pos)
             res, ms = timed(s, a, args.reps)
-            emit(config="adversarial", label=label, haystack_bytes=n_bytes, found=res, kernel_ms=round(ms, 3),
+            emit(config="adversarial", label=label, filter_bytes=list(s.filter), haystack_bytes=n_bytes, found=res, kernel_ms=round(ms, 3),
                  gbps=round(n_bytes / ms / 1e6, 1))
         del a
+        # long needles on random bytes: `new` keeps the filter pair within 15 bytes (single-stream kernel); the
+        # reference's pair (0, n-1) needs the cross-lane kernel (n <= 1008) or a second load stream (beyond)
+        for n in (128, 1000, 2000):
+            nd = absent(n)
+            for how, s in (("new()", ss.DynamicHipSearcher.new(nd)), ("with_position(n-1)", ss.DynamicHipSearcher.with_position(nd, n - 1))):
+                res, ms = timed(s, hay, args.reps)
+                emit(config="long-needle", needle_len=n, how=how, filter_bytes=list(s.filter), haystack_bytes=n_bytes, found=res,
+                     kernel_ms=round(ms, 4), gbps=round(n_bytes / ms / 1e6, 1))
 
     if "1" not in skip:
         gd = os.path.join(ROOT, "tests", "golden", "data")

@@ -1,13 +1,22 @@
-// native_bench.cpp - the headline measurement with nothing but the C ABI and the HIP runtime (no Python,
-// no torch): a synthetic haystack generated on the device, a 16-byte absent needle, K timed search_in calls.
-//   hipcc -O2 -std=c++17 -I include tools/native_bench.cpp -o /tmp/native_bench \
-//         -L sliceslice-rs_amd/csrc -lsliceslice_hip -Wl,-rpath,$PWD/sliceslice-rs_amd/csrc
-//   /tmp/native_bench [GiB=64] [steps=20]
+// native_bench.cpp - measurements with nothing but the C ABI and the HIP runtime in the loop (no Python, no
+// torch).  Built by sliceslice-rs_amd/_build.py:build_native_bench() into tools/native_bench; bench.py runs the
+// `latency` and `config1` modes and embeds their JSON in its line.
+//
+//   native_bench headline [GiB=64] [steps=20]     the headline measurement (synthetic haystack, 16-byte absent needle)
+//   native_bench latency  [calls=2000]            per-call microseconds of ss_search_device / ss_find_device /
+//                                                 ss_search_host on 1 KiB, 64 KiB, 1 MiB, 16 MiB haystacks
+//   native_bench config1  <i386.txt> <words.txt> [iters=5]
+//        BASELINE.json configs[0] on the GPU: one ss_search_device call per needle over the resident text - the
+//        literal drop-in shape of bench/benches/i386.rs:246-256 - next to ONE ss_search_batched launch.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
 #include <vector>
 
 #include "sliceslice_hip.h"
@@ -19,17 +28,23 @@
             return 1;                                                          \
         }                                                                      \
     } while (0)
+#define HK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e_ = (x);                                                   \
+        if (e_ != hipSuccess) {                                                \
+            std::fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e_)); \
+            return 1;                                                          \
+        }                                                                      \
+    } while (0)
 
-int main(int argc, char **argv)
+using clk = std::chrono::steady_clock;
+static double seconds_since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+static int headline(double gib, int steps)
 {
-    const double gib = argc > 1 ? std::atof(argv[1]) : 64.0;
-    const int steps = argc > 2 ? std::atoi(argv[2]) : 20;
     const size_t len = (size_t)(gib * (double)(1ull << 30));
     void *d_hay = nullptr;
-    if (hipMalloc(&d_hay, len) != hipSuccess) {
-        std::fprintf(stderr, "hipMalloc(%zu) failed\n", len);
-        return 1;
-    }
+    HK(hipMalloc(&d_hay, len));
     CK(ss_fill_random_device(d_hay, 0, len, 0x5EED0001ull, nullptr));
     uint8_t needle[16];
     CK(ss_fill_random_host(needle, 0, 16, 0x5EED0002ull));
@@ -40,26 +55,207 @@ int main(int argc, char **argv)
     int found = 1;
     for (int w = 0; w < 5; ++w) CK(ss_search_device(s, d_hay, len, nullptr, &found));
     std::vector<float> kms;
-    (void)hipDeviceSynchronize();
-    const auto t0 = std::chrono::steady_clock::now();
+    HK(hipDeviceSynchronize());
+    const auto t0 = clk::now();
     for (int k = 0; k < steps; ++k) {
         CK(ss_search_device(s, d_hay, len, nullptr, &found));
         float ms = 0;
         CK(ss_searcher_last_kernel_ms(s, &ms));
         kms.push_back(ms);
     }
-    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double wall = seconds_since(t0);
     double ksum = 0;
     for (float m : kms) ksum += m;
     char name[256];
     int cus = 0;
     size_t mem = 0;
     CK(ss_device_info(name, sizeof name, &cus, &mem));
-    std::printf("{\"device\": \"%s\", \"haystack_bytes\": %zu, \"found\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
-                "\"value_gbps\": %.1f, \"kernel_ms_avg\": %.4f, \"kernel_gbps\": %.1f, \"frac_of_8tbps\": %.4f}\n",
+    std::printf("{\"mode\": \"headline\", \"device\": \"%s\", \"haystack_bytes\": %zu, \"found\": %d, \"steps\": %d, "
+                "\"ms_per_step\": %.4f, \"value_gbps\": %.1f, \"kernel_ms_avg\": %.4f, \"kernel_gbps\": %.1f, "
+                "\"frac_of_8tbps\": %.4f}\n",
                 name, len, found, steps, wall / steps * 1e3, (double)len * steps / wall / 1e9, ksum / steps,
                 (double)len / (ksum / steps) / 1e6, (double)len / (ksum / steps) / 1e6 / 8000.0);
     ss_searcher_free(s);
     (void)hipFree(d_hay);
     return found != 0;
+}
+
+// median of per-call wall times, microseconds
+template <class F>
+static double median_us(int calls, F &&call)
+{
+    std::vector<double> us;
+    us.reserve(calls);
+    for (int k = 0; k < calls; ++k) {
+        const auto t0 = clk::now();
+        call();
+        us.push_back(seconds_since(t0) * 1e6);
+    }
+    std::nth_element(us.begin(), us.begin() + us.size() / 2, us.end());
+    return us[us.size() / 2];
+}
+
+__global__ void null_kernel(int *p)
+{
+    if (p && threadIdx.x == 9999) *p = 1;
+}
+
+static int latency(int calls)
+{
+    const size_t sizes[] = {1u << 10, 64u << 10, 1u << 20, 16u << 20};
+    const size_t cap = 16u << 20;
+    void *d_hay = nullptr;
+    HK(hipMalloc(&d_hay, cap));
+    CK(ss_fill_random_device(d_hay, 0, cap, 0x5EED0001ull, nullptr));
+    std::vector<uint8_t> h_hay(cap);
+    CK(ss_fill_random_host(h_hay.data(), 0, cap, 0x5EED0001ull));
+    uint8_t needle[16];
+    CK(ss_fill_random_host(needle, 0, 16, 0x5EED0002ull));
+    needle[8] = 0xFF;
+    ss_searcher *s = nullptr;
+    CK(ss_searcher_new(needle, 16, &s));
+    // a needle that IS there (the first 16 bytes of the haystack): the early-exit / found path
+    ss_searcher *sp = nullptr;
+    CK(ss_searcher_new(h_hay.data(), 16, &sp));
+    hipStream_t st = nullptr;
+    HK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int found = 0, rc = 0;
+    uint64_t pos = 0;
+    // the floor on this stack: an empty kernel + hipStreamSynchronize on the same stream
+    for (int w = 0; w < 200; ++w) { null_kernel<<<1, 64, 0, st>>>(nullptr); (void)hipStreamSynchronize(st); }
+    const double floor_us = median_us(calls, [&] { null_kernel<<<1, 64, 0, st>>>(nullptr); (void)hipStreamSynchronize(st); });
+    const double launch_only_us = median_us(calls, [&] { null_kernel<<<1, 64, 0, st>>>(nullptr); });
+    HK(hipStreamSynchronize(st));
+    std::printf("{\"mode\": \"latency\", \"calls\": %d, \"needle_len\": 16, \"unit\": \"us per call (median)\", "
+                "\"empty_kernel_plus_stream_sync\": %.2f, \"empty_kernel_launch_only\": %.2f, \"rows\": [", calls, floor_us, launch_only_us);
+    bool first = true;
+    for (size_t len : sizes) {
+        for (int w = 0; w < 200; ++w) rc |= ss_search_device(s, d_hay, len, st, &found);
+        const double dev_absent = median_us(calls, [&] { rc |= ss_search_device(s, d_hay, len, st, &found); });
+        const int f0 = found;
+        const double dev_present = median_us(calls, [&] { rc |= ss_search_device(sp, d_hay, len, st, &found); });
+        const int f1 = found;
+        const double find_absent = median_us(calls, [&] { rc |= ss_find_device(s, d_hay, len, st, &pos); });
+        const uint64_t p0 = pos;
+        const double find_present = median_us(calls, [&] { rc |= ss_find_device(sp, d_hay, len, st, &pos); });
+        const uint64_t p1 = pos;
+        for (int w = 0; w < 50; ++w) rc |= ss_search_host(s, h_hay.data(), len, &found);
+        const double host_absent = median_us(std::max(200, calls / 4), [&] { rc |= ss_search_host(s, h_hay.data(), len, &found); });
+        if (rc != 0 || f0 != 0 || f1 != 1 || p0 != SS_NPOS || p1 != 0) {
+            std::fprintf(stderr, "latency: wrong answer (rc %d, found %d/%d, pos %llu/%llu): %s\n", rc, f0, f1,
+                         (unsigned long long)p0, (unsigned long long)p1, ss_last_error());
+            return 1;
+        }
+        std::printf("%s{\"haystack_bytes\": %zu, \"search_device_absent\": %.2f, \"search_device_present_at_0\": %.2f, "
+                    "\"find_device_absent\": %.2f, \"find_device_present_at_0\": %.2f, \"search_host_absent\": %.2f}",
+                    first ? "" : ", ", len, dev_absent, dev_present, find_absent, find_present, host_absent);
+        first = false;
+    }
+    std::printf("]}\n");
+    ss_searcher_free(s);
+    ss_searcher_free(sp);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(d_hay);
+    return 0;
+}
+
+static bool read_file(const char *path, std::vector<uint8_t> *out)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return true;
+}
+
+static int config1(const char *hay_path, const char *words_path, int iters)
+{
+    std::vector<uint8_t> hay, wordsblob;
+    if (!read_file(hay_path, &hay) || !read_file(words_path, &wordsblob)) {
+        std::fprintf(stderr, "cannot read %s / %s\n", hay_path, words_path);
+        return 1;
+    }
+    std::vector<std::pair<size_t, size_t>> words;       // (begin, end) of every non-empty line
+    for (size_t b = 0, i = 0; i <= wordsblob.size(); ++i)
+        if (i == wordsblob.size() || wordsblob[i] == '\n') {
+            if (i > b) words.emplace_back(b, i);
+            b = i + 1;
+        }
+    void *d_hay = nullptr;
+    HK(hipMalloc(&d_hay, hay.size()));
+    HK(hipMemcpy(d_hay, hay.data(), hay.size(), hipMemcpyHostToDevice));
+    std::vector<ss_searcher *> searchers(words.size());
+    for (size_t w = 0; w < words.size(); ++w)           // searchers are prebuilt, as in bench/benches/i386.rs:247-250
+        CK(ss_searcher_new(wordsblob.data() + words[w].first, words[w].second - words[w].first, &searchers[w]));
+    hipStream_t st = nullptr;
+    HK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    size_t hits = 0;
+    int found = 0;
+    for (ss_searcher *s : searchers) {                  // warm-up pass
+        CK(ss_search_device(s, d_hay, hay.size(), st, &found));
+        hits += found != 0;
+    }
+    const auto t0 = clk::now();
+    for (int it = 0; it < iters; ++it)
+        for (ss_searcher *s : searchers) CK(ss_search_device(s, d_hay, hay.size(), st, &found));
+    const double per_call_ms = seconds_since(t0) / iters * 1e3;
+
+    // the same loop as ONE launch: every needle range against the one haystack range
+    const size_t W = words.size();
+    std::vector<uint64_t> hb(W, 0), he(W, hay.size()), nb(W), ne(W);
+    for (size_t w = 0; w < W; ++w) { nb[w] = words[w].first; ne[w] = words[w].second; }
+    void *d_words = nullptr;
+    uint64_t *d_rng = nullptr;
+    int *d_found = nullptr;
+    HK(hipMalloc(&d_words, wordsblob.size()));
+    HK(hipMemcpy(d_words, wordsblob.data(), wordsblob.size(), hipMemcpyHostToDevice));
+    HK(hipMalloc((void **)&d_rng, 4 * W * sizeof(uint64_t)));
+    HK(hipMemcpy(d_rng, hb.data(), W * 8, hipMemcpyHostToDevice));
+    HK(hipMemcpy(d_rng + W, he.data(), W * 8, hipMemcpyHostToDevice));
+    HK(hipMemcpy(d_rng + 2 * W, nb.data(), W * 8, hipMemcpyHostToDevice));
+    HK(hipMemcpy(d_rng + 3 * W, ne.data(), W * 8, hipMemcpyHostToDevice));
+    HK(hipMalloc((void **)&d_found, W * sizeof(int)));
+    std::vector<int> flags(W);
+    auto batched = [&]() -> int {
+        CK(ss_search_batched(d_hay, d_rng, d_rng + W, d_words, d_rng + 2 * W, d_rng + 3 * W, nullptr, W, st, d_found));
+        HK(hipMemcpyAsync(flags.data(), d_found, W * sizeof(int), hipMemcpyDeviceToHost, st));
+        HK(hipStreamSynchronize(st));
+        return 0;
+    };
+    for (int w = 0; w < 3; ++w)
+        if (batched()) return 1;
+    const auto t1 = clk::now();
+    for (int it = 0; it < iters * 4; ++it)
+        if (batched()) return 1;
+    const double batched_ms = seconds_since(t1) / (iters * 4) * 1e3;
+    size_t bhits = 0;
+    for (int f : flags) bhits += f == 1;
+    std::printf("{\"mode\": \"config1\", \"haystack_bytes\": %zu, \"needles\": %zu, \"hits\": %zu, \"batched_hits\": %zu, "
+                "\"per_call_ms_per_iteration\": %.3f, \"per_call_us_per_search\": %.3f, "
+                "\"batched_ms_per_iteration\": %.4f, \"reference_published_ms\": 35.181, "
+                "\"note\": \"per-call = one ss_search_device (launch + stream wait + flag) per needle, natively; batched = one "
+                "ss_search_batched launch + flag read-back for all needles\"}\n",
+                hay.size(), W, hits, bhits, per_call_ms, per_call_ms * 1e3 / (double)W, batched_ms);
+    for (ss_searcher *s : searchers) ss_searcher_free(s);
+    (void)hipFree(d_found);
+    (void)hipFree(d_rng);
+    (void)hipFree(d_words);
+    (void)hipFree(d_hay);
+    (void)hipStreamDestroy(st);
+    return (hits == W && bhits == W) ? 0 : 1;           // every word of words.txt occurs in i386.txt (tests/i386.rs:61-70)
+}
+
+int main(int argc, char **argv)
+{
+    const std::string mode = argc > 1 ? argv[1] : "headline";
+    if (mode == "latency") return latency(argc > 2 ? std::atoi(argv[2]) : 2000);
+    if (mode == "config1") {
+        if (argc < 4) {
+            std::fprintf(stderr, "usage: native_bench config1 <i386.txt> <words.txt> [iters]\n");
+            return 2;
+        }
+        return config1(argv[2], argv[3], argc > 4 ? std::atoi(argv[4]) : 5);
+    }
+    if (mode == "headline") return headline(argc > 2 ? std::atof(argv[2]) : 64.0, argc > 3 ? std::atoi(argv[3]) : 20);
+    // backwards compatible: native_bench <GiB> <steps>
+    return headline(std::atof(argv[1]), argc > 2 ? std::atoi(argv[2]) : 20);
 }
