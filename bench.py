@@ -250,7 +250,7 @@ def other_configs(ss, shard, reps=10):
             res, ms = median_kernel_ms(s, hay, reps)
             assert res is False
             rows.append({"needle_len": n, "kernel_ms": round(ms, 4), "gbps": round(gib / ms / 1e6, 1),
-                         "frac": round(gib / ms / 1e6 / HBM_PEAK_GBPS, 4), "filter_bytes": list(s.filter)})
+                         "frac": round(gib / ms / 1e6 / HBM_PEAK_GBPS, 4), "filter_bytes": list(s.filter3)})
         out["3"] = {"workload": "1 GiB synthetic haystack (the first GiB of the headline haystack), absent needles of "
                                 "{1,2,4,8,16,32,128} bytes, ss_search_device", "rows": rows}
     count, each = 4096, 1 << 20
@@ -468,7 +468,7 @@ def main():
                                   "x this run's bytes per launch" % pj.get("source", "?"))
             except Exception:
                 traffic = traffic_source = None
-        fa, fb = inner.filter
+        fa, fb, fc = inner.filter3
         out = {
             "metric": "haystack GB/s scanned (and % HBM roofline), 16-byte needle, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -476,10 +476,10 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {
                 "workload": "%.4g GiB synthetic random-byte haystack (0xFF-free), %d-byte absent needle, `new` (API position %d; "
-                            "device filter bytes %d and %d); range-sharded over %d GPU(s) with %d B overlap, one "
+                            "device filter bytes %d, %d and %d); range-sharded over %d GPU(s) with %d B overlap, one "
                             "all-reduce(MAX) of the found flag"
-                            % (total / (1 << 30), n, n - 1, fa, fb, world, n - 1),
-                "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n, "filter_bytes": [fa, fb],
+                            % (total / (1 << 30), n, n - 1, fa, fb, fc, world, n - 1),
+                "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n, "filter_bytes": [fa, fb, fc],
                 "ranks": dist.get_world_size() if dist is not None else 1, "rccl_ranks": rccl_ranks,
                 "transport": (transport if backend == "nccl" or transport == "rccl" else transport + " over " + backend) if dist is not None else "none",
                 "launcher": os.environ.get("SS_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),

@@ -72,19 +72,28 @@ void ss_searcher_free(ss_searcher *s);
 size_t ss_searcher_needle_len(const ss_searcher *s);
 size_t ss_searcher_position(const ss_searcher *s);
 
-/* The two needle bytes the device filter tests, needle[first] and needle[second] (first <= second < n).
- * The reference tests needle[0] and needle[position] (src/x86.rs:297-316) and proves with its own tests that
- * the result does not depend on `position` (src/lib.rs:375-378).  ss_searcher_with_position keeps the
- * reference's pair (0, position).  ss_searcher_new - whose caller did not choose - picks both bytes by a
- * static rarity ranking of the needle's bytes, at most 15 apart, so that text-like haystacks rarely pass the
- * filter and long needles stay on the single-stream kernels; ss_searcher_position() still reports n-1.
- * SLICESLICE_AUTO_FILTER=0 in the environment keeps (0, n-1) for ss_searcher_new as well.
- * ss_searcher_set_filter overrides the pair (tests, tuning, a caller with corpus statistics - see
- * ss_byte_histogram_device); SS_ERR_POSITION if out of range.  Not thread-safe against running searches. */
+/* The needle bytes the device filter tests: needle[first], needle[second] (first <= second < n) and, in the
+ * single-stream kernels (second - first <= 15), a third byte needle[third] with first < third <= first + 15
+ * (third == second: none).  The reference tests needle[0] and needle[position] (src/x86.rs:297-316) and proves
+ * with its own tests that the result does not depend on `position` (src/lib.rs:375-378); every further byte
+ * is one more necessary condition of a match, so it cannot change a result either.
+ *   ss_searcher_with_position keeps the reference's pair (0, position) and, for position < 16, adds the rarest
+ *     other byte of needle[1..15] as the third.
+ *   ss_searcher_new - whose caller did not choose - picks all three by a static rarity ranking of the needle's
+ *     bytes (first byte + the two rarest of the 15 bytes behind it, over the first 1024 needle bytes), so that
+ *     text-like haystacks rarely pass the filter and long needles stay on the single-stream kernels;
+ *     ss_searcher_position() still reports n-1.  SLICESLICE_AUTO_FILTER=0 in the environment makes
+ *     ss_searcher_new behave like ss_searcher_with_position(n-1).
+ *   ss_searcher_set_filter overrides the pair and drops the third byte (a plain two-byte filter);
+ *     ss_searcher_set_filter3 sets all three.  Tests, tuning, or a caller with corpus statistics (see
+ *     ss_byte_histogram_device).  SS_ERR_POSITION if out of range.  Not thread-safe against running searches. */
 int ss_searcher_filter(const ss_searcher *s, size_t *first, size_t *second);
+int ss_searcher_filter3(const ss_searcher *s, size_t *first, size_t *second, size_t *third);
 int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second);
-/* The pair ss_searcher_new would pick for this needle (pure host function, no device needed). */
+int ss_searcher_set_filter3(ss_searcher *s, size_t first, size_t second, size_t third);
+/* What ss_searcher_new would pick for this needle (pure host functions, no device needed). */
 int ss_choose_filter_pair(const uint8_t *needle, size_t n, size_t *first, size_t *second);
+int ss_choose_filter_triple(const uint8_t *needle, size_t n, size_t *first, size_t *second, size_t *third);
 
 /* DynamicAvx2Searcher::search_in (src/x86.rs:523-525) on a haystack ALREADY RESIDENT in device
  * memory (any alignment, any length up to the device's memory).  Enqueues on `hip_stream`

@@ -73,6 +73,10 @@ struct Problem {
     uint32_t mis;             // hay - base, 0..15
     uint32_t r;               // (position % 16) % 4: byte part of the shift
     uint32_t n0x4, nlx4;      // needle[0] and needle[position] splatted over a dword
+    // MODE 0 kernels test a THIRD needle byte in the first phase (position3 = 4*q3 + r3 < 16, relative to the first
+    // filter byte like `position`; == position when the needle has no third byte to offer): text passes a two-byte
+    // filter often enough that most tiles would enter the second phase, a three-byte filter hardly ever.
+    uint32_t n3x4, q3, r3;
     uint32_t norder;          // second-level filter: number of extra needle bytes to test (<= 15)
     uint64_t order_idx[2];    //   their indices K (1 <= K < min(n,16), K != position), rarest byte first, 1 byte each
     uint64_t order_val[2];    //   needle[K] in the same order, 1 byte each (entry t: word t/8, bits 8(t%8)..)
@@ -170,6 +174,33 @@ __device__ __forceinline__ void filter_piece(const u32x4 &A, const uint32_t w[4]
     g[3] = zero_byte_flags(d3 | __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r));
 }
 
+// Three-byte filter of one piece (MODE 0: both extra bytes within 15 bytes of the first).  The RAW dwords of the next
+// lane's chunk are moved once (DPP commutes with the xor), then every filter byte costs five xors, four
+// v_alignbyte and four ors, and ONE zero-byte test per dword decides all three bytes.  A = this lane's chunk;
+// NX = what lane 63 must see as "the next lane's chunk" (lane 0 of the next piece, already rotated into lane 63, or
+// the halo chunk); only dwords 0 .. max(Q, Q3) of it are used.
+template <int Q, int Q3>
+__device__ __forceinline__ void filter_piece3(const u32x4 &A, const uint32_t NX[4], const Problem &pr, uint32_t g[4])
+{
+    constexpr int QM = Q > Q3 ? Q : Q3;
+    uint32_t x[8];
+    x[0] = A.x; x[1] = A.y; x[2] = A.z; x[3] = A.w;
+    x[4] = from_next_lane_or(NX[0], A.x);
+    x[5] = QM >= 1 ? from_next_lane_or(NX[1], A.y) : 0u;
+    x[6] = QM >= 2 ? from_next_lane_or(NX[2], A.z) : 0u;
+    x[7] = QM >= 3 ? from_next_lane_or(NX[3], A.w) : 0u;
+    uint32_t y[5], z[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        y[k] = x[Q + k] ^ pr.nlx4;
+        z[k] = x[Q3 + k] ^ pr.n3x4;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        g[j] = zero_byte_flags((x[j] ^ pr.n0x4) | __builtin_amdgcn_alignbyte(y[j + 1], y[j], pr.r) |
+                               __builtin_amdgcn_alignbyte(z[j + 1], z[j], pr.r3));
+}
+
 // ---- second-level filter ------------------------------------------------------------------------------
 // Run only by waves that have candidates: AND the candidate flags with the flags of needle[K] at byte
 // offset K, for up to 15 further needle bytes, still entirely in registers.  Text-like haystacks pass
@@ -202,14 +233,14 @@ __host__ __device__ inline int byte_rarity_rank(uint8_t b)
 
 // Indices 1 .. min(n,16)-1 except `position`, sorted rarest-first; packed one byte each.
 __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, uint64_t n, uint64_t position,
-                                                       uint64_t idx[2], uint64_t val[2])
+                                                       uint64_t idx[2], uint64_t val[2], uint64_t position3 = ~0ull)
 {
     uint8_t ks[15];
     int rk[15];
     uint32_t m = 0;
     const int lim = n < 16 ? (int)n : 16;
     for (int K = 1; K < lim; ++K) {
-        if ((uint64_t)K == position) continue;                 // already tested by the first-level filter
+        if ((uint64_t)K == position || (uint64_t)K == position3) continue;   // already tested by the first-level filter
         const int r = byte_rarity_rank(needle[K]);
         int at = (int)m;
         while (at > 0 && rk[at - 1] > r) {                     // insertion sort, stable
@@ -233,10 +264,10 @@ __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, ui
 // needle[K]; four rarity classes are emitted in turn from wave ballots.  Coarser than the host sort,
 // which only changes the order of the checks.
 __device__ __forceinline__ uint32_t build_refine_order_wave(const uint8_t *needle, uint64_t n, uint64_t position,
-                                                            int lane, uint64_t idx[2], uint64_t val[2])
+                                                            int lane, uint64_t idx[2], uint64_t val[2], uint64_t position3 = ~0ull)
 {
     const int lim = n < 16 ? (int)n : 16;
-    const bool valid = lane >= 1 && lane < lim && (uint64_t)lane != position;
+    const bool valid = lane >= 1 && lane < lim && (uint64_t)lane != position && (uint64_t)lane != position3;
     const uint32_t b = valid ? needle[lane] : 0u;
     const int r = byte_rarity_rank((uint8_t)b);
     const int cls = !valid ? -1 : (r < 64 ? 0 : (r < 128 ? 1 : (r < 192 ? 2 : 3)));
@@ -553,7 +584,8 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
     const int wpb = (int)(blockDim.x / kWave);                              // waves per workgroup (launch-time)
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
-    bool staged = false;
+    bool staged = false, ordered = !LAZY_ORDER;
+    constexpr bool THREE = MODE == 0 && !ONE_BYTE;                          // three-byte first phase
     RefineOrder ro = {pr.norder, {pr.order_idx[0], pr.order_idx[1]}, {pr.order_val[0], pr.order_val[1]}};
     bool dense = false;                                                     // L8: the previous tile had candidates
     const int d = (int)pr.d;                                                // SHIFTED: 1 <= d <= 62
@@ -616,8 +648,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         uint32_t G[U][4];
         uint32_t any_tile = 0;
         int stop = 0;
-        auto load_and_filter = [&](auto loaded_c, auto full_c) {
+        auto load_and_filter = [&](auto loaded_c, auto full_c, auto q3_c) {
             constexpr bool LOADED = decltype(loaded_c)::value, FULL = decltype(full_c)::value;
+            constexpr int Q3 = decltype(q3_c)::value;
             if constexpr (!LOADED && FULL) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -652,11 +685,24 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 
             // ---- phase 1: the two-byte filter for all U pieces, straight-line (loads are consumed in order) ----
             uint32_t wcur[4] = {0, 0, 0, 0}, wnext[4] = {0, 0, 0, 0}, wlast[4] = {0, 0, 0, 0};
-            if (!ONE_BYTE) position_diffs(TWO ? B[0] : A[0], pr.nlx4, wcur);
+            if (!ONE_BYTE && !THREE) position_diffs(TWO ? B[0] : A[0], pr.nlx4, wcur);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t *g = G[u];
-                if (SHIFTED) {
+                if (THREE) {
+                    // lane 63's next lane: lane 0 of the next piece (raw dwords, rotated in), or the halo chunk
+                    constexpr int QM = Q > Q3 ? Q : Q3;
+                    uint32_t nx[4] = {0, 0, 0, 0};
+                    if (u + 1 < U) {
+                        nx[0] = rotate_from_next_lane(A[u + 1].x);
+                        if (QM >= 1) nx[1] = rotate_from_next_lane(A[u + 1].y);
+                        if (QM >= 2) nx[2] = rotate_from_next_lane(A[u + 1].z);
+                        if (QM >= 3) nx[3] = rotate_from_next_lane(A[u + 1].w);
+                    } else {
+                        nx[0] = H.x; nx[1] = H.y; nx[2] = H.z; nx[3] = H.w;
+                    }
+                    filter_piece3<Q, Q3>(A[u], nx, pr, g);
+                } else if (SHIFTED) {
                     // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
                     position_diffs(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
                     uint32_t x[8];
@@ -683,16 +729,29 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
                 }
                 any_tile |= g[0] | g[1] | g[2] | g[3];
-                if (!ONE_BYTE && (SHIFTED || u + 1 < U)) {
+                if (!ONE_BYTE && !THREE && (SHIFTED || u + 1 < U)) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) wcur[j] = wnext[j];
                 }
             }
 
         };
-        if (have16) load_and_filter(std::true_type{}, std::true_type{});
-        else if (full) load_and_filter(std::false_type{}, std::true_type{});
-        else load_and_filter(std::false_type{}, std::false_type{});
+        // the third byte's dword window is wave-uniform run-time data: one copy of the phase per window
+        auto run_phase1 = [&](auto loaded_c, auto full_c) {
+            if constexpr (THREE) {
+                switch (pr.q3) {
+                case 0: load_and_filter(loaded_c, full_c, std::integral_constant<int, 0>{}); break;
+                case 1: load_and_filter(loaded_c, full_c, std::integral_constant<int, 1>{}); break;
+                case 2: load_and_filter(loaded_c, full_c, std::integral_constant<int, 2>{}); break;
+                default: load_and_filter(loaded_c, full_c, std::integral_constant<int, 3>{}); break;
+                }
+            } else {
+                load_and_filter(loaded_c, full_c, std::integral_constant<int, 0>{});
+            }
+        };
+        if (have16) run_phase1(std::true_type{}, std::true_type{});
+        else if (full) run_phase1(std::false_type{}, std::true_type{});
+        else run_phase1(std::false_type{}, std::false_type{});
         if (FIND) {
             const uint64_t first = chunk0 * 16 > pr.mis ? chunk0 * 16 - pr.mis : 0;   // lowest index this wave can report
             if (best_now <= pr.find_base + first) {                                     // all of it lies right of a match
@@ -709,22 +768,33 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             return;
         }
         if (cand_tile) {
-            if (!staged) {
-                stage_needle_wave(s_needle, pr.needle, pr.n, lane);
-                if (LAZY_ORDER && !ONE_BYTE) {
+            if (!ordered) {
+                if (!ONE_BYTE) {
                     const uint64_t position = pr.d * 16 + 4 * Q + pr.r;
+                    const uint64_t position3 = THREE ? (uint64_t)(4 * pr.q3 + pr.r3) : ~0ull;
                     ro.n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)build_refine_order_wave(pr.needle, pr.n, position, lane, ro.idx, ro.val));
+                        (int)build_refine_order_wave(pr.needle, pr.n, position, lane, ro.idx, ro.val, position3));
                     for (int t = 0; t < 2; ++t) {
                         ro.idx[t] = uniform64(ro.idx[t]);
                         ro.val[t] = uniform64(ro.val[t]);
                     }
                 }
-                staged = true;
+                ordered = true;
             }
+            // The needle is staged into LDS only by a wave that still has a candidate AFTER the in-register
+            // second-level filter (next to nobody, on random bytes and on text alike): staging costs a pass over
+            // min(n, 2 KiB) needle bytes, which at 2^-16 candidates per offset and short-lived workgroups made a
+            // 2000-byte needle 13 % slower than a 16-byte one.
+            auto stage_once = [&]() {
+                if (!staged && !ONE_BYTE) {
+                    stage_needle_wave(s_needle, pr.needle, pr.n, lane);
+                    staged = true;
+                }
+            };
             // second-level filter in registers (wave-uniform), up to the first 16 needle bytes, tile-wide
             constexpr bool TILE_WIDE = MODE != 2;
             if (!ONE_BYTE && TILE_WIDE && !refine_tile<U, MODE>(A, H, ro, G)) continue;
+            if (TILE_WIDE) stage_once();
             bool hit = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -734,6 +804,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     np.N = u + 1 < U ? A[u + 1] : H;
                     np.kind = 1;                                  // MODE 2: the halo chunks sit in lanes 0..d of H
                     if (!refine_piece(A[u], np, ro, g)) continue;
+                    stage_once();
                 } else if (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) == 0) {
                     continue;
                 }
@@ -886,6 +957,26 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
     pr.r = s % 4;
     pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[0]);
     pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[position]);
+    // third first-phase byte (single-stream kernels): the rarest of needle[1..15] other than needle[position],
+    // later bytes winning ties; lane K ranks needle[K], four rarity classes are tried in turn
+    uint32_t p3 = s;
+    if (pr.d == 0 && n >= 3) {
+        const int lane = threadIdx.x & (kWave - 1);
+        const int lim = n < 16 ? (int)n : 16;
+        const bool valid = lane >= 1 && lane < lim && (uint32_t)lane != s;
+        const int rk = valid ? byte_rarity_rank(pr.needle[lane]) : 0;
+        const int cls = !valid ? -1 : (rk < 64 ? 0 : (rk < 128 ? 1 : (rk < 192 ? 2 : 3)));
+        uint32_t pick = 0;
+#pragma unroll
+        for (int c = 3; c >= 0; --c) {
+            const uint32_t m = (uint32_t)__ballot(cls == c) & 0xFFFFu;
+            if (m) pick = m;                                  // ends up as the lowest non-empty class
+        }
+        if (pick) p3 = 31u - (uint32_t)__builtin_clz(pick);
+    }
+    pr.q3 = p3 / 4;
+    pr.r3 = p3 % 4;
+    pr.n3x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[pr.d == 0 ? p3 : 0]);
     // the second-level schedule is built lazily by the waves that need it (scan_tiles<..., LAZY_ORDER>)
     pr.norder = 0;
     pr.order_idx[0] = pr.order_idx[1] = pr.order_val[0] = pr.order_val[1] = 0;
@@ -1065,11 +1156,13 @@ __global__ void __launch_bounds__(kBlock) byte_histogram_kernel(const uint8_t *h
 }
 
 // find(): hands the final minimum to the host through its pinned mirror (one system-scope store), stream-ordered
-// behind the scan - the read-back of ss_find_device without a device-to-host copy command.
-__global__ void publish_best_kernel(const uint64_t *d_best, uint64_t *h_best)
+// behind the scan - the read-back of ss_find_device without a device-to-host copy command - and re-arms the
+// slot (all ones) for its next user.
+__global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best)
 {
-    __hip_atomic_store(h_best, __hip_atomic_load(d_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t v = __hip_atomic_load(d_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h_best, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (v != ~0ull) __hip_atomic_store(d_best, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Cross-lane self-test: the DPP controls and v_alignbyte the scan relies on, next to __shfl statements.

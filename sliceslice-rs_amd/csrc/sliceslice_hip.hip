@@ -85,7 +85,6 @@ struct PerDevice {
     uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
     uint64_t *h_best = nullptr; // pinned mirror
     uint64_t free_mask = 0;
-    uint64_t best_dirty = 0;    // find(): slots whose d_best holds a result and must be re-armed before their next use
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
 };
 constexpr int kSlots = 64;
@@ -119,6 +118,9 @@ struct ss_searcher {
     // reference's filter; `new` callers get a pair chosen by choose_filter_pair.  The result of a search never
     // depends on the pair (src/lib.rs:375-378 asserts that for every position).
     size_t fa = 0, fb = 0;
+    // Third byte of the first-phase filter, fa < fc <= fa + 15 (== fb: none).  Only used when fb - fa <= 15 (the
+    // single-stream kernels); an extra test, so it cannot change a result either.
+    size_t fc = 0;
     int variant = 0;
     int grid = 0;
     bool timing = false;
@@ -180,16 +182,6 @@ int acquire_slot(const ss_searcher *s, PerDevice *p)
     const int k = __builtin_ctzll(p->free_mask);
     p->free_mask &= p->free_mask - 1;
     return k;
-}
-
-// find(): true when slot k still holds an earlier result and has to be re-armed (all ones) before use;
-// clears the mark.
-bool take_best_dirty(const ss_searcher *s, PerDevice *p, int k)
-{
-    std::lock_guard<std::mutex> lock(s->mu);
-    const bool dirty = (p->best_dirty >> k) & 1;
-    p->best_dirty &= ~(1ull << k);
-    return dirty;
 }
 
 // The value that means "found" for the call that owns slot k: fresh per call, never 0.  On the (2^31
@@ -317,8 +309,15 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.r = sh % 4;
     pr.n0x4 = 0x01010101u * s->needle[fa];
     pr.nlx4 = 0x01010101u * s->needle[fb];
+    // third first-phase byte (single-stream kernels only, i.e. d == 0); "none" = the second byte once more
+    const bool three = !one_byte && pr.d == 0 && s->fc > fa && s->fc - fa <= 15 && s->fc < n;
+    const size_t position3 = three ? s->fc - fa : position % 16;
+    pr.q3 = (uint32_t)(position3 / 4);
+    pr.r3 = (uint32_t)(position3 % 4);
+    pr.n3x4 = 0x01010101u * s->needle[one_byte ? 0 : fa + position3];
     // second-level filter: up to 15 further needle bytes behind the first filter byte
-    pr.norder = ss::build_refine_order(s->needle.data() + fa, n - fa, position, pr.order_idx, pr.order_val);
+    pr.norder = ss::build_refine_order(s->needle.data() + fa, n - fa, position, pr.order_idx, pr.order_val,
+                                       pr.d == 0 ? (uint64_t)position3 : ~0ull);
     pr.find_base = find_base;
     pr.host_flag = host_flag;
     pr.epoch = epoch;
@@ -404,29 +403,68 @@ inline int rarity_class(uint8_t b)
     return r < 64 ? 0 : r;          // everything that is not text-like counts as equally rare
 }
 
-void choose_filter_pair(const uint8_t *needle, size_t n, size_t *fa, size_t *fb)
+// Third byte for a given pair (single-stream kernels: fb - fa <= 15): the rarest byte among needle[fa+1 .. fa+15]
+// other than needle[fb]'s index; ties to the later byte.  Returns fb when there is none.
+size_t choose_third(const uint8_t *needle, size_t n, size_t fa, size_t fb)
 {
-    *fa = 0;
-    *fb = n ? n - 1 : 0;
-    if (n < 2) { *fb = 0; return; }
+    if (n < 3 || fb < fa || fb - fa > 15) return fb;
+    size_t best = fb;
+    int bc = INT_MAX;
+    for (size_t k = fa + 1; k < n && k <= fa + 15; ++k) {
+        if (k == fb) continue;
+        const int c = rarity_class(needle[k]);
+        if (c <= bc) {
+            bc = c;
+            best = k;
+        }
+    }
+    return best;
+}
+
+// (fa, fb, fc): the first byte plus the two rarest bytes of the 15 that follow it, for the first byte that makes
+// that sum smallest.  Ties: the reference's first byte (0) when it is among the best, else the earliest; among
+// equally rare followers the later ones (for needles of <= 16 bytes of equal rarity that is the reference's
+// pair (0, n-1) plus n-2).  fb > fc is not required; fb is the rarer (or later) of the two.
+void choose_filter_triple(const uint8_t *needle, size_t n, size_t *fa, size_t *fb, size_t *fc)
+{
+    *fa = *fb = *fc = 0;
+    if (n < 2) return;
     const size_t w = n < kFilterWindow ? n : kFilterWindow;
     int best = INT_MAX;
-    size_t ba = 0, bb = 1;
+    size_t ba = 0, bb = 1, bc = 1;
     for (size_t a = 0; a + 1 < w; ++a) {
         const int ca = rarity_class(needle[a]);
         if (ca > best) continue;
+        // two smallest classes among a+1 .. a+15 (later index wins ties)
+        int c1 = INT_MAX, c2 = INT_MAX;
+        size_t i1 = a + 1, i2 = a + 1;
         for (size_t b = a + 1; b < w && b <= a + 15; ++b) {
-            const int c = ca + rarity_class(needle[b]);
-            if (c < best || (c == best && b - a > bb - ba)) {
-                best = c;
-                ba = a;
-                bb = b;
+            const int c = rarity_class(needle[b]);
+            if (c <= c1) {
+                c2 = c1; i2 = i1;
+                c1 = c; i1 = b;
+            } else if (c <= c2) {
+                c2 = c; i2 = b;
             }
         }
+        const bool has2 = c2 != INT_MAX;
+        const int cost = ca + c1 + (has2 ? c2 : 255);          // no third byte to offer: as bad as the most common one
+        if (cost < best) {
+            best = cost;
+            ba = a;
+            bb = i1;
+            bc = has2 ? i2 : i1;
+        }
     }
-    if (n <= 16 && rarity_class(needle[0]) + rarity_class(needle[n - 1]) == best) return;   // the reference's pair is as good
     *fa = ba;
     *fb = bb;
+    *fc = bc;
+}
+
+void choose_filter_pair(const uint8_t *needle, size_t n, size_t *fa, size_t *fb)
+{
+    size_t fc;
+    choose_filter_triple(needle, n, fa, fb, &fc);
 }
 
 int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_filter, ss_searcher **out)
@@ -447,7 +485,8 @@ int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_fi
     s->position = position;
     s->fa = 0;
     s->fb = n >= 2 ? position : 0;
-    if (auto_filter) choose_filter_pair(s->needle.data(), n, &s->fa, &s->fb);
+    if (auto_filter) choose_filter_triple(s->needle.data(), n, &s->fa, &s->fb, &s->fc);
+    else s->fc = choose_third(s->needle.data(), n, s->fa, s->fb);       // with_position: the reference's pair + one more byte
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) {      // uploads the needle to the current device now
         delete s;
@@ -487,6 +526,33 @@ int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second)
     if (first > second || second >= s->n) return fail(SS_ERR_POSITION, "filter pair (%zu, %zu) out of range for a needle of %zu bytes", first, second, s->n);
     s->fa = first;
     s->fb = second;
+    s->fc = second;                 // a plain two-byte filter; ss_searcher_set_filter3 adds a third byte
+    return SS_OK;
+}
+
+int ss_searcher_set_filter3(ss_searcher *s, size_t first, size_t second, size_t third)
+{
+    if (int rc = ss_searcher_set_filter(s, first, second)) return rc;
+    if (s->n < 2 || third == second) return SS_OK;
+    if (second - first > 15 || third <= first || third - first > 15 || third >= s->n)
+        return fail(SS_ERR_POSITION, "third filter byte %zu must lie within 15 bytes behind the first (%zu), as must the second (%zu)", third, first, second);
+    s->fc = third;
+    return SS_OK;
+}
+
+int ss_searcher_filter3(const ss_searcher *s, size_t *first, size_t *second, size_t *third)
+{
+    if (!s || !first || !second || !third) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    *first = s->fa;
+    *second = s->fb;
+    *third = (s->n >= 2 && s->fb - s->fa <= 15) ? s->fc : s->fb;
+    return SS_OK;
+}
+
+int ss_choose_filter_triple(const uint8_t *needle, size_t n, size_t *first, size_t *second, size_t *third)
+{
+    if (!first || !second || !third || (n && !needle)) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    choose_filter_triple(needle, n, first, second, third);
     return SS_OK;
 }
 
@@ -639,34 +705,17 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     const int k = acquire_slot(s, pd);
-    // A slot that still holds the result of an earlier find() is re-armed (all ones) here, stream-ordered in
-    // front of this call's kernel: the earlier call has synchronised, so nothing else touches the slot, and the
-    // call that found something does not pay a second synchronisation for the reset.
-    int rc = SS_OK;
-    const bool dirty = take_best_dirty(s, pd, k);
-    if (dirty && hipMemsetAsync(pd->d_best + k, 0xFF, sizeof(uint64_t), st) != hipSuccess)
-        rc = fail(SS_ERR_HIP, "slot reset failed");
-    if (rc == SS_OK) rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0);
+    // Slots are all-ones whenever they are free: the one-lane kernel behind the scan stores the minimum to the
+    // slot's pinned-host mirror (no device-to-host copy command) and re-arms the slot.
+    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0);
     if (rc == SS_OK) {
-        // read-back through the pinned mirror: a one-lane kernel behind the scan stores the minimum to host memory
-        // (SLICESLICE_FIND_READBACK=memcpy: a device-to-host copy command instead; tools/native_bench latency compares)
-        static const bool by_copy = []() { const char *v = getenv("SLICESLICE_FIND_READBACK"); return v && !strcmp(v, "memcpy"); }();
-        hipError_t e;
-        if (by_copy) {
-            e = hipMemcpyAsync(pd->h_best + k, pd->d_best + k, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
-        } else {
-            ss::publish_best_kernel<<<1, 1, 0, st>>>(pd->d_best + k, pd->h_best + k);
-            e = hipGetLastError();
-        }
+        ss::publish_best_kernel<<<1, 1, 0, st>>>(pd->d_best + k, pd->h_best + k);
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(SS_ERR_HIP, "position read-back: %s", hipGetErrorString(e));
     }
     if (rc == SS_OK) {
         *position = __atomic_load_n(pd->h_best + k, __ATOMIC_ACQUIRE);
-        if (*position != SS_NPOS) {
-            std::lock_guard<std::mutex> lk(s->mu);
-            pd->best_dirty |= 1ull << k;
-        }
     } else {
         (void)hipDeviceSynchronize();
         (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));
@@ -818,7 +867,6 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
     uint8_t **dbuf = lease.set->d;
     hipStream_t *st = lease.set->st;
     const int k = acquire_slot(s, pd);
-    if (take_best_dirty(s, pd, k)) (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));   // left by ss_find_device
     int rc = SS_OK;
     size_t idx = 0;
     bool hit = false;

@@ -44,6 +44,9 @@ ABI = {
     "ss_searcher_filter": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_searcher_set_filter": (_int, [_vp, _sz, _sz]),
     "ss_choose_filter_pair": (_int, [_vp, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_searcher_filter3": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_searcher_set_filter3": (_int, [_vp, _sz, _sz, _sz]),
+    "ss_choose_filter_triple": (_int, [_vp, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
     "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
@@ -267,8 +270,18 @@ class DynamicHipSearcher:
         _check(lib().ss_searcher_filter(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
-    def set_filter(self, first, second):
-        _check(lib().ss_searcher_set_filter(self._h, first, second))
+    @property
+    def filter3(self):
+        """(first, second, third): the bytes of the first-phase filter (third == second: a two-byte filter)."""
+        a, b, c = _sz(0), _sz(0), _sz(0)
+        _check(lib().ss_searcher_filter3(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_filter(self, first, second, third=None):
+        if third is None:
+            _check(lib().ss_searcher_set_filter(self._h, first, second))
+        else:
+            _check(lib().ss_searcher_set_filter3(self._h, first, second, third))
 
     def set_timing(self, on=True):
         _check(lib().ss_searcher_set_timing(self._h, int(on)))
@@ -538,6 +551,14 @@ def choose_filter_pair(needle):
     a, b = _sz(0), _sz(0)
     _check(lib().ss_choose_filter_pair(nb, len(nb), ctypes.byref(a), ctypes.byref(b)))
     return a.value, b.value
+
+
+def choose_filter_triple(needle):
+    """(first, second, third) that `DynamicHipSearcher.new(needle)` lets the device filter test."""
+    nb = bytes(needle)
+    a, b, c = _sz(0), _sz(0), _sz(0)
+    _check(lib().ss_choose_filter_triple(nb, len(nb), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
 
 
 def fill_random_device(tensor, seed, global_offset=0, stream=None):

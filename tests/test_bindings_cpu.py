@@ -152,16 +152,25 @@ def test_filter_pair_choice_properties():
         alpha = rng.choice([bytes(range(256)), b"etaoin shrdlu", b"ab", b"the quick brown fox jumps over the lazy dog.,;!"])
         nd = bytes(rng.choice(alpha) for _ in range(n))
         a, b = ss.choose_filter_pair(nd)
-        assert 0 <= a < b < n and b - a <= 15 or (n <= 16 and (a, b) == (0, n - 1)), (nd[:20], a, b)
+        assert 0 <= a < b < n and b - a <= 15, (nd[:20], a, b)
         assert b < 1024
     assert ss.choose_filter_pair(b"") == (0, 0) and ss.choose_filter_pair(b"x") == (0, 0)
-    assert ss.choose_filter_pair(b"ab") == (0, 1)
-    assert ss.choose_filter_pair(bytes(range(200, 216))) == (0, 15)          # nothing to choose between: the reference's pair
-    assert ss.choose_filter_pair(b" the quick brown fox ") == (5, 19)        # 'q' and 'x' instead of ' ' and ' '
-    assert ss.choose_filter_pair(b"a" * 15 + b"b") == (0, 15)
-    assert ss.choose_filter_pair(b"ab" + b"a" * 14) == (1, 15)              # 'b' is in the pair wherever it sits
-    a, b = ss.choose_filter_pair(b"e" * 2000 + b"\x07\x08")                  # only the first 1024 bytes are looked at
-    assert b < 1024
+    assert ss.choose_filter_triple(b"ab") == (0, 1, 1)                        # no third byte: the second one once more
+    assert ss.choose_filter_triple(b"abc") == (0, 1, 2)
+    assert ss.choose_filter_triple(bytes(range(200, 216))) == (0, 15, 14)    # nothing to choose between: the reference's pair + one
+    assert ss.choose_filter_triple(b" the quick brown fox ") == (5, 19, 9)   # 'q', 'x', 'k' instead of ' ' and ' '
+    assert ss.choose_filter_triple(b"a" * 15 + b"b") == (0, 15, 14)
+    assert 1 in ss.choose_filter_triple(b"ab" + b"a" * 14)                   # 'b' is in the filter wherever it sits
+    assert ss.choose_filter_triple(b"privilege level zero!")[1] == 20        # '!'
+    a, b, c = ss.choose_filter_triple(b"e" * 2000 + b"\x07\x08")            # only the first 1024 bytes are looked at
+    assert max(b, c) < 1024
+    rng = random.Random(2)
+    for _ in range(2000):
+        n = rng.choice([3, 4, 16, 17, 100, 2000])
+        nd = bytes(rng.choice(b"etaoinshr dlu,.XQ\x00\xfe") for _ in range(n))
+        a, b, c = ss.choose_filter_triple(nd)
+        assert a < b < n and a < c < n and b != c and b - a <= 15 and c - a <= 15, (nd[:24], a, b, c)
+        assert ss.choose_filter_pair(nd) == (a, b)
 
 
 def test_bench_line_fields_of_the_committed_round2_capture():
@@ -171,7 +180,7 @@ def test_bench_line_fields_of_the_committed_round2_capture():
         import pytest
         pytest.skip("no round-2 capture committed yet")
     d = json.loads(open(path).read())
-    assert d["n_gpus"] == 1 and d["config"]["ranks"] == 1 and d["config"]["filter_bytes"] == [0, 15]
+    assert d["n_gpus"] == 1 and d["config"]["ranks"] == 1 and d["config"]["filter_bytes"] == [0, 15, 13]
     assert d["roofline"]["traffic_source"].startswith("stored ratio")
     assert set(d["configs"]) >= {"1", "3", "5", "latency_us"}
     assert [r["needle_len"] for r in d["configs"]["3"]["rows"]] == [1, 2, 4, 8, 16, 32, 128]

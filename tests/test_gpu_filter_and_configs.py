@@ -57,12 +57,20 @@ def test_every_filter_pair_gives_the_reference_answer_on_the_kats(ss, kat):
                 if n < 2 and (a, b) != (0, 0):
                     continue
                 s.set_filter(a, b)
-                assert s.filter == (a, b)
+                assert s.filter == (a, b) and s.filter3 == (a, b, b)
                 assert s.search_in(dh) == row["expected"], (row, a, b)
                 assert s.search_in(hay) == row["expected"], (row, a, b)           # host path
                 p = s.find(dh)
                 want = hay.find(needle)
                 assert p == (None if want < 0 else want), (row, a, b)
+                # ... and with every third byte the single-stream kernels can take (short needles: all of them)
+                if n >= 3 and b > a and b - a <= 15:
+                    thirds = [c for c in range(a + 1, min(n, a + 16)) if c != b]
+                    for c in (thirds if n <= 12 else thirds[::5]):
+                        s.set_filter(a, b, c)
+                        assert s.filter3 == (a, b, c)
+                        assert s.search_in(dh) == row["expected"], (row, a, b, c)
+                        assert s.find(dh) == (None if want < 0 else want), (row, a, b, c)
 
 
 def test_filter_pair_bounds_are_checked(ss):
@@ -70,6 +78,17 @@ def test_filter_pair_bounds_are_checked(ss):
     for a, b in ((1, 0), (0, 6), (6, 6), (5, 7)):
         with pytest.raises(ss.PositionError):
             s.set_filter(a, b)
+    for a, b, c in ((0, 3, 0), (2, 4, 1), (0, 3, 6), (1, 2, 1)):
+        with pytest.raises(ss.PositionError):
+            s.set_filter(a, b, c)
+    long = ss.DynamicHipSearcher.new(bytes(range(1, 101)))
+    long.set_filter(0, 16)                              # 16 apart: cross-lane kernel, no third byte
+    with pytest.raises(ss.PositionError):
+        long.set_filter(0, 16, 5)
+    with pytest.raises(ss.PositionError):
+        long.set_filter(0, 5, 16)
+    long.set_filter(3, 18, 4)
+    assert long.filter3 == (3, 18, 4)
     s1 = ss.DynamicHipSearcher.new(b"a")
     s1.set_filter(0, 0)
     with pytest.raises(ss.PositionError):
@@ -79,8 +98,12 @@ def test_filter_pair_bounds_are_checked(ss):
 def test_new_picks_rare_bytes_and_with_position_keeps_the_reference_pair(ss):
     s = ss.DynamicHipSearcher.new(b" the quick brown fox ")
     assert s.position == 20 and s.filter == ss.choose_filter_pair(b" the quick brown fox ") == (5, 19)   # 'q', 'x'
+    assert s.filter3 == ss.choose_filter_triple(b" the quick brown fox ") == (5, 19, 9)                  # ... and 'k'
     for p in (0, 7, 20):
-        assert ss.DynamicHipSearcher.with_position(b" the quick brown fox ", p).filter == (0, p)
+        w = ss.DynamicHipSearcher.with_position(b" the quick brown fox ", p)
+        assert w.filter == (0, p)                            # the reference's pair is kept
+    assert ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 7).filter3 == (0, 7, 5)        # + 'q' as the third
+    assert ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 20).filter3 == (0, 20, 20)     # 20 apart: none
     # a 2000-byte needle: the default position 1999 would need two load streams; `new` stays within 15 bytes
     long_needle = (b"lorem ipsum dolor sit amet, " * 80)[:2000]
     a, b = ss.DynamicHipSearcher.new(long_needle).filter
@@ -130,6 +153,11 @@ def test_filter_pairs_on_text_and_random_haystacks_vs_oracle(ss, O, corpus):
                 s.set_filter(a, b)
                 assert s.search_in(view) == want, (n, mis, a, b)
                 assert s.find(view) == (None if wantp < 0 else wantp), (n, mis, a, b)
+                if n >= 3 and 0 < b - a <= 15:
+                    for c in {rng.randrange(a + 1, min(n, a + 16)) for _ in range(3)} - {b}:
+                        s.set_filter(a, b, c)
+                        assert s.search_in(view) == want, (n, mis, a, b, c)
+                        assert s.find(view) == (None if wantp < 0 else wantp), (n, mis, a, b, c)
 
 
 def test_filter_stream_never_reads_outside_the_haystack(ss):
@@ -143,8 +171,8 @@ def test_filter_stream_never_reads_outside_the_haystack(ss):
         assert hip.hipMemset(p, 0x2E, ctypes.c_size_t(size)) == 0
         needle = bytes([0x30 + k for k in range(40)])
         s = ss.DynamicHipSearcher.new(needle)
-        for a, b in ((0, 39), (38, 39), (20, 35), (0, 1), (3, 3), (39, 39)):
-            s.set_filter(a, b)
+        for a, b, c in ((0, 39, None), (38, 39, None), (20, 35, 34), (0, 1, 15), (3, 3, None), (39, 39, None), (24, 39, 38)):
+            s.set_filter(a, b, c)
             for ln in (40, 41, 4097, size):
                 assert s.search_in((p.value + size - ln, ln)) is False, (a, b, ln)
                 assert s.search_in((p.value, ln)) is False, (a, b, ln)

@@ -164,12 +164,12 @@ def main():
             s = ss.DynamicHipSearcher.new(nd)
             res, ms = timed(s, text, args.reps)
             emit(config="text", needle=nd.decode("latin1"), label=label + "; new() - filter bytes chosen by the library",
-                 filter_bytes=list(s.filter), filter_chars=[chr(nd[k]) for k in s.filter], haystack_bytes=text.numel(), found=res,
+                 filter_bytes=list(s.filter3), filter_chars=[chr(nd[k]) for k in s.filter3], haystack_bytes=text.numel(), found=res,
                  kernel_ms=round(ms, 3), gbps=round(text.numel() / ms / 1e6, 1))
             s = ss.DynamicHipSearcher.with_position(nd, len(nd) - 1)
             res, ms = timed(s, text, args.reps)
             emit(config="text", needle=nd.decode("latin1"), label=label + "; with_position(n-1): the reference's pair (0, n-1)",
-                 filter_bytes=list(s.filter), haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
+                 filter_bytes=list(s.filter3), haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
                  gbps=round(text.numel() / ms / 1e6, 1))
             # row f3: the same needle with the position chosen from a byte histogram of (a sample of) the haystack
             hist = ss.byte_histogram(text, sample_bytes=64 << 20)
@@ -187,7 +187,7 @@ def main():
                                (b"ab" + b"a" * 14, None, "first byte common, last byte common, fails at byte 1")):
             s = ss.DynamicHipSearcher(nd, pos)
             res, ms = timed(s, a, args.reps)
-            emit(config="adversarial", label=label, filter_bytes=list(s.filter), haystack_bytes=n_bytes, found=res, kernel_ms=round(ms, 3),
+            emit(config="adversarial", label=label, filter_bytes=list(s.filter3), haystack_bytes=n_bytes, found=res, kernel_ms=round(ms, 3),
                  gbps=round(n_bytes / ms / 1e6, 1))
         del a
         # long needles on random bytes: `new` keeps the filter pair within 15 bytes (single-stream kernel); the
@@ -196,7 +196,7 @@ def main():
             nd = absent(n)
             for how, s in (("new()", ss.DynamicHipSearcher.new(nd)), ("with_position(n-1)", ss.DynamicHipSearcher.with_position(nd, n - 1))):
                 res, ms = timed(s, hay, args.reps)
-                emit(config="long-needle", needle_len=n, how=how, filter_bytes=list(s.filter), haystack_bytes=n_bytes, found=res,
+                emit(config="long-needle", needle_len=n, how=how, filter_bytes=list(s.filter3), haystack_bytes=n_bytes, found=res,
                      kernel_ms=round(ms, 4), gbps=round(n_bytes / ms / 1e6, 1))
 
     if "1" not in skip:

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>_<case>_{kt,pmc,sq} (tools/profile_kernels.sh) -> profiles/<round>/kernels.json + kernels.md:
+per case the dominant kernel's name, rocprofv3 average duration, achieved GB/s and fraction of the 8 TB/s peak,
+HBM bytes fetched per launch (FETCH_SIZE x 2 x 1024: the gfx950 correction and KiB unit of
+MI355X_MICROARCH.md's HBM section) over the algorithmic bytes, and the SQ instruction mix per KiB piece."""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+rows = []
+for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
+    case = os.path.basename(kt)[len(tag) + 1:-3]
+    line = None
+    for l in open(kt + ".log", errors="replace"):
+        if l.startswith('{"case"'):
+            line = json.loads(l)
+    if line is None:
+        continue
+    want = line["kernel"]
+    stats = [r for r in csv.DictReader(open(os.path.join(kt, "r_kernel_stats.csv"))) if want in r["Name"]]
+    stats.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    if not stats:
+        continue
+    k = stats[0]
+    alg = line["algorithmic_bytes_per_launch"]
+    avg_ns = float(k["AverageNs"])
+    row = {"case": case, "kernel": k["Name"], "calls": int(k["Calls"]), "rocprof_avg_ms": round(avg_ns / 1e6, 4),
+           "hipevent_median_ms": line["ms"], "algorithmic_bytes_per_launch": alg,
+           "gbps": round(alg / avg_ns, 1), "frac_of_8tbps": round(alg / avg_ns / 8000, 4), "filter_bytes": line.get("filter_bytes")}
+    pmc = os.path.join(src, f"{tag}_{case}_pmc", "r_counter_collection.csv")
+    if os.path.exists(pmc):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(pmc)) if want in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+        if vals:
+            fetched = 2 * statistics.median(vals) * 1024
+            row.update(vgpr=None, hbm_bytes_fetched_per_launch=fetched, fetched_over_algorithmic=round(fetched / alg, 4))
+        regs = [r for r in csv.DictReader(open(pmc)) if want in r["Kernel_Name"]]
+        if regs:
+            row["vgpr"] = int(regs[0]["VGPR_Count"])
+            row["lds_block_size"] = int(regs[0]["LDS_Block_Size"])
+    sq = os.path.join(src, f"{tag}_{case}_sq", "r_counter_collection.csv")
+    if os.path.exists(sq):
+        acc = {}
+        for r in csv.DictReader(open(sq)):
+            if want in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        pieces = alg / 1024
+        med = {c: statistics.median(v) for c, v in acc.items()}
+        row["sq_per_kib"] = {c.replace("SQ_INSTS_", "").lower(): round(v / pieces, 2) for c, v in med.items() if c.startswith("SQ_INSTS_")}
+        if med.get("SQ_WAVE_CYCLES"):
+            row["wait_fraction"] = round(med.get("SQ_WAIT_ANY", 0) / med["SQ_WAVE_CYCLES"], 3)
+    rows.append(row)
+    for kind in ("kt",):
+        os.makedirs(os.path.join(dst, "kernel_stats"), exist_ok=True)
+        import shutil
+        shutil.copy(os.path.join(kt, "r_kernel_stats.csv"), os.path.join(dst, "kernel_stats", f"{case}_kernel_stats.csv"))
+json.dump(rows, open(os.path.join(dst, "kernels.json"), "w"), indent=1)
+with open(os.path.join(dst, "kernels.md"), "w") as fh:
+    fh.write("| case | kernel | rocprofv3 avg ms | GB/s | frac of 8 TB/s | fetched / algorithmic | VGPR | VALU / SALU / LDS / VMEM per KiB | wait |\n|---|---|---|---|---|---|---|---|---|\n")
+    for r in rows:
+        sqk = r.get("sq_per_kib", {})
+        fh.write("| %s | `%s` | %.4f | %.0f | %.3f | %s | %s | %s / %s / %s / %s | %s |\n" % (
+            r["case"], r["kernel"].replace("void ", "")[:70], r["rocprof_avg_ms"], r["gbps"], r["frac_of_8tbps"],
+            r.get("fetched_over_algorithmic", "-"), r.get("vgpr", "-"), sqk.get("valu", "-"), sqk.get("salu", "-"), sqk.get("lds", "-"),
+            sqk.get("vmem_rd", "-"), r.get("wait_fraction", "-")))
+print(open(os.path.join(dst, "kernels.md")).read())

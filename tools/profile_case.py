@@ -1,6 +1,20 @@
 #!/usr/bin/env python3
-"""One scan of one (haystack kind, needle) case - a target for rocprofv3 --pmc runs.
-  kinds: random | text | a      needle: python bytes literal, e.g. "b'ab' + b'a'*14"   [position]"""
+"""One named workload, a few launches of ONE kernel - a target for `rocprofv3 --kernel-trace --stats` and the
+separate `--pmc` passes (tools/profile_kernels.sh).  Prints one JSON line: the case, the kernel family expected,
+the algorithmic bytes per launch and the kernel time by hipEvents.
+
+  cases:  headline1g   1 GiB random, 16-byte absent needle, new()              (scan_kernel<3,0,...>)
+          onebyte      1 GiB random, 1-byte absent needle (8-byte loads)       (scan_kernel<0,0,true,...,L8>)
+          mode2        1 GiB random, 128-byte needle, with_position(127)       (scan_kernel<.,2,...> cross-lane)
+          mode1        1 GiB random, 2000-byte needle, with_position(1999)     (scan_kernel<.,1,...> two streams)
+          long_new     1 GiB random, 2000-byte needle, new()                   (single stream again)
+          find         1 GiB random, 16-byte absent needle, find()             (FIND kernel)
+          batched      4096 x 1 MiB, 4096 absent 16-byte needles, one launch   (scan_batched_kernel<4>)
+          text_worst   i386.txt tiled to 1 GiB, letters-only absent phrase, new()
+          text_refpair the same phrase with the reference's pair (0, n-1)
+          text_spaces  ' the quick brown fox ' with the reference's pair (' ', ' ')
+"""
+import json
 import os
 import sys
 
@@ -10,19 +24,72 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
 
-kind, needle = sys.argv[1], eval(sys.argv[2])
-pos = int(sys.argv[3]) if len(sys.argv) > 3 else None
-n_bytes = 1 << 30
-if kind == "random":
-    hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
-    ss.fill_random_device(hay, 0x5EED0001)
-elif kind == "a":
-    hay = torch.full((n_bytes,), 0x61, dtype=torch.uint8, device="cuda")
-else:
-    raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
-    hay = torch.from_numpy(raw.copy()).cuda().repeat(n_bytes // raw.size)
-s = ss.DynamicHipSearcher(needle, pos)
-s.set_timing(True)
-for _ in range(3):
-    r = s.search_in(hay)
-print(kind, needle[:24], pos, "found", r, "ms", round(s.last_kernel_ms(), 4), "GB/s", round(hay.numel() / s.last_kernel_ms() / 1e6, 1))
+SEED_HAY, SEED_NEEDLE = 0x5EED0001, 0x5EED0002
+
+
+def absent(n, seed=SEED_NEEDLE):
+    nd = bytearray(ss.fill_random_host(n, seed).tobytes())
+    nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+    return bytes(nd)
+
+
+def main():
+    case = sys.argv[1]
+    launches = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    n_bytes = 1 << 30
+    out = {"case": case, "launches": launches}
+    if case.startswith("text"):
+        raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
+        hay = torch.from_numpy(raw.copy()).cuda().repeat(n_bytes // raw.size)
+    elif case == "batched":
+        hay = torch.empty(4096 << 20, dtype=torch.uint8, device="cuda")
+        ss.fill_random_device(hay, SEED_HAY)
+    else:
+        hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+        ss.fill_random_device(hay, SEED_HAY)
+    torch.cuda.synchronize()
+    out["algorithmic_bytes_per_launch"] = hay.numel()
+    if case == "batched":
+        count, each = 4096, 1 << 20
+        nd = bytearray(ss.fill_random_host(16 * count, SEED_NEEDLE + 1).tobytes())
+        for i in range(count):
+            nd[16 * i + 8] = 0xFF
+        nblob = torch.from_numpy(np.frombuffer(bytes(nd), dtype=np.uint8).copy()).cuda()
+        hay_off = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
+        nd_off = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        for _ in range(launches):
+            e0.record()
+            found = ss.search_batched(hay, hay_off, nblob, nd_off)
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        assert int(found.sum().item()) == 0
+        out.update(kernel="scan_batched_kernel", ms=round(float(np.median(ms)), 4))
+    else:
+        phrase = b"segment descriptor table entries are"
+        s = {
+            "headline1g": lambda: ss.DynamicHipSearcher.new(absent(16)),
+            "onebyte": lambda: ss.DynamicHipSearcher.new(absent(1)),
+            "mode2": lambda: ss.DynamicHipSearcher.with_position(absent(128), 127),
+            "mode1": lambda: ss.DynamicHipSearcher.with_position(absent(2000), 1999),
+            "long_new": lambda: ss.DynamicHipSearcher.new(absent(2000)),
+            "find": lambda: ss.DynamicHipSearcher.new(absent(16)),
+            "text_worst": lambda: ss.DynamicHipSearcher.new(phrase),
+            "text_refpair": lambda: ss.DynamicHipSearcher.with_position(phrase, len(phrase) - 1),
+            "text_spaces": lambda: ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 20),
+        }[case]()
+        s.set_timing(True)
+        ms = []
+        for _ in range(launches):
+            r = s.find(hay) if case == "find" else s.search_in(hay)
+            ms.append(s.last_kernel_ms())
+        assert r in (False, None), r
+        out.update(kernel="scan_kernel", filter_bytes=list(s.filter3), ms=round(float(np.median(ms)), 4))
+    out["gbps"] = round(hay.numel() / out["ms"] / 1e6, 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
