@@ -124,3 +124,11 @@ def build_native_bench(force=False, verbose=False):
               "-L", _CSRC, "-lsliceslice_hip", "-Wl,-rpath,$ORIGIN/../sliceslice-rs_amd/csrc", "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
         os.replace(tmp, _NATIVE_BENCH)
         return _NATIVE_BENCH
+
+
+def build_ab(name, defines, force=False, verbose=False):
+    """A/B builds of the SAME sources with extra -D flags -> csrc/libsliceslice_hip_<name>.so (tuning only; load
+    with SLICESLICE_HIP_LIB=<path>, see tools/ab_compare.py)."""
+    so = os.path.join(_CSRC, "libsliceslice_hip_%s.so" % name)
+    with _Lock(".build_ab_%s.lock" % name):
+        return _build_variant(so, ".%s.o" % name, ["-D" + d for d in defines], [], force, verbose)

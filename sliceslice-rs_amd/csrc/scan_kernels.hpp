@@ -84,6 +84,12 @@ struct Problem {
     int *host_flag;           // optional pinned-host mirror of the found flag (saves the D2H copy); may be null
     int epoch;                // the value that means "found" in the flag (1 for caller-owned flags; pool slots
                               // use a fresh value per call, so a slot never has to be cleared)
+    // Completion word (small grids of ss_search_device only; both null otherwise): every workgroup counts itself
+    // out on *done_counter; the last one stores 2*epoch + found to the pinned-host word *host_done and re-zeroes the
+    // counter.  The host spins on that word instead of waiting for the stream: one PCIe write instead of the
+    // completion-signal round trip.
+    int *done_counter;
+    long long *host_done;
 };
 
 __device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) { return (x - 0x01010101u) & ~x; }
@@ -121,6 +127,14 @@ __device__ __forceinline__ bool verify_candidate(const Problem &pr, const uint8_
     const uint8_t *h = pr.hay + i;
     const uint64_t n_lds = pr.n < (uint64_t)kNeedleLds ? pr.n : (uint64_t)kNeedleLds;
     uint64_t k = 0;
+    // sixteen bytes per step: the four haystack dwords are loaded together (one memory round trip per 16 bytes
+    // instead of one per 4 - what a true match, whose every byte has to be looked at, is bound by)
+    for (; k + 16 <= n_lds; k += 16) {
+        const uint32_t a0 = reinterpret_cast<const UnalignedU32 *>(h + k)->v, a1 = reinterpret_cast<const UnalignedU32 *>(h + k + 4)->v;
+        const uint32_t a2 = reinterpret_cast<const UnalignedU32 *>(h + k + 8)->v, a3 = reinterpret_cast<const UnalignedU32 *>(h + k + 12)->v;
+        const u32x4 nd = *reinterpret_cast<const u32x4 *>(s_needle + k);
+        if (((a0 ^ nd.x) | (a1 ^ nd.y) | (a2 ^ nd.z) | (a3 ^ nd.w)) != 0) return false;
+    }
     for (; k + 4 <= n_lds; k += 4)
         if (reinterpret_cast<const UnalignedU32 *>(h + k)->v != *reinterpret_cast<const uint32_t *>(s_needle + k))
             return false;
@@ -585,7 +599,11 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     const int wpb = (int)(blockDim.x / kWave);                              // waves per workgroup (launch-time)
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
     bool staged = false, ordered = !LAZY_ORDER;
+#ifdef SS_TWO_BYTE_PHASE1       // A/B builds only (tools/ab_build.py): the round-1 two-byte first phase
+    constexpr bool THREE = false;
+#else
     constexpr bool THREE = MODE == 0 && !ONE_BYTE;                          // three-byte first phase
+#endif
     RefineOrder ro = {pr.norder, {pr.order_idx[0], pr.order_idx[1]}, {pr.order_val[0], pr.order_val[1]}};
     bool dense = false;                                                     // L8: the previous tile had candidates
     const int d = (int)pr.d;                                                // SHIFTED: 1 <= d <= 62
@@ -793,16 +811,39 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             };
             // second-level filter in registers (wave-uniform), up to the first 16 needle bytes, tile-wide
             constexpr bool TILE_WIDE = MODE != 2;
-            if (!ONE_BYTE && TILE_WIDE && !refine_tile<U, MODE>(A, H, ro, G)) continue;
-            if (TILE_WIDE) stage_once();
+            // Which pieces of the tile hold candidates?  With the three-byte first phase a tile that gets here
+            // usually holds ONE (text: a frequent phrase that shares the filter bytes); the second-level filter
+            // then runs on that piece alone instead of on all U - a quarter of the work.  Tiles dense with
+            // candidates (a caller-chosen pair of common bytes) keep the tile-wide form, whose scalar bookkeeping is
+            // paid once per needle byte instead of once per piece and byte.
+            uint32_t pm = (1u << U) - 1;
+            bool per_piece = !TILE_WIDE;
+            if (!ONE_BYTE && TILE_WIDE) {
+                pm = 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (__ballot(((G[u][0] | G[u][1] | G[u][2] | G[u][3]) & 0x80808080u) != 0) != 0) pm |= 1u << u;
+#ifdef SS_NO_SPARSE_REFINE       // A/B builds only
+                per_piece = false;
+#else
+                per_piece = __builtin_popcount(pm) <= 2;
+#endif
+                if (!per_piece) {
+                    if (!refine_tile<U, MODE>(A, H, ro, G)) continue;
+                    stage_once();
+                }
+            }
             bool hit = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t *g = G[u];
-                if (!ONE_BYTE && !TILE_WIDE) {
+                if (!ONE_BYTE && per_piece) {
+                    if (((pm >> u) & 1u) == 0) continue;
                     NextPiece np;
                     np.N = u + 1 < U ? A[u + 1] : H;
-                    np.kind = 1;                                  // MODE 2: the halo chunks sit in lanes 0..d of H
+                    // lane 63's next lane: lane 0 of the next piece (rotated in); after the last piece the halo chunk
+                    // sitting in lane 63 (MODE 0), lanes 0..d of H (MODE 2), or unknown (MODE 1: settled by the compare)
+                    np.kind = u + 1 < U ? 1 : (MODE == 0 ? 0 : (MODE == 2 ? 1 : 2));
                     if (!refine_piece(A[u], np, ro, g)) continue;
                     stage_once();
                 } else if (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) == 0) {
@@ -868,29 +909,47 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
     static_assert((U & (U - 1)) == 0, "U is a power of two");
     const unsigned tile_shift = (unsigned)__builtin_ctz(blockDim.x / kWave) + (unsigned)__builtin_ctz(U);
     uint64_t t0 = tiles_per_block ? (uint64_t)blockIdx.x * tiles_per_block : blockIdx.x;
+    bool skip = false;
     if (blockIdx.x >= kPeekFromBlock) {
+        // a peek hit is confirmed with one coherent load before the workgroup leaves: the scalar cache is not
+        // coherent, and a caller-owned sink (re-armed by the caller, e.g. on every hipGraph replay) has no
+        // epoch that would make a line cached by an earlier launch harmless
         if (FIND) {
             const uint64_t first_chunk = (t0 << tile_shift) * 64;
             const uint64_t first = first_chunk * 16 > pr.mis ? first_chunk * 16 - pr.mis : 0;
-            // a peek hit is confirmed with one coherent load before the workgroup leaves: the scalar cache is not
-            // coherent, and a caller-owned sink (re-armed by the caller, e.g. on every hipGraph replay) has no
-            // epoch that would make a line cached by an earlier launch harmless
-            if (scalar_peek64(static_cast<const uint64_t *>(found)) <= pr.find_base + first &&
-                uniform64(__hip_atomic_load(static_cast<const uint64_t *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <=
-                    pr.find_base + first)
-                return;
-        } else if (scalar_peek(static_cast<const int *>(found)) == pr.epoch && poll_found(static_cast<const int *>(found), pr.epoch)) {
-            return;
+            skip = scalar_peek64(static_cast<const uint64_t *>(found)) <= pr.find_base + first &&
+                   uniform64(__hip_atomic_load(static_cast<const uint64_t *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <=
+                       pr.find_base + first;
+        } else {
+            skip = scalar_peek(static_cast<const int *>(found)) == pr.epoch && poll_found(static_cast<const int *>(found), pr.epoch);
         }
     }
-    const uint64_t ntiles = (pr.npieces + ((uint64_t)1 << tile_shift) - 1) >> tile_shift;
-    // one call site (one copy of the code): contiguous run, or grid-stride when tiles_per_block == 0
-    uint64_t step = gridDim.x, t1 = ntiles;
-    if (tiles_per_block) {
-        step = 1;
-        t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+    if (!skip) {
+        const uint64_t ntiles = (pr.npieces + ((uint64_t)1 << tile_shift) - 1) >> tile_shift;
+        // one call site (one copy of the code): contiguous run, or grid-stride when tiles_per_block == 0
+        uint64_t step = gridDim.x, t1 = ntiles;
+        if (tiles_per_block) {
+            step = 1;
+            t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+        }
+        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
     }
-    scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
+    if (!FIND && pr.done_counter != nullptr) {
+        // Completion word.  Every wave of the workgroup is past its last read of the haystack at the barrier; one lane
+        // counts the workgroup out.  The count is relaxed: whoever set the found flag did so with an atomic exchange whose
+        // result it waited for before it got here, and the last workgroup reads the flag with an atomic load - both
+        // performed at the L2, the agent's point of coherence - behind an acquire fence.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(pr.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (int)gridDim.x - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int f = __hip_atomic_load(static_cast<const int *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pr.epoch;
+                __hip_atomic_store(pr.done_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pr.host_done, 2ll * pr.epoch + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 #ifdef SS_MISC_KERNELS   // only the API translation unit (sliceslice_hip.hip) compiles what follows
@@ -983,6 +1042,8 @@ __global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
     pr.find_base = 0;
     pr.host_flag = nullptr;
     pr.epoch = 1;
+    pr.done_counter = nullptr;
+    pr.host_done = nullptr;
 
     if (n == 1) {
         scan_tiles<0, 0, true, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found);

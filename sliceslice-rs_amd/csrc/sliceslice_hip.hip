@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <condition_variable>
 #include <cstdarg>
@@ -84,6 +85,8 @@ struct PerDevice {
     int *h_flags = nullptr;     // pinned-host mirror written by the finding wave (no D2H copy per call)
     uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
     uint64_t *h_best = nullptr; // pinned mirror
+    int *d_done = nullptr;      // kSlots wave counters of the completion word (zero whenever a slot is free)
+    long long *h_done = nullptr;// pinned: 2*epoch + found, stored by the last wave of a small grid
     uint64_t free_mask = 0;
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
 };
@@ -157,7 +160,12 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         memset(p.h_flags, 0, kSlots * sizeof(int));   // pinned memory is recycled: a stale value must not equal an epoch
         if ((e = hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
         if ((e = hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
-        return hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault);
+        if ((e = hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&p.d_done, kSlots * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMemset(p.d_done, 0, kSlots * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void **)&p.h_done, kSlots * sizeof(long long), hipHostMallocDefault)) != hipSuccess) return e;
+        memset(p.h_done, 0, kSlots * sizeof(long long));
+        return hipSuccess;
     };
     const hipError_t e = alloc();
     if (e != hipSuccess) {                             // nothing half-built is left behind
@@ -166,6 +174,8 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         (void)hipHostFree(p.h_flags);
         (void)hipFree(p.d_best);
         (void)hipHostFree(p.h_best);
+        (void)hipFree(p.d_done);
+        (void)hipHostFree(p.h_done);
         return fail(e == hipErrorNoDevice ? SS_ERR_NO_DEVICE : (e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP),
                     "per-device setup: %s", hipGetErrorString(e));
     }
@@ -191,7 +201,9 @@ int next_epoch(PerDevice *p, int k)
     if (p->epoch[k] >= INT_MAX - 1 || p->epoch[k] < 0) {
         (void)hipDeviceSynchronize();
         (void)hipMemset(p->d_flags + k, 0, sizeof(int));
+        (void)hipMemset(p->d_done + k, 0, sizeof(int));
         p->h_flags[k] = 0;
+        p->h_done[k] = 0;
         p->epoch[k] = 0;
     }
     return ++p->epoch[k];
@@ -282,8 +294,14 @@ void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, OR-ed
 // (0 -> 1), never cleared.  find == true: *d_sink is a uint64, atomicMin'ed with find_base + offset of
 // every match the grid sees (the leftmost one survives).  Preconditions: 1 <= n <= len.
+// done_slot >= 0: the call owns flag slot `done_slot` and would like to wait on the slot's completion word
+// instead of the stream; granted (*used_done = true) for grids of at most kDoneMaxBlocks workgroups.
+constexpr uint64_t kDoneMaxBlocks = 256;         // one atomic per workgroup on ONE address: small grids only (4 MiB);
+                                                 // measured: 1 KiB 8.6 vs 11.9 us per call, break-even near 1 MiB
+
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st,
-                 void *d_sink, bool find = false, uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1)
+                 void *d_sink, bool find = false, uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1,
+                 int done_slot = -1, bool *used_done = nullptr)
 {
     void *d_flag = d_sink;
     ss::Problem pr;
@@ -321,6 +339,8 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.find_base = find_base;
     pr.host_flag = host_flag;
     pr.epoch = epoch;
+    pr.done_counter = nullptr;
+    pr.host_done = nullptr;
 
     const Launch l = pick_variant(s->variant, pr.d, one_byte, position);
     const uint64_t wpb = l.block / ss::kWave;
@@ -356,6 +376,13 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     }
     if (blocks < 1) blocks = 1;
     const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
+    if (used_done) *used_done = false;
+    if (!find && done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks) {
+        pr.done_counter = pd->d_done + done_slot;
+        pr.host_done = pd->h_done + done_slot;
+        pr.host_flag = nullptr;                          // the completion word carries the answer
+        *used_done = true;
+    }
 
     ThreadTimer &tm = g_timer;
     const bool timed = s->timing && pd->dev >= 0 && pd->dev < kMaxDevices;
@@ -583,6 +610,8 @@ void ss_searcher_free(ss_searcher *s)
         (void)hipHostFree(p.h_flags);
         (void)hipFree(p.d_best);
         (void)hipHostFree(p.h_best);
+        (void)hipFree(p.d_done);
+        (void)hipHostFree(p.h_done);
     }
     (void)hipSetDevice(cur);
     if (g_timer.owner == s) g_timer.owner = nullptr;
@@ -666,13 +695,41 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     // early exit) AND to its pinned-host mirror, so the answer needs neither a device-to-host copy nor a
     // reset of the slot afterwards: launch, wait for the stream, compare.
     const int epoch = next_epoch(pd, k);                // the slot is owned by this call
-    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch);
-    if (rc == SS_OK) {
+    static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
+    bool used_done = false;
+    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch, spin_ok ? k : -1,
+                          &used_done);
+    bool answered = false;
+    if (rc == SS_OK && used_done) {
+        // Small grid: the last wave of the kernel stores 2*epoch + found to the slot's pinned word.  Spin on it for a
+        // bounded time (the whole call is a few microseconds); after that - a long kernel behind other work on the
+        // stream, or a fault - fall back to the stream wait, which also reports errors.
+        const long long want = 2ll * epoch;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            const long long v = __atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE);
+            if ((v >> 1) == (want >> 1)) {
+                *found = (int)(v & 1);
+                answered = true;
+                // every 256th call still waits for the stream, so that the runtime retires its completed commands
+                // in bounded batches instead of whenever the caller next synchronises
+                if ((epoch & 255) == 0) (void)hipStreamSynchronize(st);
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+        }
+    }
+    if (rc == SS_OK && !answered) {
         const hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(SS_ERR_HIP, "stream wait: %s", hipGetErrorString(e));
+        else if (used_done) *found = (int)(__atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE) == 2ll * epoch + 1);
+        else *found = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
     }
-    if (rc == SS_OK) *found = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
-    else (void)hipDeviceSynchronize();
+    if (rc != SS_OK) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(pd->d_done + k, 0, sizeof(int));     // a failed launch may have left the wave count behind
+    }
     release_slot(s, pd, k);
     return rc;
 }

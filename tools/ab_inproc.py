@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""In-process A/B of library builds: every build is dlopen()ed (RTLD_LOCAL) into ONE process and scans the SAME
+device buffer, launches interleaved build by build - haystack placement, clocks and box are identical, so
+differences of a percent are visible (separate processes differ by +-2 % from placement alone).
+    python tools/ab_inproc.py --libs cur=...so two=...so --gib 8 --cases n16,n1,tworst"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from settle import wait_for_vram_reclaim  # noqa: E402
+
+vp, sz = ctypes.c_void_p, ctypes.c_size_t
+
+
+def load(path):
+    L = ctypes.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    L.ss_searcher_new.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.ss_search_device.argtypes = [vp, vp, sz, vp, ctypes.POINTER(ctypes.c_int)]
+    L.ss_searcher_set_timing.argtypes = [vp, ctypes.c_int]
+    L.ss_searcher_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    L.ss_searcher_free.argtypes = [vp]
+    L.ss_fill_random_device.argtypes = [vp, ctypes.c_uint64, sz, ctypes.c_uint64, vp]
+    L.ss_fill_random_host.argtypes = [vp, ctypes.c_uint64, sz, ctypes.c_uint64]
+    L.ss_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--libs", nargs="+", required=True)
+    ap.add_argument("--gib", type=float, default=8.0)
+    ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--cases", default="n16,n1,n2000,tworst,tspaces")
+    args = ap.parse_args()
+    wait_for_vram_reclaim()
+    libs = [(l.split("=", 1)[0], load(l.split("=", 1)[1])) for l in args.libs]
+    n_bytes = int(args.gib * (1 << 30))
+    hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    assert libs[0][1].ss_fill_random_device(hay.data_ptr(), 0, n_bytes, 0x5EED0001, None) == 0
+    torch.cuda.synchronize()
+    text = None
+
+    def absent(n):
+        a = np.empty(n, dtype=np.uint8)
+        libs[0][1].ss_fill_random_host(a.ctypes.data, 0, n, 0x5EED0002)
+        a[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+        return a.tobytes()
+    table = {}
+    for c in args.cases.split(","):
+        if c.startswith("n"):
+            nd, h = absent(int(c[1:])), hay
+        else:
+            if text is None:
+                raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
+                text = torch.from_numpy(raw.copy()).cuda().repeat((1 << 30) // raw.size)
+            nd = {"tworst": b"segment descriptor table entries are", "tspaces": b" the quick brown fox ", "tpriv": b"privilege level zero!",
+                  "tcommon": b"there is not another one of these", "tmid": b"protection exception handler must"}[c]
+            h = text
+        hs = []
+        for name, L in libs:
+            s = vp()
+            assert L.ss_searcher_new(nd, len(nd), ctypes.byref(s)) == 0, L.ss_last_error()
+            L.ss_searcher_set_timing(s, 1)
+            hs.append((name, L, s))
+        found, ms = ctypes.c_int(0), ctypes.c_float(0)
+        t_end = time.perf_counter() + 0.2
+        while time.perf_counter() < t_end:
+            for name, L, s in hs:
+                L.ss_search_device(s, h.data_ptr(), h.numel(), None, ctypes.byref(found))
+        acc = {name: [] for name, _, _ in hs}
+        for r in range(args.rounds):
+            for name, L, s in hs:
+                for _ in range(args.reps):
+                    assert L.ss_search_device(s, h.data_ptr(), h.numel(), None, ctypes.byref(found)) == 0
+                    L.ss_searcher_last_kernel_ms(s, ctypes.byref(ms))
+                    acc[name].append(ms.value)
+        row = {name: round(h.numel() / statistics.median(v) / 1e6, 1) for name, v in acc.items()}
+        table[c] = row
+        print(json.dumps({"case": c, "found": found.value, "gbps": row}), flush=True)
+        for name, L, s in hs:
+            L.ss_searcher_free(s)
+    print(json.dumps({"median_gbps": table}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
