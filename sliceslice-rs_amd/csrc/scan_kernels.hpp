@@ -9,29 +9,28 @@
 //     Every load is an aligned chunk that contains at least one in-range byte, so no load can cross
 //     into an unmapped page (the guarantee the reference gets from its overlapped tail chunk,
 //     lib.rs:276-284).  Pieces do not overlap: HBM traffic == haystack bytes (+16 B per wave-tile).
-//   * the "first byte" filter (hay[i] == needle[0]) and the "position byte" filter
-//     (hay[i+position] == needle[position]) work on byte DIFFERENCES, 4 bytes per VALU op:
-//     A ^ splat(needle[0]) has a zero byte where the first byte matches, B ^ splat(needle[position]) where
-//     the position byte matches; the latter is moved `position` bytes down the stream and OR-ed onto the
-//     former, and ONE zero-byte test  z(x) = (x - 0x01010101) & ~x  per dword flags the offsets at which
-//     both match (bit 7 of every zero byte of x is set; it can also flag a 0x01 byte sitting above a zero
-//     byte - a false POSITIVE only, and candidates are verified, so the boolean is unaffected).
-//   * position = 16*d + 4*Q + r.  The position-byte differences of lane l's candidates live in the
-//     dwords of chunk c+d (and c+d+1): for d == 0 (position < 16 - every needle of <= 16 bytes) that is the
-//     lane's own chunk, the chunk c+1 part comes from the neighbouring lane with one DPP wave_shl:1 per
-//     dword, Q selects the dword window at compile time and r is a v_alignbyte_b32.
+//   * the filter works on byte DIFFERENCES, 4 bytes per VALU op: A ^ splat(b) has a zero byte where the haystack byte
+//     equals needle byte b.  The differences of the further filter bytes are moved down the stream by their distance
+//     from the first filter byte and OR-ed onto the first byte's differences, and ONE zero-byte test
+//     z(x) = (x - 0x01010101) & ~x  per dword flags the offsets at which ALL of them match (bit 7 of every zero
+//     byte of x is set; it can also flag a 0x01 byte sitting above a zero byte - a false POSITIVE only, and
+//     candidates are verified, so the boolean is unaffected).
+//   * distance of the second filter byte = 16*d + 4*Q + r.  d == 0 (MODE 0: what `new` always picks, and every
+//     with_position(p < 16)): THREE filter bytes.  The raw dwords of the next lane's chunk are moved once (DPP
+//     wave_shl:1; the xor commutes with the move), Q selects the second byte's dword window at compile time, the
+//     third byte's window is wave-uniform run-time data, the byte parts are v_alignbyte_b32.
 //   * lane 63's neighbour is lane 0 of the NEXT piece.  A wave owns U consecutive pieces, so that is a
 //     register of the same wave (one DPP wave_rol:1 feeds it in as the `old` operand of the wave_shl);
 //     after the wave's last piece it is a single 16-byte halo chunk loaded by lane 63 alone.
-//   * position >= 16 (d > 0): MODE 2 keeps ONE non-temporal load stream and fetches the position-byte
-//     differences from the lane that owns chunk c+d with ds_bpermute (d <= 62); MODE 1 (larger d) issues a
-//     second, plain load stream at +d chunks.
+//   * d > 0 (with_position >= 16), two filter bytes: MODE 2 keeps ONE non-temporal load stream and fetches the
+//     position-byte differences from the lane that owns chunk c+d with ds_bpermute (d <= 62); MODE 1 (larger d)
+//     issues a second, plain load stream at +d chunks.
 //   * a tile (U pieces per wave) is filtered in one straight-line phase; `__ballot(any flag)` is the wave's
-//     movemask: zero (2^-16 per offset on random bytes) -> next tile.  Otherwise a second-level filter
-//     clears the flags where one of up to 15 more needle bytes differs, rarest byte first, still in
-//     registers, with a ballot after each byte; what survives is walked lowest-first (`__ffs`, clear lowest
-//     set bit - lib.rs:220-247) and compared with the needle - staged in LDS by the wave the first time it
-//     gets here - four bytes per step; the first equal candidate sets the found flag (lib.rs:242-244).
+//     movemask: zero -> next tile.  Otherwise a second-level filter clears the flags where one of the remaining
+//     bytes of the 16 behind the first filter byte differs, rarest byte first, still in registers, with a ballot
+//     after each byte - on the one or two pieces that hold candidates, or tile-wide when most do.  A wave that STILL
+//     has a candidate stages the needle in LDS, walks its flags lowest-first (`__ffs`, clear lowest set bit -
+//     lib.rs:220-247) and compares 16 bytes per step; the first equal candidate sets the found flag (lib.rs:242-244).
 //   * workgroups are short-lived (one or two tiles each): the hardware dispatcher hands out tiles in address
 //     order.  Every workgroup but the first few peeks at the found flag through the scalar cache before it
 //     loads anything, and every tile polls it coherently behind its data loads, so a hit stops the grid

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01", "bench64g.json")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r02", "bench64g.json")) as fh:
         d = json.loads(fh.read())
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
@@ -22,6 +22,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["traffic"] is None or r["traffic"] >= 0.99 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "GB/s" and c["cores"] >= 1 and "sample" in c and c["value"] > 0
+    assert c["cores"] == c["threads_used"] <= c["host_hardware_threads"] and c["host_physical_cores"] >= 1
+    assert r["traffic_source"].startswith("stored ratio") and d["config"]["ranks"] == d["n_gpus"] == 1
     # whole-job value and kernel-only roofline agree within the launch/sync overhead
     assert 0.9 * r["achieved"] <= d["value"] <= 1.001 * r["achieved"]
 

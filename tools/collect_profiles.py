@@ -56,3 +56,21 @@ with open(os.path.join(dst, "bench64g_pmc_sq.csv"), "w", newline="") as fh:
 ks = [r for r in csv.DictReader(open(os.path.join(dst, "bench64g_kernel_stats.csv"))) if "scan_kernel" in r["Name"]]
 print("traffic/haystack", round(traffic / hay, 4), "| bench value", bench["value"], "kernel_ms_avg", bench["roofline"]["kernel_ms_avg"],
       "| rocprof avg ns", ks[0]["AverageNs"] if ks else None, "calls", ks[0]["Calls"] if ks else None)
+
+# rocprofv3's own durations of the TIMED launches (the last `steps` scan launches of the traced command) next to the
+# hipEvent average bench.py printed in that same command
+try:
+    under = json.load(open(os.path.join(dst, "bench64g_under_rocprofv3.json")))
+    tr = [r for r in csv.DictReader(open(os.path.join(src, f"{tag}_kt", "r_kernel_trace.csv"))) if "scan_kernel" in r["Kernel_Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    last = tr[-under["steps"]:]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in last]
+    agree = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs",
+             "rocprofv3_avg_ms_of_the_timed_launches": round(sum(durs) / len(durs), 4), "launches": len(durs),
+             "rocprofv3_avg_ms_all_launches_incl_warmup": round(float(ks[0]["AverageNs"]) / 1e6, 4) if ks else None,
+             "bench_hipevent_kernel_ms_avg": under["roofline"]["kernel_ms_avg"],
+             "achieved_gbps_from_rocprofv3": round(hay / (sum(durs) / len(durs)) / 1e6, 1)}
+    json.dump(agree, open(os.path.join(dst, "rocprof_vs_hipevents.json"), "w"), indent=1)
+    print(agree)
+except Exception as e:
+    print("agreement file not written:", e)
