@@ -105,6 +105,21 @@ def build_sanitized(force=False, verbose=False):
         return _build_variant(so, ".asan.o", _SAN_FLAGS, ["-fsanitize=address,undefined", "-shared-libsan"], force, verbose)
 
 
+_TSAN_FLAGS = ["-fsanitize=thread", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+def build_tsan(force=False, verbose=False):
+    """ThreadSanitizer build of the host code -> csrc/libsliceslice_hip_tsan.so (tests/test_gpu_native.py)."""
+    so = os.path.join(_CSRC, "libsliceslice_hip_tsan.so")
+    with _Lock(".build_tsan.lock"):
+        return _build_variant(so, ".tsan.o", _TSAN_FLAGS, ["-fsanitize=thread", "-shared-libsan"], force, verbose)
+
+
+def tsan_runtime():
+    out = subprocess.check_output([_hipcc(), "-print-file-name=libclang_rt.tsan-x86_64.so"], text=True).strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
 def asan_runtime():
     """Path of the clang ASan runtime that build_sanitized() links against (to LD_PRELOAD into python)."""
     out = subprocess.check_output([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()

@@ -91,3 +91,26 @@ def test_native_bench_modes():
     out = subprocess.run([exe, "headline", "1", "3"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert json.loads(out.stdout.strip().splitlines()[-1])["found"] == 0
+
+
+def test_host_library_stress_under_tsan(tmp_path):
+    """ThreadSanitizer build of the library's host code under the same stress.  The HIP / HSA runtimes are not
+    instrumented, so races TSan reports INSIDE them (their own allocator and queue bookkeeping, seen without their
+    synchronisation) are suppressed by library name; anything else - a racing access in this library or in the
+    test - fails the test."""
+    import sys
+    import sliceslice_rs_amd as ss
+    b = sys.modules["sliceslice_rs_amd._build"]
+    so = b.build_tsan()
+    rt = b.tsan_runtime()
+    assert rt, "clang TSan runtime not found"
+    exe = str(tmp_path / "host_stress_test_tsan")
+    _build_native(os.path.join(ROOT, "tests", "native", "host_stress_test.cpp"), exe, so,
+                  ["-fsanitize=thread", "-fno-gpu-sanitize", "-shared-libsan", "-g", "-Wl,-rpath," + os.path.dirname(rt)])
+    supp = tmp_path / "tsan.supp"
+    supp.write_text("race:libamdhip64.so\nrace:libhsa-runtime64.so\nrace:librccl.so\n")
+    env = dict(os.environ, TSAN_OPTIONS="suppressions=%s:halt_on_error=0:report_signal_unsafe=0:exitcode=66" % supp)
+    out = subprocess.run([exe, "48"], capture_output=True, text=True, timeout=1800, env=env)
+    assert "host_stress_test ok" in out.stdout, out.stdout[-2000:] + out.stderr[-6000:]
+    assert "WARNING: ThreadSanitizer" not in out.stderr, out.stderr[-8000:]
+    assert out.returncode == 0, out.stderr[-4000:]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test on the GPU: search_in / find through the C ABI against Python's bytes.find over
-random (haystack kind, length, misalignment, needle, position, kernel variant, launch shape).  Runs for
+random (haystack kind, length, misalignment, needle, position or filter triple, kernel variant, launch shape).  Runs for
 argv[1] seconds (default 60) with seed argv[2]; a third argument (GiB) selects the large-haystack mode.  Prints a
 JSON summary, exits non-zero on the first mismatch."""
 import json
@@ -41,6 +41,22 @@ def make_haystack(rng, n_bytes):
     return kind, a
 
 
+def random_filter(rng, s, n):
+    """A third of the searchers get a random filter pair / triple instead of what the constructor picked."""
+    if n < 2 or rng.random() < 0.66:
+        return None
+    a = rng.randrange(n - 1) if rng.random() < 0.7 else 0
+    near = rng.random() < 0.7
+    b = rng.randrange(a + 1, min(n, a + 16)) if near else rng.randrange(a, n)
+    c = None
+    if n >= 3 and 0 < b - a <= 15 and rng.random() < 0.7:
+        c = rng.randrange(a + 1, min(n, a + 16))
+        if c == b:
+            c = None
+    s.set_filter(a, b, c)
+    return s.filter3
+
+
 def big(seconds, seed, gib):
     """Large haystacks (two-tile workgroups, entry peek, early exit): the same needle planted at several random
     offsets of a random haystack; find must return the leftmost, search_in true; then every copy is destroyed
@@ -66,6 +82,7 @@ def big(seconds, seed, gib):
             hay[o:o + n] = t
         pos = None if rng.random() < 0.5 else (0 if n == 1 else rng.randrange(n))
         s = ss.DynamicHipSearcher(nd, pos)
+        flt = random_filter(rng, s, n)
         s.set_variant(rng.choice([0, 0, 41, 141, 241, 1041]))
         s.set_grid(rng.choice([0, 0, 0, -1, -2, -5, 8192]))
         got_b, got_p = s.search_in(hay), s.find(hay)
@@ -74,7 +91,7 @@ def big(seconds, seed, gib):
         absent_b, absent_p = s.search_in(hay), s.find(hay)
         rounds += 1
         if got_b is not True or got_p != offs[0] or absent_b is not False or absent_p is not None:
-            print(json.dumps({"MISMATCH": True, "mode": "big", "needle_len": n, "position": pos, "planted": offs,
+            print(json.dumps({"MISMATCH": True, "mode": "big", "needle_len": n, "position": pos, "filter": flt, "planted": offs,
                               "search_in": got_b, "find": got_p, "after_restore": [absent_b, absent_p], "seed": seed}))
             sys.exit(1)
     print(json.dumps({"fuzz": "ok", "mode": "big", "gib": gib, "seconds": seconds, "seed": seed, "rounds": rounds,
@@ -114,6 +131,7 @@ def main():
             pos = None if rng.random() < 0.5 else (0 if n == 1 else rng.randrange(n))
             want = hb.find(nd)
             s = ss.DynamicHipSearcher(nd, pos)
+            flt = random_filter(rng, s, n)
             s.set_variant(rng.choice(VARIANTS))
             s.set_grid(rng.choice(GRIDS))
             got_b = s.search_in(hay)
@@ -121,7 +139,7 @@ def main():
             got_p = s.find(hay)
             searches += 2
             if got_b != (want >= 0) or got_p != (want if want >= 0 else None):
-                print(json.dumps({"MISMATCH": True, "kind": kind, "len": n_bytes, "mis": mis, "needle_len": n, "position": pos,
+                print(json.dumps({"MISMATCH": True, "kind": kind, "len": n_bytes, "mis": mis, "needle_len": n, "position": pos, "filter": flt,
                                   "want": want, "search_in": got_b, "find": got_p, "seed": seed, "case": cases}))
                 sys.exit(1)
     print(json.dumps({"fuzz": "ok", "seconds": seconds, "seed": seed, "haystacks": cases, "searches": searches}))
