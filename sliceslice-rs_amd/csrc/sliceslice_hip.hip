@@ -246,28 +246,41 @@ constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 constexpr uint64_t kShiftMaxD = 62;      // d + 1 halo chunks must fit one piece (tools/tune.py: wins up to d = 62)
 
-Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
+// Unused dynamic LDS that leaves room for exactly `occ` workgroups of `block` threads per CU (160 KiB of LDS).
+uint32_t occupancy_pad(int occ, unsigned block)
+{
+    const uint32_t per = (160u * 1024u) / (uint32_t)occ;
+    const uint32_t fixed = (block / ss::kWave) * ss::kNeedleLds;
+    uint32_t pad = per > fixed + 1024 ? ((per - fixed) & ~1023u) : 0;
+    if (pad > 64u * 1024u - fixed) pad = 64u * 1024u - fixed;
+    return pad;
+}
+
+// Workgroups per CU.  The three-byte kernels need 121 VGPRs, which caps them at four workgroups of four waves per CU
+// by itself.  The one-byte kernel (8-byte loads, 70 VGPRs) would fit seven; capped at four through unused LDS it is
+// 1 % faster at every size from 2 GiB (64 GiB 7.45-7.47 vs 7.36-7.40 TB/s, in one process on one buffer:
+// profiles/r02/occupancy_by_size.jsonl).  The same file has the experiment for a 95-VGPR build of the three-byte
+// kernel: five workgroups per CU are 1-5 % SLOWER than four up to 8 GiB and 0.6 % faster from 16 GiB.
+Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position, uint64_t len)
 {
     Launch l;
     l.U = kAutoU;
     l.mode = d == 0 ? 0 : (d <= kShiftMaxD ? 2 : 1);
     l.nt = l.mode == 1 ? 0 : 1;
     l.l8 = one_byte;
-    l.dyn_lds = 0;
     l.block = ss::kBlock;
+    l.dyn_lds = one_byte ? occupancy_pad(4, l.block) : 0;
+    (void)len;
     (void)position;
     if (variant > 0) {
+        l.dyn_lds = 0;
         if (variant >= 100000) {                                // Bxxxxx: workgroup size
             const int b = variant / 100000;
             l.block = b == 1 ? 128 : (b == 3 ? 512 : 256);
             variant %= 100000;
         }
         if (variant >= 10000) {                                 // OCCxxxx: at most OCC workgroups per CU (160 KiB LDS)
-            const int occ = variant / 10000;
-            const uint32_t per = (160u * 1024u) / (uint32_t)occ;
-            const uint32_t fixed = (l.block / ss::kWave) * ss::kNeedleLds;
-            l.dyn_lds = per > fixed + 1024 ? ((per - fixed) & ~1023u) : 0;
-            if (l.dyn_lds > 64u * 1024u - fixed) l.dyn_lds = 64u * 1024u - fixed;
+            l.dyn_lds = occupancy_pad(variant / 10000, l.block);
             variant %= 10000;
         }
         if (variant >= 1000) l.l8 = variant / 1000 == 2;       // 1xxx: 16-byte layout, 2xxx: 8-byte first phase
@@ -342,7 +355,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.done_counter = nullptr;
     pr.host_done = nullptr;
 
-    const Launch l = pick_variant(s->variant, pr.d, one_byte, position);
+    const Launch l = pick_variant(s->variant, pr.d, one_byte, position, (uint64_t)len);
     const uint64_t wpb = l.block / ss::kWave;
     const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
     uint64_t blocks, tpb;

@@ -44,7 +44,13 @@ def main():
     ap.add_argument("--cases", default="n16,n1,n2000,tworst,tspaces")
     args = ap.parse_args()
     wait_for_vram_reclaim()
-    libs = [(l.split("=", 1)[0], load(l.split("=", 1)[1])) for l in args.libs]
+    # name=path[@variant]: the same build can appear twice with different kernel-variant overrides
+    libs, variants = [], {}
+    for l in args.libs:
+        name, rest = l.split("=", 1)
+        path, _, var = rest.partition("@")
+        libs.append((name, load(path)))
+        variants[name] = int(var) if var else 0
     n_bytes = int(args.gib * (1 << 30))
     hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
     assert libs[0][1].ss_fill_random_device(hay.data_ptr(), 0, n_bytes, 0x5EED0001, None) == 0
@@ -72,6 +78,9 @@ def main():
             s = vp()
             assert L.ss_searcher_new(nd, len(nd), ctypes.byref(s)) == 0, L.ss_last_error()
             L.ss_searcher_set_timing(s, 1)
+            if variants[name]:
+                L.ss_searcher_set_variant.argtypes = [vp, ctypes.c_int]
+                assert L.ss_searcher_set_variant(s, variants[name]) == 0
             hs.append((name, L, s))
         found, ms = ctypes.c_int(0), ctypes.c_float(0)
         t_end = time.perf_counter() + 0.2
