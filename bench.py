@@ -282,15 +282,19 @@ def other_configs(ss, shard, reps=10):
     return out
 
 
-def native_measurements(ss):
-    """tools/native_bench (C ABI + HIP runtime only): per-call latencies and the config-1 per-needle loop."""
+def native_measurements(ss, headline_gib=None):
+    """tools/native_bench (C ABI + HIP runtime only, no Python or torch in the process): per-call latencies, the
+    config-1 per-needle loop and - when there is room for a second haystack - the headline measurement itself."""
     import subprocess
     out = {}
     try:
         exe = sys.modules["sliceslice_rs_amd._build"].build_native_bench()
         gd = os.path.join(ROOT, "tests", "golden", "data")
-        for key, cmd in (("latency_us", [exe, "latency", "1000"]),
-                         ("1", [exe, "config1", os.path.join(gd, "i386.txt"), os.path.join(gd, "words.txt"), "3"])):
+        jobs = [("latency_us", [exe, "latency", "1000"]),
+                ("1", [exe, "config1", os.path.join(gd, "i386.txt"), os.path.join(gd, "words.txt"), "3"])]
+        if headline_gib:
+            jobs.append(("headline_native", [exe, "headline", "%g" % headline_gib, "10"]))
+        for key, cmd in jobs:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             out[key] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:], "rc": r.returncode}
@@ -413,8 +417,19 @@ def main():
     needle = absent_needle(ss, n)
 
     rccl_ranks = None
+    transport_note = None
     if dist is not None:
-        searcher = ss.ShardedSearcher(needle, group=None, backend=transport)
+        try:
+            searcher = ss.ShardedSearcher(needle, group=None, backend=transport)
+        except ss.SlicesliceError as e:
+            # the native communicator could not be built (librccl not loadable, ncclCommInitRank refused): every rank
+            # sees the same failure, so all of them fall back to torch.distributed for the 4-byte flag - and say so
+            if transport != "rccl":
+                raise
+            transport_note = "native RCCL transport failed (%s); flag moved by torch.distributed instead" % e
+            log("bench.py: " + transport_note)
+            transport = "torch"
+            searcher = ss.ShardedSearcher(needle, group=None, backend=transport)
         inner = searcher._searcher
         rccl_ranks = searcher.rccl_ranks()                     # ncclCommCount of the native communicator
         if transport == "rccl" and rccl_ranks != world:
@@ -482,6 +497,7 @@ def main():
                 "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n, "filter_bytes": [fa, fb, fc],
                 "ranks": dist.get_world_size() if dist is not None else 1, "rccl_ranks": rccl_ranks,
                 "transport": (transport if backend == "nccl" or transport == "rccl" else transport + " over " + backend) if dist is not None else "none",
+                "transport_note": transport_note,
                 "launcher": os.environ.get("SS_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
                 "devices_visible": torch.cuda.device_count(), "ranks_share_one_gpu": bool(share and world > 1),
                 "variant": args.variant,
@@ -500,9 +516,11 @@ def main():
             out["roofline"]["read_ceiling_gbps"] = round(ceiling, 2)
         if world == 1 and not args.no_configs:
             cfg = other_configs(ss, shard)
-            cfg.update(native_measurements(ss))
+            room = torch.cuda.mem_get_info()[0] > total + (8 << 30)          # a second haystack of the same size fits
+            cfg.update(native_measurements(ss, total / (1 << 30) if room else None))
             cfg["note"] = ("untimed extras of the N = 1 run; the headline fields above are config 2/4's shape.  3 and 5: kernel "
-                           "GB/s by hipEvents; 1 and latency_us: tools/native_bench (C ABI only, no Python in the loop)")
+                           "GB/s by hipEvents; 1, latency_us and headline_native (the headline workload once more, in a process "
+                           "without Python or torch): tools/native_bench (C ABI only)")
             out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:
             del shard
