@@ -5,6 +5,7 @@
 //   native_bench headline [GiB=64] [steps=20]     the headline measurement (synthetic haystack, 16-byte absent needle)
 //   native_bench latency  [calls=2000]            per-call microseconds of ss_search_device / ss_find_device /
 //                                                 ss_search_host on 1 KiB, 64 KiB, 1 MiB, 16 MiB haystacks
+//   native_bench sharded  [GiB=8] [steps=50]      the multi-GPU entry points on every visible GPU: per-search overhead
 //   native_bench config1  <i386.txt> <words.txt> [iters=5]
 //        BASELINE.json configs[0] on the GPU: one ss_search_device call per needle over the resident text - the
 //        literal drop-in shape of bench/benches/i386.rs:246-256 - next to ONE ss_search_batched launch.
@@ -244,6 +245,78 @@ static int config1(const char *hay_path, const char *words_path, int iters)
     return (hits == W && bhits == W) ? 0 : 1;           // every word of words.txt occurs in i386.txt (tests/i386.rs:61-70)
 }
 
+// Per-search overhead of the multi-GPU entry points on however many GPUs are visible (one on the test box): the same
+// shard through ss_search_device, ss_search_sharded (one process per GPU; here a communicator of ONE rank) and
+// ss_search_sharded_all (one process, all visible devices; RCCL combine and host combine).  wall - kernel = what the
+// launch, the all-reduce, the read-back and the stream waits cost per search.
+static int sharded(double gib, int steps)
+{
+    int ndev = 0;
+    HK(hipGetDeviceCount(&ndev));
+    if (ndev > 8) ndev = 8;
+    const size_t total = (size_t)(gib * (double)(1ull << 30));
+    uint8_t needle[16];
+    CK(ss_fill_random_host(needle, 0, 16, 0x5EED0002ull));
+    needle[8] = 0xFF;
+    ss_searcher *s = nullptr;
+    CK(ss_searcher_new(needle, 16, &s));
+    CK(ss_searcher_set_timing(s, 1));
+    std::vector<void *> bufs(ndev);
+    std::vector<const void *> shards(ndev);
+    std::vector<size_t> lens(ndev);
+    for (int g = 0; g < ndev; ++g) {
+        size_t b = 0, e = 0;
+        CK(ss_shard_range(total, 16, ndev, g, &b, &e));
+        HK(hipSetDevice(g));
+        HK(hipMalloc(&bufs[g], e - b));
+        CK(ss_fill_random_device(bufs[g], b, e - b, 0x5EED0001ull, nullptr));
+        HK(hipDeviceSynchronize());
+        shards[g] = bufs[g];
+        lens[g] = e - b;
+    }
+    HK(hipSetDevice(0));
+    ss_comm_set *set = nullptr;
+    CK(ss_comm_init_all(ndev, nullptr, &set));
+    uint8_t id[SS_UNIQUE_ID_BYTES];
+    ss_comm *c = nullptr;
+    if (ndev == 1) {                                   // a one-rank communicator only makes sense on a one-GPU box
+        CK(ss_comm_unique_id(id));
+        CK(ss_comm_init_rank(id, 1, 0, &c));
+    }
+    int found = 1;
+    auto timed = [&](auto &&call) -> double {
+        for (int w = 0; w < 5; ++w) call();
+        const auto t0 = clk::now();
+        for (int k = 0; k < steps; ++k) call();
+        return seconds_since(t0) / steps * 1e3;
+    };
+    int rc = 0;
+    const double dev_ms = ndev == 1 ? timed([&] { rc |= ss_search_device(s, shards[0], lens[0], nullptr, &found); }) : 0.0;
+    float kms = 0;
+    if (ndev == 1) CK(ss_searcher_last_kernel_ms(s, &kms));
+    const double one_rank_ms = c ? timed([&] { rc |= ss_search_sharded(s, shards[0], lens[0], c, nullptr, &found); }) : 0.0;
+    CK(ss_comm_set_combine(set, SS_COMBINE_RCCL));
+    const double all_rccl_ms = timed([&] { rc |= ss_search_sharded_all(s, shards.data(), lens.data(), set, &found); });
+    CK(ss_comm_set_combine(set, SS_COMBINE_HOST));
+    const double all_host_ms = timed([&] { rc |= ss_search_sharded_all(s, shards.data(), lens.data(), set, &found); });
+    if (rc != 0 || found != 0) {
+        std::fprintf(stderr, "sharded: rc %d found %d: %s\n", rc, found, ss_last_error());
+        return 1;
+    }
+    std::printf("{\"mode\": \"sharded\", \"devices\": %d, \"haystack_bytes\": %zu, \"steps\": %d, \"kernel_ms_one_device\": %.4f, "
+                "\"search_device_ms\": %.4f, \"search_sharded_one_rank_ms\": %.4f, \"search_sharded_all_rccl_ms\": %.4f, "
+                "\"search_sharded_all_host_combine_ms\": %.4f, \"aggregate_gbps_all_rccl\": %.1f}\n",
+                ndev, total, steps, kms, dev_ms, one_rank_ms, all_rccl_ms, all_host_ms, (double)total / all_rccl_ms / 1e6);
+    if (c) ss_comm_free(c);
+    ss_comm_set_free(set);
+    ss_searcher_free(s);
+    for (int g = 0; g < ndev; ++g) {
+        (void)hipSetDevice(g);
+        (void)hipFree(bufs[g]);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "headline";
@@ -255,6 +328,7 @@ int main(int argc, char **argv)
         }
         return config1(argv[2], argv[3], argc > 4 ? std::atoi(argv[4]) : 5);
     }
+    if (mode == "sharded") return sharded(argc > 2 ? std::atof(argv[2]) : 8.0, argc > 3 ? std::atoi(argv[3]) : 50);
     if (mode == "headline") return headline(argc > 2 ? std::atof(argv[2]) : 64.0, argc > 3 ? std::atoi(argv[3]) : 20);
     // backwards compatible: native_bench <GiB> <steps>
     return headline(std::atof(argv[1]), argc > 2 ? std::atoi(argv[2]) : 20);
