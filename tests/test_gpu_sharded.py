@@ -136,3 +136,21 @@ def test_bench_launches_its_own_ranks():
         assert d["config"]["rccl_ranks"] == 2 and d["config"]["transport"] == "rccl"
     assert d["config"]["haystack_bytes"] == 1 << 29 and d["config"]["shard_bytes"] == (1 << 28) + 15
     assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+def test_bench_native_rccl_path_with_one_rank():
+    """The N > 1 code path of bench.py (ShardedSearcher over the native RCCL transport: ss_comm_init_rank,
+    ss_search_sharded, ncclCommCount) with the only rank count a one-GPU box allows."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SS_BENCH_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                          "--haystack-gib", "2", "--no-cpu-baseline", "--no-configs", "--no-ceiling"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["transport"] == "rccl" and d["config"]["rccl_ranks"] == 1
+    assert d["config"]["transport_note"] is None and d["config"]["launcher"] == "external"
+    assert d["roofline"]["achieved"] > 3000 and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-3
