@@ -36,6 +36,15 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
@@ -714,7 +723,7 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
                           &used_done);
     bool answered = false;
     if (rc == SS_OK && used_done) {
-        // Small grid: the last wave of the kernel stores 2*epoch + found to the slot's pinned word.  Spin on it for a
+        // Small grid: the last workgroup of the kernel stores 2*epoch + found to the slot's pinned word.  Spin on it for a
         // bounded time (the whole call is a few microseconds); after that - a long kernel behind other work on the
         // stream, or a fault - fall back to the stream wait, which also reports errors.
         const long long want = 2ll * epoch;
@@ -729,7 +738,7 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
                 if ((epoch & 255) == 0) (void)hipStreamSynchronize(st);
                 break;
             }
-            __builtin_ia32_pause();
+            cpu_relax();
             if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
         }
     }

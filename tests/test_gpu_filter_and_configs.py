@@ -330,3 +330,41 @@ def test_epoch_wrap_of_the_flag_slots(ss):
         assert s.search_in(yes) is True, it
         assert s.search_in(no) is False, it
         assert s.search_in(yes.cpu().numpy()) is True, it
+
+
+def test_completion_word_path_behind_a_long_kernel_and_across_sizes(ss):
+    """Small grids answer through a pinned completion word the host spins on (bounded), larger ones through the stream
+    wait.  A small search queued BEHIND a long scan on the same stream outlives the spin budget and must fall back to
+    the stream wait with the right answer; sizes on both sides of the 256-workgroup threshold agree with Python."""
+    big = torch.empty(6 << 30, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(big, 0x5EED0001)
+    small = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    small[777:780] = torch.tensor([5, 6, 7], dtype=torch.uint8)
+    s_long = ss.DynamicHipSearcher.new(absent_needle(ss, 16))
+    s_yes, s_no = ss.DynamicHipSearcher.new(bytes([5, 6, 7])), ss.DynamicHipSearcher.new(bytes([5, 6, 8]))
+    st = torch.cuda.Stream()
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(5):
+        with torch.cuda.stream(st):
+            for _ in range(4):                                    # ~3 ms of queued work in front of the small searches
+                s_long.search_in_async(big, flag)
+        assert s_yes.search_in(small, stream=st.cuda_stream) is True
+        assert s_no.search_in(small, stream=st.cuda_stream) is False
+    st.synchronize()
+    assert int(flag.item()) == 0
+    del big
+    rng = random.Random(9)
+    for ln in (1, 100, 16 << 10, (4 << 20) - 3, 4 << 20, (4 << 20) + 16385, 8 << 20, (8 << 20) + 1, 40 << 20):
+        host = np.frombuffer(rng.randbytes(ln), dtype=np.uint8).copy()
+        dh = dev(host)
+        for _ in range(6):
+            n = rng.choice([1, 2, 3, 16, 40])
+            if n > ln:
+                continue
+            at = rng.randrange(ln - n + 1)
+            nd = host[at:at + n].tobytes() if rng.random() < 0.5 else rng.randbytes(n)
+            want = host.tobytes().find(nd)
+            s = ss.DynamicHipSearcher.new(nd)
+            for _ in range(3):
+                assert s.search_in(dh) == (want >= 0), (ln, n)
+            assert s.find(dh) == (None if want < 0 else want), (ln, n)
