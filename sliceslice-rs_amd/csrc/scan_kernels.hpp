@@ -103,7 +103,9 @@ __device__ __forceinline__ uint32_t from_next_lane_or(uint32_t last, uint32_t cu
 // lane l receives lane (l+1) mod 64: lane 63 gets lane 0 (DPP wave_rol:1).
 __device__ __forceinline__ uint32_t rotate_from_next_lane(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+    // every lane has a source lane under wave_rol, so the `old` operand is never read: mov_dpp leaves it undefined and
+    // saves the v_mov that update_dpp(0, ...) needs to materialise it (one VALU per moved dword)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
 }
 
 template <bool NT>
