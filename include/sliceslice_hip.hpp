@@ -137,9 +137,84 @@ public:
     size_t needle_len() const { return ss_searcher_needle_len(h_); }
     ss_searcher *handle() const { return h_; }
 
+    // The needle bytes the device filter tests (first, second, third; third == second: none).  `with_position`
+    // keeps the reference's pair (0, position); `new_` lets the library pick (sliceslice_hip.h).
+    struct Filter {
+        size_t first, second, third;
+    };
+    Filter filter() const
+    {
+        Filter f{0, 0, 0};
+        check(ss_searcher_filter3(h_, &f.first, &f.second, &f.third));
+        return f;
+    }
+    void set_filter(size_t first, size_t second) { check(ss_searcher_set_filter(h_, first, second)); }
+    void set_filter(size_t first, size_t second, size_t third) { check(ss_searcher_set_filter3(h_, first, second, third)); }
+
 private:
     explicit DynamicHipSearcher(ss_searcher *h) : h_(h) {}
     ss_searcher *h_;
+};
+
+// All GPUs of a node behind ONE search_in (ss_comm_init_all / ss_search_sharded_all): the haystack is range-partitioned
+// into one shard per device (n-1 bytes of overlap: shard_range), each resident in its device's HBM; a search is one scan
+// per device plus one grouped all-reduce(MAX) of the found flag.  What a drop-in for `search_in(&self, &[u8]) -> bool`
+// (src/x86.rs:523) over several GPUs calls - no launcher, no rendezvous.
+class NodeSearcher {
+public:
+    NodeSearcher(const uint8_t *needle, size_t n, int ndev, const int *devices = nullptr)
+        : searcher_(DynamicHipSearcher::new_(needle, n)), n_(n), ndev_(ndev)
+    {
+        check(ss_comm_init_all(ndev, devices, &set_));
+    }
+    NodeSearcher(const std::string &needle, int ndev)
+        : NodeSearcher(reinterpret_cast<const uint8_t *>(needle.data()), needle.size(), ndev) {}
+    NodeSearcher(const NodeSearcher &) = delete;
+    NodeSearcher &operator=(const NodeSearcher &) = delete;
+    ~NodeSearcher() { ss_comm_set_free(set_); }
+
+    int devices() const { return ndev_; }
+    int device(int index) const
+    {
+        int d = -1;
+        check(ss_comm_set_device(set_, index, &d));
+        return d;
+    }
+    // byte range [begin, end) of shard `g` of a haystack of `len` bytes
+    std::pair<size_t, size_t> shard_range(size_t len, int g) const
+    {
+        size_t b = 0, e = 0;
+        check(ss_shard_range(len, n_, ndev_, g, &b, &e));
+        return {b, e};
+    }
+    // SS_COMBINE_RCCL (default): one grouped ncclAllReduce; SS_COMBINE_HOST: the host ORs the pinned flag mirrors
+    void set_combine(int mode) { check(ss_comm_set_combine(set_, mode)); }
+
+    // shards[g]: device pointer + length of shard g, resident on device(g)
+    bool search_in(const DeviceSlice *shards) const
+    {
+        const void *ptrs[64];
+        size_t lens[64];
+        for (int g = 0; g < ndev_ && g < 64; ++g) { ptrs[g] = shards[g].ptr; lens[g] = shards[g].len; }
+        int found = 0;
+        check(ss_search_sharded_all(searcher_.handle(), ptrs, lens, set_, &found));
+        return found != 0;
+    }
+    uint64_t find(const DeviceSlice *shards, const uint64_t *shard_begins) const
+    {
+        const void *ptrs[64];
+        size_t lens[64];
+        for (int g = 0; g < ndev_ && g < 64; ++g) { ptrs[g] = shards[g].ptr; lens[g] = shards[g].len; }
+        uint64_t pos = DynamicHipSearcher::npos;
+        check(ss_find_sharded_all(searcher_.handle(), ptrs, lens, shard_begins, set_, &pos));
+        return pos;
+    }
+
+private:
+    DynamicHipSearcher searcher_;
+    size_t n_;
+    int ndev_;
+    ss_comm_set *set_ = nullptr;
 };
 
 }  // namespace hip

@@ -71,6 +71,49 @@ int main()
         CHECK(!DynamicHipSearcher::new_("not in the file at all").search_in_file(path));
         std::remove(path.c_str());
     }
+    // the filter bytes: with_position keeps the reference's pair, new_ picks rare bytes; results are the same
+    {
+        const std::string text = " the quick brown fox ";
+        auto ref = DynamicHipSearcher::with_position(text, 20);
+        auto chosen = DynamicHipSearcher::new_(text);
+        CHECK(ref.filter().first == 0 && ref.filter().second == 20 && ref.position() == 20);
+        CHECK(chosen.filter().first == 5 && chosen.filter().second == 19 && chosen.filter().third == 9 && chosen.position() == 20);
+        const std::string hay = "jumps over the quick brown fox and runs";
+        CHECK(ref.search_in(hay) && chosen.search_in(hay));
+        chosen.set_filter(1, 2, 3);
+        CHECK(chosen.search_in(hay) && !chosen.search_in(std::string("the quick brown cat ")));
+    }
+    // every visible GPU from this process (one on the test box): NodeSearcher
+    {
+        int ndev = 0;
+        CHECK(hipGetDeviceCount(&ndev) == hipSuccess && ndev >= 1);
+        if (ndev > 8) ndev = 8;
+        const std::string nd = "sixteen byte key";
+        sliceslice::hip::NodeSearcher node(nd, ndev);
+        const size_t total = (8u << 20) + 77;
+        std::vector<uint8_t *> bufs(ndev);
+        std::vector<DeviceSlice> shards(ndev);
+        std::vector<uint64_t> begins(ndev);
+        for (int g = 0; g < ndev; ++g) {
+            auto [b, e] = node.shard_range(total, g);
+            CHECK(hipSetDevice(node.device(g)) == hipSuccess);
+            CHECK(hipMalloc((void **)&bufs[g], e - b) == hipSuccess);
+            CHECK(hipMemset(bufs[g], 0x2E, e - b) == hipSuccess);
+            if (g == ndev - 1) CHECK(hipMemcpy(bufs[g] + (e - b) - nd.size(), nd.data(), nd.size(), hipMemcpyHostToDevice) == hipSuccess);
+            shards[g] = DeviceSlice{bufs[g], e - b};
+            begins[g] = b;
+        }
+        CHECK(hipSetDevice(0) == hipSuccess);
+        for (int mode : {SS_COMBINE_RCCL, SS_COMBINE_HOST}) {
+            node.set_combine(mode);
+            CHECK(node.search_in(shards.data()));
+            CHECK(node.find(shards.data(), begins.data()) == total - nd.size());
+        }
+        sliceslice::hip::NodeSearcher other(std::string("not there at all"), ndev);
+        CHECK(!other.search_in(shards.data()));
+        CHECK(other.find(shards.data(), begins.data()) == DynamicHipSearcher::npos);
+        for (int g = 0; g < ndev; ++g) (void)hipFree(bufs[g]);
+    }
     std::puts("veneer_test ok");
     return 0;
 }
