@@ -38,6 +38,7 @@ static std::atomic<int> g_failures{0};
 int main(int argc, char **argv)
 {
     const int nthreads = argc > 1 ? std::atoi(argv[1]) : 128;
+    const int iterations = argc > 2 ? std::atoi(argv[2]) : 16;
     const size_t len = 2u << 20;
     const uint8_t needle[7] = {9, 8, 7, 6, 5, 4, 3};
     std::vector<uint8_t> h_no(len, 0), h_yes(len, 0);
@@ -84,7 +85,7 @@ int main(int argc, char **argv)
         pool.emplace_back([&, k]() {
             hipStream_t st = nullptr;
             TCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
-            for (int it = 0; it < 16; ++it) {
+            for (int it = 0; it < iterations; ++it) {
                 int found = -1;
                 uint64_t pos = 1;
                 switch ((k + it) % 6) {

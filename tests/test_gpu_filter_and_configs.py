@@ -368,3 +368,18 @@ def test_completion_word_path_behind_a_long_kernel_and_across_sizes(ss):
             for _ in range(3):
                 assert s.search_in(dh) == (want >= 0), (ln, n)
             assert s.find(dh) == (None if want < 0 else want), (ln, n)
+
+
+def test_short_differential_campaign():
+    """tools/fuzz_gpu.py for a few seconds in both modes: random haystack kinds / lengths / misalignments / needles /
+    positions or filter triples / kernel variants / launch shapes, search_in and find against Python's bytes.find."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["2"]):                         # small-haystack mode; 2 GiB planted-needle mode
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "12", "4242"] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        assert d["fuzz"] == "ok" and d["searches"] > 1000, d

@@ -65,7 +65,7 @@ def test_host_library_stress_under_asan_ubsan(tmp_path):
                   ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-g", "-Wl,-rpath," + os.path.dirname(rt)])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:protect_shadow_gap=0",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    out = subprocess.run([exe, "96"], capture_output=True, text=True, timeout=1800, env=env)
+    out = subprocess.run([exe, "80", "8"], capture_output=True, text=True, timeout=1800, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-6000:]
     assert "host_stress_test ok" in out.stdout
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-6000:]
@@ -110,7 +110,7 @@ def test_host_library_stress_under_tsan(tmp_path):
     supp = tmp_path / "tsan.supp"
     supp.write_text("race:libamdhip64.so\nrace:libhsa-runtime64.so\nrace:librccl.so\n")
     env = dict(os.environ, TSAN_OPTIONS="suppressions=%s:halt_on_error=0:report_signal_unsafe=0:exitcode=66" % supp)
-    out = subprocess.run([exe, "48"], capture_output=True, text=True, timeout=1800, env=env)
+    out = subprocess.run([exe, "40", "8"], capture_output=True, text=True, timeout=1800, env=env)
     assert "host_stress_test ok" in out.stdout, out.stdout[-2000:] + out.stderr[-6000:]
     assert "WARNING: ThreadSanitizer" not in out.stderr, out.stderr[-8000:]
     assert out.returncode == 0, out.stderr[-4000:]
