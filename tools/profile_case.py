@@ -13,6 +13,8 @@ the algorithmic bytes per launch and the kernel time by hipEvents.
           text_worst   i386.txt tiled to 1 GiB, letters-only absent phrase, new()
           text_refpair the same phrase with the reference's pair (0, n-1)
           text_spaces  ' the quick brown fox ' with the reference's pair (' ', ' ')
+          text_spaces_new   the same needle through new(): filter bytes 'q', 'x', 'k'
+          text_common_new   'there is not another one of these' through new(): common letters only
 """
 import json
 import os
@@ -79,6 +81,8 @@ def main():
             "text_worst": lambda: ss.DynamicHipSearcher.new(phrase),
             "text_refpair": lambda: ss.DynamicHipSearcher.with_position(phrase, len(phrase) - 1),
             "text_spaces": lambda: ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 20),
+            "text_spaces_new": lambda: ss.DynamicHipSearcher.new(b" the quick brown fox "),
+            "text_common_new": lambda: ss.DynamicHipSearcher.new(b"there is not another one of these"),
         }[case]()
         s.set_timing(True)
         ms = []
