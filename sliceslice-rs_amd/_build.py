@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_CSRC, "libsliceslice_hip.so")
-_SOURCES = ["sliceslice_hip.hip", "scan_inst_u4.hip", "scan_inst_u8.hip", "scan_inst_find.hip"]
+_SOURCES = ["sliceslice_hip.hip", "scan_inst_u4_nt0.hip", "scan_inst_u4_nt1.hip", "scan_inst_u8_nt0.hip", "scan_inst_u8_nt1.hip", "scan_inst_find_nt0.hip", "scan_inst_find_nt1.hip"]
 _HEADERS = ["scan_kernels.hpp", "scan_launch.hpp", os.path.join("..", "..", "include", "sliceslice_hip.h")]
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
 # Host-side sanitizer build (the reference's guard on its unsafe code is its ASAN CI job,
@@ -65,11 +65,16 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
-def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose):
+def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host_only=False):
+    """host_only: only the API translation unit (sliceslice_hip.hip - all of the host logic) is compiled with
+    `extra_flags`; the kernel-instantiation units come from the regular build (their host side is launch stubs)."""
     newest_header = max(_mtime(h) for h in _HEADERS)
-    objs = [os.path.join(_CSRC, s[:-4] + obj_suffix) for s in _SOURCES]
+    own = _SOURCES[:1] if host_only else _SOURCES
+    objs = [os.path.join(_CSRC, s[:-4] + (obj_suffix if s in own else ".o")) for s in _SOURCES]
     todo = []
     for src, obj in zip(_SOURCES, objs):
+        if src not in own:
+            continue
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(_mtime(src), newest_header):
             todo.append((src, obj))
     if not todo and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(o) for o in objs):
@@ -98,11 +103,13 @@ def build(force=False, verbose=False):
 
 
 def build_sanitized(force=False, verbose=False):
-    """The same sources with ASan + UBSan on the host code -> csrc/libsliceslice_hip_asan.so (test builds only:
+    """The host logic (sliceslice_hip.hip) with ASan + UBSan -> csrc/libsliceslice_hip_asan.so (test builds only:
     load it with SLICESLICE_HIP_LIB=<path> and the ASan runtime preloaded; see tests/test_gpu_sanitizer.py)."""
     so = os.path.join(_CSRC, "libsliceslice_hip_asan.so")
+    build(verbose=verbose)                                  # the kernel-instantiation objects are shared with the regular build
     with _Lock(".build_asan.lock"):
-        return _build_variant(so, ".asan.o", _SAN_FLAGS, ["-fsanitize=address,undefined", "-shared-libsan"], force, verbose)
+        return _build_variant(so, ".asan.o", _SAN_FLAGS, ["-fsanitize=address,undefined", "-shared-libsan"], force, verbose,
+                              host_only=True)
 
 
 _TSAN_FLAGS = ["-fsanitize=thread", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"]
@@ -111,8 +118,9 @@ _TSAN_FLAGS = ["-fsanitize=thread", "-fno-gpu-sanitize", "-fno-omit-frame-pointe
 def build_tsan(force=False, verbose=False):
     """ThreadSanitizer build of the host code -> csrc/libsliceslice_hip_tsan.so (tests/test_gpu_native.py)."""
     so = os.path.join(_CSRC, "libsliceslice_hip_tsan.so")
+    build(verbose=verbose)
     with _Lock(".build_tsan.lock"):
-        return _build_variant(so, ".tsan.o", _TSAN_FLAGS, ["-fsanitize=thread", "-shared-libsan"], force, verbose)
+        return _build_variant(so, ".tsan.o", _TSAN_FLAGS, ["-fsanitize=thread", "-shared-libsan"], force, verbose, host_only=True)
 
 
 def tsan_runtime():
