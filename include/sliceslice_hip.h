@@ -94,6 +94,11 @@ int ss_searcher_set_filter3(ss_searcher *s, size_t first, size_t second, size_t 
 /* What ss_searcher_new would pick for this needle (pure host functions, no device needed). */
 int ss_choose_filter_pair(const uint8_t *needle, size_t n, size_t *first, size_t *second);
 int ss_choose_filter_triple(const uint8_t *needle, size_t n, size_t *first, size_t *second, size_t *third);
+/* The same choice driven by a byte histogram of (a sample of) the haystack - ss_byte_histogram_device - instead of the
+ * static ranking (hist == NULL: the static ranking): cost of a byte = log2(count + 1), so sums compare products of
+ * frequencies.  Apply with ss_searcher_set_filter3.  Row f3 of SURVEY.md 8f for the three-byte filter. */
+int ss_choose_filter_triple_hist(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *first, size_t *second,
+                                 size_t *third);
 
 /* DynamicAvx2Searcher::search_in (src/x86.rs:523-525) on a haystack ALREADY RESIDENT in device
  * memory (any alignment, any length up to the device's memory).  Enqueues on `hip_stream`

@@ -452,16 +452,37 @@ inline int rarity_class(uint8_t b)
     return r < 64 ? 0 : r;          // everything that is not text-like counts as equally rare
 }
 
+// Cost of one filter byte: the static class above, or - with a byte histogram of (a sample of) the haystack -
+// 8 * log2(count + 1): summing costs then compares PRODUCTS of frequencies, which is what the candidate rate of
+// a multi-byte filter is (bytes taken as independent).
+struct ByteCost {
+    int cost[256];
+    explicit ByteCost(const uint64_t *hist)
+    {
+        for (int b = 0; b < 256; ++b) {
+            if (!hist) {
+                cost[b] = rarity_class((uint8_t)b);
+            } else {
+                const uint64_t c = hist[b] + 1;
+                const int lg = 63 - __builtin_clzll(c);                      // floor(log2 c)
+                const int frac = lg >= 3 ? (int)((c >> (lg - 3)) & 7) : (int)((c << (3 - lg)) & 7);
+                cost[b] = 8 * lg + frac;                                     // ~8 * log2(c), 0 .. 511
+            }
+        }
+    }
+    int operator()(uint8_t b) const { return cost[b]; }
+};
+
 // Third byte for a given pair (single-stream kernels: fb - fa <= 15): the rarest byte among needle[fa+1 .. fa+15]
 // other than needle[fb]'s index; ties to the later byte.  Returns fb when there is none.
-size_t choose_third(const uint8_t *needle, size_t n, size_t fa, size_t fb)
+size_t choose_third(const uint8_t *needle, size_t n, size_t fa, size_t fb, const ByteCost &cost)
 {
     if (n < 3 || fb < fa || fb - fa > 15) return fb;
     size_t best = fb;
     int bc = INT_MAX;
     for (size_t k = fa + 1; k < n && k <= fa + 15; ++k) {
         if (k == fb) continue;
-        const int c = rarity_class(needle[k]);
+        const int c = cost(needle[k]);
         if (c <= bc) {
             bc = c;
             best = k;
@@ -474,7 +495,7 @@ size_t choose_third(const uint8_t *needle, size_t n, size_t fa, size_t fb)
 // that sum smallest.  Ties: the reference's first byte (0) when it is among the best, else the earliest; among
 // equally rare followers the later ones (for needles of <= 16 bytes of equal rarity that is the reference's
 // pair (0, n-1) plus n-2).  fb > fc is not required; fb is the rarer (or later) of the two.
-void choose_filter_triple(const uint8_t *needle, size_t n, size_t *fa, size_t *fb, size_t *fc)
+void choose_filter_triple(const uint8_t *needle, size_t n, size_t *fa, size_t *fb, size_t *fc, const ByteCost &cost)
 {
     *fa = *fb = *fc = 0;
     if (n < 2) return;
@@ -482,13 +503,13 @@ void choose_filter_triple(const uint8_t *needle, size_t n, size_t *fa, size_t *f
     int best = INT_MAX;
     size_t ba = 0, bb = 1, bc = 1;
     for (size_t a = 0; a + 1 < w; ++a) {
-        const int ca = rarity_class(needle[a]);
+        const int ca = cost(needle[a]);
         if (ca > best) continue;
-        // two smallest classes among a+1 .. a+15 (later index wins ties)
+        // two smallest costs among a+1 .. a+15 (later index wins ties)
         int c1 = INT_MAX, c2 = INT_MAX;
         size_t i1 = a + 1, i2 = a + 1;
         for (size_t b = a + 1; b < w && b <= a + 15; ++b) {
-            const int c = rarity_class(needle[b]);
+            const int c = cost(needle[b]);
             if (c <= c1) {
                 c2 = c1; i2 = i1;
                 c1 = c; i1 = b;
@@ -497,9 +518,9 @@ void choose_filter_triple(const uint8_t *needle, size_t n, size_t *fa, size_t *f
             }
         }
         const bool has2 = c2 != INT_MAX;
-        const int cost = ca + c1 + (has2 ? c2 : 255);          // no third byte to offer: as bad as the most common one
-        if (cost < best) {
-            best = cost;
+        const int total = ca + c1 + (has2 ? c2 : 512);         // no third byte to offer: worse than the most common one
+        if (total < best) {
+            best = total;
             ba = a;
             bb = i1;
             bc = has2 ? i2 : i1;
@@ -513,7 +534,7 @@ void choose_filter_triple(const uint8_t *needle, size_t n, size_t *fa, size_t *f
 void choose_filter_pair(const uint8_t *needle, size_t n, size_t *fa, size_t *fb)
 {
     size_t fc;
-    choose_filter_triple(needle, n, fa, fb, &fc);
+    choose_filter_triple(needle, n, fa, fb, &fc, ByteCost(nullptr));
 }
 
 int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_filter, ss_searcher **out)
@@ -534,8 +555,9 @@ int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_fi
     s->position = position;
     s->fa = 0;
     s->fb = n >= 2 ? position : 0;
-    if (auto_filter) choose_filter_triple(s->needle.data(), n, &s->fa, &s->fb, &s->fc);
-    else s->fc = choose_third(s->needle.data(), n, s->fa, s->fb);       // with_position: the reference's pair + one more byte
+    const ByteCost cost(nullptr);
+    if (auto_filter) choose_filter_triple(s->needle.data(), n, &s->fa, &s->fb, &s->fc, cost);
+    else s->fc = choose_third(s->needle.data(), n, s->fa, s->fb, cost);  // with_position: the reference's pair + one more byte
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) {      // uploads the needle to the current device now
         delete s;
@@ -601,7 +623,15 @@ int ss_searcher_filter3(const ss_searcher *s, size_t *first, size_t *second, siz
 int ss_choose_filter_triple(const uint8_t *needle, size_t n, size_t *first, size_t *second, size_t *third)
 {
     if (!first || !second || !third || (n && !needle)) return fail(SS_ERR_ARGUMENT, "NULL argument");
-    choose_filter_triple(needle, n, first, second, third);
+    choose_filter_triple(needle, n, first, second, third, ByteCost(nullptr));
+    return SS_OK;
+}
+
+int ss_choose_filter_triple_hist(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *first, size_t *second,
+                                 size_t *third)
+{
+    if (!first || !second || !third || (n && !needle)) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    choose_filter_triple(needle, n, first, second, third, ByteCost(hist));
     return SS_OK;
 }
 

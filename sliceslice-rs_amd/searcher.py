@@ -47,6 +47,7 @@ ABI = {
     "ss_searcher_filter3": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_searcher_set_filter3": (_int, [_vp, _sz, _sz, _sz]),
     "ss_choose_filter_triple": (_int, [_vp, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_choose_filter_triple_hist": (_int, [_vp, _sz, _vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
     "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
     "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
@@ -553,11 +554,16 @@ def choose_filter_pair(needle):
     return a.value, b.value
 
 
-def choose_filter_triple(needle):
-    """(first, second, third) that `DynamicHipSearcher.new(needle)` lets the device filter test."""
+def choose_filter_triple(needle, hist=None):
+    """(first, second, third) that `DynamicHipSearcher.new(needle)` lets the device filter test; with `hist` (256
+    byte counts of the haystack, `byte_histogram`) the corpus-aware choice to apply with `set_filter`."""
     nb = bytes(needle)
     a, b, c = _sz(0), _sz(0), _sz(0)
-    _check(lib().ss_choose_filter_triple(nb, len(nb), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    if hist is None:
+        _check(lib().ss_choose_filter_triple(nb, len(nb), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    else:
+        h = np.ascontiguousarray(hist, dtype=np.uint64)
+        _check(lib().ss_choose_filter_triple_hist(nb, len(nb), h.ctypes.data, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
     return a.value, b.value, c.value
 
 

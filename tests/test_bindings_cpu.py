@@ -173,6 +173,28 @@ def test_filter_pair_choice_properties():
         assert ss.choose_filter_pair(nd) == (a, b)
 
 
+def test_histogram_driven_filter_choice():
+    """ss_choose_filter_triple_hist: the same chooser with log2(count + 1) of a byte histogram as the cost."""
+    import numpy as np
+    text = open(os.path.join(ROOT, "tests", "golden", "data", "i386.txt"), "rb").read()
+    hist = np.bincount(np.frombuffer(text, dtype=np.uint8), minlength=256).astype(np.uint64)
+    for nd in (b" the quick brown fox ", b"segment descriptor table entries are", b"privilege level zero!", b"ab", b"abc"):
+        a, b, c = ss.choose_filter_triple(nd, hist)
+        n = len(nd)
+        assert 0 <= a < b < n and a < c < n and b - a <= 15 and c - a <= 15 and (c != b or n == 2), (nd, a, b, c)
+        # no other triple anchored at the same first byte is rarer under the histogram
+        lg = lambda x: np.log2(float(hist[x]) + 1.0)                                       # noqa: E731
+        cost = lg(nd[b]) + lg(nd[c])
+        others = sorted(lg(nd[k]) for k in range(a + 1, min(n, a + 16)))
+        assert n == 2 or cost <= others[0] + others[1] + 0.3, (nd, a, b, c)              # 1/8-bit fixed point in the library
+    # a corpus the static ranking is wrong about: all 'a' - the one 'e' must be in the filter
+    ha = np.zeros(256, dtype=np.uint64)
+    ha[ord("a")] = 10 ** 9
+    assert 40 in ss.choose_filter_triple(b"a" * 40 + b"e", ha)
+    assert 40 not in ss.choose_filter_triple(b"a" * 40 + b"e")          # the static guess ranks 'e' as the commonest letter
+    assert ss.choose_filter_triple(b"xyz", None) == ss.choose_filter_triple(b"xyz")
+
+
 def test_bench_line_fields_of_the_committed_round2_capture():
     """Shape of the round-2 bench line (committed under profiles/r02 once captured on the GPU box)."""
     path = os.path.join(ROOT, "profiles", "r02", "bench64g.json")

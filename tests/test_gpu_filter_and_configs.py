@@ -160,6 +160,30 @@ def test_filter_pairs_on_text_and_random_haystacks_vs_oracle(ss, O, corpus):
                         assert s.find(view) == (None if wantp < 0 else wantp), (n, mis, a, b, c)
 
 
+def test_histogram_driven_triple_on_an_adversarial_corpus(ss):
+    """A corpus the static ranking is wrong about (all 'a', needle a...ae): `new` filters on three 'a's and every offset
+    reaches the second level; the histogram-driven triple contains the 'e' and nothing passes.  Same answers."""
+    ln = 64 << 20
+    hay = torch.full((ln,), 0x61, dtype=torch.uint8, device="cuda")
+    needle = b"a" * 40 + b"e"
+    s = ss.DynamicHipSearcher.new(needle)
+    assert s.search_in(hay) is False and s.find(hay) is None
+    hist = ss.byte_histogram(hay, sample_bytes=1 << 20)
+    a, b, c = ss.choose_filter_triple(needle, hist)
+    assert 40 in (a, b, c)
+    s.set_timing(True)
+    s.search_in(hay)
+    slow = s.last_kernel_ms()
+    s.set_filter(a, b, c)
+    assert s.search_in(hay) is False and s.find(hay) is None
+    s.search_in(hay)
+    fast = s.last_kernel_ms()
+    assert fast < slow                                   # the point of the policy (it is several times faster)
+    hay[ln - 41:] = dev(needle)
+    assert s.search_in(hay) is True and s.find(hay) == ln - 41
+    assert ss.DynamicHipSearcher.new(needle).find(hay) == ln - 41
+
+
 def test_filter_stream_never_reads_outside_the_haystack(ss):
     """hay + first is the start of the filter stream: with the haystack flush against BOTH ends of an allocation
     no pair may fault or report the needle copies that sit just outside."""

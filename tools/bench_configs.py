@@ -173,11 +173,12 @@ def main():
                  gbps=round(text.numel() / ms / 1e6, 1))
             # row f3: the same needle with the position chosen from a byte histogram of (a sample of) the haystack
             hist = ss.byte_histogram(text, sample_bytes=64 << 20)
-            pos = ss.choose_position(nd, hist)
-            s = ss.DynamicHipSearcher.with_position(nd, pos)
+            s = ss.DynamicHipSearcher.new(nd)
+            s.set_filter(*ss.choose_filter_triple(nd, hist))
             res, ms = timed(s, text, args.reps)
-            emit(config="text", needle=nd.decode("latin1"), label=label + "; position chosen by ss_choose_position",
-                 position=pos, position_byte=chr(nd[pos]), haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
+            emit(config="text", needle=nd.decode("latin1"), label=label + "; filter bytes chosen from a byte histogram of the haystack "
+                 "(ss_byte_histogram_device + ss_choose_filter_triple_hist)", filter_bytes=list(s.filter3),
+                 filter_chars=[chr(nd[k]) for k in s.filter3], haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
                  gbps=round(text.numel() / ms / 1e6, 1))
         del text
         a = torch.full((n_bytes,), 0x61, dtype=torch.uint8, device="cuda")
