@@ -138,6 +138,9 @@ int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t le
  * set that lives for the rest of the process and is lent to one call at a time (a concurrent call on the
  * same device builds and frees a private set), so a small haystack costs tens of microseconds per call. */
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
+/* Slices of up to 64 KiB take a shorter road (ss_find_host too): the CPU copies them into a pinned, device-visible
+ * buffer of the calling thread and the kernel reads them over PCIe - no upload command (10-12 us per call instead of
+ * 16-24; SLICESLICE_HOST_ZERO_COPY=0 switches it off). */
 
 /* Row f2: the host-file front end of examples/grep.rs:42-56 (open the file, one
  * search_in) as a pipeline: reader threads pread() 64 MiB chunks into pinned buffers while earlier
