@@ -1504,6 +1504,7 @@ struct ss_comm_set {
     std::vector<hipStream_t> streams;
     std::vector<int *> d_flag, d_recv, h_flag;          // h_flag[g]: pinned mirror written by device g's finding wave
     std::vector<uint64_t *> d_best, d_best_recv;
+    bool no_rccl = false;                               // test sets (SLICESLICE_COMM_SET_NO_RCCL): host combine only
     int *h_recv = nullptr;                              // pinned: device 0's all-reduce result
     uint64_t *h_best = nullptr;                         // pinned: ndev offsets (host combine) / [0] = all-reduce result
 };
@@ -1692,19 +1693,25 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
     *out = nullptr;
     int visible = 0;
     HIP_TRY(hipGetDeviceCount(&visible));
-    if (ndev < 1 || ndev > visible) return fail(SS_ERR_ARGUMENT, "%d devices requested, %d visible", ndev, visible);
-    Rccl *r = rccl();
-    if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    // SLICESLICE_COMM_SET_NO_RCCL=1 (tests): no communicators are created and a device may be listed several times, so
+    // that the per-device bookkeeping of a G > 1 set can run on a one-GPU box; such a set only offers the host combine.
+    const char *nr = getenv("SLICESLICE_COMM_SET_NO_RCCL");
+    const bool no_rccl = nr && nr[0] == '1';
+    Rccl *r = no_rccl ? nullptr : rccl();
+    if (!no_rccl && !r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    if (ndev < 1 || ndev > (no_rccl ? 64 : visible)) return fail(SS_ERR_ARGUMENT, "%d devices requested, %d visible", ndev, visible);
     ss_comm_set *set = new (std::nothrow) ss_comm_set;
     if (!set) return fail(SS_ERR_NOMEM, "out of memory");
     set->ndev = ndev;
+    set->no_rccl = no_rccl;
+    if (no_rccl) set->combine = SS_COMBINE_HOST;
     for (int g = 0; g < ndev; ++g) {
         const int d = devs ? devs[g] : g;
         if (d < 0 || d >= visible) {
             delete set;
             return fail(SS_ERR_ARGUMENT, "device %d out of range (%d visible)", d, visible);
         }
-        for (int k = 0; k < g; ++k)
+        for (int k = 0; k < g && !no_rccl; ++k)
             if (set->devs[k] == d) {
                 delete set;
                 return fail(SS_ERR_ARGUMENT, "device %d listed twice", d);
@@ -1719,7 +1726,7 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
     set->d_best.assign(ndev, nullptr);
     set->d_best_recv.assign(ndev, nullptr);
     DeviceGuard guard;
-    if (int rc = r->CommInitAll(set->comms.data(), ndev, set->devs.data())) {
+    if (int rc = no_rccl ? 0 : r->CommInitAll(set->comms.data(), ndev, set->devs.data())) {
         set->comms.assign(ndev, nullptr);
         free_comm_set(set);
         return rccl_fail(r, rc, "ncclCommInitAll");
@@ -1763,6 +1770,7 @@ int ss_comm_set_device(const ss_comm_set *set, int index, int *device)
 int ss_comm_set_combine(ss_comm_set *set, int combine)
 {
     if (!set || (combine != SS_COMBINE_RCCL && combine != SS_COMBINE_HOST)) return fail(SS_ERR_ARGUMENT, "bad combine mode");
+    if (set->no_rccl && combine == SS_COMBINE_RCCL) return fail(SS_ERR_RCCL, "this set was created without communicators");
     set->combine = combine;
     return SS_OK;
 }
@@ -1772,8 +1780,8 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
 {
     if (!s || !d_shards || !shard_lens || !set || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (s->n == 0) { *found = 1; return SS_OK; }            // N0 (x86.rs:500)
-    Rccl *r = rccl();
-    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    Rccl *r = set->combine == SS_COMBINE_RCCL ? rccl() : nullptr;
+    if (set->combine == SS_COMBINE_RCCL && !r) return fail(SS_ERR_RCCL, "librccl not loaded");
     const int G = set->ndev;
     for (int g = 0; g < G; ++g)
         if (shard_lens[g] && !d_shards[g]) return fail(SS_ERR_ARGUMENT, "shard %d is NULL", g);
@@ -1825,8 +1833,8 @@ int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const
                         const uint64_t *shard_begins, ss_comm_set *set, uint64_t *position)
 {
     if (!s || !d_shards || !shard_lens || !shard_begins || !set || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
-    Rccl *r = rccl();
-    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    Rccl *r = set->combine == SS_COMBINE_RCCL ? rccl() : nullptr;
+    if (set->combine == SS_COMBINE_RCCL && !r) return fail(SS_ERR_RCCL, "librccl not loaded");
     const int G = set->ndev;
     DeviceGuard guard;
     int rc = SS_OK;

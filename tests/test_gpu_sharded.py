@@ -154,3 +154,55 @@ def test_bench_native_rccl_path_with_one_rank():
     assert d["n_gpus"] == 1 and d["config"]["transport"] == "rccl" and d["config"]["rccl_ranks"] == 1
     assert d["config"]["transport_note"] is None and d["config"]["launcher"] == "external"
     assert d["roofline"]["achieved"] > 3000 and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-3
+
+
+def test_comm_set_bookkeeping_with_three_and_eight_shards_on_one_gpu():
+    """G > 1 in ss_search_sharded_all / ss_find_sharded_all on a one-GPU box: a test set (SLICESLICE_COMM_SET_NO_RCCL=1) lists
+    device 0 several times and creates no communicators, so the per-shard streams, flags, pinned mirrors, epochs and the
+    host-side combine run with G = 3 and G = 8 (the grouped RCCL all-reduce itself needs G distinct devices).  Matches
+    are planted at 0, at the end and across every shard edge."""
+    import numpy as np
+    import torch
+    import sliceslice_rs_amd as ss
+    os.environ["SLICESLICE_COMM_SET_NO_RCCL"] = "1"
+    try:
+        for G in (3, 8):
+            needle = bytes(range(100, 133))                      # 33 bytes: shards overlap by 32
+            n = len(needle)
+            total = (24 << 20) + 4321
+            node = ss.NodeSearcher(needle, devices=[0] * G)
+            with pytest.raises(ss.SlicesliceError):
+                node.set_combine(ss.NodeSearcher.COMBINE_RCCL)   # no communicators in a test set
+            ranges = [node.shard_range(total, g) for g in range(G)]
+            S = -(-total // G)
+            logical = torch.empty(total, dtype=torch.uint8, device="cuda")
+            ss.fill_random_device(logical, 0x5EED0001)
+            pn = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+            begins = [b for b, _ in ranges]
+
+            def shards():
+                return [logical[b:e].clone() for b, e in ranges]  # every shard its own allocation, like on G devices
+            assert node.search_in(shards()) is False and node.find(shards(), begins) is None
+            spots = [0, total - n, total // 2] + [r * S - k for r in range(1, G) for k in (1, n // 2, n - 1)] + [r * S for r in range(1, G)]
+            for at in spots:
+                saved = logical[at:at + n].clone()
+                logical[at:at + n] = pn
+                sh = shards()
+                assert node.search_in(sh) is True, (G, at)
+                assert node.find(sh, begins) == at, (G, at)
+                logical[at:at + n] = saved
+            # two occurrences in different shards: the leftmost wins
+            a1, a2 = S + 100, (G - 1) * S + 5000
+            logical[a1:a1 + n] = pn
+            logical[a2:a2 + n] = pn
+            assert node.find(shards(), begins) == a1
+            # epoch wrap of the set
+            assert ss.lib().ss_debug_set_comm_epoch(None, node._set, 2**31 - 3) == 0
+            for it in range(4):
+                assert node.search_in(shards()) is True
+            node.close()
+            absent = ss.NodeSearcher(bytes([255] * 20), devices=[0] * G)
+            assert absent.search_in(shards()) is False and absent.find(shards(), begins) is None
+            absent.close()
+    finally:
+        del os.environ["SLICESLICE_COMM_SET_NO_RCCL"]
