@@ -208,3 +208,20 @@ def test_bench_line_fields_of_the_committed_round2_capture():
     assert [r["needle_len"] for r in d["configs"]["3"]["rows"]] == [1, 2, 4, 8, 16, 32, 128]
     c = d["cpu_baseline"]
     assert c["cores"] == c["threads_used"] and c["host_physical_cores"] >= 1
+
+
+def test_rccl_enum_values_the_library_hard_codes():
+    """librccl is dlopen()ed, so sliceslice_hip.hip restates four enum values of rccl.h instead of including it; they
+    must agree with the header of the ROCm this image ships."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        import pytest
+        pytest.skip("no rccl.h in this image")
+    text = open(hdr).read()
+    src = open(os.path.join(ROOT, "sliceslice-rs_amd", "csrc", "sliceslice_hip.hip")).read()
+    for name, const in (("ncclInt32", "kNcclInt32"), ("ncclUint64", "kNcclUint64"), ("ncclMax", "kNcclMax"), ("ncclMin", "kNcclMin")):
+        want = int(re.search(r"\b%s\s*=\s*(\d+)" % name, text).group(1))
+        got = int(re.search(r"constexpr int %s = (\d+);" % const, src).group(1))
+        assert got == want, (name, got, want)
+    assert "#define SS_UNIQUE_ID_BYTES 128" in open(os.path.join(ROOT, "include", "sliceslice_hip.h")).read()
+    assert re.search(r"#define NCCL_UNIQUE_ID_BYTES 128", text)
