@@ -6,6 +6,7 @@
 //   native_bench latency  [calls=2000]            per-call microseconds of ss_search_device / ss_find_device /
 //                                                 ss_search_host on 1 KiB, 64 KiB, 1 MiB, 16 MiB haystacks
 //   native_bench sharded  [GiB=8] [steps=50]      the multi-GPU entry points on every visible GPU: per-search overhead
+//   native_bench soak     [calls=2000000]         small searches through every per-call entry point; RSS / VRAM before and after
 //   native_bench config1  <i386.txt> <words.txt> [iters=5]
 //        BASELINE.json configs[0] on the GPU: one ss_search_device call per needle over the resident text - the
 //        literal drop-in shape of bench/benches/i386.rs:246-256 - next to ONE ss_search_batched launch.
@@ -317,6 +318,61 @@ static int sharded(double gib, int steps)
     return 0;
 }
 
+// Soak: millions of small searches through every per-call entry point, resident set size and free device memory before
+// and after - the completion-word path returns without a stream wait, so this is where an unbounded backlog of
+// un-retired commands or a leaked slot would show.
+static long rss_kib()
+{
+    std::ifstream f("/proc/self/status");
+    std::string line;
+    while (std::getline(f, line))
+        if (line.rfind("VmRSS:", 0) == 0) return std::atol(line.c_str() + 6);
+    return -1;
+}
+
+static int soak(long calls)
+{
+    const size_t len = 64u << 10;
+    void *d_hay = nullptr;
+    HK(hipMalloc(&d_hay, len));
+    CK(ss_fill_random_device(d_hay, 0, len, 0x5EED0001ull, nullptr));
+    std::vector<uint8_t> h_hay(len);
+    CK(ss_fill_random_host(h_hay.data(), 0, len, 0x5EED0001ull));
+    uint8_t needle[16];
+    CK(ss_fill_random_host(needle, 0, 16, 0x5EED0002ull));
+    needle[8] = 0xFF;
+    ss_searcher *s = nullptr, *sp = nullptr;
+    CK(ss_searcher_new(needle, 16, &s));
+    CK(ss_searcher_new(h_hay.data() + 1000, 16, &sp));
+    int found = 0, rc = 0;
+    uint64_t pos = 0;
+    for (int w = 0; w < 10000; ++w) rc |= ss_search_device(s, d_hay, len, nullptr, &found);
+    size_t free0 = 0, free1 = 0, tot = 0;
+    HK(hipMemGetInfo(&free0, &tot));
+    const long rss0 = rss_kib();
+    const auto t0 = clk::now();
+    long wrong = 0;
+    for (long k = 0; k < calls; ++k) {
+        switch (k & 3) {
+        case 0: rc |= ss_search_device(s, d_hay, len, nullptr, &found); wrong += found != 0; break;
+        case 1: rc |= ss_search_device(sp, d_hay, len, nullptr, &found); wrong += found != 1; break;
+        case 2: rc |= ss_search_host(sp, h_hay.data(), len, &found); wrong += found != 1; break;
+        default: rc |= ss_find_device(sp, d_hay, len, nullptr, &pos); wrong += pos != 1000; break;
+        }
+    }
+    const double secs = seconds_since(t0);
+    HK(hipDeviceSynchronize());
+    HK(hipMemGetInfo(&free1, &tot));
+    const long rss1 = rss_kib();
+    std::printf("{\"mode\": \"soak\", \"calls\": %ld, \"seconds\": %.1f, \"us_per_call\": %.2f, \"rc\": %d, \"wrong_answers\": %ld, "
+                "\"rss_kib_before\": %ld, \"rss_kib_after\": %ld, \"device_free_before\": %zu, \"device_free_after\": %zu}\n",
+                calls, secs, secs / (double)calls * 1e6, rc, wrong, rss0, rss1, free0, free1);
+    ss_searcher_free(s);
+    ss_searcher_free(sp);
+    (void)hipFree(d_hay);
+    return (rc == 0 && wrong == 0) ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "headline";
@@ -328,6 +384,7 @@ int main(int argc, char **argv)
         }
         return config1(argv[2], argv[3], argc > 4 ? std::atoi(argv[4]) : 5);
     }
+    if (mode == "soak") return soak(argc > 2 ? std::atol(argv[2]) : 2000000);
     if (mode == "sharded") return sharded(argc > 2 ? std::atof(argv[2]) : 8.0, argc > 3 ? std::atoi(argv[3]) : 50);
     if (mode == "headline") return headline(argc > 2 ? std::atof(argv[2]) : 64.0, argc > 3 ? std::atoi(argv[3]) : 20);
     // backwards compatible: native_bench <GiB> <steps>
