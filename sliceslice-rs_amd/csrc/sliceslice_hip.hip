@@ -94,8 +94,8 @@ struct PerDevice {
     int *h_flags = nullptr;     // pinned-host mirror written by the finding wave (no D2H copy per call)
     uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
     uint64_t *h_best = nullptr; // pinned mirror
-    int *d_done = nullptr;      // kSlots wave counters of the completion word (zero whenever a slot is free)
-    long long *h_done = nullptr;// pinned: 2*epoch + found, stored by the last wave of a small grid
+    int *d_done = nullptr;      // kSlots workgroup counters of the completion word (zero whenever a slot is free)
+    long long *h_done = nullptr;// pinned: 2*epoch + found, stored by the last workgroup of a small grid
     uint64_t free_mask = 0;
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
 };
@@ -270,7 +270,7 @@ uint32_t occupancy_pad(int occ, unsigned block)
 // 1 % faster at every size from 2 GiB (64 GiB 7.45-7.47 vs 7.36-7.40 TB/s, in one process on one buffer:
 // profiles/r02/occupancy_by_size.jsonl).  The same file has the experiment for a 95-VGPR build of the three-byte
 // kernel: five workgroups per CU are 1-5 % SLOWER than four up to 8 GiB and 0.6 % faster from 16 GiB.
-Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position, uint64_t len)
+Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
 {
     Launch l;
     l.U = kAutoU;
@@ -279,7 +279,6 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position, u
     l.l8 = one_byte;
     l.block = ss::kBlock;
     l.dyn_lds = one_byte ? occupancy_pad(4, l.block) : 0;
-    (void)len;
     (void)position;
     if (variant > 0) {
         l.dyn_lds = 0;
@@ -364,7 +363,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.done_counter = nullptr;
     pr.host_done = nullptr;
 
-    const Launch l = pick_variant(s->variant, pr.d, one_byte, position, (uint64_t)len);
+    const Launch l = pick_variant(s->variant, pr.d, one_byte, position);
     const uint64_t wpb = l.block / ss::kWave;
     const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
     uint64_t blocks, tpb;
@@ -434,16 +433,16 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     return SS_OK;
 }
 
-// ---- filter-pair choice for `new` callers ---------------------------------------------------------------
+// ---- filter-byte choice for `new` callers -------------------------------------------------------------
 // The reference tests needle[0] and needle[position] and leaves `position` to the caller, defaulting to the last
-// byte (x86.rs:252-255, 285); the result never depends on it (lib.rs:375-378).  On the GPU the pair decides how
+// byte (x86.rs:252-255, 285); the result never depends on it (lib.rs:375-378).  On the GPU the bytes decide how
 // often the second phase runs (text passes a {' ', ' '} filter at percent rates) and, through the distance
-// between the two bytes, which kernel runs (a distance >= 16 needs cross-lane traffic or a second load stream).
-// For `new` callers the library therefore picks BOTH bytes: the pair (a, b), a < b <= a + 15, among the first
-// kFilterWindow needle bytes with the lowest summed rarity rank (ss::byte_rarity_rank: a static, corpus-free
-// guess; bytes outside text are all "rare" alike).  Ties go to the reference's own pair (0, n-1) when it is
-// among the best, else to the widest pair (neighbouring text bytes are correlated), else to the earliest.
-// with_position callers keep (0, position).
+// between the first two, which kernel runs (a distance >= 16 needs cross-lane traffic or a second load stream).
+// For `new` callers the library therefore picks all of them (choose_filter_triple below): a first byte among the
+// first kFilterWindow needle bytes and the two cheapest of the 15 bytes behind it, cheapest sum first; the cost of
+// a byte is a static, corpus-free rarity class (ss::byte_rarity_rank; bytes outside text are all "rare" alike) or,
+// on request, the log of its count in a histogram of the haystack.  with_position callers keep (0, position) and
+// get the cheapest other byte of needle[1..15] as the third when position < 16.
 constexpr size_t kFilterWindow = 1024;
 
 inline int rarity_class(uint8_t b)
@@ -582,7 +581,7 @@ int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, 
 int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out)
 {
     // x86.rs:457: position = n.wrapping_sub(1) - what ss_searcher_position keeps reporting.  The filter bytes
-    // the device tests are chosen by choose_filter_pair (SLICESLICE_AUTO_FILTER=0: the reference's pair (0, n-1)).
+    // the device tests are chosen by choose_filter_triple (SLICESLICE_AUTO_FILTER=0: as with_position(n-1)).
     const char *e = getenv("SLICESLICE_AUTO_FILTER");
     return make_searcher(needle, n, n - 1, !(e && e[0] == '0'), out);
 }
@@ -780,7 +779,7 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     }
     if (rc != SS_OK) {
         (void)hipDeviceSynchronize();
-        (void)hipMemset(pd->d_done + k, 0, sizeof(int));     // a failed launch may have left the wave count behind
+        (void)hipMemset(pd->d_done + k, 0, sizeof(int));     // a failed launch may have left the workgroup count behind
     }
     release_slot(s, pd, k);
     return rc;
