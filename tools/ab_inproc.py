@@ -44,13 +44,15 @@ def main():
     ap.add_argument("--cases", default="n16,n1,n2000,tworst,tspaces")
     args = ap.parse_args()
     wait_for_vram_reclaim()
-    # name=path[@variant]: the same build can appear twice with different kernel-variant overrides
-    libs, variants = [], {}
+    # name=path[@variant[:grid]]: the same build can appear several times with different kernel-variant / grid overrides
+    libs, variants, grids = [], {}, {}
     for l in args.libs:
         name, rest = l.split("=", 1)
         path, _, var = rest.partition("@")
+        var, _, grid = var.partition(":")
         libs.append((name, load(path)))
         variants[name] = int(var) if var else 0
+        grids[name] = int(grid) if grid else 0
     n_bytes = int(args.gib * (1 << 30))
     hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
     assert libs[0][1].ss_fill_random_device(hay.data_ptr(), 0, n_bytes, 0x5EED0001, None) == 0
@@ -81,6 +83,9 @@ def main():
             if variants[name]:
                 L.ss_searcher_set_variant.argtypes = [vp, ctypes.c_int]
                 assert L.ss_searcher_set_variant(s, variants[name]) == 0
+            if grids[name]:
+                L.ss_searcher_set_grid.argtypes = [vp, ctypes.c_int]
+                assert L.ss_searcher_set_grid(s, grids[name]) == 0
             hs.append((name, L, s))
         found, ms = ctypes.c_int(0), ctypes.c_float(0)
         t_end = time.perf_counter() + 0.2
