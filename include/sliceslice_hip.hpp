@@ -156,6 +156,47 @@ private:
     ss_searcher *h_;
 };
 
+// Counterpart of `x86::Avx2Searcher` (src/x86.rs:266-382): needles of at least one byte.  An empty needle panics in the
+// reference (`assert!(position < size)` with position = size.wrapping_sub(1), src/x86.rs:285-300; test
+// `avx2_empty_needle`, src/x86.rs:545-549) where the dynamic searcher answers true; everything else is the dynamic
+// searcher.
+class HipSearcher : public DynamicHipSearcher {
+public:
+    static HipSearcher new_(const uint8_t *needle, size_t n)
+    {
+        if (n == 0) throw PositionPanic(SS_ERR_POSITION, "Avx2Searcher contract: the needle must not be empty");
+        return HipSearcher(DynamicHipSearcher::new_(needle, n));
+    }
+    static HipSearcher new_(const std::string &needle) { return new_(reinterpret_cast<const uint8_t *>(needle.data()), needle.size()); }
+    static HipSearcher with_position(const uint8_t *needle, size_t n, size_t position)
+    {
+        if (position >= n) throw PositionPanic(SS_ERR_POSITION, "position out of range (src/x86.rs:300)");
+        return HipSearcher(DynamicHipSearcher::with_position(needle, n, position));
+    }
+    static HipSearcher with_position(const std::string &needle, size_t position)
+    {
+        return with_position(reinterpret_cast<const uint8_t *>(needle.data()), needle.size(), position);
+    }
+
+private:
+    explicit HipSearcher(DynamicHipSearcher &&d) : DynamicHipSearcher(std::move(d)) {}
+};
+
+// Counterpart of `MemchrSearcher` (src/lib.rs:119-142): one byte; false for an empty haystack.
+class MemchrHipSearcher {
+public:
+    static MemchrHipSearcher new_(uint8_t needle) { return MemchrHipSearcher(needle); }
+    template <class H>
+    bool search_in(H &&haystack) const { return inner_.search_in(std::forward<H>(haystack)); }
+    bool search_in(const uint8_t *haystack, size_t len) const { return inner_.search_in(haystack, len); }
+    template <class H>
+    bool inlined_search_in(H &&haystack) const { return search_in(std::forward<H>(haystack)); }
+
+private:
+    explicit MemchrHipSearcher(uint8_t b) : inner_(DynamicHipSearcher::new_(&b, 1)) {}
+    DynamicHipSearcher inner_;
+};
+
 // All GPUs of a node behind ONE search_in (ss_comm_init_all / ss_search_sharded_all): the haystack is range-partitioned
 // into one shard per device (n-1 bytes of overlap: shard_range), each resident in its device's HBM; a search is one scan
 // per device plus one grouped all-reduce(MAX) of the found flag.  What a drop-in for `search_in(&self, &[u8]) -> bool`

@@ -166,6 +166,34 @@ impl<N: Needle> Drop for DynamicHipSearcher<N> {
     fn drop(&mut self) { unsafe { ss_searcher_free(self.handle) } }
 }
 
+/// Counterpart of `x86::Avx2Searcher<N>` (src/x86.rs:266-382): needles of at least one byte; an empty needle panics
+/// like the reference (`assert!(position < size)`, src/x86.rs:300; test `avx2_empty_needle`).
+pub struct HipSearcher<N: Needle>(DynamicHipSearcher<N>);
+
+impl<N: Needle> HipSearcher<N> {
+    pub fn new(needle: N) -> Self {
+        assert!(!needle.as_bytes().is_empty());
+        Self(DynamicHipSearcher::new(needle))
+    }
+    pub fn with_position(needle: N, position: usize) -> Self {
+        assert!(position < needle.as_bytes().len());
+        Self(DynamicHipSearcher::with_position(needle, position))
+    }
+    #[inline]
+    pub fn inlined_search_in(&self, haystack: &[u8]) -> bool { self.0.inlined_search_in(haystack) }
+    pub fn search_in(&self, haystack: &[u8]) -> bool { self.0.search_in(haystack) }
+}
+
+/// Counterpart of `MemchrSearcher` (src/lib.rs:119-142).
+pub struct MemchrHipSearcher(DynamicHipSearcher<[u8; 1]>);
+
+impl MemchrHipSearcher {
+    pub fn new(needle: u8) -> Self { Self(DynamicHipSearcher::new([needle])) }
+    #[inline]
+    pub fn inlined_search_in(&self, haystack: &[u8]) -> bool { self.0.inlined_search_in(haystack) }
+    pub fn search_in(&self, haystack: &[u8]) -> bool { self.0.search_in(haystack) }
+}
+
 /// All GPUs of the node behind ONE `search_in`: the haystack is range-partitioned into one shard per
 /// device (n-1 bytes of overlap, `ss_shard_range`), resident in that device's HBM; a search is one scan per
 /// device plus one grouped all-reduce(MAX) of the found flag (`ss_search_sharded_all`).
@@ -220,6 +248,15 @@ mod tests {
     }
 
     crate::generate_tests!(dynamic_hip_searcher, DynamicHipSearcher);
+
+    impl TestSearcher for super::HipSearcher<&[u8]> {
+        fn with_position(needle: &'static [u8], position: usize) -> Self { super::HipSearcher::with_position(needle, position) }
+        fn search_in(&self, haystack: &[u8]) -> bool { super::HipSearcher::search_in(self, haystack) }
+    }
+
+    #[test]
+    #[should_panic]
+    fn hip_empty_needle() { let _ = super::HipSearcher::new(Box::<[u8]>::from(&b""[..])); }               // x86.rs:545-549
 
     #[test]
     #[should_panic]

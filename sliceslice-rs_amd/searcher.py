@@ -4,6 +4,8 @@ Names and argument meaning follow the reference (all paths under /root/reference
 
     DynamicHipSearcher.new(needle)                  DynamicAvx2Searcher::new            src/x86.rs:454
     DynamicHipSearcher.with_position(needle, pos)   DynamicAvx2Searcher::with_position  src/x86.rs:468
+    HipSearcher.new / .with_position                Avx2Searcher::new / ::with_position src/x86.rs:282,297
+    MemchrHipSearcher.new(byte)                     MemchrSearcher::new                 src/lib.rs:124
     searcher.search_in(haystack) -> bool            DynamicAvx2Searcher::search_in      src/x86.rs:523
     PositionError                                   the `assert!` panics                src/x86.rs:300,473
 
@@ -302,6 +304,44 @@ class DynamicHipSearcher:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.ss_searcher_free(h)
+
+
+class HipSearcher(DynamicHipSearcher):
+    """GPU counterpart of ``sliceslice::x86::Avx2Searcher`` (src/x86.rs:266-382): the searcher for needles of at
+    least one byte - an EMPTY needle panics in the reference (`position = size.wrapping_sub(1)` fails
+    `assert!(position < size)`, src/x86.rs:285-300; test `avx2_empty_needle`, src/x86.rs:545-549), where the dynamic
+    searcher answers `true`.  Everything else is the dynamic searcher's behaviour."""
+
+    def __init__(self, needle, position=None):
+        nb = needle.astype(np.uint8).tobytes() if isinstance(needle, np.ndarray) else bytes(needle)
+        if len(nb) == 0:
+            raise PositionError(SS_ERR_POSITION, "Avx2Searcher contract: the needle must not be empty (src/x86.rs:300)")
+        if position is not None and position >= len(nb):
+            raise PositionError(SS_ERR_POSITION, "position %d out of range for a needle of %d bytes" % (position, len(nb)))
+        super().__init__(nb, position)
+
+
+class MemchrHipSearcher:
+    """GPU counterpart of ``sliceslice::MemchrSearcher`` (src/lib.rs:119-142): one byte, `search_in` is false for an
+    empty haystack."""
+
+    def __init__(self, needle):
+        b = int(needle)
+        if not 0 <= b <= 255:
+            raise ValueError("MemchrHipSearcher takes one byte (0..255)")
+        self._inner = DynamicHipSearcher(bytes([b]))
+
+    @classmethod
+    def new(cls, needle):
+        return cls(needle)
+
+    def search_in(self, haystack, stream=None):
+        return self._inner.search_in(haystack, stream)
+
+    inlined_search_in = search_in
+
+    def find(self, haystack, stream=None):
+        return self._inner.find(haystack, stream)
 
 
 def shard_range(length, needle_len, nranks, rank):

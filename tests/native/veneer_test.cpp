@@ -36,6 +36,18 @@ int main()
         panicked = true;
     }
     CHECK(panicked);
+    {   // Avx2Searcher's contract (src/x86.rs:533-549): avx2_invalid_position, avx2_empty_needle
+        using sliceslice::hip::HipSearcher;
+        using sliceslice::hip::MemchrHipSearcher;
+        bool p1 = false, p2 = false;
+        try { (void)HipSearcher::with_position("foo", 3); } catch (const PositionPanic &) { p1 = true; }
+        try { (void)HipSearcher::new_(""); } catch (const PositionPanic &) { p2 = true; }
+        CHECK(p1 && p2);
+        CHECK(HipSearcher::new_("ipsum").search_in(std::string("Lorem ipsum dolor")));
+        // MemchrSearcher (src/lib.rs:303-331)
+        CHECK(MemchrHipSearcher::new_('a').search_in(std::string("a")) && !MemchrHipSearcher::new_('a').search_in(std::string("")));
+        CHECK(MemchrHipSearcher::new_('z').search_in(std::string("xyz")) && !MemchrHipSearcher::new_('q').search_in(std::string("xyz")));
+    }
     CHECK(DynamicHipSearcher::new_("").search_in(std::string("")));            // N0
     CHECK(!DynamicHipSearcher::new_("x").search_in(std::string("")));          // MemchrSearcher, empty haystack
 

@@ -92,6 +92,27 @@ def test_constructor_contract(ss, kat):
                 ss.DynamicHipSearcher.with_position(needle, row["position"])
 
 
+def test_avx2_and_memchr_searcher_counterparts(ss, kat):
+    """The reference's two other searcher types on this path: Avx2Searcher (src/x86.rs:282-382; tests
+    avx2_invalid_position, avx2_empty_needle at :533-549) and MemchrSearcher (src/lib.rs:119-142; KATs :303-331)."""
+    with pytest.raises(ss.PositionError):
+        ss.HipSearcher.with_position(b"foo", 3)                    # avx2_invalid_position
+    with pytest.raises(ss.PositionError):
+        ss.HipSearcher.new(b"")                                     # avx2_empty_needle
+    assert ss.DynamicHipSearcher.new(b"").search_in(dev(b"abc")) is True        # the dynamic searcher's N0 arm instead
+    for row in kat["generic"]:
+        hay, needle = row["haystack"].encode(), row["needle"].encode()
+        if needle:
+            assert ss.HipSearcher.new(needle).search_in(dev(hay)) == row["expected"], row
+            assert ss.HipSearcher.with_position(needle, len(needle) // 2).search_in(hay) == row["expected"], row
+    for row in kat["memchr"]:
+        hay, needle = row["haystack"].encode(), row["needle"].encode()
+        assert len(needle) == 1
+        m = ss.MemchrHipSearcher.new(needle[0])
+        assert m.search_in(dev(hay)) == row["expected"] and m.search_in(hay) == row["expected"], row
+    assert ss.MemchrHipSearcher.new(0x61).search_in(dev(b"")) is False          # lib.rs:131-133
+
+
 def test_empty_needle_and_short_haystacks(ss):
     e = dev(b"")
     assert ss.DynamicHipSearcher.new(b"").search_in(e) is True          # x86.rs:500

@@ -87,3 +87,13 @@ def test_host_generator_matches_oracle_restatement():
     a = ss.fill_random_host(1 << 20, 1)
     counts = np.bincount(a, minlength=256)
     assert counts[255] == 0 and counts[1:255].min() > 3500 and counts[0] > 7000
+
+
+def test_avx2_searcher_contract_is_checked_before_the_device_is_touched():
+    # Avx2Searcher::new(empty) and ::with_position(needle, len) panic in the reference (src/x86.rs:300, 545-549)
+    with pytest.raises(ss.PositionError):
+        ss.HipSearcher.new(b"")
+    with pytest.raises(ss.PositionError):
+        ss.HipSearcher.with_position(b"foo", 3)
+    with pytest.raises(ValueError):
+        ss.MemchrHipSearcher.new(256)
