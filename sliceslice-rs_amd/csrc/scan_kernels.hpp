@@ -246,52 +246,65 @@ __host__ __device__ inline int byte_rarity_rank(uint8_t b)
     return 20;                                                 // control bytes, 0x80..0xFE
 }
 
-// Indices 1 .. min(n,16)-1 except `position`, sorted rarest-first; packed one byte each.
+// The second level's schedule: up to 15 of the indices 1 .. min(n,32)-1 (relative to the first filter byte) other than the
+// first-phase bytes, packed one byte each.  Bytes 16..31 - the next lane's chunk, one more cross-lane hop - come FIRST, rarest
+// first (at most kFarFirst of them), then bytes 1..15 rarest first: a candidate that has passed three rare bytes on text is
+// usually an occurrence of a stock phrase around those bytes, and what tells the needle from the phrase is more likely to
+// sit in the NEXT words than between the filter bytes.  Only the order (and which 15 of up to 29 bytes are tried before the
+// compare) depends on this; the result of a search never does.
+constexpr int kRefineWindow = 32;
+constexpr uint32_t kFarFirst = 10;
+
 __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, uint64_t n, uint64_t position,
                                                        uint64_t idx[2], uint64_t val[2], uint64_t position3 = ~0ull)
 {
-    uint8_t ks[15];
-    int rk[15];
-    uint32_t m = 0;
-    const int lim = n < 16 ? (int)n : 16;
+    uint8_t ks[2][kRefineWindow];            // [0] = far (K >= 16), [1] = near; each sorted by rarity rank
+    int rk[2][kRefineWindow];
+    uint32_t cnt[2] = {0, 0};
+    const int lim = n < (uint64_t)kRefineWindow ? (int)n : kRefineWindow;
     for (int K = 1; K < lim; ++K) {
         if ((uint64_t)K == position || (uint64_t)K == position3) continue;   // already tested by the first-level filter
+        const int g = K >= 16 ? 0 : 1;
         const int r = byte_rarity_rank(needle[K]);
-        int at = (int)m;
-        while (at > 0 && rk[at - 1] > r) {                     // insertion sort, stable
-            rk[at] = rk[at - 1];
-            ks[at] = ks[at - 1];
+        int at = (int)cnt[g];
+        while (at > 0 && rk[g][at - 1] > r) {                  // insertion sort, stable
+            rk[g][at] = rk[g][at - 1];
+            ks[g][at] = ks[g][at - 1];
             --at;
         }
-        rk[at] = r;
-        ks[at] = (uint8_t)K;
-        ++m;
+        rk[g][at] = r;
+        ks[g][at] = (uint8_t)K;
+        ++cnt[g];
     }
     idx[0] = idx[1] = val[0] = val[1] = 0;
-    for (uint32_t t = 0; t < m; ++t) {
-        idx[t >> 3] |= (uint64_t)ks[t] << (8 * (t & 7));
-        val[t >> 3] |= (uint64_t)needle[ks[t]] << (8 * (t & 7));
-    }
+    uint32_t m = 0;
+    auto emit = [&](uint8_t K) {
+        idx[m >> 3] |= (uint64_t)K << (8 * (m & 7));
+        val[m >> 3] |= (uint64_t)needle[K] << (8 * (m & 7));
+        ++m;
+    };
+    uint32_t far_used = 0;
+    for (; far_used < cnt[0] && far_used < kFarFirst; ++far_used) emit(ks[0][far_used]);
+    for (uint32_t t = 0; t < cnt[1] && m < 15; ++t) emit(ks[1][t]);
+    for (; far_used < cnt[0] && m < 15; ++far_used) emit(ks[0][far_used]);
     return m;
 }
 
 // Device form for kernels that build the problem descriptor themselves (batched): lane K ranks
-// needle[K]; four rarity classes are emitted in turn from wave ballots.  Coarser than the host sort,
-// which only changes the order of the checks.
+// needle[K] (K < 32); far bytes first, then near ones, four rarity classes each, emitted from wave ballots.  Coarser than
+// the host sort, which only changes the order of the checks.
 __device__ __forceinline__ uint32_t build_refine_order_wave(const uint8_t *needle, uint64_t n, uint64_t position,
                                                             int lane, uint64_t idx[2], uint64_t val[2], uint64_t position3 = ~0ull)
 {
-    const int lim = n < 16 ? (int)n : 16;
+    const int lim = n < (uint64_t)kRefineWindow ? (int)n : kRefineWindow;
     const bool valid = lane >= 1 && lane < lim && (uint64_t)lane != position && (uint64_t)lane != position3;
     const uint32_t b = valid ? needle[lane] : 0u;
     const int r = byte_rarity_rank((uint8_t)b);
     const int cls = !valid ? -1 : (r < 64 ? 0 : (r < 128 ? 1 : (r < 192 ? 2 : 3)));
     uint64_t i0 = 0, i1 = 0, v0 = 0, v1 = 0;
     uint32_t m = 0;
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-        uint32_t mask = (uint32_t)__ballot(cls == c) & 0xFFFFu;
-        while (mask) {
+    auto take = [&](uint32_t mask, uint32_t cap) {
+        while (mask && m < cap) {
             const int K = __ffs((int)mask) - 1;
             mask &= mask - 1;
             const uint64_t v = (uint32_t)__builtin_amdgcn_readlane((int)b, K) & 0xFF;
@@ -300,7 +313,11 @@ __device__ __forceinline__ uint32_t build_refine_order_wave(const uint8_t *needl
             else { i1 |= (uint64_t)K << sh; v1 |= v << sh; }
             ++m;
         }
-    }
+    };
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) take((uint32_t)__ballot(cls == c) & 0xFFFF0000u, kFarFirst);     // bytes 16..31
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) take((uint32_t)__ballot(cls == c) & 0x0000FFFFu, 15u);            // bytes 1..15
     idx[0] = i0; idx[1] = i1; val[0] = v0; val[1] = v1;
     return m;
 }
@@ -323,21 +340,34 @@ __device__ __forceinline__ uint32_t next_lane_diffs(uint32_t own, uint32_t nword
     return from_next_lane_or(last, own);
 }
 
-// One needle byte at offset K = 4*QK + rk (1..15): the differences to needle[K], moved down by K bytes, clear
+// The value two lanes ahead in the concatenation {this piece, next piece}: a second wave_shl:1 on top of next_lane_diffs.
+// Lane 62 receives what lane 63 got in the first hop; lane 63 needs lane 1 of the next piece, which exists only when that
+// piece is a register of this wave (kind 1) - otherwise it is unknown and passes ("matches"; the compare settles it).
+__device__ __forceinline__ uint32_t next2_lane_diffs(uint32_t hop1, uint32_t nword, uint32_t nkx4, int kind)
+{
+    uint32_t last = 0u;
+    if (kind == 1) last = rotate_from_next_lane(rotate_from_next_lane(nword ^ nkx4));
+    return from_next_lane_or(last, hop1);
+}
+
+// One needle byte at offset K = 4*QK + rk (1..31): the differences to needle[K], moved down by K bytes, clear
 // the candidate flags where they are not zero.  QK is a template parameter so that only the window dwords
-// QK .. QK+4 are built (QK+1 next-lane dwords instead of four, no run-time selects); rk is a run-time byte shift.
+// QK .. QK+4 of {own chunk, next lane's, the lane after's} are built (no run-time selects); rk is a run-time byte shift.
 template <int QK>
 __device__ __forceinline__ void refine_flags_q(const u32x4 &A, const NextPiece &np, uint32_t nkx4, uint32_t rk, uint32_t g[4])
 {
-    uint32_t e[8];
-    e[0] = A.x ^ nkx4;
-    e[1] = A.y ^ nkx4;
-    e[2] = A.z ^ nkx4;
-    e[3] = A.w ^ nkx4;
-    e[4] = next_lane_diffs(e[0], np.N.x, nkx4, np.kind);
-    e[5] = QK >= 1 ? next_lane_diffs(e[1], np.N.y, nkx4, np.kind) : 0u;
-    e[6] = QK >= 2 ? next_lane_diffs(e[2], np.N.z, nkx4, np.kind) : 0u;
-    e[7] = QK >= 3 ? next_lane_diffs(e[3], np.N.w, nkx4, np.kind) : 0u;
+    static_assert(QK >= 0 && QK <= 7, "second-level bytes lie within 32 bytes of the first filter byte");
+    constexpr auto need = [](int i) { return i >= QK && i <= QK + 4; };
+    const uint32_t own[4] = {A.x ^ nkx4, A.y ^ nkx4, A.z ^ nkx4, A.w ^ nkx4};
+    const uint32_t nw[4] = {np.N.x, np.N.y, np.N.z, np.N.w};
+    uint32_t e[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        e[j] = own[j];
+        e[4 + j] = e[8 + j] = 0u;
+        if (need(4 + j) || need(8 + j)) e[4 + j] = next_lane_diffs(own[j], nw[j], nkx4, np.kind);
+        if (need(8 + j)) e[8 + j] = next2_lane_diffs(e[4 + j], nw[j], nkx4, np.kind);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) g[j] &= zero_byte_flags(__builtin_amdgcn_alignbyte(e[j + QK + 1], e[j + QK], rk));
 }
@@ -384,7 +414,11 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
         case 0: apply(std::integral_constant<int, 0>{}, nkx4, rk); break;
         case 1: apply(std::integral_constant<int, 1>{}, nkx4, rk); break;
         case 2: apply(std::integral_constant<int, 2>{}, nkx4, rk); break;
-        default: apply(std::integral_constant<int, 3>{}, nkx4, rk); break;
+        case 3: apply(std::integral_constant<int, 3>{}, nkx4, rk); break;
+        case 4: apply(std::integral_constant<int, 4>{}, nkx4, rk); break;
+        case 5: apply(std::integral_constant<int, 5>{}, nkx4, rk); break;
+        case 6: apply(std::integral_constant<int, 6>{}, nkx4, rk); break;
+        default: apply(std::integral_constant<int, 7>{}, nkx4, rk); break;
         }
         any = any_left();
     }
@@ -408,7 +442,11 @@ __device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np
         case 0: refine_flags_q<0>(A, np, nkx4, rk, g); break;
         case 1: refine_flags_q<1>(A, np, nkx4, rk, g); break;
         case 2: refine_flags_q<2>(A, np, nkx4, rk, g); break;
-        default: refine_flags_q<3>(A, np, nkx4, rk, g); break;
+        case 3: refine_flags_q<3>(A, np, nkx4, rk, g); break;
+        case 4: refine_flags_q<4>(A, np, nkx4, rk, g); break;
+        case 5: refine_flags_q<5>(A, np, nkx4, rk, g); break;
+        case 6: refine_flags_q<6>(A, np, nkx4, rk, g); break;
+        default: refine_flags_q<7>(A, np, nkx4, rk, g); break;
         }
         any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
     }

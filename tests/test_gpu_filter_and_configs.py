@@ -407,3 +407,41 @@ def test_short_differential_campaign():
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         d = json.loads(out.stdout.strip().splitlines()[-1])
         assert d["fuzz"] == "ok" and d["searches"] > 1000, d
+
+
+def test_second_level_far_bytes_at_lane_piece_and_tile_edges(ss):
+    """The second level looks up to 31 bytes behind the first filter byte: bytes 16..31 come from the next lane's chunk and
+    the one after it (two cross-lane hops; for lanes 62 / 63 from the wave's next piece, or - after the wave's last
+    piece - from the halo chunk / not at all).  A 40-byte needle is planted so that its candidate falls into lanes
+    60..63 and 0..1 of the first and last piece of the first and last wave of a tile; exact copies must be found at their
+    offset, copies with ONE byte changed (a near byte, far bytes on both sides of every hop, bytes past the window) must not."""
+    ln = 1 << 20
+    base = torch.full((ln + 64,), 0x2E, dtype=torch.uint8, device="cuda")
+    needle = bytes(range(0x41, 0x41 + 40))
+    nd = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+    s = ss.DynamicHipSearcher.new(needle)
+    for mis in (0, 7):
+        hay = base[mis:mis + ln]
+        for first, second, third in ((0, 5, 9), (3, 18, 11), (7, 8, 9)):
+            s.set_filter(first, second, third)
+            for tile in (0, 5):
+                for wave in (0, 3):
+                    for piece in (0, 3):
+                        for lane in (60, 61, 62, 63, 0, 1):
+                            # aligned coordinates are those of hay + first (16-byte grid of the device pointer)
+                            chunk = ((tile * 4 + wave) * 4 + piece) * 64 + lane
+                            phase = (hay.data_ptr() + first) & 15
+                            at = chunk * 16 - phase - first + 3                 # candidate byte 3 of that chunk
+                            if at < 0 or at + 40 > ln:
+                                continue
+                            hay[at:at + 40] = nd
+                            assert s.search_in(hay) is True, (mis, first, tile, wave, piece, lane)
+                            assert s.find(hay) == at, (mis, first, tile, wave, piece, lane)
+                            for k in (1, 15, 16, 17, 19, 20, 27, 31, 32, 35, 39):
+                                if k in (first, second, third):
+                                    continue
+                                hay[at + k] = 0x7E
+                                assert s.search_in(hay) is False, (mis, first, tile, wave, piece, lane, k)
+                                hay[at + k] = needle[k]
+                            hay[at:at + 40] = 0x2E
+        assert s.search_in(hay) is False
