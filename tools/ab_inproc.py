@@ -73,12 +73,17 @@ def main():
                 raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
                 text = torch.from_numpy(raw.copy()).cuda().repeat((1 << 30) // raw.size)
             nd = {"tworst": b"segment descriptor table entries are", "tspaces": b" the quick brown fox ", "tpriv": b"privilege level zero!",
-                  "tcommon": b"there is not another one of these", "tmid": b"protection exception handler must"}[c]
+                  "tcommon": b"there is not another one of these", "tmid": b"protection exception handler must",
+                  "trefspaces": b" the quick brown fox ", "trefworst": b"segment descriptor table entries are", "trefshort": b" quick fox "}[c]
             h = text
         hs = []
         for name, L in libs:
             s = vp()
-            assert L.ss_searcher_new(nd, len(nd), ctypes.byref(s)) == 0, L.ss_last_error()
+            if c.startswith("tref"):                      # the reference's pair (0, n-1) on text: with_position
+                L.ss_searcher_with_position.argtypes = [vp, sz, sz, ctypes.POINTER(vp)]
+                assert L.ss_searcher_with_position(nd, len(nd), len(nd) - 1, ctypes.byref(s)) == 0, L.ss_last_error()
+            else:
+                assert L.ss_searcher_new(nd, len(nd), ctypes.byref(s)) == 0, L.ss_last_error()
             L.ss_searcher_set_timing(s, 1)
             if variants[name]:
                 L.ss_searcher_set_variant.argtypes = [vp, ctypes.c_int]
