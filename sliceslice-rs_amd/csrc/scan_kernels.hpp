@@ -1009,8 +1009,10 @@ struct BatchArgs {
 };
 constexpr int kBadPosition = -1;   // SS_BATCH_BAD_POSITION: flag of a problem whose position breaks the with_position rules
 
+// waves_per_eu(4, 4): without it the allocator ends at 129 VGPRs - one over the 128 that four waves per SIMD allow - and the
+// kernel runs three workgroups per CU instead of four.
 template <int U>
-__global__ void __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock) scan_batched_kernel(const BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     const uint64_t prob = blockIdx.x;

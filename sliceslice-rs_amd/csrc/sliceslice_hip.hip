@@ -1246,13 +1246,15 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     HIP_TRY(hipGetDevice(&dev));
     DeviceInfo di;
     if (int rc = device_info(dev, &di)) return rc;
+    if (count > 0x7fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
     HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
-    // The haystack lengths live on the device, so the grid is chosen from the problem count alone: about
-    // half as many workgroups in total as the single-problem kernel launches (64 per CU; short-lived workgroups
-    // that each scan a contiguous run of their problem's tiles balance the tail better than one long-lived
-    // workgroup per problem).  Surplus slices of short haystacks exit before touching the needle.
+    // The haystack lengths live on the device, so the grid is chosen from the problem count alone: 96 workgroups per
+    // CU in total (short-lived workgroups that each scan a contiguous run of their problem's tiles balance the tail
+    // better than one long-lived workgroup per problem).  Surplus slices of short haystacks exit before touching the
+    // needle.  Measured at 4,096 x 1 MiB with the kernel held to four waves per SIMD (tools/batch_probe.py,
+    // profiles/r02/batched_wg_sweep.jsonl): 64 / 96 / 128 / 160 / 192 per CU = 7.09 / 7.17 / 7.16 / 6.98 / 6.86 TB/s.
     // SLICESLICE_BATCH_WGS overrides the total (tuning aid).
-    uint64_t wg_target = (uint64_t)di.cus * 64;
+    uint64_t wg_target = (uint64_t)di.cus * 96;
     if (const char *e = getenv("SLICESLICE_BATCH_WGS")) {
         const long v = atol(e);
         if (v > 0) wg_target = (uint64_t)v;
@@ -1260,8 +1262,6 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     uint64_t slices = (wg_target + count - 1) / count;
     if (slices < 1) slices = 1;
     if (slices > 4096) slices = 4096;
-    if (count > 0x7fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
-    if (slices > 65535) slices = 65535;
     ss::scan_batched_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), 0, st>>>(a);
     HIP_TRY(hipGetLastError());
     return SS_OK;
