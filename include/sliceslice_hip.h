@@ -77,14 +77,17 @@ size_t ss_searcher_position(const ss_searcher *s);
  * (third == second: none).  The reference tests needle[0] and needle[position] (src/x86.rs:297-316) and proves
  * with its own tests that the result does not depend on `position` (src/lib.rs:375-378); every further byte
  * is one more necessary condition of a match, so it cannot change a result either.
- *   ss_searcher_with_position keeps the reference's pair (0, position) and, for position < 16, adds the rarest
- *     other byte of needle[1..15] as the third.
+ *   ss_searcher_with_position always tests the caller's byte needle[position].  Up to position 15 its partner is the
+ *     reference's needle[0], plus the rarest other byte of needle[1..15] as the third; from position 16 the partner is a
+ *     byte at most 15 in front of `position` (see ss_choose_filter_for_position), so that every constructor-built
+ *     searcher runs on the single-stream kernels.  ss_searcher_position() reports `position` either way.
  *   ss_searcher_new - whose caller did not choose - picks all three by a static rarity ranking of the needle's
  *     bytes (first byte + the two rarest of the 15 bytes behind it, over the first 1024 needle bytes), so that
  *     text-like haystacks rarely pass the filter and long needles stay on the single-stream kernels;
- *     ss_searcher_position() still reports n-1.  SLICESLICE_AUTO_FILTER=0 in the environment makes
- *     ss_searcher_new behave like ss_searcher_with_position(n-1).
- *   ss_searcher_set_filter overrides the pair and drops the third byte (a plain two-byte filter);
+ *     ss_searcher_position() still reports n-1.  SLICESLICE_AUTO_FILTER=0 in the environment makes both
+ *     constructors test the reference's pair (needle[0], needle[position]) at any distance.
+ *   ss_searcher_set_filter overrides the pair and drops the third byte (a plain two-byte filter; a pair 16 or
+ *     more apart - e.g. the reference's (0, n-1) for a long needle - runs on the cross-lane or two-stream kernels);
  *     ss_searcher_set_filter3 sets all three.  Tests, tuning, or a caller with corpus statistics (see
  *     ss_byte_histogram_device).  SS_ERR_POSITION if out of range.  Not thread-safe against running searches. */
 int ss_searcher_filter(const ss_searcher *s, size_t *first, size_t *second);
@@ -94,6 +97,12 @@ int ss_searcher_set_filter3(ss_searcher *s, size_t first, size_t second, size_t 
 /* What ss_searcher_new would pick for this needle (pure host functions, no device needed). */
 int ss_choose_filter_pair(const uint8_t *needle, size_t n, size_t *first, size_t *second);
 int ss_choose_filter_triple(const uint8_t *needle, size_t n, size_t *first, size_t *second, size_t *third);
+/* What ss_searcher_with_position would pick: `second` == position always; position < 16: first == 0 (the reference's pair,
+ * x86.rs:297-316) plus the rarest other byte of needle[1..15] as `third`; position >= 16: `first` is a byte at most 15 in
+ * front of `position` and `third` one of the 15 behind `first`, so that one 16-byte load serves all three - the result never
+ * depends on which bytes are tested (lib.rs:375-378).  ss_searcher_set_filter(s, 0, position) restores the reference's pair
+ * at any distance.  SS_ERR_POSITION as the constructor. */
+int ss_choose_filter_for_position(const uint8_t *needle, size_t n, size_t position, size_t *first, size_t *second, size_t *third);
 /* The same choice driven by a byte histogram of (a sample of) the haystack - ss_byte_histogram_device - instead of the
  * static ranking (hist == NULL: the static ranking): cost of a byte = log2(count + 1), so sums compare products of
  * frequencies.  Apply with ss_searcher_set_filter3.  Row f3 of SURVEY.md 8f for the three-byte filter. */
@@ -164,7 +173,8 @@ int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256]
  * Everything lives in device memory; the four range arrays hold `count` uint64 each.  CSR callers
  * pass (off, off + 1); ranges may alias, e.g. 4,585 needles against ONE haystack - the loop of
  * bench/benches/i386.rs:252-256 as a single launch.  position[i] follows the with_position rules
- * (NULL = the `new` default n_i - 1).  Writes `count` int32 flags to d_found (device), each with the
+ * (NULL = the `new` default n_i - 1) and is always one of the bytes the device tests; its partner bytes are picked on
+ * the device by the rule of ss_choose_filter_for_position (coarser ranking).  Writes `count` int32 flags to d_found (device), each with the
  * semantics of ss_search_device for its problem; a problem whose position breaks those rules - where the
  * reference panics while building the searcher, src/x86.rs:300,473 - gets SS_BATCH_BAD_POSITION instead
  * (a device array cannot be validated on the host without a read-back).  One workgroup (or more) per

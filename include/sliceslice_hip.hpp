@@ -138,7 +138,8 @@ public:
     ss_searcher *handle() const { return h_; }
 
     // The needle bytes the device filter tests (first, second, third; third == second: none).  `with_position`
-    // keeps the reference's pair (0, position); `new_` lets the library pick (sliceslice_hip.h).
+    // keeps the caller's byte (second == position; first == 0 up to position 15); `new_` lets the library pick all
+    // three (sliceslice_hip.h).
     struct Filter {
         size_t first, second, third;
     };

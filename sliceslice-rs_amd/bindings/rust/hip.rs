@@ -44,6 +44,7 @@ extern "C" {
     pub fn ss_searcher_filter3(s: *const ss_searcher, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
     pub fn ss_searcher_set_filter3(s: *mut ss_searcher, first: usize, second: usize, third: usize) -> c_int;
     pub fn ss_choose_filter_triple(needle: *const u8, n: usize, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
+    pub fn ss_choose_filter_for_position(needle: *const u8, n: usize, position: usize, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
     pub fn ss_choose_filter_triple_hist(needle: *const u8, n: usize, hist: *const u64, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
     // search_in (src/x86.rs:498-525)
     pub fn ss_search_device(s: *const ss_searcher, d_haystack: *const c_void, len: usize, hip_stream: *mut c_void, found: *mut c_int) -> c_int;

@@ -829,8 +829,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                 if (!ONE_BYTE) {
                     const uint64_t position = pr.d * 16 + 4 * Q + pr.r;
                     const uint64_t position3 = THREE ? (uint64_t)(4 * pr.q3 + pr.r3) : ~0ull;
+                    const uint64_t anchor = (uint64_t)((pr.base + pr.mis) - pr.hay);      // index of the first filter byte
                     ro.n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)build_refine_order_wave(pr.needle, pr.n, position, lane, ro.idx, ro.val, position3));
+                        (int)build_refine_order_wave(pr.needle + anchor, pr.n - anchor, position, lane, ro.idx, ro.val, position3));
                     for (int t = 0; t < 2; ++t) {
                         ro.idx[t] = uniform64(ro.idx[t]);
                         ro.val[t] = uniform64(ro.val[t]);
@@ -1033,38 +1034,58 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     }
     if (len < n) return;                            // flag stays 0
 
+    // A `position` 16 or more behind needle[0] keeps its byte in the filter but gets a partner at most 15 in front of it
+    // instead of needle[0] (same rule as the host's choose_anchor, coarser ranking): lane K ranks
+    // needle[position - 15 + K]; the rarest class wins, the byte closest to `position` within it.  The filter then
+    // works in the coordinates of hay + anchor, and every problem runs in the single-stream kernel.
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint8_t *needle = a.needles + uniform64(n0);
+    position = uniform64(position);
+    uint64_t anchor = 0;
+    if (position >= 16) {
+        const bool valid = lane < 15;
+        const int rk = valid ? byte_rarity_rank(needle[position - 15 + lane]) : 0;
+        const int cls = !valid ? -1 : (rk < 64 ? 0 : (rk < 128 ? 1 : (rk < 192 ? 2 : 3)));
+        uint32_t pick = 1;
+#pragma unroll
+        for (int c = 3; c >= 0; --c) {
+            const uint32_t m = (uint32_t)__ballot(cls == c) & 0x7FFFu;
+            if (m) pick = m;                                  // ends up as the lowest non-empty class
+        }
+        anchor = position - 15 + (31u - (uint32_t)__builtin_clz(pick));
+    }
+
     // every field below is wave-uniform; uniform64 tells the compiler so (SGPRs, no scratch)
     Problem pr;
     pr.hay = a.haystacks + uniform64(h0);
-    pr.mis = (uint32_t)((uintptr_t)pr.hay & 15);
-    pr.base = pr.hay - pr.mis;
+    const uint8_t *hf = pr.hay + anchor;
+    pr.mis = (uint32_t)((uintptr_t)hf & 15);
+    pr.base = hf - pr.mis;
     pr.n = uniform64(n);
     pr.end = uniform64(len - n + 1);
-    pr.nchunks_all = (pr.mis + uniform64(len) + 15) / 16;
+    pr.nchunks_all = (pr.mis + uniform64(len) - anchor + 15) / 16;
     pr.npieces = ((pr.mis + pr.end + 15) / 16 + 63) / 64;
     // contiguous run of tiles per slice (same launch shape as the single-problem kernel); surplus slices
-    // of a short haystack leave before anything that depends on the needle is loaded
+    // of a short haystack leave before anything else that depends on the needle is loaded
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
     const uint64_t per = (ntiles + nslices - 1) / nslices;
     const uint64_t t0 = (uint64_t)slice * per;
     const uint64_t te = t0 + per < ntiles ? t0 + per : ntiles;
     if (t0 >= te) return;
 
-    pr.needle = a.needles + uniform64(n0);
-    position = uniform64(position);
-    pr.d = position / 16;
-    const uint32_t s = (uint32_t)(position % 16);
+    pr.needle = needle;
+    const uint32_t s = (uint32_t)(position - anchor);          // distance between the two filter bytes: 0 .. 15
+    pr.d = 0;
     pr.r = s % 4;
-    pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[0]);
-    pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[position]);
-    // third first-phase byte (single-stream kernels): the rarest of needle[1..15] other than needle[position],
-    // later bytes winning ties; lane K ranks needle[K], four rarity classes are tried in turn
+    pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor]);
+    pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[position]);
+    // third first-phase byte: the rarest of the 15 bytes behind the anchor other than needle[position],
+    // later bytes winning ties; lane K ranks needle[anchor + K], four rarity classes are tried in turn
     uint32_t p3 = s;
-    if (pr.d == 0 && n >= 3) {
-        const int lane = threadIdx.x & (kWave - 1);
-        const int lim = n < 16 ? (int)n : 16;
+    if (n - anchor >= 3) {
+        const int lim = n - anchor < 16 ? (int)(n - anchor) : 16;
         const bool valid = lane >= 1 && lane < lim && (uint32_t)lane != s;
-        const int rk = valid ? byte_rarity_rank(pr.needle[lane]) : 0;
+        const int rk = valid ? byte_rarity_rank(needle[anchor + lane]) : 0;
         const int cls = !valid ? -1 : (rk < 64 ? 0 : (rk < 128 ? 1 : (rk < 192 ? 2 : 3)));
         uint32_t pick = 0;
 #pragma unroll
@@ -1076,7 +1097,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     }
     pr.q3 = p3 / 4;
     pr.r3 = p3 % 4;
-    pr.n3x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.needle[pr.d == 0 ? p3 : 0]);
+    pr.n3x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor + p3]);
     // the second-level schedule is built lazily by the waves that need it (scan_tiles<..., LAZY_ORDER>)
     pr.norder = 0;
     pr.order_idx[0] = pr.order_idx[1] = pr.order_val[0] = pr.order_val[1] = 0;
@@ -1090,28 +1111,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
         scan_tiles<0, 0, true, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found);
         return;
     }
-    const int q = (int)(s / 4);
-    if (pr.d == 0) {                                // single stream: non-temporal loads
-        switch (q) {
-        case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        }
-    } else if (pr.d <= 62) {                        // one stream + cross-lane position flags (MODE 2)
-        switch (q) {
-        case 0: scan_tiles<0, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        case 1: scan_tiles<1, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        case 2: scan_tiles<2, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        default: scan_tiles<3, 2, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        }
-    } else {                                        // two streams: plain loads (the re-read must hit)
-        switch (q) {
-        case 0: scan_tiles<0, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        case 1: scan_tiles<1, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        case 2: scan_tiles<2, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        default: scan_tiles<3, 1, false, U, 0, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-        }
+    switch (s / 4) {                                // single stream, non-temporal loads
+    case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
     }
 }
 

@@ -441,8 +441,9 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
 // For `new` callers the library therefore picks all of them (choose_filter_triple below): a first byte among the
 // first kFilterWindow needle bytes and the two cheapest of the 15 bytes behind it, cheapest sum first; the cost of
 // a byte is a static, corpus-free rarity class (ss::byte_rarity_rank; bytes outside text are all "rare" alike) or,
-// on request, the log of its count in a histogram of the haystack.  with_position callers keep (0, position) and
-// get the cheapest other byte of needle[1..15] as the third when position < 16.
+// on request, the log of its count in a histogram of the haystack.  with_position callers keep their byte: with
+// position < 16 the pair is the reference's (0, position) plus the cheapest other byte of needle[1..15]; a farther
+// position gets a partner close in front of it (choose_anchor).  ss_searcher_set_filter sets any pair verbatim.
 constexpr size_t kFilterWindow = 1024;
 
 inline int rarity_class(uint8_t b)
@@ -530,13 +531,56 @@ void choose_filter_triple(const uint8_t *needle, size_t n, size_t *fa, size_t *f
     *fc = bc;
 }
 
+// with_position callers whose byte lies 16 or more behind needle[0]: the caller's byte stays a first-phase byte, but its
+// PARTNER becomes a byte at most 15 in front of it instead of needle[0] (the result does not depend on which bytes are
+// tested, lib.rs:375-378) - one 16-byte load then covers both, so the search runs in the single-stream kernel rather than
+// the cross-lane (distance < 1,008) or two-stream one.  (fa, fc): the cheapest anchor of needle[position-15 .. position-1]
+// together with its cheapest third byte of needle[fa+1 .. fa+15] other than `position`; ties to the later anchor.
+void choose_anchor(const uint8_t *needle, size_t n, size_t position, size_t *fa, size_t *fc, const ByteCost &cost)
+{
+    int best = INT_MAX;
+    size_t ba = position - 1, bc = position;
+    for (size_t a = position - 15; a < position; ++a) {
+        int c3 = 512;
+        size_t i3 = position;
+        for (size_t k = a + 1; k < n && k <= a + 15; ++k) {
+            if (k == position) continue;
+            const int c = cost(needle[k]);
+            if (c <= c3) {
+                c3 = c;
+                i3 = k;
+            }
+        }
+        const int total = cost(needle[a]) + c3;
+        if (total <= best) {
+            best = total;
+            ba = a;
+            bc = i3;
+        }
+    }
+    *fa = ba;
+    *fc = bc;
+}
+
+// with_position: the caller's byte plus the reference's partner needle[0] and one more byte when position < 16 (or always,
+// without the third byte at a distance >= 16, when the reference's exact pair is asked for), else choose_anchor's partner.
+void filter_for_position(const uint8_t *needle, size_t n, size_t position, bool exact_pair, size_t *fa, size_t *fb, size_t *fc,
+                         const ByteCost &cost)
+{
+    *fa = 0;
+    *fb = *fc = n >= 2 ? position : 0;
+    if (n < 2) return;
+    if (position >= 16 && !exact_pair) choose_anchor(needle, n, position, fa, fc, cost);
+    else *fc = choose_third(needle, n, *fa, *fb, cost);
+}
+
 void choose_filter_pair(const uint8_t *needle, size_t n, size_t *fa, size_t *fb)
 {
     size_t fc;
     choose_filter_triple(needle, n, fa, fb, &fc, ByteCost(nullptr));
 }
 
-int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_filter, ss_searcher **out)
+int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_filter, ss_searcher **out, bool exact_pair = false)
 {
     if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -552,11 +596,9 @@ int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_fi
     s->needle.assign(needle, needle + n);
     s->n = n;
     s->position = position;
-    s->fa = 0;
-    s->fb = n >= 2 ? position : 0;
     const ByteCost cost(nullptr);
     if (auto_filter) choose_filter_triple(s->needle.data(), n, &s->fa, &s->fb, &s->fc, cost);
-    else s->fc = choose_third(s->needle.data(), n, s->fa, s->fb, cost);  // with_position: the reference's pair + one more byte
+    else filter_for_position(s->needle.data(), n, position, exact_pair, &s->fa, &s->fb, &s->fc, cost);
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) {      // uploads the needle to the current device now
         delete s;
@@ -575,7 +617,9 @@ const char *ss_version(void) { return "sliceslice-hip 0.1 (gfx950)"; }
 
 int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out)
 {
-    return make_searcher(needle, n, position, false, out);
+    // SLICESLICE_AUTO_FILTER=0: the reference's pair (needle[0], needle[position]) at any distance
+    const char *e = getenv("SLICESLICE_AUTO_FILTER");
+    return make_searcher(needle, n, position, false, out, e && e[0] == '0');
 }
 
 int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out)
@@ -583,7 +627,8 @@ int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out)
     // x86.rs:457: position = n.wrapping_sub(1) - what ss_searcher_position keeps reporting.  The filter bytes
     // the device tests are chosen by choose_filter_triple (SLICESLICE_AUTO_FILTER=0: as with_position(n-1)).
     const char *e = getenv("SLICESLICE_AUTO_FILTER");
-    return make_searcher(needle, n, n - 1, !(e && e[0] == '0'), out);
+    const bool exact = e && e[0] == '0';
+    return make_searcher(needle, n, n - 1, !exact, out, exact);
 }
 
 int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second)
@@ -623,6 +668,17 @@ int ss_choose_filter_triple(const uint8_t *needle, size_t n, size_t *first, size
 {
     if (!first || !second || !third || (n && !needle)) return fail(SS_ERR_ARGUMENT, "NULL argument");
     choose_filter_triple(needle, n, first, second, third, ByteCost(nullptr));
+    return SS_OK;
+}
+
+int ss_choose_filter_for_position(const uint8_t *needle, size_t n, size_t position, size_t *first, size_t *second, size_t *third)
+{
+    if (!first || !second || !third || (n && !needle)) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    *first = *second = *third = 0;
+    if (n == 1 && position != 0) return fail(SS_ERR_POSITION, "position must be 0 for a one-byte needle");
+    if (n >= 2 && position >= n) return fail(SS_ERR_POSITION, "position %zu out of range for needle of %zu bytes", position, n);
+    const char *e = getenv("SLICESLICE_AUTO_FILTER");
+    filter_for_position(needle, n, position, e && e[0] == '0', first, second, third, ByteCost(nullptr));
     return SS_OK;
 }
 

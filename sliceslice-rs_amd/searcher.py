@@ -49,6 +49,7 @@ ABI = {
     "ss_searcher_filter3": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_searcher_set_filter3": (_int, [_vp, _sz, _sz, _sz]),
     "ss_choose_filter_triple": (_int, [_vp, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_choose_filter_for_position": (_int, [_vp, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_choose_filter_triple_hist": (_int, [_vp, _sz, _vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
     "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
@@ -604,6 +605,15 @@ def choose_filter_triple(needle, hist=None):
     else:
         h = np.ascontiguousarray(hist, dtype=np.uint64)
         _check(lib().ss_choose_filter_triple_hist(nb, len(nb), h.ctypes.data, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
+
+
+def choose_filter_for_position(needle, position):
+    """(first, second, third) that `DynamicHipSearcher.with_position(needle, position)` lets the device filter test:
+    `second == position`; `first == 0` (the reference's pair) when `position < 16`, else a byte at most 15 in front of it."""
+    nb = bytes(needle)
+    a, b, c = _sz(0), _sz(0), _sz(0)
+    _check(lib().ss_choose_filter_for_position(nb, len(nb), position, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
     return a.value, b.value, c.value
 
 

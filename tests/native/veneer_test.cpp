@@ -83,12 +83,14 @@ int main()
         CHECK(!DynamicHipSearcher::new_("not in the file at all").search_in_file(path));
         std::remove(path.c_str());
     }
-    // the filter bytes: with_position keeps the reference's pair, new_ picks rare bytes; results are the same
+    // the filter bytes: with_position keeps the caller's byte (and needle[0] up to 15 apart), new_ picks rare bytes; results are the same
     {
         const std::string text = " the quick brown fox ";
         auto ref = DynamicHipSearcher::with_position(text, 20);
         auto chosen = DynamicHipSearcher::new_(text);
-        CHECK(ref.filter().first == 0 && ref.filter().second == 20 && ref.position() == 20);
+        CHECK(ref.filter().first == 5 && ref.filter().second == 20 && ref.filter().third == 19 && ref.position() == 20);
+        auto near = DynamicHipSearcher::with_position(text, 7);
+        CHECK(near.filter().first == 0 && near.filter().second == 7 && near.position() == 7);
         CHECK(chosen.filter().first == 5 && chosen.filter().second == 19 && chosen.filter().third == 9 && chosen.position() == 20);
         const std::string hay = "jumps over the quick brown fox and runs";
         CHECK(ref.search_in(hay) && chosen.search_in(hay));

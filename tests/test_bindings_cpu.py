@@ -12,6 +12,8 @@ import re
 import subprocess
 import sys
 
+import pytest
+
 import sliceslice_rs_amd as ss
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -171,6 +173,37 @@ def test_filter_pair_choice_properties():
         a, b, c = ss.choose_filter_triple(nd)
         assert a < b < n and a < c < n and b != c and b - a <= 15 and c - a <= 15, (nd[:24], a, b, c)
         assert ss.choose_filter_pair(nd) == (a, b)
+
+
+def test_filter_choice_for_a_callers_position():
+    """ss_choose_filter_for_position (pure host code): the caller's byte is always tested; up to 15 bytes from needle[0] the
+    partner is the reference's needle[0], further away a byte at most 15 in front of `position`, and a third byte within 15
+    of the partner whenever the needle has one to offer."""
+    import random
+    rng = random.Random(3)
+    for _ in range(3000):
+        n = rng.choice([1, 2, 3, 16, 17, 18, 40, 200, 1100, 3000])
+        nd = bytes(rng.choice(b"etaoinshr dlu,.XQ\x00\xfe") for _ in range(n))
+        p = rng.choice([0, n - 1, n // 2, rng.randrange(n)])
+        a, b, c = ss.choose_filter_for_position(nd, p)
+        assert b == p and ss.choose_position(nd) == n - 1
+        if p < 16:
+            others = [k for k in range(1, min(16, n)) if k != p]                 # what needle[1..15] has to offer as a third byte
+            assert a == 0 and (c in others if others and n >= 3 else c == b), (n, p, a, b, c)
+        else:
+            assert p - 15 <= a < p and a < c <= min(a + 15, n - 1) and c != p, (n, p, a, b, c)
+    assert ss.choose_filter_for_position(b" the quick brown fox ", 20) == (5, 20, 19)      # 'q' ... ' ' + 'x'
+    assert ss.choose_filter_for_position(b" the quick brown fox ", 7) == (0, 7, 5)
+    assert ss.choose_filter_for_position(b"", 5) == (0, 0, 0)                             # N0: any position (x86.rs:470)
+    assert ss.choose_filter_for_position(b"x", 0) == (0, 0, 0)
+    for nd, p in ((b"x", 1), (b"foo", 3), (b"a" * 40, 40)):                               # x86.rs:300, 473
+        with pytest.raises(ss.PositionError):
+            ss.choose_filter_for_position(nd, p)
+    os.environ["SLICESLICE_AUTO_FILTER"] = "0"
+    try:
+        assert ss.choose_filter_for_position(b"a" * 39 + b"b", 39) == (0, 39, 39)         # the reference's pair at any distance
+    finally:
+        del os.environ["SLICESLICE_AUTO_FILTER"]
 
 
 def test_histogram_driven_filter_choice():

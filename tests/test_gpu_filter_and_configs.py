@@ -95,22 +95,30 @@ def test_filter_pair_bounds_are_checked(ss):
         s1.set_filter(0, 1)
 
 
-def test_new_picks_rare_bytes_and_with_position_keeps_the_reference_pair(ss):
+def test_new_picks_rare_bytes_and_with_position_keeps_the_callers_byte(ss):
     s = ss.DynamicHipSearcher.new(b" the quick brown fox ")
     assert s.position == 20 and s.filter == ss.choose_filter_pair(b" the quick brown fox ") == (5, 19)   # 'q', 'x'
     assert s.filter3 == ss.choose_filter_triple(b" the quick brown fox ") == (5, 19, 9)                  # ... and 'k'
-    for p in (0, 7, 20):
+    for p in (0, 7, 15):
         w = ss.DynamicHipSearcher.with_position(b" the quick brown fox ", p)
-        assert w.filter == (0, p)                            # the reference's pair is kept
+        assert w.position == p and w.filter == (0, p)        # up to 15 apart the reference's pair is kept
     assert ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 7).filter3 == (0, 7, 5)        # + 'q' as the third
-    assert ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 20).filter3 == (0, 20, 20)     # 20 apart: none
-    # a 2000-byte needle: the default position 1999 would need two load streams; `new` stays within 15 bytes
+    # further apart the caller's byte stays, its partner moves next to it: 'q', ' ' (position 20), 'x'
+    w = ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 20)
+    assert w.position == 20 and w.filter3 == ss.choose_filter_for_position(b" the quick brown fox ", 20) == (5, 20, 19)
+    w.set_filter(0, 20)                                      # the reference's pair, verbatim (cross-lane kernel)
+    assert w.filter3 == (0, 20, 20)
+    # a 2000-byte needle: the default position 1999 would need two load streams; `new` and `with_position` stay within 15 bytes
     long_needle = (b"lorem ipsum dolor sit amet, " * 80)[:2000]
     a, b = ss.DynamicHipSearcher.new(long_needle).filter
     assert a < b <= a + 15
+    for p in (16, 500, 1007, 1008, 1999):
+        a, b, c = ss.DynamicHipSearcher.with_position(long_needle, p).filter3
+        assert b == p and p - 15 <= a < p and a < c <= a + 15 and c != p
     os.environ["SLICESLICE_AUTO_FILTER"] = "0"
     try:
         assert ss.DynamicHipSearcher.new(long_needle).filter == (0, 1999)
+        assert ss.DynamicHipSearcher.with_position(long_needle, 1000).filter3 == (0, 1000, 1000)
     finally:
         del os.environ["SLICESLICE_AUTO_FILTER"]
 

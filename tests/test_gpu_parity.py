@@ -61,14 +61,29 @@ def test_cross_lane_primitives(ss):
         assert out[128 + l] == (((hi << 32) | lo) >> (8 * r)) & 0xFFFFFFFF
 
 
+def position_searchers(ss, needle, position):
+    """with_position(needle, position) as the library runs it and - for a position 16 or more behind needle[0], where the
+    library pairs the caller's byte with one close in front of it - the reference's own pair (needle[0], needle[position])
+    too: the cross-lane kernel up to a distance of 1,007, the two-stream kernel beyond."""
+    s = ss.DynamicHipSearcher.with_position(needle, position)
+    if position >= 16:
+        a, b, c = s.filter3
+        assert b == position and 1 <= b - a <= 15 and (c == b or 1 <= c - a <= 15), (position, s.filter3)
+        e = ss.DynamicHipSearcher.with_position(needle, position)
+        e.set_filter(0, position)
+        assert e.filter3 == (0, position, position)
+        return [s, e]
+    return [s]
+
+
 def test_generic_kats_every_position(ss, kat):
     # src/lib.rs:370-381 - device-resident and host haystack paths
     for row in kat["generic"]:
         hay, needle = row["haystack"].encode(), row["needle"].encode()
         dh = dev(hay)
         for position in range(len(needle)):
-            s = ss.DynamicHipSearcher.with_position(needle, position)
-            assert s.search_in(dh) == row["expected"], (row, position)
+            for s in position_searchers(ss, needle, position):
+                assert s.search_in(dh) == row["expected"], (row, position, s.filter3)
         s = ss.DynamicHipSearcher.new(needle)
         assert s.search_in(dh) == row["expected"], row
         assert s.search_in(hay) == row["expected"], row         # ss_search_host
@@ -145,7 +160,8 @@ def test_long_haystack_absent_words(ss, O, corpus):
             want = needle in corpus["i386"]
             assert ss.DynamicHipSearcher.new(needle).search_in(dh) == want, needle
             p = rng.randrange(len(needle))
-            assert ss.DynamicHipSearcher.with_position(needle, p).search_in(dh) == want, (needle, p)
+            for s in position_searchers(ss, needle, p):
+                assert s.search_in(dh) == want, (needle, p, s.filter3)
 
 
 def test_random_grid(ss, corpus, checksums):
@@ -179,8 +195,8 @@ def test_boundary_sweep_vs_oracle(ss, O):
             view = big[mis:mis + ln]
             view.copy_(torch.from_numpy(hay))
             for position in {0, n - 1, n // 2, rng.randrange(n)}:
-                got = ss.DynamicHipSearcher.with_position(needle, position).search_in(view)
-                assert got == want, (n, end, mis, position)
+                for s in position_searchers(ss, needle, position):
+                    assert s.search_in(view) == want, (n, end, mis, position, s.filter3)
 
 
 def test_single_match_at_every_kind_of_edge(ss):
@@ -203,8 +219,8 @@ def test_single_match_at_every_kind_of_edge(ss):
                         continue
                     hay[a:a + n] = nd
                     for position in {0, n - 1, n // 2}:
-                        s = ss.DynamicHipSearcher.with_position(needle, position)
-                        assert s.search_in(hay) is True, (n, mis, a, position)
+                        for s in position_searchers(ss, needle, position):
+                            assert s.search_in(hay) is True, (n, mis, a, position, s.filter3)
                     hay[a:a + n] = 0x2E
             assert ss.DynamicHipSearcher.new(needle).search_in(hay) is False
 
@@ -310,6 +326,15 @@ def test_all_kernel_variants_agree(ss, O):
                 s.set_variant(variant)
                 s.set_grid(grid)
                 assert s.search_in(t) == want, (len(nd), variant, grid)
+            if len(nd) > 16:
+                # the reference's pair (needle[0], needle[n-1]), which no constructor picks at this distance: the mode digit
+                # (x1xx two streams, x2xx cross-lane up to a distance of 1,007) takes effect only here
+                for grid in (0, 7, -3):
+                    s = ss.DynamicHipSearcher.new(nd)
+                    s.set_filter(0, len(nd) - 1)
+                    s.set_variant(variant)
+                    s.set_grid(grid)
+                    assert s.search_in(t) == want, (len(nd), variant, grid, "reference pair")
 
 
 def test_candidate_heavy_inputs(ss, O):
@@ -588,7 +613,8 @@ def test_find_leftmost_vs_python(ss, corpus):
         for at in (0, 1, 15, 16, 1023, 1024, 1025, 16383, 16384, 65535, 65536, 200000 - n):
             hay[at:at + n] = nd
             for position in {0, n - 1, n // 2}:
-                assert ss.DynamicHipSearcher.with_position(needle, position).find(hay) == at, (n, at, position)
+                for s in position_searchers(ss, needle, position):
+                    assert s.find(hay) == at, (n, at, position, s.filter3)
             hay[at:at + n] = 0x2E
     # random data, short needles: first occurrence somewhere in the middle
     r = torch.empty(4 << 20, dtype=torch.uint8, device="cuda")
@@ -766,8 +792,8 @@ def test_offsets_beyond_4gib_and_long_needles(ss):
         assert sl.search_in(t) is True and sl.find(t) == at, n
         bad = bytearray(cut)
         bad[n - 3] ^= 0x55
-        sb = ss.DynamicHipSearcher.with_position(bytes(bad), n // 2)
-        assert sb.search_in(t) is False, n
+        for sb in position_searchers(ss, bytes(bad), n // 2):
+            assert sb.search_in(t) is False, (n, sb.filter3)
     del t
 
 

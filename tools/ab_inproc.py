@@ -66,20 +66,25 @@ def main():
         return a.tobytes()
     table = {}
     for c in args.cases.split(","):
-        if c.startswith("n"):
-            nd, h = absent(int(c[1:])), hay
+        if c.startswith("n"):                             # n16, nref2000 (reference pair), nwp2000 (with_position(n-1))
+            nd, h = absent(int(c.lstrip("nrefwp"))), hay
         else:
             if text is None:
                 raw = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
                 text = torch.from_numpy(raw.copy()).cuda().repeat((1 << 30) // raw.size)
-            nd = {"tworst": b"segment descriptor table entries are", "tspaces": b" the quick brown fox ", "tpriv": b"privilege level zero!",
+            nd = {"twpworst": b"segment descriptor table entries are", "twpspaces": b" the quick brown fox ",
+                  "tworst": b"segment descriptor table entries are", "tspaces": b" the quick brown fox ", "tpriv": b"privilege level zero!",
                   "tcommon": b"there is not another one of these", "tmid": b"protection exception handler must",
                   "trefspaces": b" the quick brown fox ", "trefworst": b"segment descriptor table entries are", "trefshort": b" quick fox "}[c]
             h = text
         hs = []
         for name, L in libs:
             s = vp()
-            if c.startswith("tref"):                      # the reference's pair (0, n-1) on text: with_position
+            if c.startswith("tref") or c.startswith("nref"):    # the reference's pair (0, n-1), verbatim
+                assert L.ss_searcher_new(nd, len(nd), ctypes.byref(s)) == 0, L.ss_last_error()
+                L.ss_searcher_set_filter.argtypes = [vp, sz, sz]
+                assert L.ss_searcher_set_filter(s, 0, len(nd) - 1) == 0, L.ss_last_error()
+            elif c.startswith("twp") or c.startswith("nwp"):    # with_position(n-1)
                 L.ss_searcher_with_position.argtypes = [vp, sz, sz, ctypes.POINTER(vp)]
                 assert L.ss_searcher_with_position(nd, len(nd), len(nd) - 1, ctypes.byref(s)) == 0, L.ss_last_error()
             else:

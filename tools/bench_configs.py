@@ -168,7 +168,12 @@ def main():
                  kernel_ms=round(ms, 3), gbps=round(text.numel() / ms / 1e6, 1))
             s = ss.DynamicHipSearcher.with_position(nd, len(nd) - 1)
             res, ms = timed(s, text, args.reps)
-            emit(config="text", needle=nd.decode("latin1"), label=label + "; with_position(n-1): the reference's pair (0, n-1)",
+            emit(config="text", needle=nd.decode("latin1"), label=label + "; with_position(n-1): the caller's byte, partner chosen next to it",
+                 filter_bytes=list(s.filter3), filter_chars=[chr(nd[k]) for k in s.filter3], haystack_bytes=text.numel(), found=res,
+                 kernel_ms=round(ms, 3), gbps=round(text.numel() / ms / 1e6, 1))
+            s.set_filter(0, len(nd) - 1)
+            res, ms = timed(s, text, args.reps)
+            emit(config="text", needle=nd.decode("latin1"), label=label + "; set_filter(0, n-1): the reference's pair, verbatim",
                  filter_bytes=list(s.filter3), haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
                  gbps=round(text.numel() / ms / 1e6, 1))
             # row f3: the same needle with the position chosen from a byte histogram of (a sample of) the haystack
@@ -191,11 +196,15 @@ def main():
             emit(config="adversarial", label=label, filter_bytes=list(s.filter3), haystack_bytes=n_bytes, found=res, kernel_ms=round(ms, 3),
                  gbps=round(n_bytes / ms / 1e6, 1))
         del a
-        # long needles on random bytes: `new` keeps the filter pair within 15 bytes (single-stream kernel); the
-        # reference's pair (0, n-1) needs the cross-lane kernel (n <= 1008) or a second load stream (beyond)
+        # long needles on random bytes: `new` and `with_position` keep the filter bytes within 15 bytes of each other
+        # (single-stream kernel); the reference's pair (0, n-1), verbatim, needs the cross-lane kernel (n <= 1008) or a
+        # second load stream (beyond)
         for n in (128, 1000, 2000):
             nd = absent(n)
-            for how, s in (("new()", ss.DynamicHipSearcher.new(nd)), ("with_position(n-1)", ss.DynamicHipSearcher.with_position(nd, n - 1))):
+            ref = ss.DynamicHipSearcher.new(nd)
+            ref.set_filter(0, n - 1)
+            for how, s in (("new()", ss.DynamicHipSearcher.new(nd)), ("with_position(n-1)", ss.DynamicHipSearcher.with_position(nd, n - 1)),
+                           ("set_filter(0, n-1)", ref)):
                 res, ms = timed(s, hay, args.reps)
                 emit(config="long-needle", needle_len=n, how=how, filter_bytes=list(s.filter3), haystack_bytes=n_bytes, found=res,
                      kernel_ms=round(ms, 4), gbps=round(n_bytes / ms / 1e6, 1))

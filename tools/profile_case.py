@@ -5,14 +5,16 @@ the algorithmic bytes per launch and the kernel time by hipEvents.
 
   cases:  headline1g   1 GiB random, 16-byte absent needle, new()              (scan_kernel<3,0,...>)
           onebyte      1 GiB random, 1-byte absent needle (8-byte loads)       (scan_kernel<0,0,true,...,L8>)
-          mode2        1 GiB random, 128-byte needle, with_position(127)       (scan_kernel<.,2,...> cross-lane)
-          mode1        1 GiB random, 2000-byte needle, with_position(1999)     (scan_kernel<.,1,...> two streams)
+          mode2        1 GiB random, 128-byte needle, set_filter(0, 127)       (scan_kernel<.,2,...> cross-lane)
+          mode1        1 GiB random, 2000-byte needle, set_filter(0, 1999)     (scan_kernel<.,1,...> two streams)
+          long_wp      1 GiB random, 2000-byte needle, with_position(1999)     (single stream: partner byte next to 1999)
           long_new     1 GiB random, 2000-byte needle, new()                   (single stream again)
           find         1 GiB random, 16-byte absent needle, find()             (FIND kernel)
           batched      4096 x 1 MiB, 4096 absent 16-byte needles, one launch   (scan_batched_kernel<4>)
           text_worst   i386.txt tiled to 1 GiB, letters-only absent phrase, new()
-          text_refpair the same phrase with the reference's pair (0, n-1)
-          text_spaces  ' the quick brown fox ' with the reference's pair (' ', ' ')
+          text_refpair the same phrase with the reference's pair (0, n-1), set verbatim
+          text_wp      the same phrase through with_position(n-1)
+          text_spaces  ' the quick brown fox ' with the reference's pair (' ', ' '), set verbatim
           text_spaces_new   the same needle through new(): filter bytes 'q', 'x', 'k'
           text_common_new   'there is not another one of these' through new(): common letters only
 """
@@ -71,16 +73,22 @@ def main():
         out.update(kernel="scan_batched_kernel", ms=round(float(np.median(ms)), 4))
     else:
         phrase = b"segment descriptor table entries are"
+        def exact(nd):                                   # the reference's pair (needle[0], needle[n-1]), verbatim
+            e = ss.DynamicHipSearcher.new(nd)
+            e.set_filter(0, len(nd) - 1)
+            return e
         s = {
             "headline1g": lambda: ss.DynamicHipSearcher.new(absent(16)),
             "onebyte": lambda: ss.DynamicHipSearcher.new(absent(1)),
-            "mode2": lambda: ss.DynamicHipSearcher.with_position(absent(128), 127),
-            "mode1": lambda: ss.DynamicHipSearcher.with_position(absent(2000), 1999),
+            "mode2": lambda: exact(absent(128)),
+            "mode1": lambda: exact(absent(2000)),
+            "long_wp": lambda: ss.DynamicHipSearcher.with_position(absent(2000), 1999),
+            "text_wp": lambda: ss.DynamicHipSearcher.with_position(phrase, len(phrase) - 1),
             "long_new": lambda: ss.DynamicHipSearcher.new(absent(2000)),
             "find": lambda: ss.DynamicHipSearcher.new(absent(16)),
             "text_worst": lambda: ss.DynamicHipSearcher.new(phrase),
-            "text_refpair": lambda: ss.DynamicHipSearcher.with_position(phrase, len(phrase) - 1),
-            "text_spaces": lambda: ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 20),
+            "text_refpair": lambda: exact(phrase),
+            "text_spaces": lambda: exact(b" the quick brown fox "),
             "text_spaces_new": lambda: ss.DynamicHipSearcher.new(b" the quick brown fox "),
             "text_common_new": lambda: ss.DynamicHipSearcher.new(b"there is not another one of these"),
         }[case]()
