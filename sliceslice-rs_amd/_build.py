@@ -6,9 +6,12 @@ whole build runs under an exclusive fcntl lock, objects and the library are writ
 and os.replace()d into place, so no process can ever CDLL a half-written file, and the up-to-date check
 compares the library with its objects (a failed link leaves an old .so behind newer .o files)."""
 import fcntl
+import json
 import os
+import re
 import shutil
 import subprocess
+import sys
 from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -84,7 +87,21 @@ def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host
 
     def compile_one(job):
         src, obj = job
-        _run([hipcc] + _FLAGS + extra_flags + ["-c", os.path.join(_CSRC, src), "-o", obj + tag], verbose)
+        cmd = [hipcc] + _FLAGS + extra_flags + ["-c", os.path.join(_CSRC, src), "-o", obj + tag]
+        if obj_suffix != ".o":
+            _run(cmd, verbose)
+        else:
+            # the regular build also records what the register allocator did with every kernel (see _resources)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            p = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+            rows = _resources(p.stderr, src)
+            if p.returncode != 0:
+                sys.stderr.write(p.stderr)
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+            with open(obj + ".res" + tag, "w") as f:
+                json.dump(rows, f)
+            os.replace(obj + ".res" + tag, obj + ".res")
         os.replace(obj + tag, obj)
 
     if todo:
@@ -93,7 +110,50 @@ def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", so + tag] + link_flags + objs +
          ["-ldl", "-pthread"], verbose)
     os.replace(so + tag, so)
+    if obj_suffix == ".o":
+        rows = []
+        for o in objs:
+            if os.path.exists(o + ".res"):
+                rows += json.load(open(o + ".res"))
+        with open(_RESOURCES + tag, "w") as f:
+            json.dump(rows, f, indent=0)
+        os.replace(_RESOURCES + tag, _RESOURCES)
     return so
+
+
+_RESOURCES = os.path.join(_CSRC, "kernel_resources.json")
+_RES_KEYS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+             "Occupancy [waves/SIMD]": "waves_per_simd", "SGPRs Spill": "sgpr_spills", "VGPRs Spill": "vgpr_spills",
+             "LDS Size [bytes/block]": "lds_bytes"}
+
+
+def _resources(remarks, tu):
+    """-Rpass-analysis=kernel-resource-usage remarks -> one row per kernel.  Kept next to the library
+    (csrc/kernel_resources.json, `kernel_resources()`): the scan kernels are fast at four waves per SIMD (<= 128 VGPRs) and
+    14 % slower at three, and which side of 128 the allocator lands on moves with unrelated edits."""
+    rows, cur = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: (?:\s*)([A-Za-z \[\]/]+): (\S+) \[-Rpass-analysis", line)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(2)
+        if key == "Function Name":
+            cur = {"kernel": val, "tu": tu}
+            rows.append(cur)
+        elif cur is not None and key in _RES_KEYS:
+            cur[_RES_KEYS[key]] = int(val)
+    if rows:
+        names = subprocess.run(["c++filt"] + [r["kernel"] for r in rows], capture_output=True, text=True)
+        if names.returncode == 0:
+            for r, n in zip(rows, names.stdout.splitlines()):
+                r["name"] = n
+    return rows
+
+
+def kernel_resources():
+    """Rows of csrc/kernel_resources.json (written by build()): kernel, name, vgprs, waves_per_simd, spills, ..."""
+    build()
+    return json.load(open(_RESOURCES))
 
 
 def build(force=False, verbose=False):

@@ -796,6 +796,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         // the third byte's dword window is wave-uniform run-time data: one copy of the phase per window
         auto run_phase1 = [&](auto loaded_c, auto full_c) {
             if constexpr (THREE) {
+                // Whoever builds the Problem orders the two further bytes so that q3 <= Q (they are interchangeable): the
+                // copies with Q3 > Q are never taken.  They stay instantiated all the same: with them pruned the register
+                // allocator needed 146 VGPRs instead of 121 for Q < 3 (tools/check_kernel_resources.py keeps an eye on it).
                 switch (pr.q3) {
                 case 0: load_and_filter(loaded_c, full_c, std::integral_constant<int, 0>{}); break;
                 case 1: load_and_filter(loaded_c, full_c, std::integral_constant<int, 1>{}); break;
@@ -932,7 +935,12 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 // ---- K1/K2/K3: one needle, one haystack ---------------------------------------------------------
 // gridDim.x workgroups; workgroup b scans tiles [b*tiles_per_block, (b+1)*tiles_per_block) when
 // tiles_per_block > 0 (contiguous runs, short-lived workgroups), or b, b+grid, ... when it is 0.
-#ifdef SS_WAVES_PER_EU      // occupancy experiments: -DSS_WAVES_PER_EU=5 asks for <= 96 VGPRs (5 waves per SIMD)
+// Four waves per SIMD (<= 128 VGPRs) is what the shipped U = 4 kernels need: at three they run at 6.3 instead of 7.4 TB/s
+// (profiles/r02/ab_filter_triples.jsonl).  The allocator lands on 121-123 by itself; asking for it with
+// amdgpu_waves_per_eu(4, 4) makes it fill all 128 and spill two registers in the cross-lane kernels, so the build records
+// every kernel's registers and occupancy instead (csrc/kernel_resources.json, checked by tests/test_bindings_cpu.py).
+// -DSS_WAVES_PER_EU=5 asks for <= 96 VGPRs (occupancy experiments).
+#ifdef SS_WAVES_PER_EU
 #define SS_SCAN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SS_WAVES_PER_EU, SS_WAVES_PER_EU)))
 #else
 #define SS_SCAN_OCCUPANCY
@@ -1074,11 +1082,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     if (t0 >= te) return;
 
     pr.needle = needle;
-    const uint32_t s = (uint32_t)(position - anchor);          // distance between the two filter bytes: 0 .. 15
+    uint32_t s = (uint32_t)(position - anchor);                // distance between the two filter bytes: 0 .. 15
     pr.d = 0;
-    pr.r = s % 4;
     pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor]);
-    pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[position]);
     // third first-phase byte: the rarest of the 15 bytes behind the anchor other than needle[position],
     // later bytes winning ties; lane K ranks needle[anchor + K], four rarity classes are tried in turn
     uint32_t p3 = s;
@@ -1095,6 +1101,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
         }
         if (pick) p3 = 31u - (uint32_t)__builtin_clz(pick);
     }
+    if (p3 / 4 > s / 4) {                           // the kernels want the third byte's dword not behind the second's
+        const uint32_t t = p3;
+        p3 = s;
+        s = t;
+    }
+    pr.r = s % 4;
+    pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor + s]);
     pr.q3 = p3 / 4;
     pr.r3 = p3 % 4;
     pr.n3x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor + p3]);

@@ -342,15 +342,20 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.end = (uint64_t)len - n + 1;
     pr.nchunks_all = ((uint64_t)pr.mis + (len - fa) + 15) / 16;
     pr.npieces = (((uint64_t)pr.mis + pr.end + 15) / 16 + 63) / 64;
-    const size_t position = fb - fa;                    // distance between the two filter bytes
+    size_t position = fb - fa;                          // distance between the two filter bytes
     pr.d = position / 16;
+    // third first-phase byte (single-stream kernels only, i.e. d == 0); "none" = the second byte once more
+    const bool three = !one_byte && pr.d == 0 && s->fc > fa && s->fc - fa <= 15 && s->fc < n;
+    size_t position3 = three ? s->fc - fa : position % 16;
+    // The two further bytes are interchangeable; the kernels are instantiated for "the third byte's dword is not behind
+    // the second's" only (10 copies of the first phase instead of 16 - and two of the six others, second byte in dword 0
+    // with the third in dword 1 or 3, came out of the compiler waiting for all four loads of a tile before the first
+    // xor: 6.3-6.4 instead of 7.4 TB/s, profiles/r02/ab_filter_triples.jsonl).
+    if (three && position3 / 4 > position / 4) std::swap(position, position3);
     const uint32_t sh = (uint32_t)(position % 16);
     pr.r = sh % 4;
     pr.n0x4 = 0x01010101u * s->needle[fa];
-    pr.nlx4 = 0x01010101u * s->needle[fb];
-    // third first-phase byte (single-stream kernels only, i.e. d == 0); "none" = the second byte once more
-    const bool three = !one_byte && pr.d == 0 && s->fc > fa && s->fc - fa <= 15 && s->fc < n;
-    const size_t position3 = three ? s->fc - fa : position % 16;
+    pr.nlx4 = 0x01010101u * s->needle[one_byte ? 0 : fa + position];
     pr.q3 = (uint32_t)(position3 / 4);
     pr.r3 = (uint32_t)(position3 % 4);
     pr.n3x4 = 0x01010101u * s->needle[one_byte ? 0 : fa + position3];

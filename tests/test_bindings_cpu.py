@@ -258,3 +258,27 @@ def test_rccl_enum_values_the_library_hard_codes():
         assert got == want, (name, got, want)
     assert "#define SS_UNIQUE_ID_BYTES 128" in open(os.path.join(ROOT, "include", "sliceslice_hip.h")).read()
     assert re.search(r"#define NCCL_UNIQUE_ID_BYTES 128", text)
+
+
+def test_kernels_the_library_launches_by_default_keep_four_waves_per_simd():
+    """build() records what the register allocator did with every kernel (csrc/kernel_resources.json).  The scan kernels run
+    at 7.4 TB/s with four waves per SIMD (<= 128 VGPRs) and at 6.3 with three, and which side of 128 a kernel lands on has
+    moved with unrelated edits before: every kernel a default launch can select must stay at >= 4 waves, without scratch."""
+    build = sys.modules["sliceslice_rs_amd._build"]
+    rows = build.kernel_resources()
+    names = [r["name"] for r in rows]
+    assert any("scan_batched_kernel<4>" in n for n in names) and any("scan_pairs_kernel" in n for n in names)
+    seen = 0
+    for r in rows:
+        m = re.match(r"void ss::scan_kernel<(\d), (\d), (true|false), (\d), (\d), (true|false), (true|false)>", r["name"])
+        if m:
+            q, mode, one_byte, u, nt, find, l8 = m.groups()
+            default = u == "4" and not (l8 == "true" and one_byte == "false")   # U = 8 and the two-byte L8 phase: set_variant only
+        else:
+            default = "scan_batched_kernel<4>" in r["name"]
+        if default:
+            seen += 1
+            assert r["waves_per_simd"] >= 4 and r["vgprs"] <= 128, r
+            assert r["scratch_bytes_per_lane"] == 0 or "scan_batched_kernel" in r["name"], r     # batched: SGPR spill slots only
+            assert r["vgpr_spills"] == 0, r
+    assert seen >= 4 * 12 + 6 + 1, seen                # 12 (Q, MODE) x {nt0, nt1} x {search, find} + one-byte kernels + batched

@@ -2,7 +2,8 @@
 """In-process A/B of library builds: every build is dlopen()ed (RTLD_LOCAL) into ONE process and scans the SAME
 device buffer, launches interleaved build by build - haystack placement, clocks and box are identical, so
 differences of a percent are visible (separate processes differ by +-2 % from placement alone).
-    python tools/ab_inproc.py --libs cur=...so two=...so --gib 8 --cases n16,n1,tworst"""
+    python tools/ab_inproc.py --libs cur=...so two=...so --gib 8 --cases n16,n1,tworst
+    python tools/ab_inproc.py --libs a=lib.so#0-15-14 b=lib.so#0-15-1 --cases n16      (one build, two filter triples)"""
 import argparse
 import ctypes
 import json
@@ -45,9 +46,12 @@ def main():
     args = ap.parse_args()
     wait_for_vram_reclaim()
     # name=path[@variant[:grid]]: the same build can appear several times with different kernel-variant / grid overrides
-    libs, variants, grids = [], {}, {}
+    # ...#a-b-c: the filter triple (ss_searcher_set_filter3; a-b: a pair) instead of the constructor's choice
+    libs, variants, grids, filters = [], {}, {}, {}
     for l in args.libs:
         name, rest = l.split("=", 1)
+        rest, _, flt = rest.partition("#")
+        filters[name] = [int(x) for x in flt.split("-")] if flt else None
         path, _, var = rest.partition("@")
         var, _, grid = var.partition(":")
         libs.append((name, load(path)))
@@ -90,6 +94,12 @@ def main():
             else:
                 assert L.ss_searcher_new(nd, len(nd), ctypes.byref(s)) == 0, L.ss_last_error()
             L.ss_searcher_set_timing(s, 1)
+            if filters[name]:
+                f = filters[name]
+                L.ss_searcher_set_filter.argtypes = [vp, sz, sz]
+                L.ss_searcher_set_filter3.argtypes = [vp, sz, sz, sz]
+                rc = L.ss_searcher_set_filter(s, f[0], f[1]) if len(f) == 2 else L.ss_searcher_set_filter3(s, f[0], f[1], f[2])
+                assert rc == 0, L.ss_last_error()
             if variants[name]:
                 L.ss_searcher_set_variant.argtypes = [vp, ctypes.c_int]
                 assert L.ss_searcher_set_variant(s, variants[name]) == 0
