@@ -128,6 +128,8 @@ impl<N: Needle> DynamicHipSearcher<N> {
         Self { handle, needle }
     }
     /// x86.rs:468-493; panics like the reference for `position >= len` (and `position != 0` for one byte).
+    /// `needle[position]` is always one of the bytes the device filter tests; its partner is `needle[0]` up to
+    /// position 15 and a byte at most 15 in front of `position` beyond (`filter()`), which cannot change a result.
     pub fn with_position(needle: N, position: usize) -> Self {
         let b = needle.as_bytes();
         let mut handle = std::ptr::null_mut();

@@ -14,6 +14,20 @@ tag, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
+# registers as the compiler allocated them (build() -> csrc/kernel_resources.json, snapshot in profiles/<round>/): rocprofv3's
+# VGPR_Count column is the architectural half of the unified file (64 for all of these), not what limits the occupancy
+res_path = os.path.join(dst, "kernel_resources.json")
+resources = json.load(open(res_path)) if os.path.exists(res_path) else []
+
+
+def allocated(kernel_name):
+    key = kernel_name.replace(" ", "")
+    for r in resources:
+        if r["name"].replace(" ", "").startswith(key.split("(")[0]):
+            return r
+    return None
+
+
 rows = []
 for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
     case = os.path.basename(kt)[len(tag) + 1:-3]
@@ -55,6 +69,9 @@ for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
         row["sq_per_kib"] = {c.replace("SQ_INSTS_", "").lower(): round(v / pieces, 2) for c, v in med.items() if c.startswith("SQ_INSTS_")}
         if med.get("SQ_WAVE_CYCLES"):
             row["wait_fraction"] = round(med.get("SQ_WAIT_ANY", 0) / med["SQ_WAVE_CYCLES"], 3)
+    a = allocated(k["Name"])
+    if a:
+        row.update(vgpr=a["vgprs"], waves_per_simd=a["waves_per_simd"], sgprs=a.get("sgprs"), scratch_bytes_per_lane=a.get("scratch_bytes_per_lane"))
     rows.append(row)
     for kind in ("kt",):
         os.makedirs(os.path.join(dst, "kernel_stats"), exist_ok=True)
@@ -62,11 +79,11 @@ for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
         shutil.copy(os.path.join(kt, "r_kernel_stats.csv"), os.path.join(dst, "kernel_stats", f"{case}_kernel_stats.csv"))
 json.dump(rows, open(os.path.join(dst, "kernels.json"), "w"), indent=1)
 with open(os.path.join(dst, "kernels.md"), "w") as fh:
-    fh.write("| case | kernel | rocprofv3 avg ms | GB/s | frac of 8 TB/s | fetched / algorithmic | VGPR | VALU / SALU / LDS / VMEM per KiB | wait |\n|---|---|---|---|---|---|---|---|---|\n")
+    fh.write("| case | kernel | rocprofv3 avg ms | GB/s | frac of 8 TB/s | fetched / algorithmic | VGPRs allocated (waves per SIMD) | VALU / SALU / LDS / VMEM per KiB | wait |\n|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
         sqk = r.get("sq_per_kib", {})
         fh.write("| %s | `%s` | %.4f | %.0f | %.3f | %s | %s | %s / %s / %s / %s | %s |\n" % (
             r["case"], r["kernel"].replace("void ", "")[:70], r["rocprof_avg_ms"], r["gbps"], r["frac_of_8tbps"],
-            r.get("fetched_over_algorithmic", "-"), r.get("vgpr", "-"), sqk.get("valu", "-"), sqk.get("salu", "-"), sqk.get("lds", "-"),
+            r.get("fetched_over_algorithmic", "-"), "%s (%s)" % (r.get("vgpr", "-"), r.get("waves_per_simd", "-")), sqk.get("valu", "-"), sqk.get("salu", "-"), sqk.get("lds", "-"),
             sqk.get("vmem_rd", "-"), r.get("wait_fraction", "-")))
 print(open(os.path.join(dst, "kernels.md")).read())
