@@ -78,9 +78,11 @@ def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host
     for src, obj in zip(_SOURCES, objs):
         if src not in own:
             continue
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(_mtime(src), newest_header):
+        stale = obj_suffix == ".o" and not os.path.exists(obj + ".res")         # objects from before the resource record
+        if force or stale or not os.path.exists(obj) or os.path.getmtime(obj) < max(_mtime(src), newest_header):
             todo.append((src, obj))
-    if not todo and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(o) for o in objs):
+    if (not todo and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(o) for o in objs) and
+            (obj_suffix != ".o" or os.path.exists(_RESOURCES))):
         return so
     hipcc = _hipcc()
     tag = ".tmp%d" % os.getpid()

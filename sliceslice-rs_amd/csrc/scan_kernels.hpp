@@ -83,10 +83,10 @@ struct Problem {
     int *host_flag;           // optional pinned-host mirror of the found flag (saves the D2H copy); may be null
     int epoch;                // the value that means "found" in the flag (1 for caller-owned flags; pool slots
                               // use a fresh value per call, so a slot never has to be cleared)
-    // Completion word (small grids of ss_search_device only; both null otherwise): every workgroup counts itself
-    // out on *done_counter; the last one stores 2*epoch + found to the pinned-host word *host_done and re-zeroes the
-    // counter.  The host spins on that word instead of waiting for the stream: one PCIe write instead of the
-    // completion-signal round trip.
+    // Completion word (small grids of ss_search_device / ss_find_device only; both null otherwise): every workgroup
+    // counts itself out on *done_counter; the last one stores 2*epoch + found (find: the leftmost offset + 1, or all ones)
+    // to the pinned-host word *host_done and re-zeroes the counter.  The host spins on that word instead of waiting for
+    // the stream: one PCIe write instead of the completion-signal round trip.
     int *done_counter;
     long long *host_done;
 };
@@ -982,7 +982,7 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         }
         scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
     }
-    if (!FIND && pr.done_counter != nullptr) {
+    if (pr.done_counter != nullptr) {
         // Completion word.  Every wave of the workgroup is past its last read of the haystack at the barrier; one lane
         // counts the workgroup out.  The count is relaxed: whoever set the found flag did so with an atomic exchange whose
         // result it waited for before it got here, and the last workgroup reads the flag with an atomic load - both
@@ -992,9 +992,18 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
             const int old = __hip_atomic_fetch_add(pr.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (int)gridDim.x - 1) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int f = __hip_atomic_load(static_cast<const int *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pr.epoch;
                 __hip_atomic_store(pr.done_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pr.host_done, 2ll * pr.epoch + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (FIND) {
+                    // find(): the word is the answer itself - leftmost offset + 1, or all ones for "absent" (the host zeroes
+                    // it before the launch) - and the slot is re-armed here instead of by publish_best_kernel
+                    uint64_t *best = static_cast<uint64_t *>(found);
+                    const uint64_t v = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != ~0ull) __hip_atomic_store(best, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(pr.host_done, v == ~0ull ? -1ll : (long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    const int f = __hip_atomic_load(static_cast<const int *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pr.epoch;
+                    __hip_atomic_store(pr.host_done, 2ll * pr.epoch + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }

@@ -403,7 +403,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     if (blocks < 1) blocks = 1;
     const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
     if (used_done) *used_done = false;
-    if (!find && done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks) {
+    if (done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks) {
         pr.done_counter = pd->d_done + done_slot;
         pr.host_done = pd->h_done + done_slot;
         pr.host_flag = nullptr;                          // the completion word carries the answer
@@ -808,6 +808,8 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     // reset of the slot afterwards: launch, wait for the stream, compare.
     const int epoch = next_epoch(pd, k);                // the slot is owned by this call
     static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
+    // the slot's completion word may hold a find()'s answer (offset + 1), which could pass for 2 * epoch + found
+    __atomic_store_n(pd->h_done + k, 0ll, __ATOMIC_RELAXED);
     bool used_done = false;
     int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch, spin_ok ? k : -1,
                           &used_done);
@@ -874,20 +876,51 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     const int k = acquire_slot(s, pd);
-    // Slots are all-ones whenever they are free: the one-lane kernel behind the scan stores the minimum to the
-    // slot's pinned-host mirror (no device-to-host copy command) and re-arms the slot.
-    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0);
-    if (rc == SS_OK) {
+    // Slots are all-ones whenever they are free.  Small grid: the scan's last workgroup stores the answer - offset + 1, or
+    // all ones - to the slot's completion word (zeroed here first: the word also serves ss_search_device, whose values
+    // carry an epoch) and re-arms the slot; the host spins on the word as ss_search_device does.  Larger grids: a one-lane
+    // kernel behind the scan stores the minimum to the slot's pinned mirror (no device-to-host copy command) and re-arms.
+    static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
+    __atomic_store_n(pd->h_done + k, 0ll, __ATOMIC_RELAXED);
+    bool used_done = false;
+    int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_best + k, true, 0, nullptr, 1, spin_ok ? k : -1, &used_done);
+    bool answered = false;
+    if (rc == SS_OK && used_done) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            const long long v = __atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE);
+            if (v != 0) {
+                *position = v == -1ll ? SS_NPOS : (uint64_t)v - 1;
+                answered = true;
+                // as in ss_search_device: a real stream wait now and then lets the runtime retire its commands
+                if ((next_epoch(pd, k) & 255) == 0) (void)hipStreamSynchronize(st);
+                break;
+            }
+            cpu_relax();
+            if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+        }
+        if (!answered) {
+            const hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                rc = fail(SS_ERR_HIP, "stream wait: %s", hipGetErrorString(e));
+            } else {
+                const long long v = __atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE);
+                if (v == 0) rc = fail(SS_ERR_HIP, "find: the completion word was not written");
+                else *position = v == -1ll ? SS_NPOS : (uint64_t)v - 1;
+                answered = rc == SS_OK;
+            }
+        }
+    } else if (rc == SS_OK) {
         ss::publish_best_kernel<<<1, 1, 0, st>>>(pd->d_best + k, pd->h_best + k);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(SS_ERR_HIP, "position read-back: %s", hipGetErrorString(e));
+        else *position = __atomic_load_n(pd->h_best + k, __ATOMIC_ACQUIRE);
     }
-    if (rc == SS_OK) {
-        *position = __atomic_load_n(pd->h_best + k, __ATOMIC_ACQUIRE);
-    } else {
+    if (rc != SS_OK) {
         (void)hipDeviceSynchronize();
         (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));
+        (void)hipMemset(pd->d_done + k, 0, sizeof(int));     // a failed launch may have left the workgroup count behind
     }
     release_slot(s, pd, k);
     return rc;

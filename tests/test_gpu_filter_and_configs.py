@@ -382,6 +382,16 @@ def test_completion_word_path_behind_a_long_kernel_and_across_sizes(ss):
                 s_long.search_in_async(big, flag)
         assert s_yes.search_in(small, stream=st.cuda_stream) is True
         assert s_no.search_in(small, stream=st.cuda_stream) is False
+        with torch.cuda.stream(st):
+            for _ in range(4):
+                s_long.search_in_async(big, flag)
+        assert s_yes.find(small, stream=st.cuda_stream) == 777      # find() answers through the same word
+        assert s_no.find(small, stream=st.cuda_stream) is None
+    # find and search_in interleaved on one handle share the slots' completion words (offset + 1 vs 2 * epoch + found)
+    for k in range(300):
+        small[777 + 3 * k:780 + 3 * k] = torch.tensor([5, 6, 7], dtype=torch.uint8)
+        assert s_yes.find(small) == 777 and s_yes.search_in(small) is True
+        assert s_no.search_in(small) is False and s_no.find(small) is None
     st.synchronize()
     assert int(flag.item()) == 0
     del big
