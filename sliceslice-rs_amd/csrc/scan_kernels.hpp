@@ -1093,14 +1093,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     pr.needle = needle;
     uint32_t s = (uint32_t)(position - anchor);                // distance between the two filter bytes: 0 .. 15
     pr.d = 0;
-    pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor]);
+    // ONE load serves all three filter bytes and the ranking: lane K holds needle[anchor + K], K < 16 (every further
+    // dependent load is a round trip a short-lived workgroup spends before its first haystack byte is requested)
+    const int lim = n - anchor < 16 ? (int)(n - anchor) : 16;
+    const uint32_t nb = lane < lim ? (uint32_t)needle[anchor + lane] : 0u;
+    pr.n0x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readlane((int)nb, 0);
     // third first-phase byte: the rarest of the 15 bytes behind the anchor other than needle[position],
-    // later bytes winning ties; lane K ranks needle[anchor + K], four rarity classes are tried in turn
+    // later bytes winning ties; four rarity classes are tried in turn
     uint32_t p3 = s;
     if (n - anchor >= 3) {
-        const int lim = n - anchor < 16 ? (int)(n - anchor) : 16;
         const bool valid = lane >= 1 && lane < lim && (uint32_t)lane != s;
-        const int rk = valid ? byte_rarity_rank(needle[anchor + lane]) : 0;
+        const int rk = valid ? byte_rarity_rank((uint8_t)nb) : 0;
         const int cls = !valid ? -1 : (rk < 64 ? 0 : (rk < 128 ? 1 : (rk < 192 ? 2 : 3)));
         uint32_t pick = 0;
 #pragma unroll
@@ -1116,10 +1119,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
         s = t;
     }
     pr.r = s % 4;
-    pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor + s]);
+    pr.nlx4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)s);
     pr.q3 = p3 / 4;
     pr.r3 = p3 % 4;
-    pr.n3x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readfirstlane((int)needle[anchor + p3]);
+    pr.n3x4 = 0x01010101u * (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)p3);
     // the second-level schedule is built lazily by the waves that need it (scan_tiles<..., LAZY_ORDER>)
     pr.norder = 0;
     pr.order_idx[0] = pr.order_idx[1] = pr.order_val[0] = pr.order_val[1] = 0;
