@@ -422,8 +422,9 @@ def main():
         try:
             searcher = ss.ShardedSearcher(needle, group=None, backend=transport)
         except ss.SlicesliceError as e:
-            # the native communicator could not be built (librccl not loadable, ncclCommInitRank refused): every rank
-            # sees the same failure, so all of them fall back to torch.distributed for the 4-byte flag - and say so
+            # the native communicator could not be built (librccl not loadable, ncclCommInitRank refused or timed out on
+            # some rank): ShardedSearcher makes the ranks agree on that before it raises, so every rank is here and all
+            # of them fall back to torch.distributed for the 4-byte flag - and say so
             if transport != "rccl":
                 raise
             transport_note = "native RCCL transport failed (%s); flag moved by torch.distributed instead" % e

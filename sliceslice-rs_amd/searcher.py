@@ -387,13 +387,44 @@ class ShardedSearcher:
     def _init_rccl(self):
         import torch
         uid = (ctypes.c_uint8 * 128)()
-        if self.rank == 0:
-            _check(lib().ss_comm_unique_id(uid))
-        box = [bytes(uid)]
-        self._dist.broadcast_object_list(box, src=0, group=self.group)
+        box = [None]
+        if self.rank == 0 and lib().ss_comm_unique_id(uid) == 0:
+            box = [bytes(uid)]
+        self._dist.broadcast_object_list(box, src=0, group=self.group)     # None: rank 0 has no id to offer
+        if box[0] is None:
+            raise SlicesliceError(SS_ERR_RCCL, "rank 0 could not create an RCCL unique id" +
+                                  (": " + lib().ss_last_error().decode("utf-8", "replace") if self.rank == 0 else ""))
         uid = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
         comm = ctypes.c_void_p()
-        _check(lib().ss_comm_init_rank(uid, self.nranks, self.rank, ctypes.byref(comm)))
+        # ncclCommInitRank is a collective: a rank on which it fails (or never returns) must not leave the others
+        # behind in it, and all ranks must take the same road afterwards.  It runs on a worker thread with a time
+        # limit (SLICESLICE_RCCL_INIT_TIMEOUT seconds, default 180); then the ranks agree - all-reduce(MIN) of "mine
+        # worked" on the torch group - and either all keep their communicator or all raise.
+        import threading
+        result = {}
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def work():
+            try:
+                if dev is not None:
+                    torch.cuda.set_device(dev)
+                result["rc"] = lib().ss_comm_init_rank(uid, self.nranks, self.rank, ctypes.byref(comm))
+                result["err"] = lib().ss_last_error().decode("utf-8", "replace") if result["rc"] else ""
+            except Exception as e:                                   # pragma: no cover - ctypes / loader failures
+                result["rc"], result["err"] = -1, repr(e)
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(float(os.environ.get("SLICESLICE_RCCL_INIT_TIMEOUT", "180")))
+        mine = 1 if (not t.is_alive() and result.get("rc") == 0) else 0
+        on_gpu = self._dist.get_backend(self.group) == "nccl"
+        ok = torch.tensor([mine], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+        self._dist.all_reduce(ok, op=self._dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) != 1:
+            if mine:
+                lib().ss_comm_free(comm)
+            why = "timed out" if t.is_alive() else (result.get("err") or "failed on another rank")
+            raise SlicesliceError(SS_ERR_RCCL, "native RCCL communicator not built on every rank (this rank: %s)" % why)
         self._comm = comm
         torch.cuda.synchronize()
 

@@ -89,3 +89,44 @@ def test_sharded_search_gloo(world):
     # every rank returns the same (combined) boolean
     for i in range(len(names)):
         assert len({out[r][i][1] for r in range(world)}) == 1
+
+
+def _rccl_refusal_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SLICESLICE_RCCL_INIT_TIMEOUT"] = "20"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sliceslice_rs_amd as ss
+        try:
+            ss.ShardedSearcher(b"needle", local_search=lambda shard: False, backend="rccl")
+            q.put((rank, "built"))
+        except ss.SlicesliceError as e:
+            q.put((rank, "refused: %s" % e))
+        dist.barrier()                                # both ranks are still in step afterwards
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_native_rccl_init_fails_on_all_ranks_together():
+    """No GPU here, so the native communicator cannot be built: every rank must get the SAME SlicesliceError (bench.py
+    then moves the flag with torch.distributed instead) - none may be left waiting in a broadcast or inside
+    ncclCommInitRank for a rank that has already given up."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the communicator may well come up")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_refusal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive, "a rank hung in the native RCCL bootstrap"
+    got = dict(q.get(timeout=5) for _ in range(world))
+    assert all(v.startswith("refused") for v in got.values()), got
