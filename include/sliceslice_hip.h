@@ -282,6 +282,10 @@ int ss_selftest_dpp(uint32_t *out);
 /* Test hooks: set the "found"-epoch counters (of every flag slot of `s` on the current device / of a
  * communicator or communicator set) so that a test can cross the 2^31 wrap. */
 int ss_debug_set_epochs(ss_searcher *s, int value);
+/* ... and the completion-word state of every slot of `s` on the current device, device counters and host copies alike:
+ * the never-reset count of workgroups (the library starts a slot over before 2^31), the count of workgroups that found
+ * the needle (wraps at 2^32) and the decreasing key of find()'s minimum (starts over at 0). */
+int ss_debug_set_completion_state(ss_searcher *s, uint32_t workgroups, uint32_t found_workgroups, uint32_t find_key);
 int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
 
 #ifdef __cplusplus

@@ -98,6 +98,7 @@ extern "C" {
     pub fn ss_version() -> *const c_char;
     pub fn ss_selftest_dpp(out: *mut u32) -> c_int;
     pub fn ss_debug_set_epochs(s: *mut ss_searcher, value: c_int) -> c_int;
+    pub fn ss_debug_set_completion_state(s: *mut ss_searcher, workgroups: u32, found_workgroups: u32, find_key: u32) -> c_int;
     pub fn ss_debug_set_comm_epoch(c: *mut ss_comm, set: *mut ss_comm_set, value: c_int) -> c_int;
 }
 

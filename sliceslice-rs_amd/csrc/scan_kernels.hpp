@@ -55,6 +55,7 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxBlock = 512;           // scan_kernel takes its workgroup size from the launch (128 / 256 / 512)
 constexpr int kMaxWavesPerBlock = kMaxBlock / kWave;
 constexpr unsigned kPeekFromBlock = 1024;   // workgroups before this one start with the launch: nothing to see yet
+constexpr int kFindOffsetBits = 40;      // completion-word find(): offsets below 2^40, the launch key above (see scan_kernel)
 constexpr int kNeedleLds = 2048;         // needle bytes staged in LDS per wave; longer needles continue from global
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -84,11 +85,15 @@ struct Problem {
     int epoch;                // the value that means "found" in the flag (1 for caller-owned flags; pool slots
                               // use a fresh value per call, so a slot never has to be cleared)
     // Completion word (small grids of ss_search_device / ss_find_device only; both null otherwise): every workgroup
-    // counts itself out on *done_counter; the last one stores 2*epoch + found (find: the leftmost offset + 1, or all ones)
-    // to the pinned-host word *host_done and re-zeroes the counter.  The host spins on that word instead of waiting for
-    // the stream: one PCIe write instead of the completion-signal round trip.
-    int *done_counter;
+    // counts itself out on *done_counter; the last one stores the answer to the pinned-host word *host_done - search:
+    // (found-half of the counter) << 32 | epoch << 1 | found; find: the leftmost offset + 1, or all ones.  The host spins
+    // on that word instead of waiting for the stream: one PCIe write instead of the completion-signal round trip.
+    unsigned long long *done_counter;
     long long *host_done;
+    // The counter is never reset: its low half counts workgroups out (the launch is complete when it reaches done_target),
+    // its high half counts the workgroups that found the needle (found == the half has moved on from done_hi).  The host
+    // keeps both halves per slot and starts over - behind a device synchronise - long before the low half could carry.
+    uint32_t done_target, done_hi;
 };
 
 __device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) { return (x - 0x01010101u) & ~x; }
@@ -624,7 +629,7 @@ __device__ __forceinline__ uint32_t from_lane_ahead(uint32_t cur, uint32_t nxt, 
 // when it first meets a candidate, next to staging the needle - not on every workgroup's way in.
 template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_block, uint64_t tile0,
-                                           uint64_t tile_step, uint64_t tile_end, void *sink)
+                                           uint64_t tile_step, uint64_t tile_end, void *sink, int *wg_found = nullptr)
 {
     static_assert(!L8 || (MODE == 0 && !FIND), "the 8-byte layout covers the single-stream bool kernels");
     constexpr bool TWO = MODE == 1;
@@ -918,8 +923,16 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     // pinned-host mirror: a needle that occurs everywhere would otherwise have every wave of
                     // the grid queue a system-scope store to the same host address (measured: 14 ms for a
                     // one-byte needle over 1 GiB instead of 0.02 ms).
-                    if (lane == __ffsll((unsigned long long)hits) - 1 &&
-                        __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.epoch) {
+                    if (wg_found != nullptr) {
+                        // Completion-word launches (small grids): the answer travels in the workgroup count (scan_kernel's
+                        // epilogue), so the device flag only serves the other workgroups' early exit - stored, not
+                        // exchanged, and nobody waits for it: two memory round trips less between the compare and the host.
+                        if (lane == __ffsll((unsigned long long)hits) - 1) {
+                            __hip_atomic_store(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(wg_found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    } else if (lane == __ffsll((unsigned long long)hits) - 1 &&
+                               __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.epoch) {
                         const int old = __hip_atomic_exchange(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (old != pr.epoch && pr.host_flag)
                             __hip_atomic_store(pr.host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -957,6 +970,13 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
     static_assert((U & (U - 1)) == 0, "U is a power of two");
     const unsigned tile_shift = (unsigned)__builtin_ctz(blockDim.x / kWave) + (unsigned)__builtin_ctz(U);
     uint64_t t0 = tiles_per_block ? (uint64_t)blockIdx.x * tiles_per_block : blockIdx.x;
+    // completion-word launches of the bool kernels: "a wave of this workgroup has found the needle"
+    __shared__ int s_wg_found;
+    const bool counted = !FIND && pr.done_counter != nullptr;      // wave-uniform (kernel argument)
+    if (counted) {
+        if (threadIdx.x == 0) __hip_atomic_store(&s_wg_found, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+    }
     bool skip = false;
     if (blockIdx.x >= kPeekFromBlock) {
         // a peek hit is confirmed with one coherent load before the workgroup leaves: the scalar cache is not
@@ -980,30 +1000,44 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
             step = 1;
             t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
         }
-        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found);
+        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found, counted ? &s_wg_found : nullptr);
     }
-    if (pr.done_counter != nullptr) {
-        // Completion word.  Every wave of the workgroup is past its last read of the haystack at the barrier; one lane
-        // counts the workgroup out.  The count is relaxed: whoever set the found flag did so with an atomic exchange whose
-        // result it waited for before it got here, and the last workgroup reads the flag with an atomic load - both
-        // performed at the L2, the agent's point of coherence - behind an acquire fence.
+    if (counted) {
+        // Completion word of the bool kernels.  Every workgroup counts itself out with ONE relaxed 64-bit atomic add that
+        // also carries "found here" in the high half, so the workgroup that brings the low half to done_target knows the
+        // answer from the sum: no flag to read back, nothing to order, nothing to reset.  The barrier is a bare s_barrier
+        // behind an lgkmcnt(0) wait: only the LDS word has to be settled, not the global store of the early-exit flag.
+        __asm__ volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __asm__ volatile("" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned long long f = (unsigned long long)__hip_atomic_load(&s_wg_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long mine = 1ull + (f << 32);
+            const unsigned long long total = __hip_atomic_fetch_add(pr.done_counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
+            if ((uint32_t)total == pr.done_target) {
+                const uint32_t hi = (uint32_t)(total >> 32);
+                const long long word = (long long)(((unsigned long long)hi << 32) | ((unsigned long long)(uint32_t)pr.epoch << 1) |
+                                                   (hi != pr.done_hi ? 1ull : 0ull));
+                __hip_atomic_store(pr.host_done, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    } else if (FIND && pr.done_counter != nullptr) {
+        // Completion word of find(): the word is the answer itself - leftmost offset + 1, or all ones for "absent" (the
+        // host zeroes it before the launch).  Every wave is past its last atomicMin at the barrier (whose release fence
+        // waits for it); the workgroup that completes the count reads the minimum behind an acquire fence.
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(pr.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (int)gridDim.x - 1) {
+            const unsigned long long total = __hip_atomic_fetch_add(pr.done_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+            if ((uint32_t)total == pr.done_target) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(pr.done_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (FIND) {
-                    // find(): the word is the answer itself - leftmost offset + 1, or all ones for "absent" (the host zeroes
-                    // it before the launch) - and the slot is re-armed here instead of by publish_best_kernel
-                    uint64_t *best = static_cast<uint64_t *>(found);
-                    const uint64_t v = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v != ~0ull) __hip_atomic_store(best, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(pr.host_done, v == ~0ull ? -1ll : (long long)(v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else {
-                    const int f = __hip_atomic_load(static_cast<const int *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pr.epoch;
-                    __hip_atomic_store(pr.host_done, 2ll * pr.epoch + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
+                // The slot is not re-armed either: find_base carries a per-launch key in the bits above kFindOffsetBits
+                // that is SMALLER for every later launch on the slot, so whatever an earlier launch left behind loses
+                // every atomicMin and reads as "absent" here.
+                const uint64_t v = __hip_atomic_load(static_cast<const uint64_t *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t off = v - pr.find_base;
+                const bool hit = v >= pr.find_base && off < (1ull << kFindOffsetBits);
+                __hip_atomic_store(pr.host_done, hit ? (long long)(off + 1) : -1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

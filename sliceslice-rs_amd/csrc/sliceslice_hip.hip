@@ -94,12 +94,21 @@ struct PerDevice {
     int *h_flags = nullptr;     // pinned-host mirror written by the finding wave (no D2H copy per call)
     uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
     uint64_t *h_best = nullptr; // pinned mirror
-    int *d_done = nullptr;      // kSlots workgroup counters of the completion word (zero whenever a slot is free)
-    long long *h_done = nullptr;// pinned: 2*epoch + found, stored by the last workgroup of a small grid
+    // Completion word (small grids).  Nothing on the device side is ever reset between calls: the counter's low half
+    // counts workgroups out towards a target the host names per launch, its high half counts the workgroups that found
+    // the needle (the host remembers where it stood), and find() keys its minimum with a per-launch tag that decreases.
+    // The host copies below belong to whoever owns the slot; start_over() resets a slot behind a device synchronise.
+    unsigned long long *d_done = nullptr;   // kSlots counters: found-workgroups << 32 | workgroups
+    long long *h_done = nullptr;            // pinned: the answer word, stored by the workgroup that completes the count
+    uint64_t *d_best_done = nullptr;        // kSlots keyed minima of find()
+    uint32_t done_low[64] = {0}, done_hi[64] = {0};
+    uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax
     uint64_t free_mask = 0;
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
 };
 constexpr int kSlots = 64;
+constexpr uint32_t kFindTagMax = (1u << (64 - ss::kFindOffsetBits)) - 2;   // keys tag << kFindOffsetBits stay below all-ones
+constexpr uint32_t kDoneLowMax = 0x7FFF0000u;                               // start over before the low half could carry
 constexpr int kMaxDevices = 64;
 
 // Kernel timing (ss_searcher_set_timing): the hipEvent pair that brackets a scan belongs to the CALLING
@@ -170,8 +179,11 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         if ((e = hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
         if ((e = hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
         if ((e = hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipMalloc((void **)&p.d_done, kSlots * sizeof(int))) != hipSuccess) return e;
-        if ((e = hipMemset(p.d_done, 0, kSlots * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&p.d_done, kSlots * sizeof(unsigned long long))) != hipSuccess) return e;
+        if ((e = hipMemset(p.d_done, 0, kSlots * sizeof(unsigned long long))) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&p.d_best_done, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
+        if ((e = hipMemset(p.d_best_done, 0xFF, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
+        for (int k = 0; k < kSlots; ++k) p.find_tag[k] = kFindTagMax;
         if ((e = hipHostMalloc((void **)&p.h_done, kSlots * sizeof(long long), hipHostMallocDefault)) != hipSuccess) return e;
         memset(p.h_done, 0, kSlots * sizeof(long long));
         return hipSuccess;
@@ -184,6 +196,7 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         (void)hipFree(p.d_best);
         (void)hipHostFree(p.h_best);
         (void)hipFree(p.d_done);
+        (void)hipFree(p.d_best_done);
         (void)hipHostFree(p.h_done);
         return fail(e == hipErrorNoDevice ? SS_ERR_NO_DEVICE : (e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP),
                     "per-device setup: %s", hipGetErrorString(e));
@@ -205,15 +218,26 @@ int acquire_slot(const ss_searcher *s, PerDevice *p)
 
 // The value that means "found" for the call that owns slot k: fresh per call, never 0.  On the (2^31
 // calls) wrap-around both copies of the flag are cleared so that no stale value can equal a new epoch.
+// Completion-word state of slot k back to its initial values (the caller owns the slot): after a failed launch, and
+// before the counter's low half or the find() key could run out.
+void start_over(PerDevice *p, int k)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(p->d_done + k, 0, sizeof(unsigned long long));
+    (void)hipMemset(p->d_best_done + k, 0xFF, sizeof(uint64_t));
+    p->h_done[k] = 0;
+    p->done_low[k] = p->done_hi[k] = 0;
+    p->find_tag[k] = kFindTagMax;
+}
+
 int next_epoch(PerDevice *p, int k)
 {
     if (p->epoch[k] >= INT_MAX - 1 || p->epoch[k] < 0) {
         (void)hipDeviceSynchronize();
         (void)hipMemset(p->d_flags + k, 0, sizeof(int));
-        (void)hipMemset(p->d_done + k, 0, sizeof(int));
         p->h_flags[k] = 0;
-        p->h_done[k] = 0;
         p->epoch[k] = 0;
+        start_over(p, k);
     }
     return ++p->epoch[k];
 }
@@ -403,10 +427,19 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     if (blocks < 1) blocks = 1;
     const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
     if (used_done) *used_done = false;
-    if (done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks) {
-        pr.done_counter = pd->d_done + done_slot;
-        pr.host_done = pd->h_done + done_slot;
+    if (done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks && (!find || len < (1ull << ss::kFindOffsetBits))) {
+        const int k = done_slot;
+        if (pd->done_low[k] > kDoneLowMax || (find && pd->find_tag[k] == 0)) start_over(pd, k);
+        pr.done_counter = pd->d_done + k;
+        pr.host_done = pd->h_done + k;
+        pr.done_target = pd->done_low[k] + (uint32_t)blocks;
+        pr.done_hi = pd->done_hi[k];
+        pd->done_low[k] = pr.done_target;                // (a launch that fails starts the slot over)
         pr.host_flag = nullptr;                          // the completion word carries the answer
+        if (find) {                                      // keyed minimum in the slot's own word: see scan_kernel
+            d_flag = pd->d_best_done + k;
+            pr.find_base += (uint64_t)pd->find_tag[k]-- << ss::kFindOffsetBits;
+        }
         *used_done = true;
     }
 
@@ -723,6 +756,7 @@ void ss_searcher_free(ss_searcher *s)
         (void)hipFree(p.d_best);
         (void)hipHostFree(p.h_best);
         (void)hipFree(p.d_done);
+        (void)hipFree(p.d_best_done);
         (void)hipHostFree(p.h_done);
     }
     (void)hipSetDevice(cur);
@@ -759,6 +793,26 @@ int ss_debug_set_epochs(ss_searcher *s, int value)
     std::lock_guard<std::mutex> lock(s->mu);
     if (pd->free_mask != ~0ull) return fail(SS_ERR_ARGUMENT, "searches in flight");
     for (int k = 0; k < kSlots; ++k) pd->epoch[k] = value;
+    return SS_OK;
+}
+
+int ss_debug_set_completion_state(ss_searcher *s, uint32_t workgroups, uint32_t found_workgroups, uint32_t find_key)
+{
+    if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (pd->free_mask != ~0ull) return fail(SS_ERR_ARGUMENT, "searches in flight");
+    if (find_key > kFindTagMax) return fail(SS_ERR_ARGUMENT, "find key above %u", kFindTagMax);
+    std::vector<unsigned long long> counters(kSlots);
+    for (int k = 0; k < kSlots; ++k) {
+        pd->done_low[k] = workgroups;
+        pd->done_hi[k] = found_workgroups;
+        pd->find_tag[k] = find_key;
+        counters[k] = ((unsigned long long)found_workgroups << 32) | workgroups;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(pd->d_done, counters.data(), kSlots * sizeof(unsigned long long), hipMemcpyHostToDevice));
     return SS_OK;
 }
 
@@ -814,16 +868,20 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch, spin_ok ? k : -1,
                           &used_done);
     bool answered = false;
+    // the answer word of a small grid: found-half of the slot's counter << 32 | epoch << 1 | found
+    auto take = [&](long long v) {
+        if (((uint32_t)v >> 1) != (uint32_t)epoch) return false;
+        *found = (int)(v & 1);
+        pd->done_hi[k] = (uint32_t)((unsigned long long)v >> 32);
+        return true;
+    };
     if (rc == SS_OK && used_done) {
-        // Small grid: the last workgroup of the kernel stores 2*epoch + found to the slot's pinned word.  Spin on it for a
-        // bounded time (the whole call is a few microseconds); after that - a long kernel behind other work on the
+        // Small grid: the workgroup that completes the count stores the answer word to the slot's pinned word.  Spin on it
+        // for a bounded time (the whole call is a few microseconds); after that - a long kernel behind other work on the
         // stream, or a fault - fall back to the stream wait, which also reports errors.
-        const long long want = 2ll * epoch;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
-            const long long v = __atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE);
-            if ((v >> 1) == (want >> 1)) {
-                *found = (int)(v & 1);
+            if (take(__atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE))) {
                 answered = true;
                 // every 256th call still waits for the stream, so that the runtime retires its completed commands
                 // in bounded batches instead of whenever the caller next synchronises
@@ -837,13 +895,10 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     if (rc == SS_OK && !answered) {
         const hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(SS_ERR_HIP, "stream wait: %s", hipGetErrorString(e));
-        else if (used_done) *found = (int)(__atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE) == 2ll * epoch + 1);
+        else if (used_done) { if (!take(__atomic_load_n(pd->h_done + k, __ATOMIC_ACQUIRE))) rc = fail(SS_ERR_HIP, "the completion word was not written"); }
         else *found = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
     }
-    if (rc != SS_OK) {
-        (void)hipDeviceSynchronize();
-        (void)hipMemset(pd->d_done + k, 0, sizeof(int));     // a failed launch may have left the workgroup count behind
-    }
+    if (rc != SS_OK) start_over(pd, k);             // a failed launch may have left a partial workgroup count behind
     release_slot(s, pd, k);
     return rc;
 }
@@ -876,10 +931,11 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     const int k = acquire_slot(s, pd);
-    // Slots are all-ones whenever they are free.  Small grid: the scan's last workgroup stores the answer - offset + 1, or
-    // all ones - to the slot's completion word (zeroed here first: the word also serves ss_search_device, whose values
-    // carry an epoch) and re-arms the slot; the host spins on the word as ss_search_device does.  Larger grids: a one-lane
-    // kernel behind the scan stores the minimum to the slot's pinned mirror (no device-to-host copy command) and re-arms.
+    // Small grid: the workgroup that completes the count stores the answer - offset + 1, or all ones - to the slot's
+    // completion word (zeroed here first: the word also serves ss_search_device, whose values carry an epoch), and the host
+    // spins on the word as ss_search_device does; the minimum lives in the slot's keyed word (enqueue_scan), which needs no
+    // re-arming.  Larger grids: slots of d_best are all-ones whenever they are free; a one-lane kernel behind the scan
+    // stores the minimum to the slot's pinned mirror (no device-to-host copy command) and re-arms the slot.
     static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
     __atomic_store_n(pd->h_done + k, 0ll, __ATOMIC_RELAXED);
     bool used_done = false;
@@ -918,9 +974,8 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
         else *position = __atomic_load_n(pd->h_best + k, __ATOMIC_ACQUIRE);
     }
     if (rc != SS_OK) {
-        (void)hipDeviceSynchronize();
+        start_over(pd, k);                                   // a failed launch may have left a partial workgroup count behind
         (void)hipMemset(pd->d_best + k, 0xFF, sizeof(uint64_t));
-        (void)hipMemset(pd->d_done + k, 0, sizeof(int));     // a failed launch may have left the workgroup count behind
     }
     release_slot(s, pd, k);
     return rc;

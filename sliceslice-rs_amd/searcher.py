@@ -89,6 +89,7 @@ ABI = {
     "ss_version": (ctypes.c_char_p, []),
     "ss_selftest_dpp": (_int, [_vp]),
     "ss_debug_set_epochs": (_int, [_vp, _int]),
+    "ss_debug_set_completion_state": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
 }
 

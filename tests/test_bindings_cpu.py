@@ -108,7 +108,7 @@ def test_ctypes_table_matches_the_header():
             return "void"
         if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or isinstance(t, type(ctypes.POINTER(ctypes.c_int))):
             return "ptr"
-        return {ctypes.c_int: "i32", ctypes.c_size_t: "usize", ctypes.c_uint64: "u64", ctypes.c_float: "f32"}[t]
+        return {ctypes.c_int: "i32", ctypes.c_size_t: "usize", ctypes.c_uint64: "u64", ctypes.c_uint32: "u32", ctypes.c_float: "f32"}[t]
     for name, (res, args) in ss.searcher.ABI.items():
         got = (cls(res), [cls(a) for a in args])
         want = c[name]

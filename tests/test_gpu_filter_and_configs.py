@@ -362,6 +362,16 @@ def test_epoch_wrap_of_the_flag_slots(ss):
         assert s.search_in(yes) is True, it
         assert s.search_in(no) is False, it
         assert s.search_in(yes.cpu().numpy()) is True, it
+    # the completion-word state - a workgroup count that is never reset, the count of workgroups that found the needle,
+    # the decreasing key of find()'s minimum - has its own limits; the hook parks all three just short of them
+    for state in ((0x7FFF0000 - 700, 5, 1000),          # the workgroup count about to start over
+                  (12345, 0xFFFFFFFA, 1000),             # the found count about to wrap
+                  (12345, 77, 3),                        # find()'s key about to run out
+                  (0x7FFF0000 - 100, 0xFFFFFFFE, 2)):    # all three at once
+        assert ss.lib().ss_debug_set_completion_state(s._h, *state) == 0
+        for it in range(16):
+            assert s.search_in(yes) is True and s.find(yes) == 1000, (state, it)
+            assert s.search_in(no) is False and s.find(no) is None, (state, it)
 
 
 def test_completion_word_path_behind_a_long_kernel_and_across_sizes(ss):
