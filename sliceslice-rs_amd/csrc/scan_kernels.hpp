@@ -926,7 +926,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     if (wg_found != nullptr) {
                         // Completion-word launches (small grids): the answer travels in the workgroup count (scan_kernel's
                         // epilogue), so the device flag only serves the other workgroups' early exit - stored, not
-                        // exchanged, and nobody waits for it: two memory round trips less between the compare and the host.
+                        // exchanged, and nobody waits for it.
                         if (lane == __ffsll((unsigned long long)hits) - 1) {
                             __hip_atomic_store(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(wg_found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
