@@ -200,7 +200,7 @@ int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);   /* of the CAL
 /* Kernel-variant override for tuning/tests: variant = 1000*LAYOUT + 100*MODE + 10*U + NT; LAYOUT 0 =
  * automatic, 1 = 16 bytes per lane, 2 = 8-bytes-per-lane first phase (position < 16 only); U in {4,8} pieces (KiB)
  * per wave per tile; NT in {0,1} (plain / non-temporal loads); MODE 0 = automatic, 1 = second load
- * stream, 2 = cross-lane position flags (position >= 16 only); 0 = automatic.  Two more decimal digits
+ * stream, 2 = cross-lane position flags (filter pairs 16 or more apart only); 0 = automatic.  Two more decimal digits
  * on top are launch-shape experiments: + 10000*OCC (at most OCC workgroups per CU) + 100000*B (workgroup
  * size: 1 = 128, 2 = 256, 3 = 512 threads).  See DESIGN.md "Kernels". */
 int ss_searcher_set_variant(ss_searcher *s, int variant);

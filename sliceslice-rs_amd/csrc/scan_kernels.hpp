@@ -15,19 +15,19 @@
 //     z(x) = (x - 0x01010101) & ~x  per dword flags the offsets at which ALL of them match (bit 7 of every zero
 //     byte of x is set; it can also flag a 0x01 byte sitting above a zero byte - a false POSITIVE only, and
 //     candidates are verified, so the boolean is unaffected).
-//   * distance of the second filter byte = 16*d + 4*Q + r.  d == 0 (MODE 0: what `new` always picks, and every
-//     with_position(p < 16)): THREE filter bytes.  The raw dwords of the next lane's chunk are moved once (DPP
+//   * distance of the second filter byte = 16*d + 4*Q + r.  d == 0 (MODE 0: what both constructors always pick):
+//     THREE filter bytes.  The raw dwords of the next lane's chunk are moved once (DPP
 //     wave_shl:1; the xor commutes with the move), Q selects the second byte's dword window at compile time, the
 //     third byte's window is wave-uniform run-time data, the byte parts are v_alignbyte_b32.
 //   * lane 63's neighbour is lane 0 of the NEXT piece.  A wave owns U consecutive pieces, so that is a
 //     register of the same wave (one DPP wave_rol:1 feeds it in as the `old` operand of the wave_shl);
 //     after the wave's last piece it is a single 16-byte halo chunk loaded by lane 63 alone.
-//   * d > 0 (with_position >= 16), two filter bytes: MODE 2 keeps ONE non-temporal load stream and fetches the
+//   * d > 0 (a pair 16 or more apart, ss_searcher_set_filter only), two filter bytes: MODE 2 keeps ONE non-temporal load stream and fetches the
 //     position-byte differences from the lane that owns chunk c+d with ds_bpermute (d <= 62); MODE 1 (larger d)
 //     issues a second, plain load stream at +d chunks.
 //   * a tile (U pieces per wave) is filtered in one straight-line phase; `__ballot(any flag)` is the wave's
 //     movemask: zero -> next tile.  Otherwise a second-level filter clears the flags where one of the remaining
-//     bytes of the 16 behind the first filter byte differs, rarest byte first, still in registers, with a ballot
+//     bytes of the 32 behind the first filter byte differs, rarest byte first, still in registers, with a ballot
 //     after each byte - on the one or two pieces that hold candidates, or tile-wide when most do.  A wave that STILL
 //     has a candidate stages the needle in LDS, walks its flags lowest-first (`__ffs`, clear lowest set bit -
 //     lib.rs:220-247) and compares 16 bytes per step; the first equal candidate sets the found flag (lib.rs:242-244).

@@ -256,7 +256,7 @@ void release_slot(const ss_searcher *s, PerDevice *p, int k)
 // 1 = 128, 3 = 512); OCC: at most OCC workgroups per CU through unused dynamic LDS (0 = no cap) - both are
 // tuning aids (profiles/r01/workgroup_size_sweep.jsonl, occupancy_sweep.jsonl).  LAYOUT 0 = automatic, 1 = 16 bytes per lane throughout,
 // 2 = 8-bytes-per-lane first phase (single-stream kernels).  U in {4,8} = pieces (KiB) per wave per tile; NT in {0,1} = plain /
-// non-temporal first-byte stream; MODE (only meaningful for position >= 16, i.e. d > 0): 0 = automatic,
+// non-temporal first-byte stream; MODE (only meaningful for a filter pair 16 or more apart, i.e. d > 0): 0 = automatic,
 // 1 = second load stream, 2 = one stream + cross-lane (ds_bpermute) position flags.  variant 0 = automatic:
 // U = 4; d == 0 -> NT; 0 < d <= kShiftMaxD -> MODE 2 with NT; larger d -> MODE 1 with plain loads (a
 // non-temporal line is not kept for the second stream's re-read; profiles/r01/readbench_8gib.txt).
@@ -404,14 +404,14 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         if (s->grid < 0) {
             tpb = (uint64_t)(-(int64_t)s->grid);
         } else {
-            // Short-lived workgroups: two tiles (32 KiB) each from 2 GiB up (from 1 GiB for position >= 16), one
+            // Short-lived workgroups: two tiles (32 KiB) each from 2 GiB up (from 1 GiB for filter pairs >= 16 apart), one
             // below.  The hardware dispatcher hands out tiles in address order, so the set of lines in flight
             // stays one narrow, advancing window, and a fresh workgroup issues its loads the moment a slot
             // frees up.  Measured (profiles/r01/tiles_per_block_sweep.jsonl, tiles_1_vs_2.txt; 16-byte needle):
             // 64 GiB 7.40-7.43 TB/s at 2 tiles per workgroup vs 7.28 at 4, 7.21 at 8, 7.11 at 64.  One tile is
             // +2 % at 1 GiB, within +-0.7 % from 4 GiB up (and +1.5 % for one-byte needles), but twice as many
             // workgroups have to be drained after an early match (the entry peek in scan_kernel), and the
-            // cross-lane kernels (position >= 16) lose 5 % with it: each wave re-loads its halo chunks per tile.
+            // cross-lane kernels (pairs >= 16 apart) lose 5 % with it: each wave re-loads its halo chunks per tile.
             DeviceInfo di;
             if (int rc = device_info(pd->dev, &di)) return rc;
             tpb = ntiles / ((uint64_t)di.cus * (l.mode == 0 ? 256 : 128));
