@@ -55,6 +55,10 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxBlock = 512;           // scan_kernel takes its workgroup size from the launch (128 / 256 / 512)
 constexpr int kMaxWavesPerBlock = kMaxBlock / kWave;
 constexpr unsigned kPeekFromBlock = 1024;   // workgroups before this one start with the launch: nothing to see yet
+#ifndef SS_BATCH_MIN_TILES
+#define SS_BATCH_MIN_TILES 8
+#endif
+constexpr uint64_t kBatchMinTiles = SS_BATCH_MIN_TILES;   // batched kernel: tiles (16 KiB each) a slice should at least hold
 constexpr int kFindOffsetBits = 40;      // completion-word find(): offsets below 2^40, the launch key above (see scan_kernel)
 constexpr int kNeedleLds = 2048;         // needle bytes staged in LDS per wave; longer needles continue from global
 
@@ -1119,7 +1123,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     // contiguous run of tiles per slice (same launch shape as the single-problem kernel); surplus slices
     // of a short haystack leave before anything else that depends on the needle is loaded
     const uint64_t ntiles = (pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
-    const uint64_t per = (ntiles + nslices - 1) / nslices;
+    // The host sizes the grid from the problem count alone (the lengths live here); a workgroup that got less than
+    // kBatchMinTiles tiles would spend more time on its start-up chain (ranges -> needle bytes -> first haystack load) than
+    // on the scan, so short haystacks are cut into fewer, longer slices and the slices left over leave right here.
+    uint64_t eff = (ntiles + kBatchMinTiles - 1) / kBatchMinTiles;
+    eff = eff < nslices ? (eff ? eff : 1) : nslices;
+    const uint64_t per = (ntiles + eff - 1) / eff;
     const uint64_t t0 = (uint64_t)slice * per;
     const uint64_t te = t0 + per < ntiles ? t0 + per : ntiles;
     if (t0 >= te) return;
