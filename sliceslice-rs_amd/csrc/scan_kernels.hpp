@@ -1329,6 +1329,15 @@ __global__ void __launch_bounds__(kBlock) byte_histogram_kernel(const uint8_t *h
     }
 }
 
+// Stream-ordered behind a scan (and the all-reduce of a sharded search): the answer word - epoch << 1 | found - for a host
+// that spins on pinned memory instead of waiting for the stream's completion signal (some 30 us quicker on this stack).
+__global__ void signal_flag_kernel(const int *d_flag, int epoch, long long *h_word)
+{
+    const int f = __hip_atomic_load(d_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    __hip_atomic_store(h_word, (long long)(((unsigned long long)(uint32_t)epoch << 1) | (unsigned long long)f), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // find(): hands the final minimum to the host through its pinned mirror (one system-scope store), stream-ordered
 // behind the scan - the read-back of ss_find_device without a device-to-host copy command - and re-arms the
 // slot (all ones) for its next user.

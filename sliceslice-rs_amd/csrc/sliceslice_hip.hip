@@ -847,6 +847,33 @@ int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t 
     return enqueue_scan(s, pd, d_haystack, len, st, d_found);
 }
 
+namespace {
+
+// Scans too large for the workgroup count of the completion word still answer through a pinned word when the scan is short
+// enough to be waited for by spinning: a one-lane kernel behind the scan (behind the all-reduce, for a sharded search) stores
+// epoch << 1 | found.  hipStreamSynchronize takes 30-40 us to notice the end of a millisecond kernel on this stack - 3 % of
+// an 8 GiB shard's scan; the spin notices within a microsecond or two.  The spin is bounded by twice the time the scan can
+// possibly take at HBM speed (+ 300 us); after that - the stream was busy with other work - the stream wait takes over.
+constexpr double kSpinMaxEstimateUs = 20000.0;
+inline double scan_estimate_us(size_t len) { return (double)len / 7.0e6; }          // 7 TB/s
+
+bool spin_for_word(const long long *word, int epoch, double estimate_us, int *found)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto budget = std::chrono::microseconds((long long)(2.0 * estimate_us) + 300);
+    for (unsigned spins = 0;; ++spins) {
+        const long long v = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if (((uint32_t)v >> 1) == (uint32_t)epoch) {
+            *found = (int)(v & 1);
+            return true;
+        }
+        cpu_relax();
+        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) return false;
+    }
+}
+
+}  // namespace
+
 int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, int *found)
 {
     if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
@@ -890,6 +917,14 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
             }
             cpu_relax();
             if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+        }
+    }
+    if (rc == SS_OK && !used_done && spin_ok && scan_estimate_us(len) <= kSpinMaxEstimateUs) {
+        // larger grid: the word is written by a one-lane kernel behind the scan
+        ss::signal_flag_kernel<<<1, 1, 0, st>>>(pd->d_flags + k, epoch, pd->h_done + k);
+        if (hipGetLastError() == hipSuccess && spin_for_word(pd->h_done + k, epoch, scan_estimate_us(len), found)) {
+            answered = true;
+            if ((epoch & 255) == 0) (void)hipStreamSynchronize(st);
         }
     }
     if (rc == SS_OK && !answered) {
@@ -967,9 +1002,26 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
             }
         }
     } else if (rc == SS_OK) {
+        // the pinned mirror starts as "pending" (a value no minimum can take), so that a scan short enough to be waited for
+        // by spinning (see spin_for_word) is: the one-lane kernel's store ends the wait
+        constexpr uint64_t kPending = ~0ull - 1;
+        __atomic_store_n(pd->h_best + k, kPending, __ATOMIC_RELAXED);
         ss::publish_best_kernel<<<1, 1, 0, st>>>(pd->d_best + k, pd->h_best + k);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        bool have = false;
+        if (e == hipSuccess && spin_ok && scan_estimate_us(len) <= kSpinMaxEstimateUs) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto budget = std::chrono::microseconds((long long)(2.0 * scan_estimate_us(len)) + 300);
+            for (unsigned spins = 0; !have; ++spins) {
+                have = __atomic_load_n(pd->h_best + k, __ATOMIC_ACQUIRE) != kPending;
+                if (!have) {
+                    cpu_relax();
+                    if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) break;
+                }
+            }
+            if (have && (next_epoch(pd, k) & 255) == 0) (void)hipStreamSynchronize(st);
+        }
+        if (e == hipSuccess && !have) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(SS_ERR_HIP, "position read-back: %s", hipGetErrorString(e));
         else *position = __atomic_load_n(pd->h_best + k, __ATOMIC_ACQUIRE);
     }
@@ -1638,6 +1690,7 @@ struct ss_comm {
     int *d_flag = nullptr;      // this rank's found flag (epoch-valued, never cleared)
     int *d_recv = nullptr;      // all-reduce(MAX) result
     int *h_flag = nullptr;      // pinned read-back
+    long long *h_word = nullptr;// pinned answer word of signal_flag_kernel (spinning read-back)
     uint64_t *d_best = nullptr; // scratch offset for ss_find_sharded
     uint64_t *h_best = nullptr;
 };
@@ -1681,6 +1734,7 @@ void free_comm(ss_comm *c)
     (void)hipFree(c->d_flag);
     (void)hipFree(c->d_recv);
     (void)hipHostFree(c->h_flag);
+    (void)hipHostFree(c->h_word);
     (void)hipFree(c->d_best);
     (void)hipHostFree(c->h_best);
     delete c;
@@ -1744,6 +1798,8 @@ int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_recv, sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_word, sizeof(long long), hipHostMallocDefault);
+    if (e == hipSuccess) *c->h_word = 0;
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_best, sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_best, sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {                               // nothing half-built is left behind (communicator included)
@@ -1807,6 +1863,22 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
         if (int rc = enqueue_scan(s, pd, d_shard, shard_len, st, c->d_flag, false, 0, nullptr, epoch)) return rc;
     }
     if (int rc = r->AllReduce(c->d_flag, c->d_recv, 1, kNcclInt32, kNcclMax, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
+    const double estimate = scan_estimate_us(shard_len) + 100.0;      // + the collective
+    if (spin_ok && estimate <= kSpinMaxEstimateUs) {
+        // the answer word behind the all-reduce, and a bounded spin on it (see spin_for_word); ranks that arrive late in
+        // the collective make the others' spins run out, which costs those nothing but the stream wait they had before
+        __atomic_store_n(c->h_word, 0ll, __ATOMIC_RELAXED);
+        ss::signal_flag_kernel<<<1, 1, 0, st>>>(c->d_recv, epoch, c->h_word);
+        HIP_TRY(hipGetLastError());
+        if (spin_for_word(c->h_word, epoch, estimate, found)) {
+            if ((epoch & 255) == 0) HIP_TRY(hipStreamSynchronize(st));
+            return SS_OK;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!spin_for_word(c->h_word, epoch, 0.0, found)) return fail(SS_ERR_HIP, "the answer word was not written");
+        return SS_OK;
+    }
     HIP_TRY(hipMemcpyAsync(c->h_flag, c->d_recv, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *found = *c->h_flag == epoch;
