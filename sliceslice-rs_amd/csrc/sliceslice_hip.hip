@@ -851,10 +851,13 @@ namespace {
 
 // Scans too large for the workgroup count of the completion word still answer through a pinned word when the scan is short
 // enough to be waited for by spinning: a one-lane kernel behind the scan (behind the all-reduce, for a sharded search) stores
-// epoch << 1 | found.  hipStreamSynchronize takes 30-40 us to notice the end of a millisecond kernel on this stack - 3 % of
-// an 8 GiB shard's scan; the spin notices within a microsecond or two.  The spin is bounded by twice the time the scan can
+// epoch << 1 | found.  A host that reaches hipStreamSynchronize before the work is done pays a wake-up on top of it (a 16 MiB
+// search: 15.2 us per call with the stream wait, 10.7 with the spin; an 8 GiB shard: 2-7 us per search, box to box).  The spin is bounded by twice the time the scan can
 // possibly take at HBM speed (+ 300 us); after that - the stream was busy with other work - the stream wait takes over.
 constexpr double kSpinMaxEstimateUs = 20000.0;
+// ... and the sharded entry points only bother from a few MiB per shard: below, the stream wait returns at once (the work is
+// done before the host gets there) and the extra launch costs 3-4 us (1 MiB shards: 24.6 -> 27.4 us per search with it).
+constexpr double kSpinMinEstimateUs = 0.5;
 inline double scan_estimate_us(size_t len) { return (double)len / 7.0e6; }          // 7 TB/s
 
 bool spin_for_word(const long long *word, int epoch, double estimate_us, int *found)
@@ -1707,6 +1710,7 @@ struct ss_comm_set {
     std::vector<uint64_t *> d_best, d_best_recv;
     bool no_rccl = false;                               // test sets (SLICESLICE_COMM_SET_NO_RCCL): host combine only
     int *h_recv = nullptr;                              // pinned: device 0's all-reduce result
+    long long *h_words = nullptr;                       // pinned: ndev answer words of signal_flag_kernel (spinning read-back)
     uint64_t *h_best = nullptr;                         // pinned: ndev offsets (host combine) / [0] = all-reduce result
 };
 
@@ -1758,6 +1762,7 @@ void free_comm_set(ss_comm_set *set)
         if (g < (int)set->d_best_recv.size()) (void)hipFree(set->d_best_recv[g]);
     }
     (void)hipHostFree(set->h_recv);
+    (void)hipHostFree(set->h_words);
     (void)hipHostFree(set->h_best);
     delete set;
 }
@@ -1865,7 +1870,7 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
     if (int rc = r->AllReduce(c->d_flag, c->d_recv, 1, kNcclInt32, kNcclMax, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
     static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
     const double estimate = scan_estimate_us(shard_len) + 100.0;      // + the collective
-    if (spin_ok && estimate <= kSpinMaxEstimateUs) {
+    if (spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(shard_len) >= kSpinMinEstimateUs) {
         // the answer word behind the all-reduce, and a bounded spin on it (see spin_for_word); ranks that arrive late in
         // the collective make the others' spins run out, which costs those nothing but the stream wait they had before
         __atomic_store_n(c->h_word, 0ll, __ATOMIC_RELAXED);
@@ -1964,6 +1969,8 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
         if (e == hipSuccess) e = hipMalloc((void **)&set->d_best_recv[g], sizeof(uint64_t));
     }
     if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_recv, sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_words, (size_t)ndev * sizeof(long long), hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) memset(set->h_words, 0, (size_t)ndev * sizeof(long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_best, (size_t)ndev * sizeof(uint64_t), hipHostMallocPortable | hipHostMallocMapped);
     if (e != hipSuccess) {
         free_comm_set(set);
@@ -2032,13 +2039,50 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
             if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
         }
     }
-    // 3. every stream is drained before the call returns: the haystacks are only borrowed for the call
+    // 3. every stream is drained before the call returns: the haystacks are only borrowed for the call.  Scans short
+    //    enough to be waited for by spinning (spin_for_word) end with a one-lane kernel per device that stores the device's
+    //    answer word - behind the scan and the all-reduce, so a word that has arrived says its stream is done - and the
+    //    host collects the G words; whatever is missing when the spin budget runs out is waited for on the stream.
+    static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
+    size_t longest = 0;
+    for (int g = 0; g < G; ++g) longest = shard_lens[g] > longest ? shard_lens[g] : longest;
+    const double estimate = scan_estimate_us(longest) + 100.0;
+    bool spun = false;
+    int any_word = 0;
+    if (rc == SS_OK && spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(longest) >= kSpinMinEstimateUs) {
+        bool launched = true;
+        for (int g = 0; g < G && launched; ++g) {
+            __atomic_store_n(set->h_words + g, 0ll, __ATOMIC_RELAXED);
+            launched = hipSetDevice(set->devs[g]) == hipSuccess;
+            if (launched) {
+                ss::signal_flag_kernel<<<1, 1, 0, set->streams[g]>>>(set->combine == SS_COMBINE_RCCL ? set->d_recv[g] : set->d_flag[g],
+                                                                     epoch, set->h_words + g);
+                launched = hipGetLastError() == hipSuccess;
+            }
+        }
+        if (launched) {
+            spun = true;
+            for (int g = 0; g < G && spun; ++g) {
+                int f = 0;
+                spun = spin_for_word(set->h_words + g, epoch, estimate, &f);
+                any_word |= f;
+            }
+            if (spun && (epoch & 255) != 0) {
+                *found = any_word;
+                return SS_OK;
+            }
+        }
+    }
     for (int g = 0; g < G; ++g) {
         hipError_t e = hipSetDevice(set->devs[g]);
         if (e == hipSuccess) e = hipStreamSynchronize(set->streams[g]);
         if (e != hipSuccess && rc == SS_OK) rc = fail(SS_ERR_HIP, "stream wait on device %d: %s", set->devs[g], hipGetErrorString(e));
     }
     if (rc != SS_OK) return rc;
+    if (spun) {
+        *found = any_word;
+        return SS_OK;
+    }
     int any = 0;
     if (set->combine == SS_COMBINE_RCCL) {
         any = *set->h_recv == epoch;
