@@ -1694,6 +1694,7 @@ struct ss_comm {
     int *d_recv = nullptr;      // all-reduce(MAX) result
     int *h_flag = nullptr;      // pinned read-back
     long long *h_word = nullptr;// pinned answer word of signal_flag_kernel (spinning read-back)
+    unsigned finds = 0;         // ss_find_sharded calls (every 256th still waits for the stream)
     uint64_t *d_best = nullptr; // scratch offset for ss_find_sharded
     uint64_t *h_best = nullptr;
 };
@@ -1902,6 +1903,31 @@ int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len,
     HIP_TRY(hipMemsetAsync(c->d_best, 0xFF, sizeof(uint64_t), st));
     if (int rc = ss_find_device_async(s, d_shard, shard_len, shard_begin, hip_stream, c->d_best)) return rc;
     if (int rc = r->AllReduce(c->d_best, c->d_best, 1, kNcclUint64, kNcclMin, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
+    const double estimate = scan_estimate_us(shard_len) + 100.0;
+    if (spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(shard_len) >= kSpinMinEstimateUs) {
+        // as ss_search_sharded: the pinned mirror starts as "pending", a one-lane kernel behind the all-reduce stores the
+        // minimum (and re-arms nothing: d_best is this communicator's scratch, set to all ones at the top of every call)
+        constexpr uint64_t kPending = ~0ull - 1;
+        __atomic_store_n(c->h_best, kPending, __ATOMIC_RELAXED);
+        ss::publish_best_kernel<<<1, 1, 0, st>>>(c->d_best, c->h_best);
+        HIP_TRY(hipGetLastError());
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
+        for (unsigned spins = 0;; ++spins) {
+            const uint64_t v = __atomic_load_n(c->h_best, __ATOMIC_ACQUIRE);
+            if (v != kPending) {
+                *position = v;
+                if ((++c->finds & 255) == 0) HIP_TRY(hipStreamSynchronize(st));
+                return SS_OK;
+            }
+            cpu_relax();
+            if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) break;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        *position = __atomic_load_n(c->h_best, __ATOMIC_ACQUIRE);
+        return SS_OK;
+    }
     HIP_TRY(hipMemcpyAsync(c->h_best, c->d_best, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *position = *c->h_best;
