@@ -284,7 +284,9 @@ uint32_t occupancy_pad(int occ, unsigned block)
 {
     const uint32_t per = (160u * 1024u) / (uint32_t)occ;
     const uint32_t fixed = (block / ss::kWave) * ss::kNeedleLds;
-    uint32_t pad = per > fixed + 1024 ? ((per - fixed) & ~1023u) : 0;
+    // (1 KiB short of the share: the kernels also own a few bytes of static LDS - the completion word's workgroup flag -
+    // and a workgroup's allocation is rounded up to the hardware's granule)
+    uint32_t pad = per > fixed + 2048 ? ((per - fixed - 1024) & ~1023u) : 0;
     if (pad > 64u * 1024u - fixed) pad = 64u * 1024u - fixed;
     return pad;
 }
