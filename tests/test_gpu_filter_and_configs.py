@@ -429,12 +429,18 @@ def test_short_differential_campaign():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["2"]):                         # small-haystack mode; 2 GiB planted-needle mode
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "12", "4242"] + extra,
-                             capture_output=True, text=True, timeout=600, cwd=root)
+    # small-haystack mode; 2 GiB planted-needle mode; both once more with every wait on the stream instead of the pinned
+    # answer words (SLICESLICE_SPIN_WAIT=0: what a service that must not busy-wait runs)
+    for extra, env in (([], {}), (["2"], {}), ([], {"SLICESLICE_SPIN_WAIT": "0"}), (["2"], {"SLICESLICE_SPIN_WAIT": "0"})):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "8", "4242"] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         d = json.loads(out.stdout.strip().splitlines()[-1])
-        assert d["fuzz"] == "ok" and d["searches"] > 1000, d
+        assert d["fuzz"] == "ok" and d["searches"] > 500, d
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_batched.py"), "8", "4242"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["fuzz_batched"] == "ok"
 
 
 def test_second_level_far_bytes_at_lane_piece_and_tile_edges(ss):
