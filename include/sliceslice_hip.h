@@ -49,7 +49,9 @@ typedef enum ss_status {
     SS_ERR_NO_DEVICE = 3,  /* no gfx950-class HIP device visible */
     SS_ERR_HIP = 4,        /* a HIP runtime call failed; see ss_last_error() */
     SS_ERR_RCCL = 5,       /* an RCCL call failed / librccl not loadable */
-    SS_ERR_NOMEM = 6
+    SS_ERR_NOMEM = 6,
+    SS_ERR_PEER = 7        /* collective searches (ss_search_sharded / ss_find_sharded): ANOTHER rank failed the local
+                              part of this search; every rank has left the collective, none has an answer */
 } ss_status;
 
 /* Opaque searcher: owns a host copy and a device copy of the needle, `position`,
@@ -287,6 +289,9 @@ int ss_debug_set_epochs(ss_searcher *s, int value);
  * the needle (wraps at 2^32) and the decreasing key of find()'s minimum (starts over at 0). */
 int ss_debug_set_completion_state(ss_searcher *s, uint32_t workgroups, uint32_t found_workgroups, uint32_t find_key);
 int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
+/* ... and make the next `count` scans launched through `s` fail before they reach the device (SS_ERR_HIP): how the tests
+ * check that a rank-local failure leaves no other rank waiting in the collective of ss_search_sharded / ss_find_sharded. */
+int ss_debug_fail_next_scans(ss_searcher *s, int count);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ pub const SS_ERR_NO_DEVICE: c_int = 3;
 pub const SS_ERR_HIP: c_int = 4;
 pub const SS_ERR_RCCL: c_int = 5;
 pub const SS_ERR_NOMEM: c_int = 6;
+pub const SS_ERR_PEER: c_int = 7;
 pub const SS_NPOS: u64 = u64::MAX;
 pub const SS_UNIQUE_ID_BYTES: usize = 128;
 pub const SS_COMBINE_RCCL: c_int = 0;
@@ -100,6 +101,7 @@ extern "C" {
     pub fn ss_debug_set_epochs(s: *mut ss_searcher, value: c_int) -> c_int;
     pub fn ss_debug_set_completion_state(s: *mut ss_searcher, workgroups: u32, found_workgroups: u32, find_key: u32) -> c_int;
     pub fn ss_debug_set_comm_epoch(c: *mut ss_comm, set: *mut ss_comm_set, value: c_int) -> c_int;
+    pub fn ss_debug_fail_next_scans(s: *mut ss_searcher, count: c_int) -> c_int;
 }
 
 /// Haystack already resident in device memory (caller-owned `hipMalloc` memory).
@@ -207,9 +209,11 @@ pub struct NodeSearcher<N: Needle> { inner: DynamicHipSearcher<N>, set: *mut ss_
 
 impl<N: Needle> NodeSearcher<N> {
     pub fn new(needle: N, ndev: usize) -> Self {
+        // the searcher first: if its constructor panics there is no communicator set yet that could leak
+        let inner = DynamicHipSearcher::new(needle);
         let mut set = std::ptr::null_mut();
         check(unsafe { ss_comm_init_all(ndev as c_int, std::ptr::null(), &mut set) });
-        Self { inner: DynamicHipSearcher::new(needle), set, ndev }
+        Self { inner, set, ndev }
     }
     /// Byte range of shard `g` of a haystack of `len` bytes.
     pub fn shard_range(&self, len: usize, g: usize) -> (usize, usize) {
@@ -227,6 +231,9 @@ impl<N: Needle> NodeSearcher<N> {
         found != 0
     }
     pub fn find(&self, haystack: &NodeHaystack) -> Option<usize> {
+        // ss_find_sharded_all reads ndev entries of each array: a shorter Vec would be an out-of-bounds read from safe code
+        assert_eq!(haystack.shards.len(), self.ndev);
+        assert_eq!(haystack.begins.len(), self.ndev);
         let ptrs: Vec<*const c_void> = haystack.shards.iter().map(|s| s.ptr).collect();
         let lens: Vec<usize> = haystack.shards.iter().map(|s| s.len).collect();
         let mut pos = SS_NPOS;

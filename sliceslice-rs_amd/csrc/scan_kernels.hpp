@@ -1028,8 +1028,12 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         }
     } else if (FIND && pr.done_counter != nullptr) {
         // Completion word of find(): the word is the answer itself - leftmost offset + 1, or all ones for "absent" (the
-        // host zeroes it before the launch).  Every wave is past its last atomicMin at the barrier (whose release fence
-        // waits for it); the workgroup that completes the count reads the minimum behind an acquire fence.
+        // host zeroes it before the launch).  A wave's atomicMin has no return value, and the barrier alone does not wait
+        // for it (gfx950 lowers __syncthreads() to `s_waitcnt lgkmcnt(0); s_barrier` - no vmcnt): every wave therefore
+        // drains its own vector-memory queue first.  vmcnt also counts no-return atomics on gfx9-class parts, and a
+        // device-scope atomic is acknowledged only once it has been performed beyond the XCD's L2, so after the wait the
+        // minimum is where the count-out atomic of thread 0 - and the reader behind it - will look for it.
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long total = __hip_atomic_fetch_add(pr.done_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
@@ -1180,6 +1184,165 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
         return;
     }
     switch (s / 4) {                                // single stream, non-temporal loads
+    case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    }
+}
+
+// ---- K4, planned form: a one-lane-per-problem plan kernel + the scan grid ------------------------------------
+// The kernel above rebuilds its problem descriptor in every workgroup: ranges -> needle bytes -> first haystack load is a
+// chain of three dependent memory round trips (3-4 us under load) in front of every slice, which is why it only does well
+// when a slice is long (4,096 x 1 MiB in ~10-tile slices: 0.88-0.90 of the HBM peak; 1,024 x 1 MiB in 8-tile slices: 0.73).
+// Here the descriptors are built ONCE per problem by batch_plan_kernel (one lane per problem; it also writes the initial
+// flag, so it replaces the memset launch), 64 bytes each, and a scan workgroup starts with ONE scalar load
+// (s_load_dwordx16 of its problem's descriptor, issued together with the entry poll of the problem's flag) before its first
+// haystack load - one round trip more than scan_kernel, whose descriptor travels in the kernel arguments.  With the start-up
+// chain gone, slices can be short (kPlanMinTiles) and the grid generous: surplus slices leave after that one scalar load.
+struct __attribute__((aligned(64))) BatchDesc {
+    const uint8_t *base;       // 16-byte-aligned start of the filter stream: hay + anchor - mis
+    uint64_t end;              // candidate offsets (0: nothing to scan - trivial problem, answered by the plan kernel)
+    uint64_t nchunks_all;
+    uint64_t n;                // needle length
+    uint64_t needle_off;       // offset of the needle in the needle blob
+    uint64_t anchor;           // index of the first filter byte in the needle
+    uint64_t per;              // tiles per slice
+    uint32_t bytes;            // needle[anchor] | second byte << 8 | third byte << 16 | (one-byte needle) << 24
+    uint32_t shifts;           // mis | r << 4 | Q << 6 | r3 << 8 | q3 << 10
+};
+static_assert(sizeof(BatchDesc) == 64, "one scalar load (s_load_dwordx16) per workgroup");
+
+__device__ __forceinline__ int rarity_class4(uint8_t b)
+{
+    const int r = byte_rarity_rank(b);
+    return r < 64 ? 0 : (r < 128 ? 1 : (r < 192 ? 2 : 3));
+}
+
+// One LANE per problem.  `nslices` = gridDim.y of the scan launch that follows, `min_tiles` = the shortest slice worth a
+// workgroup.  Same rules as scan_batched_kernel: needle[position] is always a first-phase byte; its partner is needle[0]
+// when position < 16, else the rarest (class) byte of the 15 in front of it, closest to `position` among equals; the third
+// byte is the rarest of the 15 behind the anchor, the later one among equals; the two are ordered by dword (q3 <= Q).
+__global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
+                                                             uint32_t nslices, uint32_t min_tiles, int tile_pieces)
+{
+    const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (prob >= count) return;
+    const uint64_t h0 = a.hay_begin[prob], h1 = a.hay_end[prob];
+    const uint64_t n0 = a.needle_begin[prob], n1 = a.needle_end[prob];
+    const uint64_t len = h1 - h0, n = n1 - n0;
+    uint64_t position = (a.position && n) ? a.position[prob] : n - 1;
+    BatchDesc d;
+    d.base = nullptr;
+    d.end = d.nchunks_all = 0;
+    d.n = n;
+    d.needle_off = n0;
+    d.anchor = 0;
+    d.per = 1;
+    d.bytes = d.shifts = 0;
+    int flag = 0;
+    if (n == 0) {
+        flag = 1;                                   // N0: found everywhere (x86.rs:500)
+    } else if (n == 1 ? position != 0 : position >= n) {
+        flag = kBadPosition;                        // the reference panics building this searcher (x86.rs:300, 473)
+    } else if (len >= n) {
+        const uint8_t *needle = a.needles + n0;
+        uint64_t anchor = 0;
+        if (position >= 16) {
+            int best_cls = 4;
+            for (int k = 0; k < 15; ++k) {          // later bytes win ties: the partner closest to `position`
+                const int c = rarity_class4(needle[position - 15 + k]);
+                if (c <= best_cls) {
+                    best_cls = c;
+                    anchor = position - 15 + k;
+                }
+            }
+        }
+        uint32_t s2 = (uint32_t)(position - anchor);            // distance between the two filter bytes: 0 .. 15
+        const int lim = n - anchor < 16 ? (int)(n - anchor) : 16;
+        uint32_t p3 = s2;
+        if (n - anchor >= 3) {
+            int best_cls = 4;
+            for (int k = 1; k < lim; ++k) {
+                if ((uint32_t)k == s2) continue;
+                const int c = rarity_class4(needle[anchor + k]);
+                if (c <= best_cls) {
+                    best_cls = c;
+                    p3 = (uint32_t)k;
+                }
+            }
+        }
+        if (p3 / 4 > s2 / 4) {                      // the kernels want the third byte's dword not behind the second's
+            const uint32_t t = p3;
+            p3 = s2;
+            s2 = t;
+        }
+        const uint8_t *hf = a.haystacks + h0 + anchor;
+        const uint32_t mis = (uint32_t)((uintptr_t)hf & 15);
+        d.base = hf - mis;
+        d.end = len - n + 1;
+        d.nchunks_all = (mis + len - anchor + 15) / 16;
+        d.anchor = anchor;
+        d.bytes = (uint32_t)needle[anchor] | ((uint32_t)needle[anchor + s2] << 8) | ((uint32_t)needle[anchor + p3] << 16) |
+                  (n == 1 ? 1u << 24 : 0u);
+        d.shifts = mis | ((s2 % 4) << 4) | ((s2 / 4) << 6) | ((p3 % 4) << 8) | ((p3 / 4) << 10);
+        const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
+        const uint64_t ntiles = (npieces + tile_pieces - 1) / tile_pieces;
+        uint64_t eff = (ntiles + min_tiles - 1) / min_tiles;
+        eff = eff < nslices ? (eff ? eff : 1) : nslices;
+        d.per = (ntiles + eff - 1) / eff;
+    }
+    a.found[prob] = flag;
+    descs[prob] = d;
+}
+
+template <int U>
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock) scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
+    const uint64_t prob = blockIdx.x;
+    const uint32_t slice = blockIdx.y;
+    int *found = a.found + prob;
+    // the entry poll and the descriptor are requested together: one round trip decides whether and what to scan
+    const int seen = slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const BatchDesc d = descs[prob];
+    const uint32_t mis = d.shifts & 15;
+    const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
+    const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+    const uint64_t t0 = (uint64_t)slice * d.per;
+    const uint64_t te = t0 + d.per < ntiles ? t0 + d.per : ntiles;
+    if (t0 >= te) return;                           // surplus slice, or a problem the plan kernel has answered
+    if (__builtin_amdgcn_readfirstlane(seen) != 0) return;   // later slices of a needle that has been found (or rejected)
+
+    Problem pr;
+    pr.base = d.base;
+    pr.hay = d.base + mis - d.anchor;
+    pr.needle = a.needles + d.needle_off;
+    pr.n = d.n;
+    pr.end = d.end;
+    pr.nchunks_all = d.nchunks_all;
+    pr.npieces = npieces;
+    pr.d = 0;
+    pr.mis = mis;
+    pr.r = (d.shifts >> 4) & 3;
+    pr.n0x4 = 0x01010101u * (d.bytes & 0xFF);
+    pr.nlx4 = 0x01010101u * ((d.bytes >> 8) & 0xFF);
+    pr.n3x4 = 0x01010101u * ((d.bytes >> 16) & 0xFF);
+    pr.r3 = (d.shifts >> 8) & 3;
+    pr.q3 = (d.shifts >> 10) & 3;
+    pr.norder = 0;                                  // the second-level schedule is built lazily (LAZY_ORDER)
+    pr.order_idx[0] = pr.order_idx[1] = pr.order_val[0] = pr.order_val[1] = 0;
+    pr.find_base = 0;
+    pr.host_flag = nullptr;
+    pr.epoch = 1;
+    pr.done_counter = nullptr;
+    pr.host_done = nullptr;
+    pr.done_target = pr.done_hi = 0;
+    if ((d.bytes >> 24) & 1) {
+        scan_tiles<0, 0, true, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found);
+        return;
+    }
+    switch ((d.shifts >> 6) & 3) {                  // single stream, non-temporal loads
     case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
     case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
     case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
@@ -1338,14 +1501,36 @@ __global__ void signal_flag_kernel(const int *d_flag, int epoch, long long *h_wo
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The same behind the all-reduce(MAX) of a sharded search, whose flag is a PAIR - {found, a rank failed its local part},
+// both epoch-valued: epoch << 2 | failed << 1 | found.
+__global__ void signal_shard_kernel(const int *d_pair, int epoch, long long *h_word)
+{
+    const unsigned long long f = __hip_atomic_load(d_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    const unsigned long long e = __hip_atomic_load(d_pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    __hip_atomic_store(h_word, (long long)(((unsigned long long)(uint32_t)epoch << 2) | (e << 1) | f), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ... and behind the all-reduce(MIN) of a sharded find: {leftmost offset, all ones unless a rank failed}.  The status word
+// first, the offset - the word the host spins on - behind it with release ordering.
+__global__ void publish_shard_best_kernel(const uint64_t *d_pair, uint64_t *h_pair)
+{
+    const uint64_t v = __hip_atomic_load(d_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t ok = __hip_atomic_load(d_pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h_pair + 1, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h_pair, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // find(): hands the final minimum to the host through its pinned mirror (one system-scope store), stream-ordered
 // behind the scan - the read-back of ss_find_device without a device-to-host copy command - and re-arms the
-// slot (all ones) for its next user.
+// slot (all ones) for its next user.  Re-arm FIRST, publish second: the host releases the slot the moment the pinned
+// word changes, and the next find() on the slot may run on another stream - its atomicMin must never meet a re-arm store
+// that is still in flight (the release ordering of the system-scope store waits for the re-arm).
 __global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best)
 {
     const uint64_t v = __hip_atomic_load(d_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(h_best, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (v != ~0ull) __hip_atomic_store(d_best, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(h_best, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Cross-lane self-test: the DPP controls and v_alignbyte the scan relies on, next to __shfl statements.

@@ -114,12 +114,25 @@ constexpr int kMaxDevices = 64;
 // Kernel timing (ss_searcher_set_timing): the hipEvent pair that brackets a scan belongs to the CALLING
 // THREAD (one pair per thread and device, created on first use), so concurrent calls on one handle never
 // share events; ss_searcher_last_kernel_ms reports the calling thread's most recent timed scan.
+// Thread-local HIP objects (timing events, the small-slice pinned buffer and its streams) are destroyed by their thread's
+// exit.  A thread that outlives exit() - detached workers, threads still unwinding while the process shuts down - would
+// call hipEventDestroy / hipHostFree into a runtime whose own static state may already be gone.  exit() runs the
+// calling thread's thread_local destructors FIRST (glibc: __call_tls_dtors), then the atexit handlers in reverse order of
+// registration; this library registers its handler after libamdhip64 (a dependency, loaded earlier) has registered its
+// own, so the mark below is set before the runtime tears anything down, and destructors that run later leak instead.
+std::atomic<bool> g_exiting{false};
+struct ExitMark {
+    ExitMark() { (void)atexit([]() { g_exiting.store(true, std::memory_order_release); }); }
+} g_exit_mark;
+inline bool process_exiting() { return g_exiting.load(std::memory_order_acquire); }
+
 struct ThreadTimer {
     hipEvent_t ev0[kMaxDevices] = {nullptr}, ev1[kMaxDevices] = {nullptr};
     const void *owner = nullptr;      // the searcher of the most recent timed scan
     int dev = -1;
     ~ThreadTimer()
     {
+        if (process_exiting()) return;                  // leak: see ExitMark
         for (int d = 0; d < kMaxDevices; ++d) {
             if (ev0[d]) (void)hipEventDestroy(ev0[d]);
             if (ev1[d]) (void)hipEventDestroy(ev1[d]);
@@ -145,12 +158,42 @@ struct ss_searcher {
     int variant = 0;
     int grid = 0;
     bool timing = false;
+    // Searches in flight (>= 0), or -1 while ss_searcher_set_filter* rewrites fa / fb / fc: the setters refuse
+    // (SS_ERR_ARGUMENT) while a search runs instead of letting it read a half-written triple.
+    mutable std::atomic<int> gate{0};
+    mutable std::atomic<int> debug_fail_scans{0};       // test hook: the next k enqueue_scan calls fail (ss_debug_fail_next_scans)
     mutable std::mutex mu;
     mutable std::condition_variable slot_cv;    // signalled when a flag slot is released
     mutable std::deque<PerDevice> per;          // deque: PerDevice pointers handed out stay valid as devices are added
 };
 
 namespace {
+
+// One search's hold on the searcher's filter bytes (see ss_searcher::gate).  Counting, so entry points may nest.
+struct SearchGate {
+    const ss_searcher *s;
+    explicit SearchGate(const ss_searcher *s_) : s(s_)
+    {
+        for (;;) {
+            int v = s->gate.load(std::memory_order_acquire);
+            if (v >= 0 && s->gate.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) return;
+            if (v < 0) std::this_thread::yield();       // a setter is writing: a handful of stores
+        }
+    }
+    ~SearchGate() { s->gate.fetch_sub(1, std::memory_order_acq_rel); }
+    SearchGate(const SearchGate &) = delete;
+    SearchGate &operator=(const SearchGate &) = delete;
+};
+
+// "One search at a time" scratch owners (communicators, communicator sets): the second concurrent call is refused.
+struct BusyGuard {
+    std::atomic<bool> *flag;
+    bool mine;
+    explicit BusyGuard(std::atomic<bool> *f) : flag(f), mine(!f->exchange(true, std::memory_order_acq_rel)) {}
+    ~BusyGuard() { if (mine) flag->store(false, std::memory_order_release); }
+    BusyGuard(const BusyGuard &) = delete;
+    BusyGuard &operator=(const BusyGuard &) = delete;
+};
 
 int get_per_device(const ss_searcher *s, PerDevice **out)
 {
@@ -350,6 +393,8 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
                  void *d_sink, bool find = false, uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1,
                  int done_slot = -1, bool *used_done = nullptr)
 {
+    if (s->debug_fail_scans.load(std::memory_order_relaxed) > 0 && s->debug_fail_scans.fetch_sub(1) > 0)
+        return fail(SS_ERR_HIP, "injected scan failure (ss_debug_fail_next_scans)");
     void *d_flag = d_sink;
     ss::Problem pr;
     const size_t n = s->n;
@@ -648,6 +693,19 @@ int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_fi
     return SS_OK;
 }
 
+// The setters' side of ss_searcher::gate: the triple is rewritten only while no search holds the searcher.
+int store_filter(ss_searcher *s, size_t fa, size_t fb, size_t fc)
+{
+    int idle = 0;
+    if (!s->gate.compare_exchange_strong(idle, -1, std::memory_order_acq_rel))
+        return fail(SS_ERR_ARGUMENT, "%d search(es) in flight on this searcher: the filter bytes cannot be changed now", idle);
+    s->fa = fa;
+    s->fb = fb;
+    s->fc = fc;
+    s->gate.store(0, std::memory_order_release);
+    return SS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -679,20 +737,17 @@ int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second)
         return SS_OK;
     }
     if (first > second || second >= s->n) return fail(SS_ERR_POSITION, "filter pair (%zu, %zu) out of range for a needle of %zu bytes", first, second, s->n);
-    s->fa = first;
-    s->fb = second;
-    s->fc = second;                 // a plain two-byte filter; ss_searcher_set_filter3 adds a third byte
-    return SS_OK;
+    return store_filter(s, first, second, second);      // a plain two-byte filter; ss_searcher_set_filter3 adds a third byte
 }
 
 int ss_searcher_set_filter3(ss_searcher *s, size_t first, size_t second, size_t third)
 {
-    if (int rc = ss_searcher_set_filter(s, first, second)) return rc;
-    if (s->n < 2 || third == second) return SS_OK;
+    if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
+    if (s->n < 2 || third == second) return ss_searcher_set_filter(s, first, second);
+    if (first > second || second >= s->n) return fail(SS_ERR_POSITION, "filter pair (%zu, %zu) out of range for a needle of %zu bytes", first, second, s->n);
     if (second - first > 15 || third <= first || third - first > 15 || third >= s->n)
         return fail(SS_ERR_POSITION, "third filter byte %zu must lie within 15 bytes behind the first (%zu), as must the second (%zu)", third, first, second);
-    s->fc = third;
-    return SS_OK;
+    return store_filter(s, first, second, third);
 }
 
 int ss_searcher_filter3(const ss_searcher *s, size_t *first, size_t *second, size_t *third)
@@ -818,6 +873,13 @@ int ss_debug_set_completion_state(ss_searcher *s, uint32_t workgroups, uint32_t 
     return SS_OK;
 }
 
+int ss_debug_fail_next_scans(ss_searcher *s, int count)
+{
+    if (!s || count < 0) return fail(SS_ERR_ARGUMENT, "bad argument");
+    s->debug_fail_scans.store(count, std::memory_order_relaxed);
+    return SS_OK;
+}
+
 int ss_searcher_set_variant(ss_searcher *s, int variant)
 {
     if (!s) return fail(SS_ERR_ARGUMENT, "searcher is NULL");
@@ -837,6 +899,7 @@ int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t 
 {
     if (!s || !d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    SearchGate gate(s);                                  // set_filter* are refused while this call runs
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
@@ -877,12 +940,30 @@ bool spin_for_word(const long long *word, int epoch, double estimate_us, int *fo
     }
 }
 
+// The answer word of a sharded search (signal_shard_kernel): epoch << 2 | "a rank failed" << 1 | found.
+bool spin_for_shard_word(const long long *word, int epoch, double estimate_us, int *found, int *failed)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto budget = std::chrono::microseconds((long long)(2.0 * estimate_us) + 300);
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long v = (unsigned long long)__atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if ((v >> 2) == (unsigned long long)(uint32_t)epoch) {
+            *found = (int)(v & 1);
+            *failed = (int)((v >> 1) & 1);
+            return true;
+        }
+        cpu_relax();
+        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) return false;
+    }
+}
+
 }  // namespace
 
 int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, int *found)
 {
     if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    SearchGate gate(s);                                  // set_filter* are refused while this call runs
     if (s->n == 0) { *found = 1; return SS_OK; }        // x86.rs:500
     if (len < s->n) { *found = 0; return SS_OK; }       // x86.rs:357-359 (len == n is decided on the device)
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -948,6 +1029,7 @@ int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t le
 {
     if (!s || !d_best) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    SearchGate gate(s);                                  // set_filter* are refused while this call runs
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
@@ -965,6 +1047,7 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
 {
     if (!s || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    SearchGate gate(s);                                  // set_filter* are refused while this call runs
     if (s->n == 0) { *position = 0; return SS_OK; }
     if (len < s->n) { *position = SS_NPOS; return SS_OK; }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -1123,6 +1206,7 @@ struct ThreadPinned {
     hipStream_t st[kMaxDevices] = {nullptr};      // one non-blocking stream per device this thread has searched on
     ~ThreadPinned()
     {
+        if (process_exiting()) return;                  // leak: see ExitMark
         if (p) (void)hipHostFree(p);
         for (hipStream_t q : st)
             if (q) (void)hipStreamDestroy(q);
@@ -1154,6 +1238,7 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
 {
     if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (len && !haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    SearchGate gate(s);                                  // set_filter* are refused while this call runs
     if (s->n == 0) { *found = 1; return SS_OK; }
     if (len < s->n) { *found = 0; return SS_OK; }
     hipStream_t small_st = nullptr;
@@ -1208,6 +1293,7 @@ int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint
 {
     if (!s || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (len && !haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    SearchGate gate(s);                                  // set_filter* are refused while this call runs
     if (s->n == 0) { *position = 0; return SS_OK; }
     if (len < s->n) { *position = SS_NPOS; return SS_OK; }
     hipStream_t small_st = nullptr;
@@ -1290,6 +1376,7 @@ bool parallel_pread(int fd, uint8_t *dst, size_t bytes, off_t off, unsigned thre
 int ss_search_file(const ss_searcher *s, const char *path, int *found)
 {
     if (!s || !path || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    SearchGate gate(s);                                  // set_filter* are refused while this call runs
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(SS_ERR_ARGUMENT, "cannot open %s", path);
     struct stat sb;
@@ -1421,6 +1508,30 @@ int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256]
     return SS_OK;
 }
 
+// ss_search_batched, planned form: tuning constants and the one-time set-up of the stream-ordered allocator.
+constexpr unsigned kPlanWgsPerCu = 256;     // total workgroups aimed at, per CU (tools/batch_shape_probe.py)
+constexpr uint32_t kPlanMinTiles = 2;       // shortest slice worth a workgroup, in 16 KiB tiles
+
+// hipMallocAsync hands memory back to the OS when the stream synchronises unless the pool is told to keep it: one
+// hipMemPoolSetAttribute per device, so that the descriptor scratch of every later call is a pool hit (microseconds).
+static int plan_scratch_ready(int dev)
+{
+    static std::mutex mu;
+    static bool done[kMaxDevices] = {false};
+    if (dev < 0 || dev >= kMaxDevices) return SS_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev]) {
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t keep = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+        done[dev] = true;
+    }
+    return SS_OK;
+}
+
 static int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint64_t *d_hay_begin,
                            const uint64_t *d_hay_end, const void *d_needles, const uint64_t *d_needle_begin,
                            const uint64_t *d_needle_end, const uint64_t *d_position, int *d_found)
@@ -1453,10 +1564,47 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     DeviceInfo di;
     if (int rc = device_info(dev, &di)) return rc;
     if (count > 0x7fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
+    // Planned form (the default; SLICESLICE_BATCH_PLAN=0 keeps the single-kernel form): batch_plan_kernel turns the range
+    // arrays into one 64-byte descriptor per problem and writes the initial flags (no memset launch), the scan grid's
+    // workgroups then start with one scalar load.  The descriptors live in stream-ordered scratch (hipMallocAsync /
+    // hipFreeAsync on the caller's stream: re-entrant, nothing shared between concurrent calls); if that allocator is not
+    // available the single-kernel form runs instead.
+    const char *pm = getenv("SLICESLICE_BATCH_PLAN");          // read per call: tools A/B the two forms in one process
+    if (!pm || pm[0] != '0') {
+        // The haystack lengths live on the device, so the grid is still sized from the problem COUNT: kPlanWgsPerCu
+        // workgroups per CU in total, at most 65,535 slices per problem (gridDim.y).  What changed is the price of being
+        // wrong: a surplus slice costs one scalar round trip, and a slice as short as kPlanMinTiles tiles is worth a
+        // workgroup because nothing but that load stands in front of its first haystack byte.
+        uint64_t wg_target = (uint64_t)di.cus * kPlanWgsPerCu;
+        uint32_t min_tiles = kPlanMinTiles;
+        if (const char *e = getenv("SLICESLICE_BATCH_WGS")) { const long v = atol(e); if (v > 0) wg_target = (uint64_t)v; }
+        if (const char *e = getenv("SLICESLICE_BATCH_MIN_TILES")) { const long v = atol(e); if (v > 0) min_tiles = (uint32_t)v; }
+        uint64_t slices = (wg_target + count - 1) / count;
+        if (slices < 1) slices = 1;
+        if (slices > 65535) slices = 65535;
+        if (int rc = plan_scratch_ready(dev)) return rc;
+        ss::BatchDesc *descs = nullptr;
+        const hipError_t me = hipMallocAsync((void **)&descs, count * sizeof(ss::BatchDesc), st);
+        if (me == hipSuccess) {
+            const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
+            ss::batch_plan_kernel<<<dim3((unsigned)pblocks), dim3(ss::kBlock), 0, st>>>(a, (uint64_t)count, descs, (uint32_t)slices,
+                                                                                      min_tiles, ss::kWavesPerBlock * 4);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) {
+                ss::scan_batched_plan_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), 0, st>>>(a, descs);
+                e = hipGetLastError();
+            }
+            const hipError_t fe = hipFreeAsync(descs, st);
+            if (e == hipSuccess) e = fe;
+            if (e != hipSuccess) return fail(SS_ERR_HIP, "batched launch: %s", hipGetErrorString(e));
+            return SS_OK;
+        }
+        (void)hipGetLastError();                           // no stream-ordered allocator here: the single-kernel form below
+    }
     HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
-    // The haystack lengths live on the device, so the grid is chosen from the problem count alone: 96 workgroups per
-    // CU in total (short-lived workgroups that each scan a contiguous run of their problem's tiles balance the tail
-    // better than one long-lived workgroup per problem).  Surplus slices of short haystacks exit before touching the
+    // Single-kernel form.  The haystack lengths live on the device, so the grid is chosen from the problem count alone: 96
+    // workgroups per CU in total (short-lived workgroups that each scan a contiguous run of their problem's tiles balance the
+    // tail better than one long-lived workgroup per problem).  Surplus slices of short haystacks exit before touching the
     // needle.  Measured at 4,096 x 1 MiB with the kernel held to four waves per SIMD (tools/batch_probe.py,
     // profiles/r02/batched_wg_sweep.jsonl): 64 / 96 / 128 / 160 / 192 per CU = 7.09 / 7.17 / 7.16 / 6.98 / 6.86 TB/s.
     // SLICESLICE_BATCH_WGS overrides the total (tuning aid).
@@ -1692,13 +1840,19 @@ struct ss_comm {
     int nranks = 1, rank = 0;
     int dev = 0;
     int epoch = 0;
-    int *d_flag = nullptr;      // this rank's found flag (epoch-valued, never cleared)
-    int *d_recv = nullptr;      // all-reduce(MAX) result
-    int *h_flag = nullptr;      // pinned read-back
-    long long *h_word = nullptr;// pinned answer word of signal_flag_kernel (spinning read-back)
+    // A PAIR of ints goes through the all-reduce(MAX): [0] = this rank's found flag, [1] = "this rank failed its local
+    // part", both epoch-valued and never cleared.  A rank whose scan could not be enqueued still takes part in the
+    // collective (nobody is left waiting in ncclAllReduce, the ranks' epochs stay in step) and every rank learns of it:
+    // the failing rank returns its own error, the others SS_ERR_PEER.
+    int *d_flag = nullptr;      // int[2]
+    int *d_recv = nullptr;      // int[2]: all-reduce(MAX) result
+    int *h_flag = nullptr;      // pinned int[2]: read-back
+    int *h_err = nullptr;       // pinned: source of the copy that raises d_flag[1]
+    long long *h_word = nullptr;// pinned answer word of signal_shard_kernel (spinning read-back)
     unsigned finds = 0;         // ss_find_sharded calls (every 256th still waits for the stream)
-    uint64_t *d_best = nullptr; // scratch offset for ss_find_sharded
-    uint64_t *h_best = nullptr;
+    uint64_t *d_best = nullptr; // uint64[2] scratch of ss_find_sharded: [0] = offset (MIN), [1] = all ones unless a rank failed
+    uint64_t *h_best = nullptr; // pinned uint64[2]
+    std::atomic<bool> busy{false};   // one search at a time per communicator: a second concurrent call is refused
 };
 
 // All ranks of a communicator inside ONE process (ncclCommInitAll): one stream, flag and read-back per device.
@@ -1715,6 +1869,7 @@ struct ss_comm_set {
     int *h_recv = nullptr;                              // pinned: device 0's all-reduce result
     long long *h_words = nullptr;                       // pinned: ndev answer words of signal_flag_kernel (spinning read-back)
     uint64_t *h_best = nullptr;                         // pinned: ndev offsets (host combine) / [0] = all-reduce result
+    std::atomic<bool> busy{false};                      // one search at a time per set: a second concurrent call is refused
 };
 
 namespace {
@@ -1726,7 +1881,7 @@ int next_comm_epoch(int *epoch, int *const *d_flags, const int *devs, int ndev, 
         for (int g = 0; g < ndev; ++g) {
             (void)hipSetDevice(devs[g]);
             (void)hipDeviceSynchronize();
-            (void)hipMemset(d_flags[g], 0, sizeof(int));
+            (void)hipMemset(d_flags[g], 0, 2 * sizeof(int));       // flag + "a rank failed" (every flag word is a pair)
             if (h_flags) *h_flags[g] = 0;
         }
         *epoch = 0;
@@ -1741,6 +1896,7 @@ void free_comm(ss_comm *c)
     (void)hipFree(c->d_flag);
     (void)hipFree(c->d_recv);
     (void)hipHostFree(c->h_flag);
+    (void)hipHostFree(c->h_err);
     (void)hipHostFree(c->h_word);
     (void)hipFree(c->d_best);
     (void)hipHostFree(c->h_best);
@@ -1802,14 +1958,16 @@ int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank
     c->nranks = nranks;
     c->rank = rank;
     hipError_t e = hipGetDevice(&c->dev);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_recv, sizeof(int));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_recv, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_recv, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, 2 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_word, sizeof(long long), hipHostMallocDefault);
     if (e == hipSuccess) *c->h_word = 0;
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_best, sizeof(uint64_t));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_best, sizeof(uint64_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_best, 2 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_best, 2 * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {                               // nothing half-built is left behind (communicator included)
         free_comm(c);
         return fail(SS_ERR_HIP, "communicator scratch: %s", hipGetErrorString(e));
@@ -1863,56 +2021,92 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
     Rccl *r = rccl();
     if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
     if (s->n == 0) { *found = 1; return SS_OK; }            // N0 (x86.rs:500): the same on every rank, nothing to combine
+    BusyGuard busy(&c->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator is in use by another search (one search at a time)");
+    SearchGate gate(s);
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int epoch = next_comm_epoch(&c->epoch, &c->d_flag, &c->dev, 1);
+    // The local part.  Whatever happens here, this rank ENTERS THE COLLECTIVE below: a rank that returned early would
+    // leave the others waiting in ncclAllReduce for good and put the ranks' epochs out of step.
+    int local_rc = SS_OK;
+    char local_msg[sizeof g_err] = "";
     if (shard_len >= s->n) {                                // a shard shorter than the needle holds no candidate
         PerDevice *pd = nullptr;
-        if (int rc = get_per_device(s, &pd)) return rc;
-        if (int rc = enqueue_scan(s, pd, d_shard, shard_len, st, c->d_flag, false, 0, nullptr, epoch)) return rc;
+        local_rc = get_per_device(s, &pd);
+        if (local_rc == SS_OK) local_rc = enqueue_scan(s, pd, d_shard, shard_len, st, c->d_flag, false, 0, nullptr, epoch);
+        if (local_rc != SS_OK) {
+            snprintf(local_msg, sizeof local_msg, "%s", g_err);
+            *c->h_err = epoch;                              // contributes "not found" and raises the pair's second word
+            (void)hipMemcpyAsync(c->d_flag + 1, c->h_err, sizeof(int), hipMemcpyHostToDevice, st);
+        }
     }
-    if (int rc = r->AllReduce(c->d_flag, c->d_recv, 1, kNcclInt32, kNcclMax, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    auto done = [&](int any_failed) {
+        if (local_rc != SS_OK) return fail(local_rc, "%s", local_msg);
+        if (any_failed) return fail(SS_ERR_PEER, "another rank failed the local part of this sharded search; no answer");
+        return (int)SS_OK;
+    };
+    if (int rc = r->AllReduce(c->d_flag, c->d_recv, 2, kNcclInt32, kNcclMax, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
     static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
     const double estimate = scan_estimate_us(shard_len) + 100.0;      // + the collective
     if (spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(shard_len) >= kSpinMinEstimateUs) {
         // the answer word behind the all-reduce, and a bounded spin on it (see spin_for_word); ranks that arrive late in
         // the collective make the others' spins run out, which costs those nothing but the stream wait they had before
         __atomic_store_n(c->h_word, 0ll, __ATOMIC_RELAXED);
-        ss::signal_flag_kernel<<<1, 1, 0, st>>>(c->d_recv, epoch, c->h_word);
+        ss::signal_shard_kernel<<<1, 1, 0, st>>>(c->d_recv, epoch, c->h_word);
         HIP_TRY(hipGetLastError());
-        if (spin_for_word(c->h_word, epoch, estimate, found)) {
+        int failed = 0;
+        if (spin_for_shard_word(c->h_word, epoch, estimate, found, &failed)) {
             if ((epoch & 255) == 0) HIP_TRY(hipStreamSynchronize(st));
-            return SS_OK;
+            return done(failed);
         }
         HIP_TRY(hipStreamSynchronize(st));
-        if (!spin_for_word(c->h_word, epoch, 0.0, found)) return fail(SS_ERR_HIP, "the answer word was not written");
-        return SS_OK;
+        if (!spin_for_shard_word(c->h_word, epoch, 0.0, found, &failed)) return fail(SS_ERR_HIP, "the answer word was not written");
+        return done(failed);
     }
-    HIP_TRY(hipMemcpyAsync(c->h_flag, c->d_recv, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_flag, c->d_recv, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    *found = *c->h_flag == epoch;
-    return SS_OK;
+    *found = c->h_flag[0] == epoch;
+    return done(c->h_flag[1] == epoch);
 }
 
 // Sharded find: every rank lowers its uint64 with shard_begin + local offset of its leftmost match, ONE
-// all-reduce(MIN) over uint64 gives the global leftmost offset (SS_NPOS = all ones = absent everywhere).
+// all-reduce(MIN) over a uint64 PAIR gives the global leftmost offset (SS_NPOS = all ones = absent everywhere) and
+// tells every rank whether some rank failed its local part (second word: all ones unless so) - collective-safe the
+// same way as ss_search_sharded.
 int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, uint64_t shard_begin, ss_comm *c,
                     void *hip_stream, uint64_t *position)
 {
     if (!s || !c || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (shard_len && !d_shard) return fail(SS_ERR_ARGUMENT, "shard is NULL");
     Rccl *r = rccl();
     if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    BusyGuard busy(&c->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator is in use by another search (one search at a time)");
+    SearchGate gate(s);
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    HIP_TRY(hipMemsetAsync(c->d_best, 0xFF, sizeof(uint64_t), st));
-    if (int rc = ss_find_device_async(s, d_shard, shard_len, shard_begin, hip_stream, c->d_best)) return rc;
-    if (int rc = r->AllReduce(c->d_best, c->d_best, 1, kNcclUint64, kNcclMin, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    int local_rc = SS_OK;
+    char local_msg[sizeof g_err] = "";
+    hipError_t e0 = hipMemsetAsync(c->d_best, 0xFF, 2 * sizeof(uint64_t), st);
+    if (e0 != hipSuccess) local_rc = fail(SS_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e0));
+    if (local_rc == SS_OK) local_rc = ss_find_device_async(s, d_shard, shard_len, shard_begin, hip_stream, c->d_best);
+    if (local_rc != SS_OK) {                                // still enter the collective: see ss_search_sharded
+        snprintf(local_msg, sizeof local_msg, "%s", g_err);
+        (void)hipMemsetAsync(c->d_best + 1, 0, sizeof(uint64_t), st);
+    }
+    auto done = [&](uint64_t status) {
+        if (local_rc != SS_OK) return fail(local_rc, "%s", local_msg);
+        if (status != ~0ull) return fail(SS_ERR_PEER, "another rank failed the local part of this sharded find; no answer");
+        return (int)SS_OK;
+    };
+    if (int rc = r->AllReduce(c->d_best, c->d_best, 2, kNcclUint64, kNcclMin, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
     static const bool spin_ok = []() { const char *v = getenv("SLICESLICE_SPIN_WAIT"); return !(v && v[0] == '0'); }();
     const double estimate = scan_estimate_us(shard_len) + 100.0;
     if (spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(shard_len) >= kSpinMinEstimateUs) {
         // as ss_search_sharded: the pinned mirror starts as "pending", a one-lane kernel behind the all-reduce stores the
-        // minimum (and re-arms nothing: d_best is this communicator's scratch, set to all ones at the top of every call)
+        // pair (and re-arms nothing: d_best is this communicator's scratch, set to all ones at the top of every call)
         constexpr uint64_t kPending = ~0ull - 1;
         __atomic_store_n(c->h_best, kPending, __ATOMIC_RELAXED);
-        ss::publish_best_kernel<<<1, 1, 0, st>>>(c->d_best, c->h_best);
+        ss::publish_shard_best_kernel<<<1, 1, 0, st>>>(c->d_best, c->h_best);
         HIP_TRY(hipGetLastError());
         const auto t0 = std::chrono::steady_clock::now();
         const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
@@ -1921,19 +2115,19 @@ int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len,
             if (v != kPending) {
                 *position = v;
                 if ((++c->finds & 255) == 0) HIP_TRY(hipStreamSynchronize(st));
-                return SS_OK;
+                return done(__atomic_load_n(c->h_best + 1, __ATOMIC_RELAXED));
             }
             cpu_relax();
             if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) break;
         }
         HIP_TRY(hipStreamSynchronize(st));
         *position = __atomic_load_n(c->h_best, __ATOMIC_ACQUIRE);
-        return SS_OK;
+        return done(__atomic_load_n(c->h_best + 1, __ATOMIC_RELAXED));
     }
-    HIP_TRY(hipMemcpyAsync(c->h_best, c->d_best, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_best, c->d_best, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    *position = *c->h_best;
-    return SS_OK;
+    *position = c->h_best[0];
+    return done(c->h_best[1]);
 }
 
 // ---- multi-GPU inside ONE process ---------------------------------------------------------------------
@@ -1988,8 +2182,8 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
     for (int g = 0; g < ndev && e == hipSuccess; ++g) {
         e = hipSetDevice(set->devs[g]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&set->streams[g], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc((void **)&set->d_flag[g], sizeof(int));
-        if (e == hipSuccess) e = hipMemset(set->d_flag[g], 0, sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_flag[g], 2 * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(set->d_flag[g], 0, 2 * sizeof(int));
         if (e == hipSuccess) e = hipMalloc((void **)&set->d_recv[g], sizeof(int));
         if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_flag[g], sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
         if (e == hipSuccess) *set->h_flag[g] = 0;
@@ -2040,6 +2234,10 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
     const int G = set->ndev;
     for (int g = 0; g < G; ++g)
         if (shard_lens[g] && !d_shards[g]) return fail(SS_ERR_ARGUMENT, "shard %d is NULL", g);
+    // the set's epoch, streams, flags and pinned words are ONE search's scratch: a second thread would corrupt both answers
+    BusyGuard busy(&set->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator set is in use by another search (one search at a time per set)");
+    SearchGate gate(s);
     DeviceGuard guard;
     const int epoch = next_comm_epoch(&set->epoch, set->d_flag.data(), set->devs.data(), G, set->h_flag.data());
     int rc = SS_OK;
@@ -2128,6 +2326,11 @@ int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const
     Rccl *r = set->combine == SS_COMBINE_RCCL ? rccl() : nullptr;
     if (set->combine == SS_COMBINE_RCCL && !r) return fail(SS_ERR_RCCL, "librccl not loaded");
     const int G = set->ndev;
+    for (int g = 0; g < G; ++g)
+        if (shard_lens[g] && !d_shards[g]) return fail(SS_ERR_ARGUMENT, "shard %d is NULL", g);
+    BusyGuard busy(&set->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator set is in use by another search (one search at a time per set)");
+    SearchGate gate(s);
     DeviceGuard guard;
     int rc = SS_OK;
     for (int g = 0; g < G && rc == SS_OK; ++g) {

@@ -25,7 +25,7 @@ import numpy as np
 
 from . import _build
 
-SS_OK, SS_ERR_POSITION, SS_ERR_ARGUMENT, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_RCCL, SS_ERR_NOMEM = range(7)
+SS_OK, SS_ERR_POSITION, SS_ERR_ARGUMENT, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_RCCL, SS_ERR_NOMEM, SS_ERR_PEER = range(8)
 
 _lib = None
 
@@ -91,6 +91,7 @@ ABI = {
     "ss_debug_set_epochs": (_int, [_vp, _int]),
     "ss_debug_set_completion_state": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
+    "ss_debug_fail_next_scans": (_int, [_vp, _int]),
 }
 
 
@@ -429,12 +430,27 @@ class ShardedSearcher:
         self._comm = comm
         torch.cuda.synchronize()
 
+    def _peer_error(self):
+        return SlicesliceError(SS_ERR_PEER, "another rank failed the local part of this sharded search; no answer")
+
     def search_in(self, shard, stream=None):
+        """Collective-safe: a rank whose local part raises still takes part in the all-reduce (contributing "not found"
+        and raising the second word of the flag pair), then re-raises; the other ranks raise SlicesliceError(SS_ERR_PEER)
+        - nobody is left waiting in the collective."""
         import torch
         if self._local_search is not None:                       # CPU tests: injected shard searcher
-            flag = torch.tensor([1 if self._local_search(shard) else 0], dtype=torch.int32)
+            err = None
+            try:
+                f = 1 if self._local_search(shard) else 0
+            except Exception as e:                                # noqa: BLE001 - re-raised behind the collective
+                err, f = e, 0
+            flag = torch.tensor([f, 1 if err is not None else 0], dtype=torch.int32)
             self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX, group=self.group)
-            return bool(flag.item())
+            if err is not None:
+                raise err
+            if int(flag[1]):
+                raise self._peer_error()
+            return bool(flag[0])
         if self.backend == "rccl":
             found = ctypes.c_int(0)
             with _on_device_of(shard):
@@ -445,18 +461,29 @@ class ShardedSearcher:
         # torch transport: the scan, the flag housekeeping and the all-reduce must all be ordered on ONE stream -
         # torch's current stream.  A caller-supplied stream (object or raw handle) is made current for the duration.
         with _on_device_of(shard), self._as_current(stream):
-            # a ring of pre-zeroed flags: one fresh zero per call, one zero_() launch per 256 calls instead of per call
+            # a ring of pre-zeroed flag PAIRS {found, a rank failed}: one fresh pair per call, one zero_() launch per 256
+            # calls instead of per call
             if self._flag is None or self._flag_next == self._flag.numel():
                 if self._flag is None:
-                    self._flag = torch.zeros(256, dtype=torch.int32, device=shard.device)
+                    self._flag = torch.zeros(512, dtype=torch.int32, device=shard.device)
                 else:
                     self._flag.zero_()
                 self._flag_next = 0
-            flag = self._flag[self._flag_next:self._flag_next + 1]
-            self._flag_next += 1
-            self._searcher.search_in_async(shard, flag)
+            flag = self._flag[self._flag_next:self._flag_next + 2]
+            self._flag_next += 2
+            err = None
+            try:
+                self._searcher.search_in_async(shard, flag[0:1])
+            except Exception as e:                                # noqa: BLE001 - re-raised behind the collective
+                err = e
+                flag[1:2].fill_(1)
             self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX, group=self.group)
-            return bool(flag.item())
+            f, failed = flag.tolist()
+            if err is not None:
+                raise err
+            if failed:
+                raise self._peer_error()
+            return bool(f)
 
     @staticmethod
     def _as_current(stream):
@@ -473,10 +500,14 @@ class ShardedSearcher:
         local leftmost match (offset + shard_begin), ONE all-reduce(MIN) combines them."""
         import torch
         none = (1 << 63) - 1                                      # int64 stand-in for SS_NPOS in the reduce
+        err = None
         if self._local_find is not None:                          # CPU tests: injected shard find
-            p = self._local_find(shard)
-            t = torch.tensor([none if p is None else p + shard_begin], dtype=torch.int64)
-        elif self.backend == "rccl":                              # native: ncclAllReduce(uint64, ncclMin)
+            try:
+                p = self._local_find(shard)
+            except Exception as e:                                # noqa: BLE001 - re-raised behind the collective
+                err, p = e, None
+            t = torch.tensor([none if p is None else p + shard_begin, -1 if err is not None else none], dtype=torch.int64)
+        elif self.backend == "rccl":                              # native: ncclAllReduce(uint64 pair, ncclMin)
             pos = _u64(0)
             with _on_device_of(shard):
                 st = stream if stream is not None else _current_stream_handle()
@@ -488,13 +519,26 @@ class ShardedSearcher:
                 if self._best is None:
                     self._best = torch.empty(1, dtype=torch.int64, device=shard.device)
                 self._best.fill_(-1)                               # all ones = SS_NPOS
-                self._searcher.find_async(shard, self._best, shard_begin)
-                t = torch.where(self._best < 0, torch.full_like(self._best, none), self._best)
+                try:
+                    self._searcher.find_async(shard, self._best, shard_begin)
+                except Exception as e:                            # noqa: BLE001
+                    err = e
+                b = torch.where(self._best < 0, torch.full_like(self._best, none), self._best)
+                t = torch.cat([b, torch.full_like(b, -1 if err is not None else none)])
                 self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
-                v = int(t.item())
+                v, status = (int(x) for x in t.tolist())
+            if err is not None:
+                raise err
+            if status != none:
+                raise self._peer_error()
             return None if v == none else v
+        # second word of the pair: `none` unless a rank failed its local part (MIN brings the -1 to everybody)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
-        v = int(t.item())
+        v, status = (int(x) for x in t.tolist())
+        if err is not None:
+            raise err
+        if status != none:
+            raise self._peer_error()
         return None if v == none else v
 
     def rccl_ranks(self):

@@ -63,6 +63,20 @@ def main():
             shard[at - b:at - b + 16] = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
         assert sh.search_in(shard) is True, backend
         assert sh.find(shard, b) == at
+        # A rank-local failure (the last rank's scan is never enqueued: ss_debug_fail_next_scans) must not keep that rank
+        # out of the collective: it raises its own error, every other rank SS_ERR_PEER, nobody hangs, and the next
+        # search finds all ranks in step.
+        for call in ("search", "find"):
+            if rank == world - 1:
+                assert ss.lib().ss_debug_fail_next_scans(sh._searcher._h, 1) == 0
+            try:
+                sh.search_in(shard) if call == "search" else sh.find(shard, b)
+                outcome = "answered"
+            except ss.SlicesliceError as exc:
+                outcome = exc.code
+            assert outcome == (ss.SS_ERR_HIP if rank == world - 1 else ss.SS_ERR_PEER), (backend, call, rank, outcome)
+            assert sh.search_in(shard) is True, (backend, call)
+            assert sh.find(shard, b) == at, (backend, call)
         sh.close()
     dist.barrier()
     dist.destroy_process_group()

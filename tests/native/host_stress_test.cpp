@@ -143,6 +143,41 @@ int main(int argc, char **argv)
             CHECK(ss_search_sharded(s, d_no, len, c, nullptr, &found) == SS_OK && found == 0);
             CHECK(ss_find_sharded(s, d_yes, len, 1000, c, nullptr, &pos) == SS_OK && pos == 1000 + len - 7);
         }
+        // a rank-local failure (injected: the scan is never enqueued) still goes through the collective, comes back as
+        // THIS rank's error - not a hang, not SS_ERR_PEER - and leaves the communicator usable
+        for (int it = 0; it < 3; ++it) {
+            int found = -1;
+            uint64_t pos = 1;
+            CHECK(ss_debug_fail_next_scans(s, 1) == SS_OK);
+            CHECK(ss_search_sharded(s, d_yes, len, c, nullptr, &found) == SS_ERR_HIP);
+            CHECK(std::strstr(ss_last_error(), "injected") != nullptr);
+            CHECK(ss_search_sharded(s, d_yes, len, c, nullptr, &found) == SS_OK && found == 1);
+            CHECK(ss_debug_fail_next_scans(s, 1) == SS_OK);
+            CHECK(ss_find_sharded(s, d_yes, len, 1000, c, nullptr, &pos) == SS_ERR_HIP);
+            CHECK(ss_find_sharded(s, d_yes, len, 1000, c, nullptr, &pos) == SS_OK && pos == 1000 + len - 7);
+            CHECK(ss_search_sharded(s, d_no, len, c, nullptr, &found) == SS_OK && found == 0);
+        }
+        // one search at a time per communicator: two threads on ONE communicator get an answer or a refusal, never a
+        // corrupted answer
+        {
+            std::atomic<int> ok{0}, refused{0};
+            std::vector<std::thread> two;
+            for (int t = 0; t < 2; ++t)
+                two.emplace_back([&, t]() {
+                    hipStream_t st = nullptr;
+                    TCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+                    for (int it = 0; it < 200; ++it) {
+                        int found = -1;
+                        const int rc = ss_search_sharded(s, t ? d_yes : d_no, len, c, st, &found);
+                        if (rc == SS_OK) { TCHECK(found == t); ++ok; }
+                        else { TCHECK(rc == SS_ERR_ARGUMENT); ++refused; }
+                    }
+                    (void)hipStreamDestroy(st);
+                });
+            for (auto &t : two) t.join();
+            CHECK(g_failures == 0 && ok > 0);
+            std::printf("communicator shared by two threads: %d answered, %d refused\n", ok.load(), refused.load());
+        }
         ss_comm_free(c);
     }
     {
@@ -176,12 +211,71 @@ int main(int argc, char **argv)
                 CHECK(hipGetDevice(&cur) == hipSuccess && cur == 0);
             }
         }
+        // one search at a time per set (include/sliceslice_hip.h): the second concurrent call is refused with
+        // SS_ERR_ARGUMENT instead of corrupting both answers
+        {
+            std::atomic<int> ok{0}, refused{0};
+            std::vector<std::thread> two;
+            for (int t = 0; t < 2; ++t)
+                two.emplace_back([&, t]() {
+                    for (int it = 0; it < 200; ++it) {
+                        int found = -1;
+                        uint64_t pos = 1;
+                        const int rc = (it & 1) ? ss_find_sharded_all(s, shards.data(), lens.data(), begins.data(), set, &pos)
+                                                : ss_search_sharded_all(s, shards.data(), lens.data(), set, &found);
+                        if (rc == SS_OK) {
+                            if (it & 1) TCHECK(pos == (uint64_t)(ndev - 1) * len + len - 7);
+                            else TCHECK(found == 1);
+                            ++ok;
+                        } else {
+                            TCHECK(rc == SS_ERR_ARGUMENT);
+                            ++refused;
+                        }
+                    }
+                });
+            for (auto &t : two) t.join();
+            CHECK(g_failures == 0 && ok > 0);
+            std::printf("communicator set shared by two threads: %d answered, %d refused\n", ok.load(), refused.load());
+        }
         for (int g = 0; g < ndev; ++g) {
             CHECK(hipSetDevice(g) == hipSuccess);
             (void)hipFree(bufs[g]);
         }
         CHECK(hipSetDevice(0) == hipSuccess);
         ss_comm_set_free(set);
+    }
+
+    // ---- ss_searcher_set_filter* against running searches: refused while any search is in flight, accepted in between;
+    //      whatever triple a search ends up with, its answer is right (src/lib.rs:375-378) ----
+    {
+        std::atomic<bool> stop{false};
+        std::atomic<int> accepted{0}, refused{0};
+        std::vector<std::thread> searchers;
+        for (int t = 0; t < 4; ++t)
+            searchers.emplace_back([&, t]() {
+                hipStream_t st = nullptr;
+                TCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+                while (!stop.load()) {
+                    int found = -1;
+                    TCHECK(ss_search_device(s, (t & 1) ? d_yes : d_no, len, st, &found) == SS_OK && found == (t & 1));
+                }
+                (void)hipStreamDestroy(st);
+            });
+        const size_t pairs[4][3] = {{0, 6, 5}, {1, 5, 3}, {0, 1, 2}, {2, 6, 4}};
+        for (int it = 0; it < 20000; ++it) {
+            const size_t *q = pairs[it & 3];
+            const int rc = (it & 4) ? ss_searcher_set_filter(s, q[0], q[1]) : ss_searcher_set_filter3(s, q[0], q[1], q[2]);
+            if (rc == SS_OK) ++accepted;
+            else { CHECK(rc == SS_ERR_ARGUMENT); ++refused; }
+        }
+        stop.store(true);
+        for (auto &t : searchers) t.join();
+        CHECK(g_failures == 0);
+        CHECK(refused > 0);                       // four threads searching back to back: most attempts meet one in flight
+        size_t a = 9, b = 9, c3 = 9;
+        CHECK(ss_searcher_set_filter3(s, 0, 6, 5) == SS_OK);          // nothing in flight now
+        CHECK(ss_searcher_filter3(s, &a, &b, &c3) == SS_OK && a == 0 && b == 6 && c3 == 5);
+        std::printf("set_filter against 4 searching threads: %d accepted, %d refused\n", accepted.load(), refused.load());
     }
 
     ss_searcher_free(s);

@@ -130,3 +130,78 @@ def test_native_rccl_init_fails_on_all_ranks_together():
     assert not alive, "a rank hung in the native RCCL bootstrap"
     got = dict(q.get(timeout=5) for _ in range(world))
     assert all(v.startswith("refused") for v in got.values()), got
+
+
+def _failing_rank_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sliceslice_rs_amd as ss
+        hay = np.frombuffer(b"x" * 1000 + b"needle" + b"y" * 1000, dtype=np.uint8)
+        calls = {"n": 0}
+
+        def local_search(shard):
+            calls["n"] += 1
+            if calls["n"] == 2 and rank == 1:                     # the second search fails on rank 1 only
+                raise RuntimeError("injected local failure on rank 1")
+            return b"needle" in shard.tobytes()
+
+        def local_find(shard):
+            calls["n"] += 1
+            if calls["n"] == 5 and rank == 1:
+                raise RuntimeError("injected local find failure on rank 1")
+            p = shard.tobytes().find(b"needle")
+            return None if p < 0 else p
+        sh = ss.ShardedSearcher(b"needle", local_search=local_search, local_find=local_find)
+        b, e = sh.shard_range(len(hay))
+        out = []
+        for step in range(3):                                     # ok, failure, ok again: the ranks stay in step
+            try:
+                out.append(("ok", sh.search_in(hay[b:e])))
+            except ss.SlicesliceError as exc:
+                out.append(("peer", exc.code))
+            except RuntimeError as exc:
+                out.append(("local", str(exc)))
+        for step in range(3):                                     # the same for find(): calls 4, 5, 6
+            try:
+                out.append(("ok", sh.find(hay[b:e], b)))
+            except ss.SlicesliceError as exc:
+                out.append(("peer", exc.code))
+            except RuntimeError as exc:
+                out.append(("local", str(exc)))
+        dist.barrier()
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_failing_rank_leaves_nobody_in_the_collective(world):
+    """a rank-local failure must not keep that rank out of the all-reduce.  The failing rank still
+    contributes ("not found" + the pair's second word), then raises its own error; every other rank raises SS_ERR_PEER;
+    the next search works again on all of them.  (Native form: ss_search_sharded / ss_find_sharded do the same with a
+    two-int all-reduce - tests/test_gpu_sharded.py injects the failure there with ss_debug_fail_next_scans.)"""
+    import sliceslice_rs_amd as ss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive, "a rank hung: somebody skipped the collective"
+    got = dict(q.get(timeout=5) for _ in range(world))
+    for rank in range(world):
+        out = got[rank]
+        assert out[0] == ("ok", True) and out[2] == ("ok", True), (rank, out)
+        assert out[3] == ("ok", 1000) and out[5] == ("ok", 1000), (rank, out)
+        if rank == 1:
+            assert out[1][0] == "local" and out[4][0] == "local", out
+        else:
+            assert out[1] == ("peer", ss.SS_ERR_PEER) and out[4] == ("peer", ss.SS_ERR_PEER), (rank, out)
