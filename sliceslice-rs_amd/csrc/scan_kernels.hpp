@@ -65,29 +65,46 @@ constexpr int kNeedleLds = 2048;         // needle bytes staged in LDS per wave;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // One haystack/needle problem in "aligned coordinates": a = byte offset from `base` (16-B aligned).
+//
+// HOT fields first: what every wave needs before and while it streams.  The COLD fields behind them are needed only by a
+// wave that has met a candidate (second-level schedule, verification, publishing) or by the last instructions of a
+// workgroup (completion word).  scan_kernel receives the whole struct as its first kernel argument but reads the cold
+// part straight from the kernarg segment, through a pointer the compiler cannot see through (ColdInKernarg), at the
+// point of use: loaded at kernel entry like the hot fields they cost ~30 scalar registers that were spilled to vector
+// lanes (v_writelane) in front of every short-lived workgroup's first load.
 struct Problem {
-    const uint8_t *base;      // hay - mis
-    const uint8_t *hay;       // the caller's pointer
-    const uint8_t *needle;    // device copy of the needle
-    uint64_t n;               // needle length (>= 1)
-    uint64_t end;             // number of candidate offsets = len - n + 1   (>= 1)
-    uint64_t nchunks_all;     // ceil((mis + len) / 16): chunks that contain a haystack byte
+    // ---- hot ----
+    const uint8_t *base;      // hay + first - mis: the 16-byte-aligned start of the filter stream
+    uint64_t nchunks_all;     // ceil((mis + len - first) / 16): chunks that contain a haystack byte
     uint64_t npieces;         // ceil(ceil((mis + end) / 16) / 64)
     uint64_t d;               // position / 16: chunk displacement of the second stream
-    uint32_t mis;             // hay - base, 0..15
+    uint64_t find_base;       // FIND kernels: global offset of hay[0] (range shards), added to the match index
+    uint32_t mis;             // 0..15
     uint32_t r;               // (position % 16) % 4: byte part of the shift
-    uint32_t n0x4, nlx4;      // needle[0] and needle[position] splatted over a dword
+    uint32_t n0x4, nlx4;      // first and second filter byte, splatted over a dword
     // MODE 0 kernels test a THIRD needle byte in the first phase (position3 = 4*q3 + r3 < 16, relative to the first
     // filter byte like `position`; == position when the needle has no third byte to offer): text passes a two-byte
     // filter often enough that most tiles would enter the second phase, a three-byte filter hardly ever.
     uint32_t n3x4, q3, r3;
-    uint32_t norder;          // second-level filter: number of extra needle bytes to test (<= 15)
-    uint64_t order_idx[2];    //   their indices K (1 <= K < min(n,16), K != position), rarest byte first, 1 byte each
-    uint64_t order_val[2];    //   needle[K] in the same order, 1 byte each (entry t: word t/8, bits 8(t%8)..)
-    uint64_t find_base;       // FIND kernels: global offset of hay[0] (range shards), added to the match index
-    int *host_flag;           // optional pinned-host mirror of the found flag (saves the D2H copy); may be null
     int epoch;                // the value that means "found" in the flag (1 for caller-owned flags; pool slots
                               // use a fresh value per call, so a slot never has to be cleared)
+    uint32_t flags;           // kProblemCounted: a completion word is in use (done_counter / host_done below)
+    uint32_t pad_;
+    // ---- cold ----
+    const uint8_t *hay;       // the caller's pointer
+    const uint8_t *needle;    // device copy of the needle
+    uint64_t n;               // needle length (>= 1)
+    uint64_t end;             // number of candidate offsets = len - n + 1   (>= 1)
+    uint64_t order_idx[2];    // second-level filter: indices K of the extra needle bytes to test (relative to the first filter
+    uint64_t order_val[2];    //   byte, rarest first, 1 byte each - entry t: word t/8, bits 8(t%8)..) and needle[K] in that order
+    uint32_t norder;          //   how many (<= 15)
+    // Exact in-register verification (the reference's const-length compare for SIZE = Some(1..=16), lib.rs:222-241):
+    // when the needle ends at most 16 bytes behind the first filter byte, tail16 holds needle[first .. n) (zero padded)
+    // and exact_len = n - first; a candidate that survives the second level is then compared against these four dwords
+    // in registers - no LDS staging, no re-read of the haystack.  exact_len == 0: the memory compare decides.
+    uint32_t exact_len;
+    uint32_t tail16[4];
+    int *host_flag;           // optional pinned-host mirror of the found flag (saves the D2H copy); may be null
     // Completion word (small grids of ss_search_device / ss_find_device only; both null otherwise): every workgroup
     // counts itself out on *done_counter; the last one stores the answer to the pinned-host word *host_done - search:
     // (found-half of the counter) << 32 | epoch << 1 | found; find: the leftmost offset + 1, or all ones.  The host spins
@@ -98,6 +115,22 @@ struct Problem {
     // its high half counts the workgroups that found the needle (found == the half has moved on from done_hi).  The host
     // keeps both halves per slot and starts over - behind a device synchronise - long before the low half could carry.
     uint32_t done_target, done_hi;
+};
+constexpr uint32_t kProblemCounted = 1u;
+
+// Where a wave finds the COLD fields of its Problem.
+struct ColdInKernarg {        // scan_kernel: the Problem is the kernel's FIRST argument, i.e. offset 0 of the kernarg segment
+    typedef const Problem __attribute__((address_space(4))) *Ptr;
+    __device__ __forceinline__ Ptr operator()() const
+    {
+        Ptr kp = (Ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        __asm__ volatile("" : "+s"(kp));     // opaque: the loads behind it stay where they are written
+        return kp;
+    }
+};
+struct ColdInRegisters {      // kernels that build their Problem themselves (batched)
+    const Problem *p;
+    __device__ __forceinline__ const Problem *operator()() const { return p; }
 };
 
 __device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) { return (x - 0x01010101u) & ~x; }
@@ -132,10 +165,11 @@ struct __attribute__((packed, aligned(1))) UnalignedU32 {
     uint32_t v;
 };
 
-__device__ __forceinline__ bool verify_candidate(const Problem &pr, const uint8_t *s_needle, uint64_t i)
+__device__ __forceinline__ bool verify_candidate(const uint8_t *hay, const uint8_t *needle, uint64_t n, const uint8_t *s_needle,
+                                                 uint64_t i)
 {
-    const uint8_t *h = pr.hay + i;
-    const uint64_t n_lds = pr.n < (uint64_t)kNeedleLds ? pr.n : (uint64_t)kNeedleLds;
+    const uint8_t *h = hay + i;
+    const uint64_t n_lds = n < (uint64_t)kNeedleLds ? n : (uint64_t)kNeedleLds;
     uint64_t k = 0;
     // sixteen bytes per step: the four haystack dwords are loaded together (one memory round trip per 16 bytes
     // instead of one per 4 - what a true match, whose every byte has to be looked at, is bound by)
@@ -150,11 +184,11 @@ __device__ __forceinline__ bool verify_candidate(const Problem &pr, const uint8_
             return false;
     for (; k < n_lds; ++k)
         if (h[k] != s_needle[k]) return false;
-    for (; k + 4 <= pr.n; k += 4)   // needles longer than the LDS slice continue from the global copy
-        if (reinterpret_cast<const UnalignedU32 *>(h + k)->v != reinterpret_cast<const UnalignedU32 *>(pr.needle + k)->v)
+    for (; k + 4 <= n; k += 4)   // needles longer than the LDS slice continue from the global copy
+        if (reinterpret_cast<const UnalignedU32 *>(h + k)->v != reinterpret_cast<const UnalignedU32 *>(needle + k)->v)
             return false;
-    for (; k < pr.n; ++k)
-        if (h[k] != pr.needle[k]) return false;
+    for (; k < n; ++k)
+        if (h[k] != needle[k]) return false;
     return true;
 }
 
@@ -263,6 +297,10 @@ __host__ __device__ inline int byte_rarity_rank(uint8_t b)
 // compare) depends on this; the result of a search never does.
 constexpr int kRefineWindow = 32;
 constexpr uint32_t kFarFirst = 10;
+#ifndef SS_REFINE_BYTES_PER_BALLOT
+#define SS_REFINE_BYTES_PER_BALLOT 2
+#endif
+constexpr uint32_t kRefineBytesPerBallot = SS_REFINE_BYTES_PER_BALLOT;   // schedule bytes applied between two wave ballots
 
 __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, uint64_t n, uint64_t position,
                                                        uint64_t idx[2], uint64_t val[2], uint64_t position3 = ~0ull)
@@ -413,21 +451,28 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
         }
     };
     bool any = any_left();
+    // TWO schedule bytes per wave ballot: the ballot -> scalar compare -> branch chain between two bytes is what a tile dense
+    // with candidates (a caller-chosen pair of common bytes on text) waits for, not the dozen VALU operations of a byte;
+    // the second byte of a pair is wasted only when the first one had already cleared the tile.
+    uint32_t t = 0;
 #pragma unroll 1
-    for (uint32_t t = 0; t < ro.n && any; ++t) {
-        const uint32_t sh = 8 * (t & 7);
-        const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
-        const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
-        const uint32_t nkx4 = 0x01010101u * v, rk = (uint32_t)(K & 3);
-        switch (K >> 2) {                            // wave-uniform
-        case 0: apply(std::integral_constant<int, 0>{}, nkx4, rk); break;
-        case 1: apply(std::integral_constant<int, 1>{}, nkx4, rk); break;
-        case 2: apply(std::integral_constant<int, 2>{}, nkx4, rk); break;
-        case 3: apply(std::integral_constant<int, 3>{}, nkx4, rk); break;
-        case 4: apply(std::integral_constant<int, 4>{}, nkx4, rk); break;
-        case 5: apply(std::integral_constant<int, 5>{}, nkx4, rk); break;
-        case 6: apply(std::integral_constant<int, 6>{}, nkx4, rk); break;
-        default: apply(std::integral_constant<int, 7>{}, nkx4, rk); break;
+    while (t < ro.n && any) {
+#pragma unroll 1
+        for (uint32_t k = 0; k < kRefineBytesPerBallot && t < ro.n; ++k, ++t) {
+            const uint32_t sh = 8 * (t & 7);
+            const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
+            const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
+            const uint32_t nkx4 = 0x01010101u * v, rk = (uint32_t)(K & 3);
+            switch (K >> 2) {                            // wave-uniform
+            case 0: apply(std::integral_constant<int, 0>{}, nkx4, rk); break;
+            case 1: apply(std::integral_constant<int, 1>{}, nkx4, rk); break;
+            case 2: apply(std::integral_constant<int, 2>{}, nkx4, rk); break;
+            case 3: apply(std::integral_constant<int, 3>{}, nkx4, rk); break;
+            case 4: apply(std::integral_constant<int, 4>{}, nkx4, rk); break;
+            case 5: apply(std::integral_constant<int, 5>{}, nkx4, rk); break;
+            case 6: apply(std::integral_constant<int, 6>{}, nkx4, rk); break;
+            default: apply(std::integral_constant<int, 7>{}, nkx4, rk); break;
+            }
         }
         any = any_left();
     }
@@ -441,21 +486,25 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
 __device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4])
 {
     bool any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
+    uint32_t t = 0;
 #pragma unroll 1
-    for (uint32_t t = 0; t < ro.n && any; ++t) {
-        const uint32_t sh = 8 * (t & 7);
-        const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
-        const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
-        const uint32_t nkx4 = 0x01010101u * v, rk = (uint32_t)(K & 3);
-        switch (K >> 2) {                            // wave-uniform
-        case 0: refine_flags_q<0>(A, np, nkx4, rk, g); break;
-        case 1: refine_flags_q<1>(A, np, nkx4, rk, g); break;
-        case 2: refine_flags_q<2>(A, np, nkx4, rk, g); break;
-        case 3: refine_flags_q<3>(A, np, nkx4, rk, g); break;
-        case 4: refine_flags_q<4>(A, np, nkx4, rk, g); break;
-        case 5: refine_flags_q<5>(A, np, nkx4, rk, g); break;
-        case 6: refine_flags_q<6>(A, np, nkx4, rk, g); break;
-        default: refine_flags_q<7>(A, np, nkx4, rk, g); break;
+    while (t < ro.n && any) {
+#pragma unroll 1
+        for (uint32_t k = 0; k < kRefineBytesPerBallot && t < ro.n; ++k, ++t) {     // two bytes per ballot: see refine_tile
+            const uint32_t sh = 8 * (t & 7);
+            const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
+            const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
+            const uint32_t nkx4 = 0x01010101u * v, rk = (uint32_t)(K & 3);
+            switch (K >> 2) {                            // wave-uniform
+            case 0: refine_flags_q<0>(A, np, nkx4, rk, g); break;
+            case 1: refine_flags_q<1>(A, np, nkx4, rk, g); break;
+            case 2: refine_flags_q<2>(A, np, nkx4, rk, g); break;
+            case 3: refine_flags_q<3>(A, np, nkx4, rk, g); break;
+            case 4: refine_flags_q<4>(A, np, nkx4, rk, g); break;
+            case 5: refine_flags_q<5>(A, np, nkx4, rk, g); break;
+            case 6: refine_flags_q<6>(A, np, nkx4, rk, g); break;
+            default: refine_flags_q<7>(A, np, nkx4, rk, g); break;
+            }
         }
         any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
     }
@@ -464,8 +513,14 @@ __device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np
 
 // Candidate verification for one lane's flags; returns true when the needle was found.  The four flag
 // dwords are walked by a run-time loop so that the compare code exists once per call site.
+// What the verification needs of a Problem's cold part, as the wave holds it once it has met a candidate.
+struct VerifyArgs {
+    const uint8_t *hay, *needle;
+    uint64_t n, end;
+};
+
 template <bool ONE_BYTE>
-__device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk, const Problem &pr,
+__device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk, const Problem &pr, const VerifyArgs &va,
                                              const uint8_t *s_needle, uint64_t &where)
 {
     bool hit = false;
@@ -481,12 +536,70 @@ __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk
             mj &= mj - 1;                               // clear lowest set bit        (lib.rs:247)
             const uint64_t a = chunk * 16 + (uint64_t)(j * 4 + (bit >> 3));
             const uint64_t i = a - pr.mis;              // wraps for bytes in front of the haystack
-            if (i < pr.end) {
-                if (ONE_BYTE) hit = pr.hay[i] == (uint8_t)pr.n0x4;
-                else hit = verify_candidate(pr, s_needle, i);
+            if (i < va.end) {
+                if (ONE_BYTE) hit = va.hay[i] == (uint8_t)pr.n0x4;
+                else hit = verify_candidate(va.hay, va.needle, va.n, s_needle, i);
                 where = i;                              // lowest match of this lane when hit
             }
         }
+    }
+    return hit;
+}
+
+// movemask of one flag dword: bit 7 of byte t -> bit t
+__device__ __forceinline__ uint32_t flag_nibble(uint32_t g)
+{
+    return ((((g >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+
+// Exact verification of one lane's surviving flags WITHOUT touching memory (MODE 0 kernels, needles that end at most 16
+// bytes behind the first filter byte - every needle of up to 16 bytes whose filter starts at byte 0): the 16 stream bytes
+// behind a candidate lie in this lane's chunk and the next lane's (raw dwords, one DPP hop - lane 63 takes lane 0 of the
+// wave's next piece or the halo chunk), are brought to the candidate's byte offset with v_alignbyte and compared with the
+// needle's dwords under a length mask.  The flags are walked lowest first (lib.rs:220-247), so `where` is the lane's leftmost
+// match.  What the filter stream cannot see - needle bytes IN FRONT of the first filter byte (filters chosen by rarity may
+// start later) - is compared in memory, for exact survivors only.
+__device__ __forceinline__ bool exact_verify_piece(const u32x4 &A, const NextPiece &np, const uint32_t g[4], uint64_t chunk,
+                                                   const Problem &pr, const VerifyArgs &va, const uint32_t tail16[4],
+                                                   uint32_t exact_len, uint64_t &where)
+{
+    // (named scalars, not an array: a select between array ELEMENTS becomes a select between addresses, and the window
+    // ends up in scratch memory behind a dynamic index)
+    auto hop = [&](uint32_t nword, uint32_t own) {
+        return from_next_lane_or(np.kind == 1 ? rotate_from_next_lane(nword) : nword, own);
+    };
+    const uint32_t w0 = A.x, w1 = A.y, w2 = A.z, w3 = A.w;
+    const uint32_t w4 = hop(np.N.x, w0), w5 = hop(np.N.y, w1), w6 = hop(np.N.z, w2), w7 = hop(np.N.w, w3);
+    uint32_t M[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rem = (int)exact_len - 4 * j;
+        M[j] = rem >= 4 ? ~0u : (rem <= 0 ? 0u : (1u << (8 * rem)) - 1u);
+    }
+    uint32_t flags = flag_nibble(g[0]) | (flag_nibble(g[1]) << 4) | (flag_nibble(g[2]) << 8) | (flag_nibble(g[3]) << 12);
+    const uint64_t anchor = (uint64_t)((pr.base + pr.mis) - va.hay);     // needle bytes in front of the filter stream
+    bool hit = false;
+    while (flags != 0 && !hit) {
+        const int b = __ffs((int)flags) - 1;            // lowest flagged byte first (tzcnt, lib.rs:221)
+        flags &= flags - 1;                             // clear lowest set bit        (lib.rs:247)
+        const uint64_t i = chunk * 16 + (uint64_t)b - pr.mis;   // wraps for bytes in front of the haystack
+        if (i >= va.end) continue;
+        const int q = b >> 2;
+        const uint32_t r = (uint32_t)(b & 3);
+        auto pick = [&](uint32_t a, uint32_t b1, uint32_t c, uint32_t d) {
+            const uint32_t lo = q & 1 ? b1 : a, hi = q & 1 ? d : c;
+            return q & 2 ? hi : lo;
+        };
+        const uint32_t sw[5] = {pick(w0, w1, w2, w3), pick(w1, w2, w3, w4), pick(w2, w3, w4, w5), pick(w3, w4, w5, w6),
+                                pick(w4, w5, w6, w7)};
+        uint32_t diff = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) diff |= (__builtin_amdgcn_alignbyte(sw[j + 1], sw[j], r) ^ tail16[j]) & M[j];
+        if (diff != 0) continue;
+        bool same = true;
+        for (uint64_t k = 0; k < anchor && same; ++k) same = va.hay[i + k] == va.needle[k];
+        hit = same;
+        where = i;                                      // lowest match of this lane when hit
     }
     return hit;
 }
@@ -631,8 +744,10 @@ __device__ __forceinline__ uint32_t from_lane_ahead(uint32_t cur, uint32_t nxt, 
 // bench/sse4-strstr/src/lib.rs:4-15); a wave only skips work that lies to the RIGHT of the best so far.
 // LAZY_ORDER (batched kernel): the descriptor arrives without the second-level schedule; a wave builds it
 // when it first meets a candidate, next to staging the needle - not on every workgroup's way in.
-template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false>
-__device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_block, uint64_t tile0,
+// `pr` is read for its HOT fields only; `cold()` yields a pointer through which the cold ones are read where they are needed.
+template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false,
+          typename ColdT = ColdInRegisters>
+__device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_t *s_needle_block, uint64_t tile0,
                                            uint64_t tile_step, uint64_t tile_end, void *sink, int *wg_found = nullptr)
 {
     static_assert(!L8 || (MODE == 0 && !FIND), "the 8-byte layout covers the single-stream bool kernels");
@@ -646,13 +761,20 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
     const int wpb = (int)(blockDim.x / kWave);                              // waves per workgroup (launch-time)
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
-    bool staged = false, ordered = !LAZY_ORDER;
+    bool staged = false, ordered = false;
 #ifdef SS_TWO_BYTE_PHASE1       // A/B builds only (tools/ab_build.py): the round-1 two-byte first phase
     constexpr bool THREE = false;
 #else
     constexpr bool THREE = MODE == 0 && !ONE_BYTE;                          // three-byte first phase
 #endif
-    RefineOrder ro = {pr.norder, {pr.order_idx[0], pr.order_idx[1]}, {pr.order_val[0], pr.order_val[1]}};
+    // The cold part of the problem, fetched by a wave when it first meets a candidate (`ordered`): what the verification
+    // needs, the second-level schedule, and the needle's dwords for the exact in-register verification
+    // (exact_verify_piece: the single-stream multi-byte kernels, needles that end at most 16 bytes behind the first filter byte).
+    RefineOrder ro = {0, {0, 0}, {0, 0}};
+    VerifyArgs va = {nullptr, nullptr, 0, 0};
+    constexpr bool EXACT_OK = MODE == 0 && !ONE_BYTE;
+    uint32_t tail16[4] = {0, 0, 0, 0};
+    uint32_t exact_len = 0u;
     bool dense = false;                                                     // L8: the previous tile had candidates
     const int d = (int)pr.d;                                                // SHIFTED: 1 <= d <= 62
 
@@ -838,15 +960,42 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
         }
         if (cand_tile) {
             if (!ordered) {
-                if (!ONE_BYTE) {
+                const auto c = cold();
+                va.hay = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(uintptr_t)c->hay));
+                va.needle = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(uintptr_t)c->needle));
+                va.n = uniform64(c->n);
+                va.end = uniform64(c->end);
+                if (!ONE_BYTE && !LAZY_ORDER) {
+                    ro.n = c->norder;
+                    ro.idx[0] = c->order_idx[0]; ro.idx[1] = c->order_idx[1];
+                    ro.val[0] = c->order_val[0]; ro.val[1] = c->order_val[1];
+                    if (EXACT_OK) {
+                        exact_len = c->exact_len;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tail16[j] = c->tail16[j];
+                    }
+                }
+                if (!ONE_BYTE && LAZY_ORDER) {
+                    // the descriptor came without the schedule (and without the needle's dwords): built here, by the waves
+                    // that need them, not on every workgroup's way in
                     const uint64_t position = pr.d * 16 + 4 * Q + pr.r;
                     const uint64_t position3 = THREE ? (uint64_t)(4 * pr.q3 + pr.r3) : ~0ull;
-                    const uint64_t anchor = (uint64_t)((pr.base + pr.mis) - pr.hay);      // index of the first filter byte
+                    const uint64_t anchor = (uint64_t)((pr.base + pr.mis) - va.hay);      // index of the first filter byte
                     ro.n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)build_refine_order_wave(pr.needle + anchor, pr.n - anchor, position, lane, ro.idx, ro.val, position3));
+                        (int)build_refine_order_wave(va.needle + anchor, va.n - anchor, position, lane, ro.idx, ro.val, position3));
                     for (int t = 0; t < 2; ++t) {
                         ro.idx[t] = uniform64(ro.idx[t]);
                         ro.val[t] = uniform64(ro.val[t]);
+                    }
+                    if (EXACT_OK && va.n - anchor <= 16) {
+                        exact_len = (uint32_t)(va.n - anchor);
+                        const uint32_t nbv = (uint32_t)lane < exact_len ? (uint32_t)va.needle[anchor + lane] : 0u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            tail16[j] = ((uint32_t)__builtin_amdgcn_readlane((int)nbv, 4 * j) & 0xFF) |
+                                        (((uint32_t)__builtin_amdgcn_readlane((int)nbv, 4 * j + 1) & 0xFF) << 8) |
+                                        (((uint32_t)__builtin_amdgcn_readlane((int)nbv, 4 * j + 2) & 0xFF) << 16) |
+                                        (((uint32_t)__builtin_amdgcn_readlane((int)nbv, 4 * j + 3) & 0xFF) << 24);
                     }
                 }
                 ordered = true;
@@ -857,7 +1006,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
             // 2000-byte needle 13 % slower than a 16-byte one.
             auto stage_once = [&]() {
                 if (!staged && !ONE_BYTE) {
-                    stage_needle_wave(s_needle, pr.needle, pr.n, lane);
+                    stage_needle_wave(s_needle, va.needle, va.n, lane);
                     staged = true;
                 }
             };
@@ -882,7 +1031,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
 #endif
                 if (!per_piece) {
                     if (!refine_tile<U, MODE>(A, H, ro, G)) continue;
-                    stage_once();
                 }
             }
             bool hit = false;
@@ -897,12 +1045,20 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     // sitting in lane 63 (MODE 0), lanes 0..d of H (MODE 2), or unknown (MODE 1: settled by the compare)
                     np.kind = u + 1 < U ? 1 : (MODE == 0 ? 0 : (MODE == 2 ? 1 : 2));
                     if (!refine_piece(A[u], np, ro, g)) continue;
-                    stage_once();
                 } else if (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) == 0) {
                     continue;
                 }
                 uint64_t where = 0;
-                const bool h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, s_needle, where);
+                bool h;
+                if (EXACT_OK && exact_len != 0) {               // wave-uniform: the needle's dwords are at hand
+                    NextPiece np;
+                    np.N = u + 1 < U ? A[u + 1] : H;
+                    np.kind = u + 1 < U ? 1 : 0;                // MODE 0: the halo chunk sits in lane 63
+                    h = exact_verify_piece(A[u], np, g, chunk0 + 64 * u + lane, pr, va, tail16, exact_len, where);
+                } else {
+                    stage_once();
+                    h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, va, s_needle, where);
+                }
                 hit |= h;
                 if (FIND) {
                     const uint64_t m = __ballot(h);
@@ -938,8 +1094,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, uint8_t *s_needle_
                     } else if (lane == __ffsll((unsigned long long)hits) - 1 &&
                                __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.epoch) {
                         const int old = __hip_atomic_exchange(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (old != pr.epoch && pr.host_flag)
-                            __hip_atomic_store(pr.host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        int *host_flag = cold()->host_flag;
+                        if (old != pr.epoch && host_flag)
+                            __hip_atomic_store(host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                     forget_scalar_cache();
                     return;
@@ -976,7 +1133,7 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
     uint64_t t0 = tiles_per_block ? (uint64_t)blockIdx.x * tiles_per_block : blockIdx.x;
     // completion-word launches of the bool kernels: "a wave of this workgroup has found the needle"
     __shared__ int s_wg_found;
-    const bool counted = !FIND && pr.done_counter != nullptr;      // wave-uniform (kernel argument)
+    const bool counted = !FIND && (pr.flags & kProblemCounted) != 0;   // wave-uniform (kernel argument)
     if (counted) {
         if (threadIdx.x == 0) __hip_atomic_store(&s_wg_found, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
@@ -1004,7 +1161,8 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
             step = 1;
             t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
         }
-        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8>(pr, s_needle, t0, step, t1, found, counted ? &s_wg_found : nullptr);
+        scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8, false, ColdInKernarg>(pr, ColdInKernarg{}, s_needle, t0, step, t1, found,
+                                                                                 counted ? &s_wg_found : nullptr);
     }
     if (counted) {
         // Completion word of the bool kernels.  Every workgroup counts itself out with ONE relaxed 64-bit atomic add that
@@ -1016,17 +1174,18 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         __builtin_amdgcn_s_barrier();
         __asm__ volatile("" ::: "memory");
         if (threadIdx.x == 0) {
+            const auto c = ColdInKernarg{}();
             const unsigned long long f = (unsigned long long)__hip_atomic_load(&s_wg_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned long long mine = 1ull + (f << 32);
-            const unsigned long long total = __hip_atomic_fetch_add(pr.done_counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
-            if ((uint32_t)total == pr.done_target) {
+            const unsigned long long total = __hip_atomic_fetch_add(c->done_counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
+            if ((uint32_t)total == c->done_target) {
                 const uint32_t hi = (uint32_t)(total >> 32);
                 const long long word = (long long)(((unsigned long long)hi << 32) | ((unsigned long long)(uint32_t)pr.epoch << 1) |
-                                                   (hi != pr.done_hi ? 1ull : 0ull));
-                __hip_atomic_store(pr.host_done, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                                   (hi != c->done_hi ? 1ull : 0ull));
+                __hip_atomic_store(c->host_done, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-    } else if (FIND && pr.done_counter != nullptr) {
+    } else if (FIND && (pr.flags & kProblemCounted) != 0) {
         // Completion word of find(): the word is the answer itself - leftmost offset + 1, or all ones for "absent" (the
         // host zeroes it before the launch).  A wave's atomicMin has no return value, and the barrier alone does not wait
         // for it (gfx950 lowers __syncthreads() to `s_waitcnt lgkmcnt(0); s_barrier` - no vmcnt): every wave therefore
@@ -1036,8 +1195,9 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned long long total = __hip_atomic_fetch_add(pr.done_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
-            if ((uint32_t)total == pr.done_target) {
+            const auto c = ColdInKernarg{}();
+            const unsigned long long total = __hip_atomic_fetch_add(c->done_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+            if ((uint32_t)total == c->done_target) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 // The slot is not re-armed either: find_base carries a per-launch key in the bits above kFindOffsetBits
                 // that is SMALLER for every later launch on the slot, so whatever an earlier launch left behind loses
@@ -1045,7 +1205,7 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
                 const uint64_t v = __hip_atomic_load(static_cast<const uint64_t *>(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint64_t off = v - pr.find_base;
                 const bool hit = v >= pr.find_base && off < (1ull << kFindOffsetBits);
-                __hip_atomic_store(pr.host_done, hit ? (long long)(off + 1) : -1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(c->host_done, hit ? (long long)(off + 1) : -1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -1178,16 +1338,21 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     pr.epoch = 1;
     pr.done_counter = nullptr;
     pr.host_done = nullptr;
+    pr.done_target = pr.done_hi = 0;
+    pr.flags = 0;
+    pr.exact_len = 0;                               // ... as are the needle's dwords for the exact verification
+    pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
 
+    const ColdInRegisters cold = {&pr};
     if (n == 1) {
-        scan_tiles<0, 0, true, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found);
+        scan_tiles<0, 0, true, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found);
         return;
     }
     switch (s / 4) {                                // single stream, non-temporal loads
-    case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-    case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-    case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-    default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
+    case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
+    case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
+    default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
     }
 }
 
@@ -1338,15 +1503,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     pr.done_counter = nullptr;
     pr.host_done = nullptr;
     pr.done_target = pr.done_hi = 0;
+    pr.flags = 0;
+    pr.exact_len = 0;                               // ... as are the needle's dwords for the exact verification
+    pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
+    const ColdInRegisters cold = {&pr};
     if ((d.bytes >> 24) & 1) {
-        scan_tiles<0, 0, true, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found);
+        scan_tiles<0, 0, true, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found);
         return;
     }
     switch ((d.shifts >> 6) & 3) {                  // single stream, non-temporal loads
-    case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-    case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-    case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
-    default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, s_needle, t0, 1, te, found); break;
+    case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
+    case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
+    case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
+    default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found); break;
     }
 }
 

@@ -438,6 +438,18 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.epoch = epoch;
     pr.done_counter = nullptr;
     pr.host_done = nullptr;
+    pr.done_target = pr.done_hi = 0;
+    pr.flags = 0;
+    pr.pad_ = 0;
+    // exact in-register verification: the needle ends at most 16 bytes behind the first filter byte (lib.rs:222-241)
+    pr.exact_len = 0;
+    pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
+    if (!one_byte && pr.d == 0 && n - fa <= 16) {
+        pr.exact_len = (uint32_t)(n - fa);
+        uint8_t t16[16] = {0};
+        memcpy(t16, s->needle.data() + fa, n - fa);
+        memcpy(pr.tail16, t16, 16);
+    }
 
     const Launch l = pick_variant(s->variant, pr.d, one_byte, position);
     const uint64_t wpb = l.block / ss::kWave;
@@ -481,6 +493,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         pr.host_done = pd->h_done + k;
         pr.done_target = pd->done_low[k] + (uint32_t)blocks;
         pr.done_hi = pd->done_hi[k];
+        pr.flags |= ss::kProblemCounted;
         pd->done_low[k] = pr.done_target;                // (a launch that fails starts the slot over)
         pr.host_flag = nullptr;                          // the completion word carries the answer
         if (find) {                                      // keyed minimum in the slot's own word: see scan_kernel

@@ -249,7 +249,7 @@ int main(int argc, char **argv)
     //      whatever triple a search ends up with, its answer is right (src/lib.rs:375-378) ----
     {
         std::atomic<bool> stop{false};
-        std::atomic<int> accepted{0}, refused{0};
+        std::atomic<int> accepted{0}, refused{0}, searched{0};
         std::vector<std::thread> searchers;
         for (int t = 0; t < 4; ++t)
             searchers.emplace_back([&, t]() {
@@ -258,11 +258,13 @@ int main(int argc, char **argv)
                 while (!stop.load()) {
                     int found = -1;
                     TCHECK(ss_search_device(s, (t & 1) ? d_yes : d_no, len, st, &found) == SS_OK && found == (t & 1));
+                    ++searched;
                 }
                 (void)hipStreamDestroy(st);
             });
         const size_t pairs[4][3] = {{0, 6, 5}, {1, 5, 3}, {0, 1, 2}, {2, 6, 4}};
-        for (int it = 0; it < 20000; ++it) {
+        while (searched.load() < 64 && g_failures == 0) std::this_thread::yield();      // all four are searching by now
+        for (int it = 0; it < 20000 || (refused == 0 && it < 2000000); ++it) {
             const size_t *q = pairs[it & 3];
             const int rc = (it & 4) ? ss_searcher_set_filter(s, q[0], q[1]) : ss_searcher_set_filter3(s, q[0], q[1], q[2]);
             if (rc == SS_OK) ++accepted;
