@@ -334,12 +334,18 @@ uint32_t occupancy_pad(int occ, unsigned block)
     return pad;
 }
 
-// Workgroups per CU.  The three-byte kernels need 121 VGPRs, which caps them at four workgroups of four waves per CU
-// by itself.  The one-byte kernel (8-byte loads, 70 VGPRs) would fit seven; capped at four through unused LDS it is
-// 1 % faster at every size from 2 GiB (64 GiB 7.45-7.47 vs 7.36-7.40 TB/s, in one process on one buffer:
-// profiles/r02/occupancy_by_size.jsonl).  The same file has the experiment for a 95-VGPR build of the three-byte
-// kernel: five workgroups per CU are 1-5 % SLOWER than four up to 8 GiB and 0.6 % faster from 16 GiB.
-Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
+// Workgroups per CU.  Since the cold half of the Problem left the registers (scan_kernels.hpp, ColdInKernarg) the multi-byte
+// kernels need 77-83 VGPRs, so the register file would admit six workgroups of four waves per CU; how many actually run is
+// set per launch through unused dynamic LDS.  Measured in one process on one buffer (tools/occ_probe.py,
+// profiles/r03/occupancy_probe.jsonl; 16-byte needle on random bytes, 1 / 8 / 32 GiB): FOUR per CU 7.36 / 7.46 / 7.42 TB/s,
+// five 7.01 / 7.20 / 7.17, six 7.00 / 7.24 / 7.23 - a streaming scan that rarely sees a candidate wants exactly one
+// workgroup per SIMD quartet.  A scan that keeps meeting candidates wants latency hiding instead: on the i386 text, phrases of
+// the manual's stock vocabulary run at 6.1-6.2 TB/s with four per CU and 7.1 with six, the reference's own pair (0, n-1) on
+// text 3.9-4.4 against 5.0-5.8.  The library cannot see the haystack, so it goes by the needle: when EVERY filter byte is
+// text-like (byte_rarity_rank >= 64: letters, digits, blanks, common punctuation, NUL) the haystack is presumably text and
+// candidates are to be expected - six per CU; otherwise (a random or binary needle: its rarest bytes are in the filter) four.
+// One-byte needles (8-byte loads, 36-68 VGPRs) stay at four: 7.28-7.44 TB/s either way.
+Launch pick_variant(int variant, uint64_t d, bool one_byte, bool text_like)
 {
     Launch l;
     l.U = kAutoU;
@@ -347,8 +353,7 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, uint64_t position)
     l.nt = l.mode == 1 ? 0 : 1;
     l.l8 = one_byte;
     l.block = ss::kBlock;
-    l.dyn_lds = one_byte ? occupancy_pad(4, l.block) : 0;
-    (void)position;
+    l.dyn_lds = occupancy_pad(!one_byte && text_like ? 6 : 4, l.block);
     if (variant > 0) {
         l.dyn_lds = 0;
         if (variant >= 100000) {                                // Bxxxxx: workgroup size
@@ -451,7 +456,9 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         memcpy(pr.tail16, t16, 16);
     }
 
-    const Launch l = pick_variant(s->variant, pr.d, one_byte, position);
+    const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
+                           ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
+    const Launch l = pick_variant(s->variant, pr.d, one_byte, text_like);
     const uint64_t wpb = l.block / ss::kWave;
     const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
     uint64_t blocks, tpb;
@@ -1545,6 +1552,15 @@ static int plan_scratch_ready(int dev)
     return SS_OK;
 }
 
+// The batched kernels (73-80 VGPRs) are held to four workgroups per CU like the single-problem scan on random bytes (see
+// pick_variant); SLICESLICE_BATCH_OCC overrides (tuning aid).  Their needle slices are static LDS, hence the "fixed" part.
+static uint32_t batch_lds_pad()
+{
+    int occ = 4;
+    if (const char *e = getenv("SLICESLICE_BATCH_OCC")) { const int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }
+    return occupancy_pad(occ, ss::kBlock);
+}
+
 static int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint64_t *d_hay_begin,
                            const uint64_t *d_hay_end, const void *d_needles, const uint64_t *d_needle_begin,
                            const uint64_t *d_needle_end, const uint64_t *d_position, int *d_found)
@@ -1604,7 +1620,7 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
                                                                                       min_tiles, ss::kWavesPerBlock * 4);
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) {
-                ss::scan_batched_plan_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), 0, st>>>(a, descs);
+                ss::scan_batched_plan_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs);
                 e = hipGetLastError();
             }
             const hipError_t fe = hipFreeAsync(descs, st);
@@ -1629,7 +1645,7 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     uint64_t slices = (wg_target + count - 1) / count;
     if (slices < 1) slices = 1;
     if (slices > 4096) slices = 4096;
-    ss::scan_batched_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), 0, st>>>(a);
+    ss::scan_batched_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), batch_lds_pad(), st>>>(a);
     HIP_TRY(hipGetLastError());
     return SS_OK;
 }

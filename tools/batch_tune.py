@@ -36,15 +36,17 @@ def timed(fn, reps=15):
     return out, float(np.median(ms)), float(np.min(ms))
 
 
-def settings(wgs_list, mt_list):
-    yield {"SLICESLICE_BATCH_PLAN": "0"}
-    for w in wgs_list:
-        for m in mt_list:
-            yield {"SLICESLICE_BATCH_PLAN": "1", "SLICESLICE_BATCH_WGS": str(w * 256), "SLICESLICE_BATCH_MIN_TILES": str(m)}
+def settings(wgs_list, mt_list, occ_list):
+    for o in occ_list:
+        yield {"SLICESLICE_BATCH_PLAN": "0", "SLICESLICE_BATCH_OCC": str(o)}
+        for w in wgs_list:
+            for m in mt_list:
+                yield {"SLICESLICE_BATCH_PLAN": "1", "SLICESLICE_BATCH_WGS": str(w * 256), "SLICESLICE_BATCH_MIN_TILES": str(m),
+                       "SLICESLICE_BATCH_OCC": str(o)}
 
 
 def apply(env):
-    for k in ("SLICESLICE_BATCH_PLAN", "SLICESLICE_BATCH_WGS", "SLICESLICE_BATCH_MIN_TILES"):
+    for k in ("SLICESLICE_BATCH_PLAN", "SLICESLICE_BATCH_WGS", "SLICESLICE_BATCH_MIN_TILES", "SLICESLICE_BATCH_OCC"):
         os.environ.pop(k, None)
     os.environ.update(env)
 
@@ -54,11 +56,13 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--wgs", default="128,256,512", help="workgroups per CU (x 256 CUs) for the planned form")
     ap.add_argument("--min-tiles", default="1,2,4")
+    ap.add_argument("--occ", default="4", help="workgroups per CU (SLICESLICE_BATCH_OCC)")
     ap.add_argument("--default-only", action="store_true", help="only the library defaults (the shipped behaviour)")
     args = ap.parse_args()
     wgs = [int(x) for x in args.wgs.split(",")]
     mts = [int(x) for x in args.min_tiles.split(",")]
-    sets = [{}] if args.default_only else list(settings(wgs, mts))
+    occs = [int(x) for x in args.occ.split(",")]
+    sets = [{}] if args.default_only else list(settings(wgs, mts, occs))
     total = 4 << 30
     hay = torch.empty(total, dtype=torch.uint8, device="cuda")
     ss.fill_random_device(hay, 0x5EED0001)
