@@ -1413,10 +1413,16 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
     } else if (len >= n) {
         const uint8_t *needle = a.needles + n0;
         uint64_t anchor = 0;
+        // (all byte loads of a step are issued together - unrolled into an array - and only then ranked: a rolled
+        // load-compare loop is one memory round trip per byte, 11 us for this kernel instead of 3)
         if (position >= 16) {
+            uint8_t nb[15];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) nb[k] = needle[position - 15 + k];
             int best_cls = 4;
+#pragma unroll
             for (int k = 0; k < 15; ++k) {          // later bytes win ties: the partner closest to `position`
-                const int c = rarity_class4(needle[position - 15 + k]);
+                const int c = rarity_class4(nb[k]);
                 if (c <= best_cls) {
                     best_cls = c;
                     anchor = position - 15 + k;
@@ -1425,12 +1431,16 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         }
         uint32_t s2 = (uint32_t)(position - anchor);            // distance between the two filter bytes: 0 .. 15
         const int lim = n - anchor < 16 ? (int)(n - anchor) : 16;
+        uint8_t fb[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fb[k] = k < lim ? needle[anchor + k] : (uint8_t)0;
         uint32_t p3 = s2;
         if (n - anchor >= 3) {
             int best_cls = 4;
-            for (int k = 1; k < lim; ++k) {
-                if ((uint32_t)k == s2) continue;
-                const int c = rarity_class4(needle[anchor + k]);
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                if (k >= lim || (uint32_t)k == s2) continue;
+                const int c = rarity_class4(fb[k]);
                 if (c <= best_cls) {
                     best_cls = c;
                     p3 = (uint32_t)k;
@@ -1448,8 +1458,13 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         d.end = len - n + 1;
         d.nchunks_all = (mis + len - anchor + 15) / 16;
         d.anchor = anchor;
-        d.bytes = (uint32_t)needle[anchor] | ((uint32_t)needle[anchor + s2] << 8) | ((uint32_t)needle[anchor + p3] << 16) |
-                  (n == 1 ? 1u << 24 : 0u);
+        uint32_t b2 = 0, b3 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {              // fb[s2], fb[p3] without a dynamic index (scratch)
+            b2 = (uint32_t)k == s2 ? fb[k] : b2;
+            b3 = (uint32_t)k == p3 ? fb[k] : b3;
+        }
+        d.bytes = (uint32_t)fb[0] | (b2 << 8) | (b3 << 16) | (n == 1 ? 1u << 24 : 0u);
         d.shifts = mis | ((s2 % 4) << 4) | ((s2 / 4) << 6) | ((p3 % 4) << 8) | ((p3 / 4) << 10);
         const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
         const uint64_t ntiles = (npieces + tile_pieces - 1) / tile_pieces;
@@ -1461,33 +1476,75 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
     descs[prob] = d;
 }
 
+// The cold fields of a planned problem, re-read from its descriptor by the waves that need them (scan_tiles' ColdT).
+struct ColdFields {
+    const uint8_t *hay, *needle;
+    uint64_t n, end;
+    uint32_t norder, exact_len;
+    uint64_t order_idx[2], order_val[2];
+    uint32_t tail16[4];
+    int *host_flag;
+    __device__ __forceinline__ const ColdFields *operator->() const { return this; }
+};
+struct ColdInDesc {
+    const BatchDesc *dp;
+    const uint8_t *needles;
+    __device__ __forceinline__ ColdFields operator()() const
+    {
+        const BatchDesc *q = dp;
+        __asm__ volatile("" : "+s"(q));             // opaque: the loads stay in the cold path
+        ColdFields f;
+        f.hay = q->base + (q->shifts & 15) - q->anchor;
+        f.needle = needles + q->needle_off;
+        f.n = q->n;
+        f.end = q->end;
+        f.norder = f.exact_len = 0;                 // LAZY_ORDER: built by the wave
+        f.order_idx[0] = f.order_idx[1] = f.order_val[0] = f.order_val[1] = 0;
+        f.tail16[0] = f.tail16[1] = f.tail16[2] = f.tail16[3] = 0;
+        f.host_flag = nullptr;
+        return f;
+    }
+};
+
+// Grid: ONE dimension.  Workgroup w < count scans slice 0 of problem w; the others come problem by problem, slices in address
+// order: w - count = p * rest + (s - 1), rest = slices per problem - 1.  All slice-0 workgroups are dispatched before any
+// other slice (needles that are present early - the reference's i386 loop: every word occurs in the text - have set their
+// flag by the time the later slices of their problem start, and those leave at the entry peek), and the later slices of one
+// problem run next to each other: consecutive addresses in flight, and one descriptor line for a run of workgroups.
 template <int U>
-__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock) scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs)
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock)
+scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t rest)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
-    const uint64_t prob = blockIdx.x;
-    const uint32_t slice = blockIdx.y;
+    const uint32_t w = blockIdx.x;
+    uint32_t prob = w, slice = 0;
+    if (w >= count) {
+        const uint32_t v = w - count;
+        prob = v / rest;
+        slice = 1 + (v - prob * rest);
+    }
     int *found = a.found + prob;
-    // the entry poll and the descriptor are requested together: one round trip decides whether and what to scan
-    const int seen = slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    const BatchDesc d = descs[prob];
+    // The descriptor and - for later slices - a peek at the problem's flag through the scalar cache, requested together:
+    // one scalar round trip decides whether and what to scan.  A stale "not found" costs a tile (every tile polls
+    // coherently); a hit is confirmed coherently before the workgroup leaves (see scalar_peek).
+    const BatchDesc *dp = descs + prob;
+    const BatchDesc d = *dp;
+    const int peek = slice != 0 ? scalar_peek(found) : 0;
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
     const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
     const uint64_t t0 = (uint64_t)slice * d.per;
     const uint64_t te = t0 + d.per < ntiles ? t0 + d.per : ntiles;
     if (t0 >= te) return;                           // surplus slice, or a problem the plan kernel has answered
-    if (__builtin_amdgcn_readfirstlane(seen) != 0) return;   // later slices of a needle that has been found (or rejected)
+    if (peek != 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
+        return;                                     // later slices of a needle that has been found
 
-    Problem pr;
+    Problem pr;                                     // hot fields only; the cold ones are re-read from the descriptor
     pr.base = d.base;
-    pr.hay = d.base + mis - d.anchor;
-    pr.needle = a.needles + d.needle_off;
-    pr.n = d.n;
-    pr.end = d.end;
     pr.nchunks_all = d.nchunks_all;
     pr.npieces = npieces;
     pr.d = 0;
+    pr.find_base = 0;
     pr.mis = mis;
     pr.r = (d.shifts >> 4) & 3;
     pr.n0x4 = 0x01010101u * (d.bytes & 0xFF);
@@ -1495,18 +1552,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBl
     pr.n3x4 = 0x01010101u * ((d.bytes >> 16) & 0xFF);
     pr.r3 = (d.shifts >> 8) & 3;
     pr.q3 = (d.shifts >> 10) & 3;
-    pr.norder = 0;                                  // the second-level schedule is built lazily (LAZY_ORDER)
-    pr.order_idx[0] = pr.order_idx[1] = pr.order_val[0] = pr.order_val[1] = 0;
-    pr.find_base = 0;
-    pr.host_flag = nullptr;
     pr.epoch = 1;
-    pr.done_counter = nullptr;
-    pr.host_done = nullptr;
-    pr.done_target = pr.done_hi = 0;
     pr.flags = 0;
-    pr.exact_len = 0;                               // ... as are the needle's dwords for the exact verification
-    pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
-    const ColdInRegisters cold = {&pr};
+    const ColdInDesc cold = {dp, a.needles};
     if ((d.bytes >> 24) & 1) {
         scan_tiles<0, 0, true, U, 1, false, false, true>(pr, cold, s_needle, t0, 1, te, found);
         return;

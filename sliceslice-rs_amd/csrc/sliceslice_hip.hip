@@ -1592,7 +1592,7 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     HIP_TRY(hipGetDevice(&dev));
     DeviceInfo di;
     if (int rc = device_info(dev, &di)) return rc;
-    if (count > 0x7fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
+    if (count > 0x3fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
     // Planned form (the default; SLICESLICE_BATCH_PLAN=0 keeps the single-kernel form): batch_plan_kernel turns the range
     // arrays into one 64-byte descriptor per problem and writes the initial flags (no memset launch), the scan grid's
     // workgroups then start with one scalar load.  The descriptors live in stream-ordered scratch (hipMallocAsync /
@@ -1609,8 +1609,8 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
         if (const char *e = getenv("SLICESLICE_BATCH_WGS")) { const long v = atol(e); if (v > 0) wg_target = (uint64_t)v; }
         if (const char *e = getenv("SLICESLICE_BATCH_MIN_TILES")) { const long v = atol(e); if (v > 0) min_tiles = (uint32_t)v; }
         uint64_t slices = (wg_target + count - 1) / count;
-        if (slices < 1) slices = 1;
-        if (slices > 65535) slices = 65535;
+        if (slices < 2) slices = 2;                            // (the kernel's index arithmetic divides by slices - 1)
+        while (slices > 2 && (uint64_t)count * slices > 0x7fffffffull) --slices;   // gridDim.x
         if (int rc = plan_scratch_ready(dev)) return rc;
         ss::BatchDesc *descs = nullptr;
         const hipError_t me = hipMallocAsync((void **)&descs, count * sizeof(ss::BatchDesc), st);
@@ -1620,7 +1620,8 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
                                                                                       min_tiles, ss::kWavesPerBlock * 4);
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) {
-                ss::scan_batched_plan_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs);
+                ss::scan_batched_plan_kernel<4><<<dim3((unsigned)((uint64_t)count * slices)), dim3(ss::kBlock), batch_lds_pad(), st>>>(
+                    a, descs, (uint32_t)count, (uint32_t)(slices - 1));
                 e = hipGetLastError();
             }
             const hipError_t fe = hipFreeAsync(descs, st);
