@@ -268,12 +268,12 @@ __device__ __forceinline__ void filter_piece3(const u32x4 &A, const uint32_t NX[
 
 // Smaller = expected to be rarer in typical haystacks (text, logs, source, binaries).  Only the ORDER
 // of the checks depends on this; the result of a search never does.
-__host__ __device__ inline int byte_rarity_rank(uint8_t b)
+__host__ __device__ constexpr inline int byte_rarity_rank(uint8_t b)
 {
     if (b == ' ') return 255;
     if (b >= 'a' && b <= 'z') {
         // 250 - 4 * (place in "etaoinshrdlcumwfgypbvkjxqz", most to least frequent English letters)
-        constexpr uint8_t kLetter[26] = {/*a*/ 242, /*b*/ 174, /*c*/ 206, /*d*/ 214, /*e*/ 250, /*f*/ 190, /*g*/ 186,
+        const uint8_t kLetter[26] = {/*a*/ 242, /*b*/ 174, /*c*/ 206, /*d*/ 214, /*e*/ 250, /*f*/ 190, /*g*/ 186,
                                          /*h*/ 222, /*i*/ 234, /*j*/ 162, /*k*/ 166, /*l*/ 210, /*m*/ 198, /*n*/ 230,
                                          /*o*/ 238, /*p*/ 178, /*q*/ 154, /*r*/ 218, /*s*/ 226, /*t*/ 246, /*u*/ 202,
                                          /*v*/ 170, /*w*/ 194, /*x*/ 158, /*y*/ 182, /*z*/ 150};
@@ -1378,25 +1378,60 @@ struct __attribute__((aligned(64))) BatchDesc {
 };
 static_assert(sizeof(BatchDesc) == 64, "one scalar load (s_load_dwordx16) per workgroup");
 
-__device__ __forceinline__ int rarity_class4(uint8_t b)
+__host__ __device__ constexpr inline int rarity_class4(uint8_t b)
 {
     const int r = byte_rarity_rank(b);
     return r < 64 ? 0 : (r < 128 ? 1 : (r < 192 ? 2 : 3));
 }
+// The four classes as two bit planes of 256 bits each (8 dwords per plane): no table in memory, no branches - the plan kernel
+// fills its LDS table from these constants.
+struct ClassPlanes {
+    uint32_t lo[8], hi[8];
+};
+constexpr ClassPlanes make_class_planes()
+{
+    ClassPlanes p = {};
+    for (int b = 0; b < 256; ++b) {
+        const int c = rarity_class4((uint8_t)b);
+        if (c & 1) p.lo[b >> 5] |= 1u << (b & 31);
+        if (c & 2) p.hi[b >> 5] |= 1u << (b & 31);
+    }
+    return p;
+}
 
-// One LANE per problem.  `nslices` = gridDim.y of the scan launch that follows, `min_tiles` = the shortest slice worth a
+// One LANE per problem.  `nslices` = slices per problem of the scan launch that follows, `min_tiles` = the shortest slice worth a
 // workgroup.  Same rules as scan_batched_kernel: needle[position] is always a first-phase byte; its partner is needle[0]
 // when position < 16, else the rarest (class) byte of the 15 in front of it, closest to `position` among equals; the third
 // byte is the rarest of the 15 behind the anchor, the later one among equals; the two are ordered by dword (q3 <= Q).
+// Written for LATENCY - the scan cannot start before this kernel has ended: the rarity classes come from a 256-entry table
+// in LDS (byte_rarity_rank is a dozen branches), and the needle bytes of a step are fetched by unconditional loads
+// (out-of-range slots re-read byte 0 of the window) that are all in flight together; a first cut with a predicated
+// load-rank loop ran 8-12 us, one memory round trip per byte.
 __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
                                                              uint32_t nslices, uint32_t min_tiles, int tile_pieces)
 {
+    __shared__ uint8_t s_class[256];
+    {
+        constexpr ClassPlanes P = make_class_planes();                         // compile-time constants, selected by wave
+        const uint32_t t = threadIdx.x, w = t >> 5;                            // kBlock == 256: one table entry per thread
+        uint32_t lo = P.lo[0], hi = P.hi[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; ++k) {
+            lo = w == k ? P.lo[k] : lo;
+            hi = w == k ? P.hi[k] : hi;
+        }
+        s_class[t] = (uint8_t)(((lo >> (t & 31)) & 1u) | (((hi >> (t & 31)) & 1u) << 1));
+    }
     const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (prob >= count) return;
-    const uint64_t h0 = a.hay_begin[prob], h1 = a.hay_end[prob];
-    const uint64_t n0 = a.needle_begin[prob], n1 = a.needle_end[prob];
+    const bool live = prob < count;
+    const uint64_t pi = live ? prob : 0;                                       // (every lane reaches the barrier)
+    const uint64_t h0 = a.hay_begin[pi], h1 = a.hay_end[pi];
+    const uint64_t n0 = a.needle_begin[pi], n1 = a.needle_end[pi];
+    const uint64_t given = a.position ? a.position[pi] : 0;
+    __syncthreads();
+    if (!live) return;
     const uint64_t len = h1 - h0, n = n1 - n0;
-    uint64_t position = (a.position && n) ? a.position[prob] : n - 1;
+    const uint64_t position = (a.position && n) ? given : n - 1;
     BatchDesc d;
     d.base = nullptr;
     d.end = d.nchunks_all = 0;
@@ -1413,44 +1448,44 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
     } else if (len >= n) {
         const uint8_t *needle = a.needles + n0;
         uint64_t anchor = 0;
-        // (all byte loads of a step are issued together - unrolled into an array - and only then ranked: a rolled
-        // load-compare loop is one memory round trip per byte, 11 us for this kernel instead of 3)
         if (position >= 16) {
-            uint8_t nb[15];
+            uint32_t cls[15];
 #pragma unroll
-            for (int k = 0; k < 15; ++k) nb[k] = needle[position - 15 + k];
-            int best_cls = 4;
+            for (int k = 0; k < 15; ++k) cls[k] = needle[position - 15 + k];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) cls[k] = s_class[cls[k]];
+            uint32_t best_cls = 4;
 #pragma unroll
             for (int k = 0; k < 15; ++k) {          // later bytes win ties: the partner closest to `position`
-                const int c = rarity_class4(nb[k]);
-                if (c <= best_cls) {
-                    best_cls = c;
-                    anchor = position - 15 + k;
-                }
+                const bool better = cls[k] <= best_cls;
+                best_cls = better ? cls[k] : best_cls;
+                anchor = better ? position - 15 + k : anchor;
             }
         }
         uint32_t s2 = (uint32_t)(position - anchor);            // distance between the two filter bytes: 0 .. 15
-        const int lim = n - anchor < 16 ? (int)(n - anchor) : 16;
-        uint8_t fb[16];
+        const uint32_t lim = n - anchor < 16 ? (uint32_t)(n - anchor) : 16u;
+        uint32_t fb[16], cls[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) fb[k] = k < lim ? needle[anchor + k] : (uint8_t)0;
-        uint32_t p3 = s2;
-        if (n - anchor >= 3) {
-            int best_cls = 4;
+        for (uint32_t k = 0; k < 16; ++k) fb[k] = needle[anchor + (k < lim ? k : 0u)];
 #pragma unroll
-            for (int k = 1; k < 16; ++k) {
-                if (k >= lim || (uint32_t)k == s2) continue;
-                const int c = rarity_class4(fb[k]);
-                if (c <= best_cls) {
-                    best_cls = c;
-                    p3 = (uint32_t)k;
-                }
-            }
+        for (uint32_t k = 0; k < 16; ++k) cls[k] = s_class[fb[k]];
+        uint32_t p3 = s2, best_cls = 4;
+#pragma unroll
+        for (uint32_t k = 1; k < 16; ++k) {         // the rarest of the 15 bytes behind the anchor, later ones winning ties
+            const bool better = k < lim && k != s2 && cls[k] <= best_cls && n - anchor >= 3;
+            best_cls = better ? cls[k] : best_cls;
+            p3 = better ? k : p3;
         }
         if (p3 / 4 > s2 / 4) {                      // the kernels want the third byte's dword not behind the second's
             const uint32_t t = p3;
             p3 = s2;
             s2 = t;
+        }
+        uint32_t b2 = 0, b3 = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {         // fb[s2], fb[p3] without a dynamic index (scratch)
+            b2 = k == s2 ? fb[k] : b2;
+            b3 = k == p3 ? fb[k] : b3;
         }
         const uint8_t *hf = a.haystacks + h0 + anchor;
         const uint32_t mis = (uint32_t)((uintptr_t)hf & 15);
@@ -1458,13 +1493,7 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         d.end = len - n + 1;
         d.nchunks_all = (mis + len - anchor + 15) / 16;
         d.anchor = anchor;
-        uint32_t b2 = 0, b3 = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {              // fb[s2], fb[p3] without a dynamic index (scratch)
-            b2 = (uint32_t)k == s2 ? fb[k] : b2;
-            b3 = (uint32_t)k == p3 ? fb[k] : b3;
-        }
-        d.bytes = (uint32_t)fb[0] | (b2 << 8) | (b3 << 16) | (n == 1 ? 1u << 24 : 0u);
+        d.bytes = fb[0] | (b2 << 8) | (b3 << 16) | (n == 1 ? 1u << 24 : 0u);
         d.shifts = mis | ((s2 % 4) << 4) | ((s2 / 4) << 6) | ((p3 % 4) << 8) | ((p3 / 4) << 10);
         const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
         const uint64_t ntiles = (npieces + tile_pieces - 1) / tile_pieces;
