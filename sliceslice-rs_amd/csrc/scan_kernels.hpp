@@ -1553,20 +1553,20 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         slice = 1 + (v - prob * rest);
     }
     int *found = a.found + prob;
-    // The descriptor and - for later slices - a peek at the problem's flag through the scalar cache, requested together:
-    // one scalar round trip decides whether and what to scan.  A stale "not found" costs a tile (every tile polls
-    // coherently); a hit is confirmed coherently before the workgroup leaves (see scalar_peek).
+    // The descriptor (one scalar load) and - for later slices - the problem's flag (one coherent load) are requested
+    // together: one round trip decides whether and what to scan.  (A peek through the scalar cache instead of the coherent
+    // load is cheaper still, but too often stale where it matters: the i386 loop, whose later slices should nearly all
+    // leave right here, went from 0.15 to 0.18-0.25 ms with it - every stale "not found" is a tile read for nothing.)
     const BatchDesc *dp = descs + prob;
+    const int seen = slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const BatchDesc d = *dp;
-    const int peek = slice != 0 ? scalar_peek(found) : 0;
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
     const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
     const uint64_t t0 = (uint64_t)slice * d.per;
     const uint64_t te = t0 + d.per < ntiles ? t0 + d.per : ntiles;
     if (t0 >= te) return;                           // surplus slice, or a problem the plan kernel has answered
-    if (peek != 0 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)
-        return;                                     // later slices of a needle that has been found
+    if (__builtin_amdgcn_readfirstlane(seen) != 0) return;   // later slices of a needle that has been found
 
     Problem pr;                                     // hot fields only; the cold ones are re-read from the descriptor
     pr.base = d.base;

@@ -1532,24 +1532,65 @@ int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256]
 constexpr unsigned kPlanWgsPerCu = 256;     // total workgroups aimed at, per CU (tools/batch_shape_probe.py)
 constexpr uint32_t kPlanMinTiles = 2;       // shortest slice worth a workgroup, in 16 KiB tiles
 
-// hipMallocAsync hands memory back to the OS when the stream synchronises unless the pool is told to keep it: one
-// hipMemPoolSetAttribute per device, so that the descriptor scratch of every later call is a pool hit (microseconds).
-static int plan_scratch_ready(int dev)
+// Descriptor scratch of the planned form: one grow-only device buffer per (device, stream), kept for the life of the process.
+// Launches on one stream execute in order, so a buffer that belongs to the stream can be reused by the next call on that
+// stream without any wait; the entry's mutex keeps the two launches of one call adjacent when several threads share a
+// stream.  (hipMallocAsync / hipFreeAsync per call did the same job at 5-10 us of extra latency per call.)  At most
+// kPlanScratchEntries streams per device are remembered; beyond that the least recently used entry is freed (hipFree waits
+// for the device, so nothing that still reads the buffer can be running).
+constexpr int kPlanScratchEntries = 32;
+struct PlanScratch {
+    hipStream_t stream = nullptr;
+    bool used = false;
+    ss::BatchDesc *buf = nullptr;
+    size_t cap = 0;             // descriptors
+    uint64_t stamp = 0;
+    std::mutex mu;              // held across the plan + scan launches of one call
+};
+static std::mutex g_plan_mu[kMaxDevices];
+static PlanScratch g_plan[kMaxDevices][kPlanScratchEntries];
+static uint64_t g_plan_clock[kMaxDevices];
+
+// Returns the stream's entry with its mutex LOCKED and room for `count` descriptors, or nullptr (no memory).
+static PlanScratch *plan_scratch_acquire(int dev, hipStream_t st, size_t count)
 {
-    static std::mutex mu;
-    static bool done[kMaxDevices] = {false};
-    if (dev < 0 || dev >= kMaxDevices) return SS_OK;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!done[dev]) {
-        hipMemPool_t pool = nullptr;
-        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-            uint64_t keep = UINT64_MAX;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    if (dev < 0 || dev >= kMaxDevices) return nullptr;
+    std::unique_lock<std::mutex> table(g_plan_mu[dev]);
+    PlanScratch *e = nullptr, *victim = nullptr;
+    for (auto &c : g_plan[dev]) {
+        if (c.used && c.stream == st) {
+            e = &c;
+            break;
         }
-        (void)hipGetLastError();
-        done[dev] = true;
+        if (!victim || (!c.used && victim->used) || (c.used == victim->used && c.stamp < victim->stamp)) victim = &c;
     }
-    return SS_OK;
+    if (e) {
+        e->mu.lock();            // another thread's call on this stream is between its two launches: brief
+    } else {
+        e = victim;              // an unused entry, else the least recently used one
+        if (!e->mu.try_lock()) return nullptr;                  // (in use right now: the caller takes the single-kernel form)
+        if (e->buf) (void)hipFree(e->buf);                      // hipFree waits for the device: nobody reads it any more
+        e->buf = nullptr;
+        e->cap = 0;
+        e->stream = st;
+        e->used = true;
+    }
+    e->stamp = ++g_plan_clock[dev];
+    table.unlock();
+    if (e->cap < count) {
+        const size_t want = count < 4096 ? 4096 : count + count / 2;
+        if (e->buf) (void)hipFree(e->buf);
+        e->buf = nullptr;
+        e->cap = 0;
+        if (hipMalloc((void **)&e->buf, want * sizeof(ss::BatchDesc)) != hipSuccess) {
+            (void)hipGetLastError();
+            e->buf = nullptr;
+            e->mu.unlock();
+            return nullptr;
+        }
+        e->cap = want;
+    }
+    return e;
 }
 
 // The batched kernels (73-80 VGPRs) are held to four workgroups per CU like the single-problem scan on random bytes (see
@@ -1595,9 +1636,8 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     if (count > 0x3fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
     // Planned form (the default; SLICESLICE_BATCH_PLAN=0 keeps the single-kernel form): batch_plan_kernel turns the range
     // arrays into one 64-byte descriptor per problem and writes the initial flags (no memset launch), the scan grid's
-    // workgroups then start with one scalar load.  The descriptors live in stream-ordered scratch (hipMallocAsync /
-    // hipFreeAsync on the caller's stream: re-entrant, nothing shared between concurrent calls); if that allocator is not
-    // available the single-kernel form runs instead.
+    // workgroups then start with one scalar load.  The descriptors live in per-stream scratch (plan_scratch_acquire); without it
+    // the single-kernel form runs instead.
     const char *pm = getenv("SLICESLICE_BATCH_PLAN");          // read per call: tools A/B the two forms in one process
     if (!pm || pm[0] != '0') {
         // The haystack lengths live on the device, so the grid is still sized from the problem COUNT: kPlanWgsPerCu
@@ -1611,10 +1651,8 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
         uint64_t slices = (wg_target + count - 1) / count;
         if (slices < 2) slices = 2;                            // (the kernel's index arithmetic divides by slices - 1)
         while (slices > 2 && (uint64_t)count * slices > 0x7fffffffull) --slices;   // gridDim.x
-        if (int rc = plan_scratch_ready(dev)) return rc;
-        ss::BatchDesc *descs = nullptr;
-        const hipError_t me = hipMallocAsync((void **)&descs, count * sizeof(ss::BatchDesc), st);
-        if (me == hipSuccess) {
+        if (PlanScratch *ps = plan_scratch_acquire(dev, st, count)) {
+            ss::BatchDesc *descs = ps->buf;
             const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
             ss::batch_plan_kernel<<<dim3((unsigned)pblocks), dim3(ss::kBlock), 0, st>>>(a, (uint64_t)count, descs, (uint32_t)slices,
                                                                                       min_tiles, ss::kWavesPerBlock * 4);
@@ -1624,12 +1662,11 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
                     a, descs, (uint32_t)count, (uint32_t)(slices - 1));
                 e = hipGetLastError();
             }
-            const hipError_t fe = hipFreeAsync(descs, st);
-            if (e == hipSuccess) e = fe;
+            ps->mu.unlock();
             if (e != hipSuccess) return fail(SS_ERR_HIP, "batched launch: %s", hipGetErrorString(e));
             return SS_OK;
         }
-        (void)hipGetLastError();                           // no stream-ordered allocator here: the single-kernel form below
+        // no descriptor scratch (out of memory, or every entry busy): the single-kernel form below
     }
     HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
     // Single-kernel form.  The haystack lengths live on the device, so the grid is chosen from the problem count alone: 96
