@@ -1649,8 +1649,8 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
         if (const char *e = getenv("SLICESLICE_BATCH_WGS")) { const long v = atol(e); if (v > 0) wg_target = (uint64_t)v; }
         if (const char *e = getenv("SLICESLICE_BATCH_MIN_TILES")) { const long v = atol(e); if (v > 0) min_tiles = (uint32_t)v; }
         uint64_t slices = (wg_target + count - 1) / count;
-        if (slices < 2) slices = 2;                            // (the kernel's index arithmetic divides by slices - 1)
-        while (slices > 2 && (uint64_t)count * slices > 0x7fffffffull) --slices;   // gridDim.x
+        if (slices < 1) slices = 1;
+        while (slices > 1 && (uint64_t)count * slices > 0x7fffffffull) --slices;   // gridDim.x
         if (PlanScratch *ps = plan_scratch_acquire(dev, st, count)) {
             ss::BatchDesc *descs = ps->buf;
             const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
@@ -1659,7 +1659,7 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) {
                 ss::scan_batched_plan_kernel<4><<<dim3((unsigned)((uint64_t)count * slices)), dim3(ss::kBlock), batch_lds_pad(), st>>>(
-                    a, descs, (uint32_t)count, (uint32_t)(slices - 1));
+                    a, descs, (uint32_t)slices);
                 e = hipGetLastError();
             }
             ps->mu.unlock();
