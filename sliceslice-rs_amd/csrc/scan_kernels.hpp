@@ -1372,7 +1372,7 @@ struct __attribute__((aligned(64))) BatchDesc {
     uint64_t n;                // needle length
     uint64_t needle_off;       // offset of the needle in the needle blob
     uint64_t anchor;           // index of the first filter byte in the needle
-    uint64_t per;              // active slices of the problem == the tile stride of each (round robin)
+    uint64_t per;              // active slices of the problem << 32 | tiles per slice (both < 2^32: the grid is one-dimensional)
     uint32_t bytes;            // needle[anchor] | second byte << 8 | third byte << 16 | (one-byte needle) << 24
     uint32_t shifts;           // mis | r << 4 | Q << 6 | r3 << 8 | q3 << 10
 };
@@ -1438,7 +1438,7 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
     d.n = n;
     d.needle_off = n0;
     d.anchor = 0;
-    d.per = 1;
+    d.per = 0;                                      // no active slice
     d.bytes = d.shifts = 0;
     int flag = 0;
     if (n == 0) {
@@ -1499,7 +1499,7 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         const uint64_t ntiles = (npieces + tile_pieces - 1) / tile_pieces;
         uint64_t eff = (ntiles + min_tiles - 1) / min_tiles;
         eff = eff < nslices ? (eff ? eff : 1) : nslices;
-        d.per = eff;                                // active slices == the stride of their round robin over the tiles
+        d.per = (eff << 32) | ((ntiles + eff - 1) / eff);
     }
     a.found[prob] = flag;
     descs[prob] = d;
@@ -1535,28 +1535,57 @@ struct ColdInDesc {
     }
 };
 
-// Grid: ONE dimension, workgroup w = problem * nslices + slice.  The `eff` (descriptor: per) active slices of a problem take its
-// tiles ROUND ROBIN - slice s scans tiles s, s + eff, s + 2 eff, ... - so the workgroups of a problem, dispatched next to each
-// other, move through the haystack side by side: consecutive addresses in flight (contiguous runs per slice in slice-major
-// dispatch order put 1,024 separate streams in flight: 162 us instead of 150 for 1,024 x 1 MiB), one descriptor line for a run
-// of workgroups, and - what the reference's i386 loop needs, every word occurs in the text - when one slice finds the needle
-// the others are at the same depth and stop at their next poll: the work is that of the sequential scan's early exit,
-// without the slice-0-first ordering the contiguous form needed for it.
+// Grid: ONE dimension, nslices workgroups per problem; two ways of laying them out, chosen by the host from the slice count
+// (the lengths live on the device; the count of problems is all the host knows):
+//   * many problems, few slices each (nslices <= kPlanSliceMajorMax): SLICE-MAJOR, w = slice * count + problem, each slice a
+//     contiguous run of the problem's tiles.  All slice-0 workgroups are dispatched before any slice-1 workgroup, so a needle
+//     that is present early (the reference's i386 loop: every word occurs in the text, most of them in the first tiles) has
+//     set its flag by the time the later slices of its problem start, and those leave at their entry poll - problem-major
+//     layouts start all slices of a problem together and ran that loop at 0.21-0.45 ms instead of 0.15.
+//   * few problems, many slices each: PROBLEM-MAJOR, w = problem * nslices + slice, and the active slices take the problem's
+//     tiles ROUND ROBIN (slice s scans tiles s, s + eff, ...): the workgroups of a problem move through its haystack side
+//     by side - consecutive addresses in flight, where slice-major puts 1,024 separate streams a haystack apart in flight
+//     (1,024 x 1 MiB: 150 us instead of 162, kernel time) - and when one of them finds the needle the others are at the same
+//     depth and stop at their next poll.
+constexpr uint32_t kPlanSliceMajorMax = 8;
 template <int U>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock)
-scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t nslices)
+scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     const uint32_t w = blockIdx.x;
-    const uint32_t prob = w / nslices, slice = w - prob * nslices;
+    const bool slice_major = nslices <= kPlanSliceMajorMax;
+    uint32_t prob, slice;
+    if (slice_major) {
+        slice = w / count;
+        prob = w - slice * count;
+    } else {
+        prob = w / nslices;
+        slice = w - prob * nslices;
+    }
     int *found = a.found + prob;
     const BatchDesc *dp = descs + prob;
-    const BatchDesc d = *dp;                        // ONE scalar load (s_load_dwordx16) in front of the first haystack load
+    // slice-major, later slices: the problem's flag (one coherent load) is requested together with the descriptor (one scalar
+    // load, s_load_dwordx16) - one round trip decides whether and what to scan
+    const int seen = slice_major && slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const BatchDesc d = *dp;
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
     const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
-    const uint64_t t0 = slice, te = ntiles, step = d.per;
-    if (slice >= step || t0 >= te) return;          // surplus slice, or a problem the plan kernel has answered
+    const uint32_t eff = (uint32_t)(d.per >> 32), per = (uint32_t)d.per;
+    if (slice >= eff) return;                       // surplus slice, or a problem the plan kernel has answered (eff == 0)
+    uint64_t t0, te, step;
+    if (slice_major) {
+        t0 = (uint64_t)slice * per;
+        te = t0 + per < ntiles ? t0 + per : ntiles;
+        step = 1;
+        if (__builtin_amdgcn_readfirstlane(seen) != 0) return;   // later slices of a needle that has been found
+    } else {
+        t0 = slice;
+        te = ntiles;
+        step = eff;
+    }
+    if (t0 >= te) return;
 
     Problem pr;                                     // hot fields only; the cold ones are re-read from the descriptor
     pr.base = d.base;

@@ -1659,7 +1659,7 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) {
                 ss::scan_batched_plan_kernel<4><<<dim3((unsigned)((uint64_t)count * slices)), dim3(ss::kBlock), batch_lds_pad(), st>>>(
-                    a, descs, (uint32_t)slices);
+                    a, descs, (uint32_t)count, (uint32_t)slices);
                 e = hipGetLastError();
             }
             ps->mu.unlock();
