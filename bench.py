@@ -15,6 +15,14 @@ host.  The haystack is synthetic (SURVEY.md 8d generator), generated on the devi
 before the timed region starts.  The logical haystack has a FIXED total size (default 64 GiB, the size
 BASELINE.json's target is quoted on; it fits one 288 GB MI355X), so scaling is "strong".
 
+`--single-process` drives all N GPUs from ONE process instead (`ss_comm_init_all` = ncclCommInitAll, one stream per device, the
+N all-reduces in one group: the form a drop-in `search_in` over a node calls, and the one without a rendezvous to fail); it
+is also what bench.py falls back to - and says so in `config.launcher` / `config.transport_note` - when the ranks of the
+multi-process form cannot be brought up.
+
+Before the `--warmup` steps every rank spins `search_in` for >= 100 ms of wall time (untimed; `config.prewarm_ms`): at 8 GPUs
+a step is ~1.2 ms, so warm-up + timed region together are shorter than the clocks' ramp after an idle gap.
+
 stdout: ONE JSON line (rank 0).  Everything else goes to stderr.
 """
 import argparse
@@ -121,6 +129,12 @@ def cpu_baseline(needle, sample_bytes):
         out["i386_long_ms_per_iter"] = round((time.perf_counter() - t) / iters * 1e3, 2)
         out["i386_long_hits_per_iter"] = hits // iters
         out["i386_long_published_ms_i7_6700"] = 35.181
+        ws = sorted(words, key=len)
+        t = time.perf_counter()
+        hits = O.bench_short(ws, 2)
+        out["i386_short_ms_per_iter"] = round((time.perf_counter() - t) / 2 * 1e3, 2)
+        out["i386_short_hits_per_iter"] = hits // 2
+        out["i386_short_published_ms_i7_6700"] = 79.416
     except Exception as e:      # pragma: no cover
         out["i386_long_error"] = repr(e)
     out["host_generate_s"] = round(gen_s, 2)
@@ -210,7 +224,8 @@ def free_port():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` with no launcher around it: start the N ranks here."""
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here.  Returns (instead of exiting) when the
+    ranks could not be brought up and printed nothing: the caller then runs the single-process form."""
     import subprocess
     visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
     share = os.environ.get("SS_BENCH_SHARE_GPU") == "1"
@@ -220,7 +235,15 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     log("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
     env = dict(os.environ, SS_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    raise SystemExit(subprocess.call(cmd, env=env))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [l for l in r.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+    if r.returncode == 0 and lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+        raise SystemExit(0)
+    if lines or share or visible < args.gpus:
+        raise SystemExit(r.returncode or 1)
+    return "the %d ranks of the multi-process form could not be brought up (torch.distributed.run exit code %d)" % (args.gpus, r.returncode)
 
 
 def median_kernel_ms(searcher, hay, reps):
@@ -236,12 +259,52 @@ def median_kernel_ms(searcher, hay, reps):
     return res, float(np.median(ms))
 
 
-def other_configs(ss, shard, reps=10):
-    """BASELINE.json configs 3 and 5 at their full shape (1 GPU), kernel time by hipEvents on the launch stream:
-    config 3 = 1 GiB haystack x needle lengths {1,2,4,8,16,32,128} (absent: every byte scanned);
-    config 5 = 4096 x 1 MiB haystacks x 4096 distinct 16-byte needles in ONE launch."""
+def _row(nbytes, ms, **kw):
+    return dict(kernel_ms=round(ms, 4), gbps=round(nbytes / ms / 1e6, 1), frac=round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), **kw)
+
+
+def _events_ms(fn, reps):
+    """`fn` bracketed by events on torch's current stream: median of `reps` single calls on an otherwise idle stream (includes
+    the host's launch path), and per call when 10 are issued back to back (it overlaps the previous call's kernels)."""
+    t_end = time.perf_counter() + 0.05
+    while time.perf_counter() < t_end:
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    for _ in range(reps):
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    steady = []
+    for _ in range(3):
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        e1.synchronize()
+        steady.append(e0.elapsed_time(e1) / 10)
+    return float(np.median(ms)), float(np.median(steady))
+
+
+def other_configs(ss, shard, reps=20):
+    """The rest of SURVEY.md 8(d) on one GPU, driver-visible (untimed extras of the N = 1 run).  Kernel time = hipEvents on the
+    launch stream, MEDIAN of `reps` launches after a 50 ms spin:
+      2_present  the headline workload's 1 GiB sibling with the needle planted at len-16 (true, and the scan's last bytes count);
+      3          1 GiB x needle lengths {1,2,4,8,16,32,128}: absent (every byte scanned) and planted at len-n;
+      text       English text (i386.txt tiled to 1 GiB): two phrases through `new`, one through the reference's pair (0, n-1);
+      adversarial  an all-'a' haystack against a...ab: every offset passes the first byte;
+      5          4096 x 1 MiB haystacks x 4096 distinct 16-byte needles in ONE ss_search_batched call;
+      5_shapes   the same call on 1 GiB cut into 1,024 / 256 / 64 / 16,384 / 65,536 problems (and 4 GiB in 65,536 x 64 KiB);
+      1_short    the reference's short-haystack loop (bench/benches/i386.rs:118-129): 10,513,405 pairs, ss_search_pairs."""
     out = {}
     gib = 1 << 30
+    gd = os.path.join(ROOT, "tests", "golden", "data")
+
+    def to_dev(b):
+        return torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
+
     if shard.numel() >= gib:
         hay = shard[:gib]
         rows = []
@@ -249,36 +312,101 @@ def other_configs(ss, shard, reps=10):
             s = ss.DynamicHipSearcher.new(absent_needle(ss, n))
             res, ms = median_kernel_ms(s, hay, reps)
             assert res is False
-            rows.append({"needle_len": n, "kernel_ms": round(ms, 4), "gbps": round(gib / ms / 1e6, 1),
-                         "frac": round(gib / ms / 1e6 / HBM_PEAK_GBPS, 4), "filter_bytes": list(s.filter3)})
-        out["3"] = {"workload": "1 GiB synthetic haystack (the first GiB of the headline haystack), absent needles of "
-                                "{1,2,4,8,16,32,128} bytes, ss_search_device", "rows": rows}
-    count, each = 4096, 1 << 20
-    if shard.numel() >= count * each:
-        blob = shard[:count * each]
+            row = _row(gib, ms, needle_len=n, filter_bytes=list(s.filter3))
+            # present variant: a generator-made (0xFF-free) needle planted at len-n - found only by the scan's last chunk
+            pres = ss.fill_random_host(n, 0x5EED0003).tobytes()
+            saved = hay[gib - n:].clone()
+            hay[gib - n:] = to_dev(pres)
+            sp = ss.DynamicHipSearcher.new(pres)
+            found, pms = median_kernel_ms(sp, hay, 5)
+            at = sp.find(hay)
+            hay[gib - n:] = saved
+            row["present_at_end"] = {"found": found, "kernel_ms": round(pms, 4), "find": at,
+                                     "note": None if at == gib - n else "a needle this short occurs earlier in random bytes: early exit"}
+            if n >= 8:
+                assert found is True and at == gib - n
+            rows.append(row)
+        out["3"] = {"workload": "1 GiB synthetic haystack (the first GiB of the headline haystack), needles of {1,2,4,8,16,32,128} bytes, "
+                                "ss_search_device: absent (0xFF inside), and present (planted at len-n)", "rows": rows}
+        r16 = [r for r in rows if r["needle_len"] == 16][0]
+        out["2_present"] = {"workload": "1 GiB, 16-byte needle planted at len-16", **r16["present_at_end"]}
+
+    # English text and the adversarial fill (SURVEY.md 8d "extra value distributions")
+    try:
+        raw = np.frombuffer(open(os.path.join(gd, "i386.txt"), "rb").read(), dtype=np.uint8)
+        text = torch.from_numpy(np.tile(raw, gib // raw.size + 1)[:gib].copy()).cuda()
+        rows = []
+        for nd, how in ((b"privilege level zero!", "new"), (b"segment descriptor table entries are", "new"),
+                        (b"segment descriptor table entries are", "with_position(n-1)"),
+                        (b" the quick brown fox ", "set_filter(0, n-1): the reference's pair, verbatim")):
+            s = ss.DynamicHipSearcher.with_position(nd, len(nd) - 1) if how.startswith("with_position") else ss.DynamicHipSearcher.new(nd)
+            if how.startswith("set_filter"):
+                s.set_filter(0, len(nd) - 1)
+            res, ms = median_kernel_ms(s, text, reps)
+            rows.append(_row(gib, ms, needle=nd.decode("latin1"), how=how, found=res, filter_bytes=list(s.filter3)))
+        out["text"] = {"workload": "i386.txt (857,425 B of English) tiled to 1 GiB, absent phrases", "rows": rows}
+        del text
+        fill = torch.full((gib,), 0x61, dtype=torch.uint8, device="cuda")
+        rows = []
+        for nd, pos in ((b"a" * 15 + b"b", None), (b"a" * 15 + b"b", 0)):
+            s = ss.DynamicHipSearcher(nd, pos)
+            res, ms = median_kernel_ms(s, fill, reps)
+            rows.append(_row(gib, ms, needle="a" * 15 + "b", how="new" if pos is None else "with_position(0)", found=res,
+                             filter_bytes=list(s.filter3)))
+        out["adversarial"] = {"workload": "1 GiB of 'a', needle a...ab: every offset passes the first filter byte", "rows": rows}
+        del fill
+    except Exception as e:      # pragma: no cover
+        out["text_error"] = repr(e)
+
+    # config 5 and its shapes
+    def batched(count, each, total_blob):
+        blob = total_blob[:count * each]
         nd = bytearray(ss.fill_random_host(16 * count, SEED_NEEDLE + 1).tobytes())
-        for i in range(count):
-            nd[16 * i + 8] = 0xFF                          # absent: 0xFF never occurs in the haystack
-        nblob = torch.from_numpy(np.frombuffer(bytes(nd), dtype=np.uint8).copy()).cuda()
+        nd[8::16] = b"\xff" * count                       # absent: 0xFF never occurs in the haystack
+        nblob = to_dev(bytes(nd))
         hay_off = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
         nd_off = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
         found = ss.search_batched(blob, hay_off, nblob, nd_off)
         assert int(found.sum().item()) == 0
-        t_end = time.perf_counter() + 0.05
-        while time.perf_counter() < t_end:
-            ss.search_batched(blob, hay_off, nblob, nd_off)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ms = []
-        for _ in range(reps):
-            e0.record()
-            ss.search_batched(blob, hay_off, nblob, nd_off)
-            e1.record()
-            e1.synchronize()
-            ms.append(e0.elapsed_time(e1))
-        med = float(np.median(ms))
-        out["5"] = {"workload": "4096 x 1 MiB haystacks, 4096 distinct absent 16-byte needles, ONE ss_search_batched launch "
-                                "(incl. the flag memset)", "launch_ms": round(med, 4),
-                    "gbps": round(count * each / med / 1e6, 1), "frac": round(count * each / med / 1e6 / HBM_PEAK_GBPS, 4)}
+        med, steady = _events_ms(lambda: ss.search_batched(blob, hay_off, nblob, nd_off), 15)
+        nb = count * each
+        return {"problems": count, "haystack_each": each, "call_ms": round(med, 4), "gbps": round(nb / med / 1e6, 1),
+                "frac": round(nb / med / 1e6 / HBM_PEAK_GBPS, 4), "steady_call_ms": round(steady, 4),
+                "gbps_steady": round(nb / steady / 1e6, 1), "frac_steady": round(nb / steady / 1e6 / HBM_PEAK_GBPS, 4)}
+    if shard.numel() >= 4 * gib:
+        r = batched(4096, 1 << 20, shard)
+        out["5"] = {"workload": "4096 x 1 MiB haystacks, 4096 distinct absent 16-byte needles, ONE ss_search_batched call (plan kernel + "
+                                "scan grid; events on the launch stream)", "launch_ms": r["call_ms"], **r,
+                    "note": "call_ms: one call on an idle stream, host launch path included; steady_call_ms: per call when 10 are "
+                            "issued back to back"}
+        out["5_shapes"] = {"workload": "the same call on other cuts of 1 GiB (and one of 4 GiB): the lengths live on the device, the "
+                                       "grid is sized from the problem count alone",
+                           "rows": [batched(c, e, shard) for c, e in ((1024, 1 << 20), (256, 4 << 20), (64, 16 << 20), (16384, 64 << 10),
+                                                                     (16384, 256 << 10), (65536, 64 << 10))]}
+
+    # config 1, short-haystack loop: every needle against every word at or after it in length order (tests/i386.rs:46-59)
+    try:
+        words = sorted([w for w in open(os.path.join(gd, "words.txt"), "rb").read().split(b"\n") if w], key=len)
+        W = len(words)
+        lens = np.array([len(w) for w in words], dtype=np.int64)
+        starts = np.zeros(W, dtype=np.int64)
+        starts[1:] = np.cumsum(lens)[:-1]
+        blob = to_dev(b"".join(words))
+        ni = np.repeat(np.arange(W, dtype=np.int64), W - np.arange(W))
+        hj = np.concatenate([np.arange(i, W, dtype=np.int64) for i in range(W)])
+        nbt, net = torch.from_numpy(starts[ni]).cuda(), torch.from_numpy(starts[ni] + lens[ni]).cuda()
+        hbt, het = torch.from_numpy(starts[hj]).cuda(), torch.from_numpy(starts[hj] + lens[hj]).cuda()
+        found = ss.search_batched(blob, None, blob, None, hay_ranges=(hbt, het), needle_ranges=(nbt, net), pairs=True)
+        hits = int(found.sum().item())
+        med, steady = _events_ms(lambda: ss.search_batched(blob, None, blob, None, hay_ranges=(hbt, het), needle_ranges=(nbt, net), pairs=True), 10)
+        out["1_short"] = {"workload": "the reference's short-haystack loop (bench/benches/i386.rs:118-129): every word of words.txt in every "
+                                      "word at or after it by length, ONE ss_search_pairs launch (a lane per pair)",
+                          "pairs": int(ni.size), "hits": hits, "hits_expected": 39105, "launch_ms": round(med, 4),
+                          "ns_per_search": round(med * 1e6 / ni.size, 3), "published_ms_i7_6700": 79.416,
+                          "note": "the C restatement's time for the same loop on this host: cpu_baseline.i386_short_ms_per_iter"}
+        assert hits == 39105
+    except Exception as e:      # pragma: no cover
+        out["1_short_error"] = repr(e)
     return out
 
 
@@ -303,6 +431,208 @@ def native_measurements(ss, headline_gib=None):
     return out
 
 
+def measure_traffic(gib=8.0, launches=6):
+    """HBM bytes the headline kernel fetches per haystack byte, measured NOW: a child `rocprofv3 --pmc FETCH_SIZE` pass over this
+    script's --traffic-child mode (the same searcher on a `gib` GiB haystack - far beyond the 256 MiB Infinity Cache), counter
+    collected and corrected as MI355X_MICROARCH.md's HBM section prescribes (KiB units; x2 on gfx950 for wide coalesced
+    streaming reads; a pass of its own with --kernel-trace only).  Returns (ratio, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="ss_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "r", "--",
+               sys.executable, os.path.abspath(__file__), "--traffic-child", "--haystack-gib", "%g" % gib, "--steps", str(launches)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 --pmc FETCH_SIZE pass failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:])
+        vals = [float(x["Counter_Value"]) for f in files for x in csv.DictReader(open(f))
+                if "scan_kernel" in x["Kernel_Name"] and x["Counter_Name"] == "FETCH_SIZE"]
+        if len(vals) < 2:
+            return None, "no FETCH_SIZE rows for ss::scan_kernel"
+        fetched = 2.0 * float(np.median(vals)) * 1024.0
+        return fetched / (gib * (1 << 30)), ("measured in this run: `rocprofv3 --pmc FETCH_SIZE --kernel-trace` over %d launches of the same "
+                                            "kernel on a %g GiB haystack (median FETCH_SIZE %.1f KiB, x2 gfx950 correction), scaled to "
+                                            "this run's bytes per launch" % (len(vals), gib, float(np.median(vals))))
+    except Exception as e:      # pragma: no cover
+        return None, "traffic pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def traffic_child(args):
+    """--traffic-child: nothing but `steps` launches of the headline kernel (the parent counts their FETCH_SIZE)."""
+    import sliceslice_rs_amd as ss
+    torch.cuda.set_device(0)
+    n = int(args.haystack_gib * (1 << 30))
+    hay = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, SEED_HAY)
+    torch.cuda.synchronize()
+    s = ss.DynamicHipSearcher.new(absent_needle(ss, args.needle_len))
+    for _ in range(max(2, args.steps)):
+        assert s.search_in(hay) is False
+
+
+def vram_settle(local_rank, share, settle_seconds):
+    """Device hygiene (untimed): the driver reclaims the VRAM of a process that has just exited lazily, and a scan that runs while
+    another process' tens of GiB are still being reclaimed is 3-4 % slower (ten back-to-back runs: 7.34-7.38 TB/s with 69 GB of
+    VRAM in use afterwards, 7.05-7.13 with 138 GB).  Wait (bounded) until the device's memory is free again before allocating."""
+    t_wait = time.perf_counter()
+    f = None
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        cand = "/sys/bus/pci/devices/%04x:%02x:%02x.0/mem_info_vram_used" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        if os.path.exists(cand):
+            f = cand
+    except Exception:
+        f = None
+
+    def used():
+        try:
+            return int(open(f).read())
+        except Exception:
+            return 0
+    at_start = used() if f else None
+    while f and not share and used() > (8 << 30) and time.perf_counter() - t_wait < settle_seconds:
+        time.sleep(0.05)
+    return time.perf_counter() - t_wait, at_start
+
+
+def prewarm(step, seconds=0.1):
+    """>= `seconds` of back-to-back searches before the warm-up steps: the clocks ramp up over the first milliseconds after an
+    idle gap, which at 8 GPUs (1.2 ms per step) is longer than warm-up and timed region together."""
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds or n < 3:
+        step()
+        n += 1
+    return (time.perf_counter() - t0) * 1e3, n
+
+
+def headline_config(args, total, n, shard_bytes, world, filt, info, **kw):
+    fa, fb, fc = filt
+    cfg = {
+        "workload": "%.4g GiB synthetic random-byte haystack (0xFF-free), %d-byte absent needle, `new` (API position %d; "
+                    "device filter bytes %d, %d and %d); range-sharded over %d GPU(s) with %d B overlap, one "
+                    "all-reduce(MAX) of the found flag" % (total / (1 << 30), n, n - 1, fa, fb, fc, world, n - 1),
+        "haystack_bytes": total, "shard_bytes": shard_bytes, "needle_len": n, "filter_bytes": [fa, fb, fc],
+        "variant": args.variant, "device": info["name"], "compute_units": info["compute_units"],
+        "devices_visible": torch.cuda.device_count(),
+    }
+    cfg.update(kw)
+    return cfg
+
+
+def roofline_block(shard_bytes, kernel_ms, value, world, traffic_ratio, traffic_source):
+    k_med, k_mean = float(np.median(kernel_ms)), float(np.mean(kernel_ms))
+    achieved = shard_bytes / (k_med * 1e-3) / 1e9
+    return {
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "traffic": None if traffic_ratio is None else traffic_ratio * shard_bytes, "traffic_source": traffic_source,
+        "traffic_per_algorithmic_byte": None if traffic_ratio is None else round(traffic_ratio, 5),
+        "kernel": "ss::scan_kernel", "kernel_ms": round(k_med, 4), "kernel_ms_stat": "median of the timed launches (hipEvents on the launch stream)",
+        "kernel_ms_avg": round(k_mean, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4), "kernel_launches": len(kernel_ms),
+        "algorithmic_bytes_per_launch": shard_bytes,
+        "frac_of_whole_job_value": round(value / world / HBM_PEAK_GBPS, 4),
+    }
+
+
+def stored_traffic():
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        pj = json.load(open(tj))
+        return pj["hbm_read_bytes_per_haystack_byte"], ("stored ratio, NOT measured in this run: FETCH_SIZE of this kernel from an earlier "
+                                                        "`rocprofv3 --pmc FETCH_SIZE` pass (profiles/pmc_traffic.json: %s)" % pj.get("source", "?"))
+    except Exception:
+        return None, None
+
+
+def write_line(real_stdout, out):
+    """THE line: the only bytes this run writes to the real stdout."""
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
+def run_single_process(args, real_stdout, why=None):
+    """All `--gpus` devices from THIS process: ss_comm_init_all (ncclCommInitAll), one shard and one stream per device, the G
+    all-reduces of a search in one ncclGroupStart/End (ss_search_sharded_all).  Same line, `config.launcher` = "single-process"."""
+    import sliceslice_rs_amd as ss
+    ss.lib()
+    G = args.gpus
+    if torch.cuda.device_count() < G:
+        fail("--gpus %d but only %d HIP device(s) visible" % (G, torch.cuda.device_count()))
+    torch.cuda.set_device(0)
+    info = ss.device_info()
+    n = args.needle_len
+    total = int(args.haystack_gib * (1 << 30))
+    waited_s, used_at_start = vram_settle(0, False, args.settle_seconds)
+    free_b = min(torch.cuda.mem_get_info(g)[0] for g in range(G))
+    while (total + G - 1) // G + n > 0.92 * free_b and total > (1 << 28):
+        total //= 2
+    needle = absent_needle(ss, n)
+    note = why
+    try:
+        node = ss.NodeSearcher(needle, devices=list(range(G)))
+        transport = "rccl (ncclCommInitAll; the G all-reduces of a search in one group)"
+    except ss.SlicesliceError as e:
+        # no communicators: the host ORs the G pinned flag mirrors instead (possible only because all ranks live here)
+        os.environ["SLICESLICE_COMM_SET_NO_RCCL"] = "1"
+        node = ss.NodeSearcher(needle, devices=list(range(G)))
+        transport = "host OR of the G pinned flag mirrors (no collective)"
+        note = ((why + "; ") if why else "") + "ncclCommInitAll failed (%s)" % e
+    shards = []
+    for g in range(G):
+        b, e = node.shard_range(total, g)
+        with torch.cuda.device(g):
+            t = torch.empty(e - b, dtype=torch.uint8, device="cuda:%d" % g)
+            ss.fill_random_device(t, SEED_HAY, b)
+            torch.cuda.synchronize()
+        shards.append(t)
+    inner = node._searcher
+    inner.set_variant(args.variant)
+    inner.set_grid(args.grid)
+    inner.set_timing(True)
+
+    def sync_all():
+        for g in range(G):
+            torch.cuda.synchronize(g)
+    prewarm_ms, prewarm_steps = prewarm(lambda: node.search_in(shards))
+    for _ in range(args.warmup):
+        assert node.search_in(shards) is False
+    kernel_ms = []
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        found = node.search_in(shards)                         # G launches -> grouped all-reduce -> bool on the host
+        kernel_ms.append(inner.last_kernel_ms())               # the last device's scan (hipEvents on its stream)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    assert found is False
+    value = total * args.steps / elapsed / 1e9
+    ratio, src = stored_traffic()
+    shard_bytes = shards[-1].numel()
+    out = {
+        "metric": "haystack GB/s scanned (and % HBM roofline), 16-byte needle, 1/2/4/8 MI355X",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": headline_config(args, total, n, shard_bytes, G, inner.filter3, info, ranks=G, rccl_ranks=G if "rccl" in transport else None,
+                                  transport=transport, transport_note=note, launcher="single-process",
+                                  ranks_share_one_gpu=False, prewarm_ms=round(prewarm_ms, 1), prewarm_steps=prewarm_steps,
+                                  waited_for_free_vram_s=round(waited_s, 2), vram_used_at_start=used_at_start),
+        "roofline": roofline_block(shard_bytes, kernel_ms, value, G, ratio, src),
+    }
+    write_line(real_stdout, out)
+    node.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +643,8 @@ def main():
     ap.add_argument("--transport", choices=["torch", "rccl"], default="rccl",
                     help="N > 1, flag all-reduce: native RCCL via the C ABI (ss_search_sharded: scan + ncclAllReduce + "
                          "read-back on one HIP stream; the default) or torch.distributed (RCCL backend)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus devices from ONE process (ss_comm_init_all / ss_search_sharded_all) instead of one rank per GPU")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -321,6 +653,9 @@ def main():
                     help="skip the plain streaming-read ceiling (roofline.read_ceiling_gbps; a few launches, untimed)")
     ap.add_argument("--ceiling", action="store_true", help="(default now) kept for compatibility")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/5 + latency block (N = 1 only, untimed)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the live `rocprofv3 --pmc FETCH_SIZE` pass (N = 1 only, untimed); roofline.traffic then uses the stored ratio")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--settle-seconds", type=float, default=20.0,
                     help="upper bound on the wait for a previous process' VRAM to be reclaimed before allocating")
     ap.add_argument("--cpu-report", action="store_true",
@@ -332,14 +667,26 @@ def main():
         with os.fdopen(os.dup(1), "wb") as out:
             cpu_report(out)
         return
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        self_launch(args)                                      # does not return
+    if args.traffic_child:
+        traffic_child(args)
+        return
+    fallback_why = None
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.single_process:
+        fallback_why = self_launch(args)                       # returns only when the ranks could not be brought up
 
     # Exactly ONE line may reach stdout.  Libraries (the RCCL banner, for one) print to fd 1, so fd 1 is
     # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    if args.single_process or fallback_why:
+        if int(os.environ.get("RANK", "0")) != 0:
+            return                                             # under a launcher: rank 0 drives every device, the others have nothing to do
+        if not torch.cuda.is_available():
+            fail("needs a GPU: the scan has no CPU path")
+        run_single_process(args, real_stdout, fallback_why)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -360,13 +707,29 @@ def main():
     force_dist = os.environ.get("SS_BENCH_FORCE_DIST") == "1"     # exercise the N > 1 code path on one GPU
     backend = "none"
     if world > 1 or force_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        try:
+            if os.environ.get("SS_BENCH_FAIL_DIST_INIT") == "1":     # test hook: the bootstrap "fails" on every rank
+                raise RuntimeError("SS_BENCH_FAIL_DIST_INIT=1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            probe = torch.zeros(1, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)                             # the first collective is where a broken fabric shows
+        except Exception as e:
+            # The ranks cannot talk to each other.  Rank 0 still has every device of the node in reach: it runs the
+            # single-process form (no rendezvous at all) and says so; the other ranks have nothing left to do.
+            log("bench.py: rank %d: torch.distributed bootstrap failed (%r)" % (rank, e))
+            if rank != 0 or share:
+                raise SystemExit(0 if not share else 1)
+            run_single_process(args, real_stdout, "torch.distributed bootstrap failed on rank 0 (%s); every device driven from rank 0's "
+                                                  "process instead" % (repr(e)[:200],))
+            return
     transport = args.transport
     if share and world > 1 and transport == "rccl":
         transport = "torch"                                    # RCCL refuses two ranks on one device
@@ -377,30 +740,8 @@ def main():
 
     n = args.needle_len
     total = int(args.haystack_gib * (1 << 30))
-    # Device hygiene (untimed): the driver reclaims the VRAM of a process that has just exited lazily, and a scan
-    # that runs while another process' tens of GiB are still being reclaimed is 3-4 % slower (ten back-to-back
-    # runs: 7.34-7.38 TB/s with 69 GB of VRAM in use afterwards, 7.05-7.13 with 138 GB).  Wait (bounded) until the
-    # device's memory is free again before allocating.
-    t_wait = time.perf_counter()
-    vram_used_file = None
-    try:
-        pr = torch.cuda.get_device_properties(local_rank)
-        cand = "/sys/bus/pci/devices/%04x:%02x:%02x.0/mem_info_vram_used" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        if os.path.exists(cand):
-            vram_used_file = cand
-    except Exception:
-        vram_used_file = None
-
-    def vram_used():
-        try:
-            return int(open(vram_used_file).read())
-        except Exception:
-            return 0
-    used_at_start = vram_used() if vram_used_file else None
-    while vram_used_file and not share and vram_used() > (8 << 30) and time.perf_counter() - t_wait < args.settle_seconds:
-        time.sleep(0.05)
+    waited_s, used_at_start = vram_settle(local_rank, share, args.settle_seconds)
     free_b, total_b = torch.cuda.mem_get_info()
-    waited_s = time.perf_counter() - t_wait
     if share:
         free_b //= world
     if dist is not None:
@@ -448,8 +789,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # every rank makes the same number of (collective) calls: a fixed count first, then rank 0's clock decides for all
+    def one():
         assert searcher.search_in(shard) is False
+    t_pw = time.perf_counter()
+    pw_steps = 0
+    while True:
+        for _ in range(8):
+            one()
+        pw_steps += 8
+        go_on = 1 if time.perf_counter() - t_pw < 0.1 else 0
+        if dist is not None:
+            g = torch.tensor([go_on], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.broadcast(g, src=0)
+            go_on = int(g.item())
+        if not go_on:
+            break
+    prewarm_ms = (time.perf_counter() - t_pw) * 1e3
+    for _ in range(args.warmup):
+        one()
     kernel_ms = []
     sync_all()
     t0 = time.perf_counter()
@@ -471,47 +829,21 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed / 1e9
-        k_ms = float(np.mean(kernel_ms))
-        achieved = shard.numel() / (k_ms * 1e-3) / 1e9
-        traffic = traffic_source = None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
-            try:
-                pj = json.load(open(tj))
-                traffic = pj["hbm_read_bytes_per_haystack_byte"] * shard.numel()
-                traffic_source = ("stored ratio, NOT measured in this run: FETCH_SIZE of this kernel from an earlier "
-                                  "`rocprofv3 --pmc FETCH_SIZE` pass of the same command (profiles/pmc_traffic.json: %s) "
-                                  "x this run's bytes per launch" % pj.get("source", "?"))
-            except Exception:
-                traffic = traffic_source = None
-        fa, fb, fc = inner.filter3
+        ratio, src = stored_traffic()
         out = {
             "metric": "haystack GB/s scanned (and % HBM roofline), 16-byte needle, 1/2/4/8 MI355X",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {
-                "workload": "%.4g GiB synthetic random-byte haystack (0xFF-free), %d-byte absent needle, `new` (API position %d; "
-                            "device filter bytes %d, %d and %d); range-sharded over %d GPU(s) with %d B overlap, one "
-                            "all-reduce(MAX) of the found flag"
-                            % (total / (1 << 30), n, n - 1, fa, fb, fc, world, n - 1),
-                "haystack_bytes": total, "shard_bytes": shard.numel(), "needle_len": n, "filter_bytes": [fa, fb, fc],
-                "ranks": dist.get_world_size() if dist is not None else 1, "rccl_ranks": rccl_ranks,
-                "transport": (transport if backend == "nccl" or transport == "rccl" else transport + " over " + backend) if dist is not None else "none",
-                "transport_note": transport_note,
-                "launcher": os.environ.get("SS_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
-                "devices_visible": torch.cuda.device_count(), "ranks_share_one_gpu": bool(share and world > 1),
-                "variant": args.variant,
-                "device": info["name"], "compute_units": info["compute_units"],
-                "waited_for_free_vram_s": round(waited_s, 2), "vram_used_at_start": used_at_start,
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "ss::scan_kernel", "kernel_ms_avg": round(k_ms, 4),
-                "algorithmic_bytes_per_launch": shard.numel(),
-                "frac_of_whole_job_value": round(value / world / HBM_PEAK_GBPS, 4),
-            },
+            "config": headline_config(
+                args, total, n, shard.numel(), world, inner.filter3, info,
+                ranks=dist.get_world_size() if dist is not None else 1, rccl_ranks=rccl_ranks,
+                transport=(transport if backend == "nccl" or transport == "rccl" else transport + " over " + backend) if dist is not None else "none",
+                transport_note=transport_note,
+                launcher=os.environ.get("SS_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
+                ranks_share_one_gpu=bool(share and world > 1), prewarm_ms=round(prewarm_ms, 1), prewarm_steps=pw_steps,
+                waited_for_free_vram_s=round(waited_s, 2), vram_used_at_start=used_at_start),
+            "roofline": roofline_block(shard.numel(), kernel_ms, value, world, ratio, src),
         }
         if ceiling is not None:
             out["roofline"]["read_ceiling_gbps"] = round(ceiling, 2)
@@ -519,16 +851,25 @@ def main():
             cfg = other_configs(ss, shard)
             room = torch.cuda.mem_get_info()[0] > total + (8 << 30)          # a second haystack of the same size fits
             cfg.update(native_measurements(ss, total / (1 << 30) if room else None))
-            cfg["note"] = ("untimed extras of the N = 1 run; the headline fields above are config 2/4's shape.  3 and 5: kernel "
-                           "GB/s by hipEvents; 1, latency_us and headline_native (the headline workload once more, in a process "
-                           "without Python or torch): tools/native_bench (C ABI only)")
+            cfg["note"] = ("untimed extras of the N = 1 run; the headline fields above are config 2/4's shape.  3, text, adversarial: "
+                           "kernel GB/s by hipEvents (median of 20 after a 50 ms spin); 5, 5_shapes, 1_short: whole calls by events; 1, "
+                           "latency_us and headline_native (the headline workload once more, in a process without Python or torch): "
+                           "tools/native_bench (C ABI only)")
             out["configs"] = cfg
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1:
             del shard
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(needle, args.cpu_sample_mib << 20)
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            if not args.no_traffic:
+                live, why = measure_traffic()
+                if live is not None:
+                    out["roofline"]["traffic"] = live * out["roofline"]["algorithmic_bytes_per_launch"]
+                    out["roofline"]["traffic_per_algorithmic_byte"] = round(live, 5)
+                    out["roofline"]["traffic_source"] = why
+                else:
+                    out["roofline"]["traffic_note"] = "live pass not available (%s)" % why
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(needle, args.cpu_sample_mib << 20)
+        write_line(real_stdout, out)
     if dist is not None:
         dist.barrier()
         if hasattr(searcher, "close"):

@@ -30,5 +30,5 @@ def test_committed_bench_line_has_the_contract_fields():
 
 def test_bench_source_keeps_exactly_one_stdout_line():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "os.dup2(2, 1)" in src and src.count("os.write(real_stdout") == 1
-    assert "print(" not in src.split("def main():")[1].replace("print(*a, file=sys.stderr", "")
+    assert "os.dup2(2, 1)" in src and src.count("os.write(real_stdout") == 1           # write_line() is the only writer
+    assert "print(" not in src.split("def measure_traffic(")[1].replace("print(*a, file=sys.stderr", "")

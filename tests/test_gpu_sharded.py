@@ -156,6 +156,76 @@ def test_bench_native_rccl_path_with_one_rank():
     assert d["roofline"]["achieved"] > 3000 and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / 8000.0) < 1e-3
 
 
+def _line(out):
+    import json
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+QUICK = ["--no-cpu-baseline", "--no-configs", "--no-ceiling", "--no-traffic"]
+
+
+def test_bench_short_timed_region_runs_on_settled_clocks():
+    """at 8 GPUs a step is ~1.2 ms, so 5 warm-up + 20 timed steps are shorter than the clocks' ramp after an
+    idle gap; bench.py therefore spins search_in for >= 100 ms first.  On an 8 GiB haystack (one rank's shard at 8 GPUs) 20 timed
+    steps must report what 200 report."""
+    short = _line(_run_bench(["--haystack-gib", "8", "--steps", "20", "--warmup", "5"] + QUICK, {}))
+    long_ = _line(_run_bench(["--haystack-gib", "8", "--steps", "200", "--warmup", "5"] + QUICK, {}))
+    assert short["config"]["prewarm_ms"] >= 100 and short["config"]["prewarm_steps"] >= 8
+    assert abs(short["value"] / long_["value"] - 1) < 0.015, (short["value"], long_["value"])
+    assert short["roofline"]["kernel_ms"] <= short["roofline"]["kernel_ms_avg"] * 1.02        # the median is the reported statistic
+    assert short["roofline"]["kernel_launches"] == 20
+
+
+def test_bench_single_process_mode_and_the_fallback_to_it():
+    """`--single-process --gpus G` (every visible G): one process, ncclCommInitAll, grouped all-reduce.  And the automatic fallback:
+    when the ranks' bootstrap fails (SS_BENCH_FAIL_DIST_INIT=1 makes it) rank 0 runs that form and says so."""
+    import torch
+    for G in range(1, torch.cuda.device_count() + 1):
+        d = _line(_run_bench(["--single-process", "--gpus", str(G), "--haystack-gib", "2", "--steps", "5", "--warmup", "2"] + QUICK, {}))
+        assert d["n_gpus"] == G and d["config"]["launcher"] == "single-process" and d["config"]["ranks"] == G
+        assert d["config"]["transport"].startswith("rccl") and d["config"]["transport_note"] is None
+        assert d["config"]["haystack_bytes"] == 2 << 30 and d["value"] > 1000
+    env = {"SS_BENCH_FORCE_DIST": "1", "SS_BENCH_FAIL_DIST_INIT": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29578"}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--haystack-gib", "2", "--steps", "5", "--warmup", "2"] + QUICK,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env), cwd=ROOT)
+    d = _line(out)
+    assert d["config"]["launcher"] == "single-process" and "bootstrap failed" in d["config"]["transport_note"]
+    assert d["n_gpus"] == 1 and d["value"] > 1000
+
+
+def test_bench_sharded_path_equals_the_plain_path_at_64_gib():
+    """The N = 1 line through the sharded code path (native RCCL, one rank) must equal the plain N = 1 line within 1 %: the
+    collective and the answer word behind it may not cost a measurable share of a 9 ms scan."""
+    plain = _line(_run_bench(["--steps", "20", "--warmup", "5"] + QUICK, {}))
+    env = {"SS_BENCH_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29579"}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"] + QUICK,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env), cwd=ROOT)
+    sharded = _line(out)
+    assert sharded["config"]["transport"] == "rccl" and sharded["config"]["rccl_ranks"] == 1
+    assert plain["config"]["haystack_bytes"] == sharded["config"]["haystack_bytes"]
+    assert abs(sharded["value"] / plain["value"] - 1) < 0.01, (sharded["value"], plain["value"])
+
+
+def test_live_bench_line_contract_and_measured_traffic():
+    """The line as the driver gets it (smaller haystack, same code path): every contract field, the roofline block's arithmetic, and
+    roofline.traffic MEASURED in the run (a child `rocprofv3 --pmc FETCH_SIZE` pass) rather than a stored ratio."""
+    d = _line(_run_bench(["--haystack-gib", "4", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-configs"], {}, timeout=1200))
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
+                     ("data", str), ("config", dict), ("roofline", dict)):
+        assert key in d and isinstance(d[key], typ), key
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["kernel_ms"] / 1e6) < 1.0
+    assert r["traffic_source"].startswith("measured in this run"), r.get("traffic_note") or r["traffic_source"]
+    assert 0.99 <= r["traffic_per_algorithmic_byte"] <= 1.05, r["traffic_per_algorithmic_byte"]
+    assert abs(r["traffic"] - r["traffic_per_algorithmic_byte"] * r["algorithmic_bytes_per_launch"]) < 1e-3 * r["traffic"]
+
+
 def test_comm_set_bookkeeping_with_three_and_eight_shards_on_one_gpu():
     """G > 1 in ss_search_sharded_all / ss_find_sharded_all on a one-GPU box: a test set (SLICESLICE_COMM_SET_NO_RCCL=1) lists
     device 0 several times and creates no communicators, so the per-shard streams, flags, pinned mirrors, epochs and the
