@@ -43,6 +43,7 @@
 // (or uint64 minimum), read with relaxed agent-scope loads and scalar-cache peeks.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -298,7 +299,7 @@ __host__ __device__ constexpr inline int byte_rarity_rank(uint8_t b)
 constexpr int kRefineWindow = 32;
 constexpr uint32_t kFarFirst = 10;
 #ifndef SS_REFINE_BYTES_PER_BALLOT
-#define SS_REFINE_BYTES_PER_BALLOT 2
+#define SS_REFINE_BYTES_PER_BALLOT 1
 #endif
 constexpr uint32_t kRefineBytesPerBallot = SS_REFINE_BYTES_PER_BALLOT;   // schedule bytes applied between two wave ballots
 
@@ -451,9 +452,10 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
         }
     };
     bool any = any_left();
-    // TWO schedule bytes per wave ballot: the ballot -> scalar compare -> branch chain between two bytes is what a tile dense
-    // with candidates (a caller-chosen pair of common bytes on text) waits for, not the dozen VALU operations of a byte;
-    // the second byte of a pair is wasted only when the first one had already cleared the tile.
+    // kRefineBytesPerBallot schedule bytes between two wave ballots.  ONE is the measured optimum (in one process on one
+    // buffer, profiles/r03/ab_refine_bytes_per_ballot.jsonl): with two, the reference's pair (0, n-1) on text - every tile
+    // dense with chance hits - ran at 5.4 TB/s instead of 6.1-6.8, with three at 4.6: the first byte clears most tiles, and
+    // the dozen VALU operations per piece of a second one cost more than the ballot -> compare -> branch chain they save.
     uint32_t t = 0;
 #pragma unroll 1
     while (t < ro.n && any) {
@@ -479,9 +481,10 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
     return any;
 }
 
-// Per-piece form of the same filter.  The MODE 2 kernels keep it: they need 95 VGPRs with it (96 allocated: 5
-// waves per SIMD) and 97 with the tile-wide form (104 allocated: 4 waves), and with 4 waves they run 2-7 %
-// slower on random bytes (profiles/r01/refine_tile_ab.txt).
+// Per-piece form of the same filter: tiles in which at most two pieces hold candidates (the usual case with three filter
+// bytes).  (Round 1 kept the MODE 2 kernels on this form for every tile - the tile-wide one cost them a wave of occupancy;
+// since the cold fields left the registers both fit, and tile-wide is worth 4.5-4.9 -> 6.1-6.2 TB/s for the reference's
+// pair on text: profiles/r03/ab_refine_bytes_per_ballot.jsonl, `m2pp` = per piece.)
 // Returns false when no lane of the wave has a candidate left in this piece.
 __device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4])
 {
@@ -1011,7 +1014,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 }
             };
             // second-level filter in registers (wave-uniform), up to the first 16 needle bytes, tile-wide
-            constexpr bool TILE_WIDE = MODE != 2;
+#ifndef SS_MODE2_TILE_WIDE
+#define SS_MODE2_TILE_WIDE 1
+#endif
+            constexpr bool TILE_WIDE = MODE != 2 || SS_MODE2_TILE_WIDE != 0;
             // Which pieces of the tile hold candidates?  With the three-byte first phase a tile that gets here
             // usually holds ONE (text: a frequent phrase that shares the filter bytes); the second-level filter
             // then runs on that piece alone instead of on all U - a quarter of the work.  Tiles dense with
@@ -1129,6 +1135,16 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
     // else.  The first workgroups of a grid start before anything can have been found and skip it.
     // Pieces per tile = waves per workgroup (2, 4 or 8) * U: a power of two, so no division anywhere.
     static_assert((U & (U - 1)) == 0, "U is a power of two");
+    // The cold half of the Problem is read from the kernarg segment where it is needed (ColdInKernarg).  Its two cache lines
+    // are TOUCHED here, next to the hot loads, so that a wave that meets a candidate finds them in the scalar cache instead of
+    // paying a memory round trip on the path a match's latency is made of (a 1 KiB haystack with the needle at 0: 11.3 us
+    // per call against 8.1 for an absent needle before this).  Two throw-away registers until the first wait below.
+    static_assert(sizeof(Problem) <= 0x100 && offsetof(Problem, hay) < 0x80, "the cold fields live in the lines at 0x80 and 0xc0");
+    uint32_t touch0, touch1;
+    {
+        ColdInKernarg::Ptr kp = (ColdInKernarg::Ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        __asm__ volatile("s_load_dword %0, %2, 0x80\n\ts_load_dword %1, %2, 0xc0" : "=&s"(touch0), "=&s"(touch1) : "s"(kp));
+    }
     const unsigned tile_shift = (unsigned)__builtin_ctz(blockDim.x / kWave) + (unsigned)__builtin_ctz(U);
     uint64_t t0 = tiles_per_block ? (uint64_t)blockIdx.x * tiles_per_block : blockIdx.x;
     // completion-word launches of the bool kernels: "a wave of this workgroup has found the needle"
@@ -1138,6 +1154,8 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         if (threadIdx.x == 0) __hip_atomic_store(&s_wg_found, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
     }
+    // (the hot fields have been waited for by now - `counted` is one - and scalar loads are waited for together)
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" : : "s"(touch0), "s"(touch1));
     bool skip = false;
     if (blockIdx.x >= kPeekFromBlock) {
         // a peek hit is confirmed with one coherent load before the workgroup leaves: the scalar cache is not
