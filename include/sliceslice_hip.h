@@ -274,6 +274,11 @@ int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const
  * straddles a boundary is seen by exactly the left rank. */
 int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *begin, size_t *end);
 
+/* Measurement: median (and minimum) microseconds of a host -> device -> host round trip through pinned memory against ONE
+ * resident device lane - the fixed cost per request of a "search service" kernel that would stay on the device instead of
+ * being launched per search, to set against ss_search_device's per-call time. */
+int ss_mailbox_round_trip_us(int iters, double *median_us, double *min_us);
+
 /* Diagnostics */
 const char *ss_last_error(void);      /* thread-local, static storage */
 int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *total_mem);

@@ -102,6 +102,7 @@ extern "C" {
     pub fn ss_debug_set_completion_state(s: *mut ss_searcher, workgroups: u32, found_workgroups: u32, find_key: u32) -> c_int;
     pub fn ss_debug_set_comm_epoch(c: *mut ss_comm, set: *mut ss_comm_set, value: c_int) -> c_int;
     pub fn ss_debug_fail_next_scans(s: *mut ss_searcher, count: c_int) -> c_int;
+    pub fn ss_mailbox_round_trip_us(iters: c_int, median_us: *mut f64, min_us: *mut f64) -> c_int;
 }
 
 /// Haystack already resident in device memory (caller-owned `hipMalloc` memory).

@@ -643,6 +643,13 @@ __device__ __forceinline__ uint64_t scalar_peek64(const uint64_t *p)
 }
 
 __device__ __forceinline__ void forget_scalar_cache() { __builtin_amdgcn_s_dcache_inv(); }
+// ... which only matters to grids large enough to peek (kPeekFromBlock).  Completion-word launches are small grids, and their
+// last instructions read the cold half of the Problem back through that very cache: invalidating it there puts a memory
+// round trip on the path a match's latency is made of.
+__device__ __forceinline__ void forget_scalar_cache_unless(bool small_grid)
+{
+    if (!small_grid) __builtin_amdgcn_s_dcache_inv();
+}
 
 __device__ __forceinline__ void publish_found(int *found, int epoch = 1)
 {
@@ -765,6 +772,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     const int wpb = (int)(blockDim.x / kWave);                              // waves per workgroup (launch-time)
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
     bool staged = false, ordered = false;
+    const bool small_grid = (pr.flags & kProblemCounted) != 0;             // completion-word launch: nobody peeks
 #ifdef SS_TWO_BYTE_PHASE1       // A/B builds only (tools/ab_build.py): the round-1 two-byte first phase
     constexpr bool THREE = false;
 #else
@@ -822,7 +830,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 tc = tn;
             }
             if (stop8) {                                      // somebody has already found the needle
-                forget_scalar_cache();
+                forget_scalar_cache_unless(small_grid);
                 return;
             }
             if (__ballot((any8 & 0x80808080u) != 0) == 0) continue;   // nothing in this tile: the common case
@@ -949,7 +957,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         if (FIND) {
             const uint64_t first = chunk0 * 16 > pr.mis ? chunk0 * 16 - pr.mis : 0;   // lowest index this wave can report
             if (best_now <= pr.find_base + first) {                                     // all of it lies right of a match
-                forget_scalar_cache();
+                forget_scalar_cache_unless(small_grid);
                 return;
             }
         }
@@ -958,7 +966,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         const bool cand_tile = __ballot((any_tile & 0x80808080u) != 0) != 0;
         if (L8) dense = cand_tile;      // stay in the 16-byte layout while tiles keep producing candidates
         if (stop) {                     // somebody has already found the needle: no point in verifying more
-            forget_scalar_cache();
+            forget_scalar_cache_unless(small_grid);
             return;
         }
         if (cand_tile) {
@@ -1050,7 +1058,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // lane 63's next lane: lane 0 of the next piece (rotated in); after the last piece the halo chunk
                     // sitting in lane 63 (MODE 0), lanes 0..d of H (MODE 2), or unknown (MODE 1: settled by the compare)
                     np.kind = u + 1 < U ? 1 : (MODE == 0 ? 0 : (MODE == 2 ? 1 : 2));
-                    if (!refine_piece(A[u], np, ro, g)) continue;
+                    // With the needle's dwords at hand the exact compare below settles a lane's candidates in ~50 VALU
+                    // operations, all lanes at once - about what TWO steps of the byte-wise schedule cost - and a true match
+                    // would sit through every one of its up to 13 steps first (a microsecond of ballots and branches).
+                    if (!(EXACT_OK && exact_len != 0) && !refine_piece(A[u], np, ro, g)) continue;
                 } else if (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) == 0) {
                     continue;
                 }
@@ -1077,7 +1088,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         // would otherwise serialise one atomic per wave on a single address)
                         if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                             __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        forget_scalar_cache();
+                        forget_scalar_cache_unless(small_grid);
                         return;                         // the wave's later pieces and tiles are further right
                     }
                 }
@@ -1090,13 +1101,12 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // the grid queue a system-scope store to the same host address (measured: 14 ms for a
                     // one-byte needle over 1 GiB instead of 0.02 ms).
                     if (wg_found != nullptr) {
-                        // Completion-word launches (small grids): the answer travels in the workgroup count (scan_kernel's
-                        // epilogue), so the device flag only serves the other workgroups' early exit - stored, not
-                        // exchanged, and nobody waits for it.
-                        if (lane == __ffsll((unsigned long long)hits) - 1) {
-                            __hip_atomic_store(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // Completion-word launches (grids of at most 256 workgroups, all of them resident from the start):
+                        // the answer travels in the workgroup count (scan_kernel's epilogue) and there is nobody left to
+                        // stop early, so the device flag is not even written - a global store in front of the count-out
+                        // atomic of the same wave is a memory round trip on the path a match's latency is made of.
+                        if (lane == __ffsll((unsigned long long)hits) - 1)
                             __hip_atomic_store(wg_found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
                     } else if (lane == __ffsll((unsigned long long)hits) - 1 &&
                                __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.epoch) {
                         const int old = __hip_atomic_exchange(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1104,7 +1114,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         if (old != pr.epoch && host_flag)
                             __hip_atomic_store(host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
-                    forget_scalar_cache();
+                    forget_scalar_cache_unless(small_grid);
                     return;
                 }
             }
@@ -1814,6 +1824,19 @@ __global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best)
     const uint64_t v = __hip_atomic_load(d_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v != ~0ull) __hip_atomic_store(d_best, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(h_best, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Mailbox round trip (ss_mailbox_round_trip_us): ONE lane answers `iters` requests posted by the host to pinned memory -
+// what a resident "search service" would pay per request before it has looked at a single haystack byte.  Every wait is
+// bounded (s_memtime ticks), so the kernel ends by itself whatever the host does.
+__global__ void mailbox_echo_kernel(const unsigned long long *req, unsigned long long *resp, unsigned iters, unsigned long long max_ticks)
+{
+    for (unsigned i = 1; i <= iters; ++i) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__hip_atomic_load(req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < i)
+            if (__builtin_readcyclecounter() - t0 > max_ticks) return;
+        __hip_atomic_store(resp, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Cross-lane self-test: the DPP controls and v_alignbyte the scan relies on, next to __shfl statements.

@@ -9,6 +9,7 @@
 // The scan itself lives in scan_kernels.hpp.  There is no CPU search path in this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -1813,6 +1814,50 @@ int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *tota
     if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (total_mem) *total_mem = prop.totalGlobalMem;
+    return SS_OK;
+}
+
+// What a resident search service (a kernel that stays on the device and takes requests from a pinned mailbox instead of
+// being launched per search) would pay per request BEFORE it looks at a haystack byte: the host posts request i to pinned
+// memory, one device lane sees it and answers to pinned memory, the host sees the answer.  Median microseconds over `iters`
+// round trips.  Measurement only (INTEGRATION.md section 6 sets it against the launch path's per-call time); all waits on
+// both sides are bounded.
+int ss_mailbox_round_trip_us(int iters, double *median_us, double *min_us)
+{
+    if (iters < 1 || iters > 1000000 || !median_us) return fail(SS_ERR_ARGUMENT, "bad argument");
+    unsigned long long *box = nullptr;
+    HIP_TRY(hipHostMalloc((void **)&box, 2 * 64, hipHostMallocPortable | hipHostMallocMapped));
+    volatile unsigned long long *req = box, *resp = box + 8;       // separate cache lines
+    *req = 0;
+    *resp = 0;
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipHostFree(box); return fail(SS_ERR_HIP, "stream: %s", hipGetErrorString(e)); }
+    // ~2 s at 100 MHz-class tick rates: far beyond any round trip, far below a test's patience
+    ss::mailbox_echo_kernel<<<1, 1, 0, st>>>(box, box + 8, (unsigned)iters, 200000000ull);
+    e = hipGetLastError();
+    std::vector<double> us;
+    us.reserve((size_t)iters);
+    bool ok = e == hipSuccess;
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));     // the kernel is up and polling
+    for (int i = 1; ok && i <= iters; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        __atomic_store_n((unsigned long long *)req, (unsigned long long)i, __ATOMIC_RELEASE);
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n((unsigned long long *)resp, __ATOMIC_ACQUIRE) >= (unsigned long long)i) break;
+            cpu_relax();
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) { ok = false; break; }
+        }
+        us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    __atomic_store_n((unsigned long long *)req, ~0ull, __ATOMIC_RELEASE);   // lets a kernel that is still waiting run through
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    (void)hipHostFree(box);
+    if (!ok || us.empty()) return fail(SS_ERR_HIP, "mailbox round trip: no answer from the device");
+    std::sort(us.begin(), us.end());
+    *median_us = us[us.size() / 2];
+    if (min_us) *min_us = us.front();
     return SS_OK;
 }
 

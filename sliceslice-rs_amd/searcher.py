@@ -92,6 +92,7 @@ ABI = {
     "ss_debug_set_completion_state": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
+    "ss_mailbox_round_trip_us": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 

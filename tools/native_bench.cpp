@@ -128,8 +128,13 @@ static int latency(int calls)
     const double floor_us = median_us(calls, [&] { null_kernel<<<1, 64, 0, st>>>(nullptr); (void)hipStreamSynchronize(st); });
     const double launch_only_us = median_us(calls, [&] { null_kernel<<<1, 64, 0, st>>>(nullptr); });
     HK(hipStreamSynchronize(st));
+    // what a resident "search service" would pay per request before touching a haystack byte: host -> pinned mailbox ->
+    // one resident device lane -> pinned answer -> host (ss_mailbox_round_trip_us)
+    double box_med = 0, box_min = 0;
+    CK(ss_mailbox_round_trip_us(2000, &box_med, &box_min));
     std::printf("{\"mode\": \"latency\", \"calls\": %d, \"needle_len\": 16, \"unit\": \"us per call (median)\", "
-                "\"empty_kernel_plus_stream_sync\": %.2f, \"empty_kernel_launch_only\": %.2f, \"rows\": [", calls, floor_us, launch_only_us);
+                "\"empty_kernel_plus_stream_sync\": %.2f, \"empty_kernel_launch_only\": %.2f, "
+                "\"mailbox_round_trip\": %.2f, \"mailbox_round_trip_min\": %.2f, \"rows\": [", calls, floor_us, launch_only_us, box_med, box_min);
     bool first = true;
     for (size_t len : sizes) {
         for (int w = 0; w < 200; ++w) rc |= ss_search_device(s, d_hay, len, st, &found);
