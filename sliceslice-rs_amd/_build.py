@@ -18,7 +18,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_CSRC, "libsliceslice_hip.so")
-_SOURCES = ["sliceslice_hip.hip", "scan_inst_u4_nt0.hip", "scan_inst_u4_nt1.hip", "scan_inst_u8_nt0.hip", "scan_inst_u8_nt1.hip", "scan_inst_find_nt0.hip", "scan_inst_find_nt1.hip"]
+# The default library: what the constructors and ss_searcher_set_filter* can select (26 scan kernels, scan_launch.hpp::kernel_built).
+_SOURCES = ["sliceslice_hip.hip", "scan_inst_u4_nt0.hip", "scan_inst_u4_nt1.hip", "scan_inst_find_nt0.hip", "scan_inst_find_nt1.hip"]
+# The tuning build (-DSS_TUNING_VARIANTS): every variant ss_searcher_set_variant can name, incl. the U = 8 families.
+_TUNING_SOURCES = _SOURCES + ["scan_inst_u8_nt0.hip", "scan_inst_u8_nt1.hip"]
 _HEADERS = ["scan_kernels.hpp", "scan_launch.hpp", os.path.join("..", "..", "include", "sliceslice_hip.h")]
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
 # Host-side sanitizer build (the reference's guard on its unsafe code is its ASAN CI job,
@@ -68,14 +71,15 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
-def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host_only=False):
+def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host_only=False, sources=None):
     """host_only: only the API translation unit (sliceslice_hip.hip - all of the host logic) is compiled with
     `extra_flags`; the kernel-instantiation units come from the regular build (their host side is launch stubs)."""
+    sources = sources or _SOURCES
     newest_header = max(_mtime(h) for h in _HEADERS)
-    own = _SOURCES[:1] if host_only else _SOURCES
-    objs = [os.path.join(_CSRC, s[:-4] + (obj_suffix if s in own else ".o")) for s in _SOURCES]
+    own = sources[:1] if host_only else sources
+    objs = [os.path.join(_CSRC, s[:-4] + (obj_suffix if s in own else ".o")) for s in sources]
     todo = []
-    for src, obj in zip(_SOURCES, objs):
+    for src, obj in zip(sources, objs):
         if src not in own:
             continue
         stale = obj_suffix == ".o" and not os.path.exists(obj + ".res")         # objects from before the resource record
@@ -166,7 +170,7 @@ def build(force=False, verbose=False):
 
 def build_sanitized(force=False, verbose=False):
     """The host logic (sliceslice_hip.hip) with ASan + UBSan -> csrc/libsliceslice_hip_asan.so (test builds only:
-    load it with SLICESLICE_HIP_LIB=<path> and the ASan runtime preloaded; see tests/test_gpu_sanitizer.py)."""
+    load it with SLICESLICE_HIP_LIB=<path> and the ASan runtime preloaded; see tests/test_gpu_native.py)."""
     so = os.path.join(_CSRC, "libsliceslice_hip_asan.so")
     build(verbose=verbose)                                  # the kernel-instantiation objects are shared with the regular build
     with _Lock(".build_asan.lock"):
@@ -209,6 +213,18 @@ def build_native_bench(force=False, verbose=False):
               "-L", _CSRC, "-lsliceslice_hip", "-Wl,-rpath,$ORIGIN/../sliceslice-rs_amd/csrc", "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
         os.replace(tmp, _NATIVE_BENCH)
         return _NATIVE_BENCH
+
+
+def tuning_library_path():
+    return os.path.join(_CSRC, "libsliceslice_hip_tuning.so")
+
+
+def build_tuning(force=False, verbose=False):
+    """Every kernel variant ss_searcher_set_variant can name (-DSS_TUNING_VARIANTS, plus the U = 8 translation units) ->
+    csrc/libsliceslice_hip_tuning.so.  Not the product: tools/ and the variant tests load it with SLICESLICE_HIP_LIB=<path>."""
+    so = tuning_library_path()
+    with _Lock(".build_tuning.lock"):
+        return _build_variant(so, ".tuning.o", ["-DSS_TUNING_VARIANTS=1"], [], force, verbose, sources=_TUNING_SOURCES)
 
 
 def build_ab(name, defines, force=False, verbose=False):

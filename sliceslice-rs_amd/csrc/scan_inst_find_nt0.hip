@@ -4,5 +4,5 @@
 #include "scan_launch.hpp"
 
 namespace ss {
-template void launch_scan_un<4, 0, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+template bool launch_scan_un<4, 0, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 }  // namespace ss

@@ -773,7 +773,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     uint8_t *s_needle = s_needle_block + wave * kNeedleLds;
     bool staged = false, ordered = false;
     const bool small_grid = (pr.flags & kProblemCounted) != 0;             // completion-word launch: nobody peeks
-#ifdef SS_TWO_BYTE_PHASE1       // A/B builds only (tools/ab_build.py): the round-1 two-byte first phase
+#ifdef SS_TWO_BYTE_PHASE1       // A/B builds only (sliceslice_rs_amd._build.build_ab + tools/ab_inproc.py): the round-1 two-byte first phase
     constexpr bool THREE = false;
 #else
     constexpr bool THREE = MODE == 0 && !ONE_BYTE;                          // three-byte first phase
@@ -940,7 +940,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
             if constexpr (THREE) {
                 // Whoever builds the Problem orders the two further bytes so that q3 <= Q (they are interchangeable): the
                 // copies with Q3 > Q are never taken.  They stay instantiated all the same: with them pruned the register
-                // allocator needed 146 VGPRs instead of 121 for Q < 3 (tools/check_kernel_resources.py keeps an eye on it).
+                // allocator needed 146 VGPRs instead of 121 for Q < 3 (build() records every kernel's registers in csrc/kernel_resources.json; tests/test_bindings_cpu.py keeps an eye on it).
                 switch (pr.q3) {
                 case 0: load_and_filter(loaded_c, full_c, std::integral_constant<int, 0>{}); break;
                 case 1: load_and_filter(loaded_c, full_c, std::integral_constant<int, 1>{}); break;
@@ -970,7 +970,11 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
             return;
         }
         if (cand_tile) {
-            if (!ordered) {
+            // Kernels whose Problem sits in the kernarg segment re-read the cold fields for EVERY tile with candidates (scalar
+            // cache hits, the lines were touched at entry) instead of carrying ~25 scalar registers from tile to tile: carried,
+            // they pushed as many loop invariants out to vector lanes in front of every workgroup's first load.  Kernels that
+            // have to BUILD the schedule (LAZY_ORDER) do it once per wave.
+            if (!LAZY_ORDER || !ordered) {
                 const auto c = cold();
                 va.hay = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(uintptr_t)c->hay));
                 va.needle = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(uintptr_t)c->needle));

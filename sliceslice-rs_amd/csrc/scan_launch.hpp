@@ -15,54 +15,77 @@ struct Shape {
     uint64_t tpb;
     uint32_t lds_pad;
 };
+// Which kernels a build holds.  The DEFAULT library has what the constructors and ss_searcher_set_filter* can reach - U = 4;
+// non-temporal loads for the single-stream (MODE 0) and cross-lane (MODE 2) kernels, plain loads for the two-stream ones
+// (MODE 1); the 8-byte first phase for one-byte needles only: 26 scan kernels.  -DSS_TUNING_VARIANTS adds every other
+// combination ss_searcher_set_variant can name (U = 8, the other load flavour per mode, the 8-byte phase for two-byte filters,
+// the 16-byte layout for one-byte needles) - tuning residue, 80 more kernels of which 42 ran at three waves per SIMD or fewer:
+// libsliceslice_hip_tuning.so (sliceslice_rs_amd._build.build_tuning), used by tools/ and by the variant tests.
+constexpr bool kernel_built(int mode, bool one_byte, int U, int NT, bool FIND, bool L8)
+{
+#ifdef SS_TUNING_VARIANTS
+    return (void)mode, (void)one_byte, (void)U, (void)NT, (void)FIND, (void)L8, true;
+#else
+    if (U != 4) return false;
+    if (one_byte) return NT == 1 && (FIND ? !L8 : L8);
+    if (L8) return false;
+    return mode == 1 ? NT == 0 : NT == 1;
+#endif
+}
+
+// Returns false when the selected kernel is not part of this build (nothing has been launched then).
 template <int U, int NT, bool FIND>
-void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Shape &sh, hipStream_t st, void *sink,
+bool launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Shape &sh, hipStream_t st, void *sink,
                     bool l8);
 
 #ifdef SS_DEFINE_LAUNCH
+template <int Q, int MODE, bool ONE_BYTE, int U, int NT, bool FIND, bool L8>
+bool launch_one(const Problem &pr, const Shape &sh, hipStream_t st, void *flag)
+{
+    if constexpr (kernel_built(MODE, ONE_BYTE, U, NT, FIND, L8)) {
+        const uint32_t dyn_lds = sh.lds_pad + (sh.block / kWave) * kNeedleLds;   // one needle slice per wave
+        scan_kernel<Q, MODE, ONE_BYTE, U, NT, FIND, L8><<<dim3(sh.blocks), dim3(sh.block), dyn_lds, st>>>(pr, flag, sh.tpb);
+        return true;
+    } else {
+        return (void)pr, (void)sh, (void)st, (void)flag, false;
+    }
+}
+
 template <int U, int NT, bool FIND>
-void launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Shape &sh, hipStream_t st, void *flag,
+bool launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Shape &sh, hipStream_t st, void *flag,
                     bool l8)
 {
-    const dim3 grid(sh.blocks), blk(sh.block);
-    const uint64_t tpb = sh.tpb;
-    const uint32_t dyn_lds = sh.lds_pad + (sh.block / kWave) * kNeedleLds;   // one needle slice per wave
     if constexpr (!FIND) {
         if (l8 && (one_byte || mode == 0)) {
-            if (one_byte) {
-                scan_kernel<0, 0, true, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb);
-                return;
-            }
+            if (one_byte) return launch_one<0, 0, true, U, NT, false, true>(pr, sh, st, flag);
             switch (q) {
-            case 0: scan_kernel<0, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
-            case 1: scan_kernel<1, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
-            case 2: scan_kernel<2, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
-            default: scan_kernel<3, 0, false, U, NT, false, true><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb); break;
+            case 0: return launch_one<0, 0, false, U, NT, false, true>(pr, sh, st, flag);
+            case 1: return launch_one<1, 0, false, U, NT, false, true>(pr, sh, st, flag);
+            case 2: return launch_one<2, 0, false, U, NT, false, true>(pr, sh, st, flag);
+            default: return launch_one<3, 0, false, U, NT, false, true>(pr, sh, st, flag);
             }
-            return;
         }
     }
-    if (one_byte) {
-        scan_kernel<0, 0, true, U, NT, FIND><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb);
-        return;
-    }
+    if (one_byte) return launch_one<0, 0, true, U, NT, FIND, false>(pr, sh, st, flag);
 #define SS_CASE(QQ, MM)                                                                            \
     case (QQ) * 3 + (MM):                                                                          \
-        scan_kernel<QQ, MM, false, U, NT, FIND><<<grid, blk, dyn_lds, st>>>(pr, flag, tpb);              \
-        break;
+        return launch_one<QQ, MM, false, U, NT, FIND, false>(pr, sh, st, flag);
     switch (q * 3 + mode) {
         SS_CASE(0, 0) SS_CASE(0, 1) SS_CASE(0, 2) SS_CASE(1, 0) SS_CASE(1, 1) SS_CASE(1, 2)
         SS_CASE(2, 0) SS_CASE(2, 1) SS_CASE(2, 2) SS_CASE(3, 0) SS_CASE(3, 1) SS_CASE(3, 2)
     }
 #undef SS_CASE
+    return false;
 }
 #else
-extern template void launch_scan_un<4, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
-extern template void launch_scan_un<4, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
-extern template void launch_scan_un<8, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
-extern template void launch_scan_un<8, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
-extern template void launch_scan_un<4, 0, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
-extern template void launch_scan_un<4, 1, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template bool launch_scan_un<4, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template bool launch_scan_un<4, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+#ifdef SS_TUNING_VARIANTS
+extern template bool launch_scan_un<8, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template bool launch_scan_un<8, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+#endif
+extern template bool launch_scan_un<4, 0, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template bool launch_scan_un<4, 1, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 #endif
 
 }  // namespace ss

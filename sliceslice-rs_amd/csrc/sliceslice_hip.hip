@@ -380,11 +380,11 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, bool text_like)
 // launch_scan_un<U, NT, FIND> is defined in scan_launch.hpp and explicitly instantiated in the
 // scan_inst_*.hip translation units, so that the kernel families compile in parallel.
 template <int U>
-void launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte, const ss::Shape &shape, hipStream_t st,
+bool launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte, const ss::Shape &shape, hipStream_t st,
                    void *flag, bool l8)
 {
-    if (nt == 0) ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, shape, st, flag, l8);
-    else ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, shape, st, flag, l8);
+    if (nt == 0) return ss::launch_scan_un<U, 0, false>(pr, q, mode, one_byte, shape, st, flag, l8);
+    return ss::launch_scan_un<U, 1, false>(pr, q, mode, one_byte, shape, st, flag, l8);
 }
 
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, OR-ed
@@ -521,15 +521,23 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         HIP_TRY(hipEventRecord(tm.ev0[pd->dev], st));
     }
     const int q = (int)(sh / 4);
+    bool launched = false;
     if (find) {   // one tile shape for find(): U = 4
         if (l.U != 4) return fail(SS_ERR_ARGUMENT, "find supports the U = 4 kernels only");
-        if (l.nt) ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, shape, st, d_flag, false);
-        else ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, shape, st, d_flag, false);
+        if (l.nt) launched = ss::launch_scan_un<4, 1, true>(pr, q, l.mode, one_byte, shape, st, d_flag, false);
+        else launched = ss::launch_scan_un<4, 0, true>(pr, q, l.mode, one_byte, shape, st, d_flag, false);
     } else if (l.U == 8) {
-        launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, shape, st, d_flag, l.l8);
+#ifdef SS_TUNING_VARIANTS
+        launched = launch_scan_u<8>(l.nt, pr, q, l.mode, one_byte, shape, st, d_flag, l.l8);
+#endif
     } else {
-        launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, shape, st, d_flag, l.l8);
+        launched = launch_scan_u<4>(l.nt, pr, q, l.mode, one_byte, shape, st, d_flag, l.l8);
     }
+    if (!launched)
+        return fail(SS_ERR_ARGUMENT, "kernel variant %d (U = %d, %s loads, mode %d%s) is not part of this build: the default library holds "
+                                     "the kernels the constructors and ss_searcher_set_filter* can select; the rest is in the tuning build "
+                                     "(-DSS_TUNING_VARIANTS, libsliceslice_hip_tuning.so)",
+                    s->variant, l.U, l.nt ? "non-temporal" : "plain", l.mode, l.l8 ? ", 8-byte first phase" : "");
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(tm.ev1[pd->dev], st));
@@ -732,7 +740,14 @@ int store_filter(ss_searcher *s, size_t fa, size_t fb, size_t fc)
 extern "C" {
 
 const char *ss_last_error(void) { return g_err; }
-const char *ss_version(void) { return "sliceslice-hip 0.1 (gfx950)"; }
+const char *ss_version(void)
+{
+#ifdef SS_TUNING_VARIANTS
+    return "sliceslice-hip 0.3 (gfx950, tuning build: every kernel variant)";
+#else
+    return "sliceslice-hip 0.3 (gfx950)";
+#endif
+}
 
 int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out)
 {

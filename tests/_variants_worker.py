@@ -1,0 +1,78 @@
+"""Worker of tests/test_gpu_parity.py::test_all_kernel_variants_agree: kernel variants x launch shapes against the oracle, in a
+process of its own so that it can run against the tuning build of the library (SLICESLICE_HIP_LIB)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sliceslice_rs_amd as ss  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+SEED_NEEDLE = 0x5EED0002
+
+
+def absent_needle(n):
+    nd = bytearray(ss.fill_random_host(n, SEED_NEEDLE).tobytes())
+    nd[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
+    return bytes(nd)
+
+
+def main():
+    which = sys.argv[1]
+    tuning = b"tuning" in ss.lib().ss_version()
+    assert tuning == (which == "tuning"), (which, ss.lib().ss_version())
+    ln = (8 << 20) + 777
+    t = torch.empty(ln + 16, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0xABCDEF)
+    t = t[3:3 + ln]
+    host = t.cpu().numpy()
+    cases = [absent_needle(n) for n in (1, 2, 16, 20, 200, 700, 1200)]
+    cases += [host[ln - n:].tobytes() for n in (1, 2, 16, 20, 200, 700, 1200)]
+    cases += [host[12345:12345 + n].tobytes() for n in (33, 100, 257, 1000)]
+    # variant = 100000*B + 10000*OCC + 1000*LAYOUT + 100*MODE + 10*U + NT (include/sliceslice_hip.h).  Launch-shape digits
+    # (1xxxxx / 3xxxxx = 128- / 512-thread workgroups, x4xxxx = occupancy cap) on top of U = 4 + non-temporal loads are part
+    # of every build; the other load flavour per mode, U = 8, the 8-byte phase for two-byte filters (2xxx) and the 16-byte
+    # layout for one-byte needles (1xxx) are tuning-build kernels.
+    everywhere = (41, 100041, 300041, 40041)
+    tuning_only = (40, 80, 81, 140, 141, 181, 240, 241, 280, 281, 1040, 1041, 1081, 2040, 2041, 2080, 2081, 100241, 300141, 302041, 130081)
+    checked = refused = 0
+    for nd in cases:
+        want = O.OracleSearcher(nd).search_in(host)
+        for variant in everywhere + (tuning_only if tuning else ()):
+            for grid in (0, 1, 7, 4096, -1, -3, -1000):
+                s = ss.DynamicHipSearcher.new(nd)
+                s.set_variant(variant)
+                s.set_grid(grid)
+                assert s.search_in(t) == want, (len(nd), variant, grid)
+                checked += 1
+            if len(nd) > 16:
+                # the reference's pair (needle[0], needle[n-1]), which no constructor picks at this distance: the mode digit
+                # (x1xx two streams, x2xx cross-lane up to a distance of 1,007) takes effect only here
+                for grid in (0, 7, -3):
+                    s = ss.DynamicHipSearcher.new(nd)
+                    s.set_filter(0, len(nd) - 1)
+                    s.set_variant(variant if tuning else 0)
+                    s.set_grid(grid)
+                    assert s.search_in(t) == want, (len(nd), variant, grid, "reference pair")
+                    assert s.find(t) == (host.tobytes().find(nd) if want else None), (len(nd), variant, grid, "reference pair, find")
+                    checked += 1
+        if not tuning:
+            # the default library refuses what it does not hold - loudly, and without launching anything
+            for variant in (81, 2041) if len(nd) > 1 else (81, 1041):
+                s = ss.DynamicHipSearcher.new(nd)
+                s.set_variant(variant)
+                try:
+                    s.search_in(t)
+                    raise AssertionError("variant %d ran in the default build" % variant)
+                except ss.SlicesliceError as e:
+                    assert e.code == ss.SS_ERR_ARGUMENT and "tuning build" in str(e), e
+                    refused += 1
+                s.set_variant(0)
+                assert s.search_in(t) == want
+    print("variants ok: %d searches checked, %d refusals" % (checked, refused))
+
+
+if __name__ == "__main__":
+    main()

@@ -261,28 +261,29 @@ def test_rccl_enum_values_the_library_hard_codes():
 
 
 def test_kernels_the_library_launches_by_default_keep_four_waves_per_simd():
-    """build() records what the register allocator did with every kernel (csrc/kernel_resources.json).  The scan kernels run
-    at 7.4 TB/s with four waves per SIMD (<= 128 VGPRs) and at 6.3 with three, and which side of 128 a kernel lands on has
-    moved with unrelated edits before: every kernel a default launch can select must stay at >= 4 waves, without scratch."""
+    """build() records what the register allocator did with every kernel (csrc/kernel_resources.json).  The default library
+    holds exactly what the constructors and ss_searcher_set_filter* can select - 26 scan kernels (scan_launch.hpp::kernel_built),
+    40 kernels in all; the tuning residue (U = 8, the other load flavour per mode, two-byte 8-byte phases) lives in the tuning
+    build.  Every one of them keeps >= 4 waves per SIMD, without scratch and without spilled vector registers: which side of a
+    register-count step a kernel lands on has moved with unrelated edits before (at three waves the scan runs at 6.3 TB/s)."""
     build = sys.modules["sliceslice_rs_amd._build"]
     rows = build.kernel_resources()
     names = [r["name"] for r in rows]
-    assert any("scan_batched_kernel<4>" in n for n in names) and any("scan_pairs_kernel" in n for n in names)
-    seen = 0
+    assert len(rows) <= 40, len(rows)
+    assert any("scan_batched_plan_kernel<4>" in n for n in names) and any("scan_pairs_kernel" in n for n in names)
+    scans = set()
     for r in rows:
         m = re.match(r"void ss::scan_kernel<(\d), (\d), (true|false), (\d), (\d), (true|false), (true|false)>", r["name"])
         if m:
             q, mode, one_byte, u, nt, find, l8 = m.groups()
-            default = u == "4" and not (l8 == "true" and one_byte == "false")   # U = 8 and the two-byte L8 phase: set_variant only
-        else:
-            default = "scan_batched_kernel<4>" in r["name"]
-        if default:
-            seen += 1
+            scans.add(m.groups())
+            assert u == "4", r["name"]
+            if one_byte == "true":
+                assert nt == "1" and (l8 == "true") == (find == "false"), r["name"]
+            else:
+                assert l8 == "false" and nt == ("0" if mode == "1" else "1"), r["name"]
+            assert r.get("lds_bytes", 0) <= 1024, r         # static LDS: the completion word's workgroup flag (occupancy_pad leaves 1 KiB)
+        if m or "scan_batched" in r["name"]:
             assert r["waves_per_simd"] >= 4 and r["vgprs"] <= 128, r
-            assert r["scratch_bytes_per_lane"] == 0 or "scan_batched_kernel" in r["name"], r     # batched: SGPR spill slots only
-            assert r["vgpr_spills"] == 0, r
-            # static LDS of the scan kernels (the completion word's workgroup flag): the occupancy pad of the one-byte kernel
-            # (occupancy_pad in sliceslice_hip.hip) leaves 1 KiB per workgroup for it - more, and only three would fit a CU
-            if m:
-                assert r.get("lds_bytes", 0) <= 1024, r
-    assert seen >= 4 * 12 + 6 + 1, seen                # 12 (Q, MODE) x {nt0, nt1} x {search, find} + one-byte kernels + batched
+            assert r["scratch_bytes_per_lane"] == 0 and r["vgpr_spills"] == 0, r
+    assert len(scans) == 26, sorted(scans)
