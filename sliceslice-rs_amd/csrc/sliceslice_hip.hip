@@ -373,6 +373,11 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, bool text_like)
         if (d != 0 && m == 1) l.mode = 1;
         if (d != 0 && m == 2 && d <= 62) l.mode = 2;
         l.nt = (variant % 10) ? 1 : 0;
+#ifndef SS_TUNING_VARIANTS
+        // the default library holds ONE load flavour per mode (scan_launch.hpp::kernel_built): the digit selects among kernels
+        // only in the tuning build, here the launch-shape digits of a variant keep working for every filter pair
+        l.nt = l.mode == 1 ? 0 : 1;
+#endif
     }
     return l;
 }

@@ -56,7 +56,8 @@ def main():
                     s.set_variant(variant if tuning else 0)
                     s.set_grid(grid)
                     assert s.search_in(t) == want, (len(nd), variant, grid, "reference pair")
-                    assert s.find(t) == (host.tobytes().find(nd) if want else None), (len(nd), variant, grid, "reference pair, find")
+                    if (variant // 10) % 10 != 8:                      # find() has the U = 4 kernels only
+                        assert s.find(t) == (host.tobytes().find(nd) if want else None), (len(nd), variant, grid, "reference pair, find")
                     checked += 1
         if not tuning:
             # the default library refuses what it does not hold - loudly, and without launching anything
