@@ -274,6 +274,33 @@ int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const
  * straddles a boundary is seen by exactly the left rank. */
 int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *begin, size_t *end);
 
+/* ---- resident search service ------------------------------------------------------------------------------------
+ * The reference answers a search of a small haystack in tens of nanoseconds (README.md:38: 10.5 M word-in-word searches in
+ * 79 ms; bench/benches/i386.rs:246-256: 4,585 searches of an 857 kB text in 35 ms = 7.7 us each); a kernel launch alone
+ * costs ss_search_device 8-10 us.  A search service is a small kernel that STAYS on the device and takes requests from a
+ * 256-byte mailbox in pinned memory: no launch, no dispatch, no completion signal - the host writes the request, the
+ * service's workgroups scan (same kernels' code), the answer arrives in a pinned word the caller spins on.
+ *   ss_service_start(workgroups, lease_ms, &sv)  on the current device; workgroups = 0: 64 (one per 4 compute units), at most
+ *       one per compute unit; lease_ms = 0: 20 ms.  The kernel is resident only while requests keep coming: after
+ *       `lease_ms` without one it leaves by itself (and is started again by the next request, at the price of one launch),
+ *       so nothing that waits for the whole device - hipDeviceSynchronize, hipFree - waits longer than the lease.
+ *   ss_service_search(sv, s, d_haystack, len, &found)  the semantics of ss_search_device, for searchers whose filter bytes
+ *       lie within 16 bytes of each other (every constructor-built searcher; else SS_ERR_ARGUMENT).  The haystack must be
+ *       COMPLETE in device memory: the service is not ordered behind work pending on any stream.  One request at a time per
+ *       service (callers queue on a mutex); any haystack length is correct, a few MiB and less is what it is for.
+ *   ss_service_set_default(sv, 1)  routes qualifying ss_search_device calls on sv's device through sv: haystacks up to 8 MiB,
+ *       no variant / grid override, no kernel timing, and only when the caller's stream is idle (hipStreamQuery).
+ *       SLICESLICE_SERVICE=1 in the environment does the same with a service the library starts itself on first use
+ *       (SLICESLICE_SERVICE_WORKGROUPS, SLICESLICE_SERVICE_LEASE_MS).
+ *   ss_service_counters  requests served / kernel launches so far (a burst of requests shares one residency).
+ *   ss_service_stop      asks the kernel to leave, waits for it, frees everything. */
+typedef struct ss_service ss_service;
+int ss_service_start(int workgroups, double lease_ms, ss_service **out);
+int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haystack, size_t len, int *found);
+int ss_service_set_default(ss_service *sv, int enabled);
+int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches);
+void ss_service_stop(ss_service *sv);
+
 /* Measurement: median (and minimum) microseconds of a host -> device -> host round trip through pinned memory against ONE
  * resident device lane - the fixed cost per request of a "search service" kernel that would stay on the device instead of
  * being launched per search, to set against ss_search_device's per-call time. */

@@ -16,6 +16,7 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 #[repr(C)] pub struct ss_searcher { _private: [u8; 0] }
 #[repr(C)] pub struct ss_comm { _private: [u8; 0] }
 #[repr(C)] pub struct ss_comm_set { _private: [u8; 0] }
+#[repr(C)] pub struct ss_service { _private: [u8; 0] }
 
 pub const SS_OK: c_int = 0;
 pub const SS_ERR_POSITION: c_int = 1;
@@ -103,6 +104,11 @@ extern "C" {
     pub fn ss_debug_set_comm_epoch(c: *mut ss_comm, set: *mut ss_comm_set, value: c_int) -> c_int;
     pub fn ss_debug_fail_next_scans(s: *mut ss_searcher, count: c_int) -> c_int;
     pub fn ss_mailbox_round_trip_us(iters: c_int, median_us: *mut f64, min_us: *mut f64) -> c_int;
+    pub fn ss_service_start(workgroups: c_int, lease_ms: f64, out: *mut *mut ss_service) -> c_int;
+    pub fn ss_service_search(sv: *mut ss_service, s: *const ss_searcher, d_haystack: *const c_void, len: usize, found: *mut c_int) -> c_int;
+    pub fn ss_service_set_default(sv: *mut ss_service, enabled: c_int) -> c_int;
+    pub fn ss_service_counters(sv: *mut ss_service, requests: *mut u64, kernel_launches: *mut u64) -> c_int;
+    pub fn ss_service_stop(sv: *mut ss_service);
 }
 
 /// Haystack already resident in device memory (caller-owned `hipMalloc` memory).

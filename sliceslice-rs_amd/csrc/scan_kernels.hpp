@@ -1830,6 +1830,138 @@ __global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best)
     __hip_atomic_store(h_best, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- resident search service (ss_service_*) ---------------------------------------------------------------
+// The launch path costs a search 8-10 us whatever its size: doorbell, command processor, dispatch, completion.  A host <->
+// device round trip through pinned memory against a kernel that is ALREADY running costs 1.4-1.6 us (mailbox_echo_kernel
+// below).  The service is that kernel: `gridDim.x` workgroups that stay on the device and take one request at a time:
+//   * the host writes the request - a whole Problem - into a 256-byte mailbox in pinned memory: four 64-byte lines, each 15
+//     payload dwords + the request's sequence number as its LAST dword.  A line read over PCIe is one snapshot, and x86
+//     stores become visible in order, so a line that shows the new number holds the new payload;
+//   * ONE wave (the leader: wave 0 of workgroup 0) polls the mailbox - 64 lanes x 4 bytes, one instruction - and when all
+//     four lines show the next number hands the payload to the others through device memory (agent-scope 4-byte stores, a
+//     release fence, then the sequence word they all poll);
+//   * every workgroup scans tiles b, b + grid, ... of the haystack with the same scan_tiles<> as every other kernel, counts
+//     itself out exactly like a completion-word launch of scan_kernel, and the workgroup that completes the count stores
+//     found-count << 32 | sequence << 1 | found to the pinned answer word the host spins on.
+// Residency is a LEASE: without a request for `idle_ticks` (100 MHz s_memrealtime) the leader announces that it is leaving,
+// looks at the mailbox once more (a request posted meanwhile is served; host and device each write their word before
+// reading the other's), tells the others and the kernel ends; the host starts it again with its next request.  Nothing that
+// waits for the whole device - hipDeviceSynchronize, hipFree - can therefore wait longer than the lease.  Every spin in here
+// is bounded.
+struct ServiceRequest {
+    Problem pr;
+    uint32_t q;            // dword window of the second filter byte (the kernels' template parameter Q)
+    uint32_t one_byte;
+    uint32_t stop;         // != 0: no search - the service ends
+    uint32_t pad_;
+};
+static_assert(sizeof(ServiceRequest) <= 240 && sizeof(ServiceRequest) % 8 == 0, "four mailbox lines of 60 payload bytes");
+constexpr uint32_t kSvcRunning = 1, kSvcLeaving = 2, kSvcExited = 3;
+constexpr unsigned long long kSvcStopSeq = ~0ull;
+
+template <int U>
+__global__ void __launch_bounds__(kBlock)
+service_kernel(const uint32_t *h_req, uint32_t *h_status, unsigned long long *h_answer, uint32_t *d_box, unsigned long long *d_seq,
+               unsigned long long *d_done, int *d_found, uint32_t first_seq, unsigned long long idle_ticks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
+    __shared__ int s_wg_found;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const bool leader = blockIdx.x == 0 && wave == 0;
+    constexpr unsigned long long kWorkerPatience = 300000000ull;           // 3 s of s_memrealtime: a worker never waits longer
+    if (leader && lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (uint32_t next = first_seq;; ++next) {
+        // ---- 1. the leader fetches request `next` and publishes it --------------------------------------------------
+        if (leader) {
+            auto poll = [&](uint32_t *v) {          // lane i <- dword i of the mailbox; true when all four lines carry `next`
+                *v = __hip_atomic_load(h_req + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return (uint32_t)__builtin_amdgcn_readlane((int)*v, 15) == next && (uint32_t)__builtin_amdgcn_readlane((int)*v, 31) == next &&
+                       (uint32_t)__builtin_amdgcn_readlane((int)*v, 47) == next && (uint32_t)__builtin_amdgcn_readlane((int)*v, 63) == next;
+            };
+            uint32_t v = 0;
+            bool have = false;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (!(have = poll(&v))) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) {
+                    // the lease is over: say so, THEN look once more (the host posts its request, THEN reads this word)
+                    if (lane == 0) __hip_atomic_store(h_status, kSvcLeaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+                    have = poll(&v);
+                    if (have && lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            // the stop flag travels in the payload (dword 50 + 50/15 = mailbox dword 53 of a 200-byte Problem + q + one_byte)
+            constexpr int kStopPayloadDword = (int)(offsetof(ServiceRequest, stop) / 4);
+            constexpr int kStopLane = kStopPayloadDword + kStopPayloadDword / 15;
+            const bool stop = !have || __builtin_amdgcn_readlane((int)v, kStopLane) != 0;
+            if (!stop) {
+                if ((lane & 15) != 15) __hip_atomic_store(d_box + (lane - (lane >> 4)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            }
+            if (lane == 0)
+                __hip_atomic_store(d_seq, stop ? kSvcStopSeq : (unsigned long long)next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- 2. everybody waits for the sequence word ------------------------------------------------------------------
+        unsigned long long seen;
+        {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                seen = uniform64(__hip_atomic_load(d_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen == kSvcStopSeq || (uint32_t)seen == next) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks + kWorkerPatience) {
+                    seen = kSvcStopSeq;                                  // the leader is gone: leave, do not hang
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (seen == kSvcStopSeq) break;
+        // ---- 3. the request, out of device memory into scalar registers ------------------------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        constexpr int kDwords = (int)(sizeof(ServiceRequest) / 4);
+        const uint32_t mine = lane < kDwords ? __hip_atomic_load(d_box + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        union {
+            ServiceRequest rq;
+            uint32_t w[kDwords];
+        } u;
+#pragma unroll
+        for (int k = 0; k < kDwords; ++k) u.w[k] = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
+        const ServiceRequest &rq = u.rq;
+        // ---- 4. scan: workgroup b takes tiles b, b + grid, ... -------------------------------------------------------------
+        if (threadIdx.x == 0) __hip_atomic_store(&s_wg_found, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        const uint64_t ntiles = (rq.pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+        const ColdInRegisters cold = {&rq.pr};
+        if (rq.one_byte) {
+            scan_tiles<0, 0, true, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found);
+        } else {
+            switch (rq.q) {
+            case 0: scan_tiles<0, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
+            case 1: scan_tiles<1, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
+            case 2: scan_tiles<2, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
+            default: scan_tiles<3, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
+            }
+        }
+        // ---- 5. count out; the workgroup that completes the count answers (scan_kernel's completion word) ---------------
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long f = (unsigned long long)__hip_atomic_load(&s_wg_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long one = 1ull + (f << 32);
+            const unsigned long long total = __hip_atomic_fetch_add(d_done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + one;
+            if ((uint32_t)total == rq.pr.done_target) {
+                const uint32_t hi = (uint32_t)(total >> 32);
+                __hip_atomic_store(h_answer, ((unsigned long long)hi << 32) | ((unsigned long long)next << 1) | (hi != rq.pr.done_hi ? 1ull : 0ull),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+    }
+    if (leader && lane == 0) __hip_atomic_store(h_status, kSvcExited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Mailbox round trip (ss_mailbox_round_trip_us): ONE lane answers `iters` requests posted by the host to pinned memory -
 // what a resident "search service" would pay per request before it has looked at a single haystack byte.  Every wait is
 // bounded (s_memtime ticks), so the kernel ends by itself whatever the host does.

@@ -46,6 +46,13 @@ inline void cpu_relax()
 #endif
 }
 
+// restores the calling thread's current device on scope exit
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
@@ -400,14 +407,19 @@ bool launch_scan_u(int nt, const ss::Problem &pr, int q, int mode, bool one_byte
 constexpr uint64_t kDoneMaxBlocks = 256;         // one atomic per workgroup on ONE address: small grids only (4 MiB);
                                                  // measured: 1 KiB 8.6 vs 11.9 us per call, break-even near 1 MiB
 
-int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st,
-                 void *d_sink, bool find = false, uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1,
-                 int done_slot = -1, bool *used_done = nullptr)
+// What a launch needs to know about a Problem besides the Problem itself.
+struct ProblemShape {
+    size_t position, position3;     // the second / third filter byte, relative to the first (ordered by dword: q3 <= Q)
+    size_t fa;                      // index of the first filter byte
+    bool one_byte;
+};
+
+// The Problem of (searcher, haystack): everything but the sink-side fields (epoch, host_flag, completion word), which the caller
+// sets.  Preconditions: 1 <= n <= len.
+void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_hay, size_t len, uint64_t find_base, ss::Problem *out,
+                  ProblemShape *shape)
 {
-    if (s->debug_fail_scans.load(std::memory_order_relaxed) > 0 && s->debug_fail_scans.fetch_sub(1) > 0)
-        return fail(SS_ERR_HIP, "injected scan failure (ss_debug_fail_next_scans)");
-    void *d_flag = d_sink;
-    ss::Problem pr;
+    ss::Problem &pr = *out;
     const size_t n = s->n;
     const bool one_byte = n == 1;
     // The filter stream starts at the FIRST filter byte: candidate i is tested through hay[fa + i] == needle[fa]
@@ -419,7 +431,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.hay = static_cast<const uint8_t *>(d_hay);
     pr.mis = (uint32_t)((uintptr_t)hf & 15);
     pr.base = hf - pr.mis;
-    pr.needle = pd->d_needle;
+    pr.needle = d_needle;
     pr.n = n;
     pr.end = (uint64_t)len - n + 1;
     pr.nchunks_all = ((uint64_t)pr.mis + (len - fa) + 15) / 16;
@@ -445,8 +457,8 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     pr.norder = ss::build_refine_order(s->needle.data() + fa, n - fa, position, pr.order_idx, pr.order_val,
                                        pr.d == 0 ? (uint64_t)position3 : ~0ull);
     pr.find_base = find_base;
-    pr.host_flag = host_flag;
-    pr.epoch = epoch;
+    pr.host_flag = nullptr;
+    pr.epoch = 1;
     pr.done_counter = nullptr;
     pr.host_done = nullptr;
     pr.done_target = pr.done_hi = 0;
@@ -461,6 +473,27 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         memcpy(t16, s->needle.data() + fa, n - fa);
         memcpy(pr.tail16, t16, 16);
     }
+    shape->position = position;
+    shape->position3 = position3;
+    shape->fa = fa;
+    shape->one_byte = one_byte;
+}
+
+int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st,
+                 void *d_sink, bool find = false, uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1,
+                 int done_slot = -1, bool *used_done = nullptr)
+{
+    if (s->debug_fail_scans.load(std::memory_order_relaxed) > 0 && s->debug_fail_scans.fetch_sub(1) > 0)
+        return fail(SS_ERR_HIP, "injected scan failure (ss_debug_fail_next_scans)");
+    void *d_flag = d_sink;
+    ss::Problem pr;
+    ProblemShape ps;
+    fill_problem(s, pd->d_needle, d_hay, len, find_base, &pr, &ps);
+    pr.host_flag = host_flag;
+    pr.epoch = epoch;
+    const bool one_byte = ps.one_byte;
+    const size_t fa = ps.fa, position = ps.position, position3 = ps.position3;
+    const uint32_t sh = (uint32_t)(position % 16);
 
     const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
                            ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
@@ -1000,6 +1033,17 @@ bool spin_for_shard_word(const long long *word, int epoch, double estimate_us, i
 
 }  // namespace
 
+}  // extern "C"
+
+struct ss_service;
+extern "C" int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haystack, size_t len, int *found);
+namespace {
+ss_service *default_service(int dev);
+constexpr size_t kServiceMaxLen = (size_t)8 << 20;        // beyond this the launch path's 8 us no longer matter
+}
+
+extern "C" {
+
 int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, int *found)
 {
     if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
@@ -1010,6 +1054,16 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
+    // A resident search service on this device (ss_service_set_default, or SLICESLICE_SERVICE=1) answers small searches
+    // without a launch.  It cannot be ordered behind work that is still pending on the caller's stream, so it is used
+    // only when that stream is idle - anything else takes the launch path below, as do filter pairs 16 or more apart,
+    // kernel-variant / grid overrides and timed searches.
+    if (len <= kServiceMaxLen && s->variant == 0 && s->grid == 0 && !s->timing && (s->n == 1 || s->fb - s->fa < 16)) {
+        if (ss_service *sv = default_service(pd->dev)) {
+            if (hipStreamQuery(st) == hipSuccess) return ss_service_search(sv, s, d_haystack, len, found);
+            (void)hipGetLastError();
+        }
+    }
     const int k = acquire_slot(s, pd);
     // The wave that finds a match stores the call's epoch to the device flag (polled by the grid for the
     // early exit) AND to its pinned-host mirror, so the answer needs neither a device-to-host copy nor a
@@ -1588,8 +1642,8 @@ static PlanScratch *plan_scratch_acquire(int dev, hipStream_t st, size_t count)
     if (e) {
         e->mu.lock();            // another thread's call on this stream is between its two launches: brief
     } else {
-        e = victim;              // an unused entry, else the least recently used one
-        if (!e->mu.try_lock()) return nullptr;                  // (in use right now: the caller takes the single-kernel form)
+        e = victim;              // an unused entry, else the least recently used one (if a call is between its two launches
+        e->mu.lock();            // on it right now: wait for that - microseconds)
         if (e->buf) (void)hipFree(e->buf);                      // hipFree waits for the device: nobody reads it any more
         e->buf = nullptr;
         e->cap = 0;
@@ -1687,15 +1741,17 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
             if (e != hipSuccess) return fail(SS_ERR_HIP, "batched launch: %s", hipGetErrorString(e));
             return SS_OK;
         }
-        // no descriptor scratch (out of memory, or every entry busy): the single-kernel form below
+#ifndef SS_TUNING_VARIANTS
+        return fail(SS_ERR_NOMEM, "no device memory for %zu problem descriptors", count);
+#endif
     }
+#ifndef SS_TUNING_VARIANTS
+    return fail(SS_ERR_ARGUMENT, "SLICESLICE_BATCH_PLAN=0 selects the single-kernel form, which is part of the tuning build only");
+#else
     HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
-    // Single-kernel form.  The haystack lengths live on the device, so the grid is chosen from the problem count alone: 96
-    // workgroups per CU in total (short-lived workgroups that each scan a contiguous run of their problem's tiles balance the
-    // tail better than one long-lived workgroup per problem).  Surplus slices of short haystacks exit before touching the
-    // needle.  Measured at 4,096 x 1 MiB with the kernel held to four waves per SIMD (tools/batch_probe.py,
-    // profiles/r02/batched_wg_sweep.jsonl): 64 / 96 / 128 / 160 / 192 per CU = 7.09 / 7.17 / 7.16 / 6.98 / 6.86 TB/s.
-    // SLICESLICE_BATCH_WGS overrides the total (tuning aid).
+    // Single-kernel form (tuning build: the reference point of tools/batch_tune.py).  The haystack lengths live on the device,
+    // so the grid is chosen from the problem count alone: 96 workgroups per CU in total; every workgroup rebuilds its problem's
+    // descriptor from the range arrays (a chain of three dependent round trips in front of its first haystack load).
     uint64_t wg_target = (uint64_t)di.cus * 96;
     if (const char *e = getenv("SLICESLICE_BATCH_WGS")) {
         const long v = atol(e);
@@ -1707,6 +1763,7 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
     ss::scan_batched_kernel<4><<<dim3((unsigned)count, (unsigned)slices), dim3(ss::kBlock), batch_lds_pad(), st>>>(a);
     HIP_TRY(hipGetLastError());
     return SS_OK;
+#endif
 }
 
 int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
@@ -1881,6 +1938,254 @@ int ss_mailbox_round_trip_us(int iters, double *median_us, double *min_us)
     return SS_OK;
 }
 
+// ---- resident search service ------------------------------------------------------------------------------------
+// Host side of ss::service_kernel (scan_kernels.hpp has the protocol).  One request at a time per service (a mutex); the
+// kernel is (re)started on demand - at the first request, and after every lease that ran out.
+
+}  // extern "C"
+
+struct ss_service {
+    int dev = 0;
+    int workgroups = 0;
+    unsigned long long idle_ticks = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *h_box = nullptr;              // pinned, 6 lines of 64 bytes: request (4) | status | answer
+    uint8_t *d_mem = nullptr;               // device: box (256 B) | seq | done counter | found flag
+    uint32_t seq = 0;                       // last request posted
+    uint32_t done_low = 0, done_hi = 0;     // the never-reset completion counter, as the host knows it
+    uint64_t requests = 0, launches = 0;
+    std::mutex mu;
+    volatile uint32_t *status() const { return h_box + 64; }
+    volatile unsigned long long *answer() const { return reinterpret_cast<volatile unsigned long long *>(h_box + 80); }
+    uint32_t *d_box() const { return reinterpret_cast<uint32_t *>(d_mem); }
+    unsigned long long *d_seq() const { return reinterpret_cast<unsigned long long *>(d_mem + 256); }
+    unsigned long long *d_done() const { return reinterpret_cast<unsigned long long *>(d_mem + 264); }
+    int *d_found() const { return reinterpret_cast<int *>(d_mem + 272); }
+};
+
+namespace {
+
+constexpr int kServiceDefaultWorkgroups = 64;
+constexpr double kServiceDefaultLeaseMs = 20.0;
+std::atomic<ss_service *> g_default_service[kMaxDevices];
+
+int service_launch(ss_service *sv, uint32_t first_seq)
+{
+    __atomic_store_n(sv->status(), 0u, __ATOMIC_RELAXED);
+    HIP_TRY(hipMemsetAsync(sv->d_seq(), 0, sizeof(unsigned long long), sv->stream));   // (ordered behind the previous residency's end)
+    ss::service_kernel<4><<<dim3((unsigned)sv->workgroups), dim3(ss::kBlock), 0, sv->stream>>>(
+        sv->h_box, const_cast<uint32_t *>(sv->status()), const_cast<unsigned long long *>(sv->answer()), sv->d_box(), sv->d_seq(), sv->d_done(),
+        sv->d_found(), first_seq, sv->idle_ticks);
+    HIP_TRY(hipGetLastError());
+    ++sv->launches;
+    return SS_OK;
+}
+
+// Posts one request and waits for its answer word (or, for a stop request, for the kernel to say it has left).
+int service_post(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq, unsigned long long *answer)
+{
+    uint32_t payload[60] = {0};
+    memcpy(payload, &rq, sizeof rq);
+    volatile uint32_t *m = sv->h_box;
+    for (int line = 0; line < 4; ++line) {
+        for (int j = 0; j < 15; ++j) __atomic_store_n(m + line * 16 + j, payload[line * 15 + j], __ATOMIC_RELAXED);
+        __atomic_store_n(m + line * 16 + 15, seq, __ATOMIC_RELEASE);      // a line that shows `seq` holds this request's payload
+    }
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);                              // the request first, THEN the kernel's state (see service_kernel)
+    uint32_t st = __atomic_load_n(sv->status(), __ATOMIC_ACQUIRE);
+    if (rq.stop && (st == 0 || st == ss::kSvcExited) && sv->launches == 0) return SS_OK;   // never started: nothing to stop
+    bool launched_now = false;
+    if (st == 0 && sv->launches == 0) {                                  // first request of this service
+        if (int rc = service_launch(sv, seq)) return rc;
+        launched_now = true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (!rq.stop) {
+            const unsigned long long a = __atomic_load_n(sv->answer(), __ATOMIC_ACQUIRE);
+            if ((uint32_t)((a >> 1) & 0x7FFFFFFFu) == seq) {
+                *answer = a;
+                return SS_OK;
+            }
+        }
+        st = __atomic_load_n(sv->status(), __ATOMIC_ACQUIRE);
+        if (st == ss::kSvcExited) {
+            if (rq.stop) return SS_OK;
+            // the lease ran out before the kernel saw this request: a new residency starts with it
+            if (int rc = service_launch(sv, seq)) return rc;
+            launched_now = true;
+        }
+        cpu_relax();
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(launched_now ? 20 : 10))
+            return fail(SS_ERR_HIP, "search service: no answer to request %u (kernel state %u)", seq, st);
+    }
+}
+
+void service_free(ss_service *sv)
+{
+    if (sv->stream) {
+        (void)hipStreamSynchronize(sv->stream);
+        (void)hipStreamDestroy(sv->stream);
+    }
+    (void)hipHostFree(sv->h_box);
+    (void)hipFree(sv->d_mem);
+    delete sv;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_service_start(int workgroups, double lease_ms, ss_service **out)
+{
+    if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    DeviceInfo di;
+    if (int rc = device_info(dev, &di)) return rc;
+    if (!di.gfx950) return fail(SS_ERR_NO_DEVICE, "HIP device %d is not a gfx950 (MI355X-class) device", dev);
+    if (workgroups == 0) workgroups = kServiceDefaultWorkgroups;
+    if (workgroups < 1 || workgroups > di.cus) return fail(SS_ERR_ARGUMENT, "1 .. %d service workgroups (one per compute unit at most)", di.cus);
+    if (lease_ms == 0) lease_ms = kServiceDefaultLeaseMs;
+    if (!(lease_ms >= 0.05 && lease_ms <= 10000.0)) return fail(SS_ERR_ARGUMENT, "lease of 0.05 .. 10000 ms");
+    ss_service *sv = new (std::nothrow) ss_service;
+    if (!sv) return fail(SS_ERR_NOMEM, "out of memory");
+    sv->dev = dev;
+    sv->workgroups = workgroups;
+    sv->idle_ticks = (unsigned long long)(lease_ms * 1e5);             // s_memrealtime: 100 MHz
+    hipError_t e = hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sv->h_box, 6 * 64, hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) memset(sv->h_box, 0, 6 * 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&sv->d_mem, 512);
+    if (e == hipSuccess) e = hipMemset(sv->d_mem, 0, 512);
+    if (e != hipSuccess) {
+        service_free(sv);
+        return fail(SS_ERR_HIP, "search service set-up: %s", hipGetErrorString(e));
+    }
+    *out = sv;
+    return SS_OK;
+}
+
+int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haystack, size_t len, int *found)
+{
+    if (!sv || !s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    if (s->n == 0) { *found = 1; return SS_OK; }        // x86.rs:500
+    if (len < s->n) { *found = 0; return SS_OK; }       // x86.rs:357-359
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != sv->dev) return fail(SS_ERR_ARGUMENT, "the service runs on device %d, the current device is %d", sv->dev, dev);
+    SearchGate gate(s);
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    ss::ServiceRequest rq;
+    memset(&rq, 0, sizeof rq);
+    ProblemShape ps;
+    fill_problem(s, pd->d_needle, d_haystack, len, 0, &rq.pr, &ps);
+    if (rq.pr.d != 0) return fail(SS_ERR_ARGUMENT, "the service runs the single-stream kernels: filter pairs 16 or more apart take the launch path");
+    rq.q = (uint32_t)((ps.position % 16) / 4);
+    rq.one_byte = ps.one_byte ? 1u : 0u;
+    std::lock_guard<std::mutex> lock(sv->mu);
+    if (sv->seq >= 0x7FFFFF00u || sv->done_low > kDoneLowMax) {
+        // sequence numbers (31 bits in the answer word) or the workgroup count about to run out: a fresh start
+        ss::ServiceRequest bye;
+        memset(&bye, 0, sizeof bye);
+        bye.stop = 1;
+        unsigned long long ignored = 0;
+        if (int rc = service_post(sv, bye, ++sv->seq, &ignored)) return rc;
+        HIP_TRY(hipStreamSynchronize(sv->stream));
+        HIP_TRY(hipMemset(sv->d_mem, 0, 512));
+        memset(sv->h_box, 0, 6 * 64);
+        sv->seq = sv->done_low = sv->done_hi = 0;
+        sv->launches = 0;
+    }
+    const uint32_t seq = ++sv->seq;
+    rq.pr.epoch = (int)seq;
+    rq.pr.flags = ss::kProblemCounted;
+    rq.pr.done_target = sv->done_low + (uint32_t)sv->workgroups;
+    rq.pr.done_hi = sv->done_hi;
+    unsigned long long a = 0;
+    if (int rc = service_post(sv, rq, seq, &a)) return rc;
+    sv->done_low = rq.pr.done_target;
+    sv->done_hi = (uint32_t)(a >> 32);
+    ++sv->requests;
+    *found = (int)(a & 1);
+    return SS_OK;
+}
+
+int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches)
+{
+    if (!sv) return fail(SS_ERR_ARGUMENT, "service is NULL");
+    std::lock_guard<std::mutex> lock(sv->mu);
+    if (requests) *requests = sv->requests;
+    if (kernel_launches) *kernel_launches = sv->launches;
+    return SS_OK;
+}
+
+int ss_service_set_default(ss_service *sv, int enabled)
+{
+    if (!sv) return fail(SS_ERR_ARGUMENT, "service is NULL");
+    if (sv->dev < 0 || sv->dev >= kMaxDevices) return fail(SS_ERR_ARGUMENT, "device index out of range");
+    if (enabled) {
+        g_default_service[sv->dev].store(sv, std::memory_order_release);
+    } else {
+        ss_service *expect = sv;
+        g_default_service[sv->dev].compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
+    }
+    return SS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// The device's default service: what ss_service_set_default installed, or - with SLICESLICE_SERVICE=1 in the environment - a
+// service started here on first use (default size and lease; it lives until the process ends).
+ss_service *default_service(int dev)
+{
+    if (dev < 0 || dev >= kMaxDevices) return nullptr;
+    ss_service *sv = g_default_service[dev].load(std::memory_order_acquire);
+    if (sv) return sv;
+    static const bool auto_on = []() { const char *v = getenv("SLICESLICE_SERVICE"); return v && v[0] == '1'; }();
+    if (!auto_on) return nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    sv = g_default_service[dev].load(std::memory_order_acquire);
+    if (sv) return sv;
+    int workgroups = 0;
+    double lease = 0;
+    if (const char *e = getenv("SLICESLICE_SERVICE_WORKGROUPS")) workgroups = atoi(e);
+    if (const char *e = getenv("SLICESLICE_SERVICE_LEASE_MS")) lease = atof(e);
+    if (ss_service_start(workgroups, lease, &sv) != SS_OK) return nullptr;
+    g_default_service[dev].store(sv, std::memory_order_release);
+    return sv;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ss_service_stop(ss_service *sv)
+{
+    if (!sv) return;
+    if (sv->dev >= 0 && sv->dev < kMaxDevices) {
+        ss_service *expect = sv;
+        g_default_service[sv->dev].compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
+    }
+    {
+        std::lock_guard<std::mutex> lock(sv->mu);
+        DeviceGuard guard;
+        (void)hipSetDevice(sv->dev);
+        ss::ServiceRequest bye;
+        memset(&bye, 0, sizeof bye);
+        bye.stop = 1;
+        unsigned long long ignored = 0;
+        (void)service_post(sv, bye, ++sv->seq, &ignored);      // (a kernel that does not answer leaves when its lease runs out)
+        service_free(sv);
+    }
+}
+
 // DPP / alignbyte self-test used by the GPU tests: out must hold 320 uint32 (host memory).
 int ss_selftest_dpp(uint32_t *out)
 {
@@ -1953,13 +2258,6 @@ int rccl_fail(Rccl *r, int code, const char *what)
 {
     return fail(SS_ERR_RCCL, "%s: %s", what, r && r->GetErrorString ? r->GetErrorString(code) : "rccl error");
 }
-
-// restores the calling thread's current device on scope exit
-struct DeviceGuard {
-    int saved = -1;
-    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
-    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
-};
 
 }  // namespace
 

@@ -93,6 +93,11 @@ ABI = {
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
     "ss_mailbox_round_trip_us": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "ss_service_start": (_int, [_int, ctypes.c_double, _pvp]),
+    "ss_service_search": (_int, [_vp, _vp, _vp, _sz, _pint]),
+    "ss_service_set_default": (_int, [_vp, _int]),
+    "ss_service_counters": (_int, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
+    "ss_service_stop": (None, [_vp]),
 }
 
 
@@ -613,6 +618,58 @@ class NodeSearcher:
             self.close()
         except Exception:
             pass
+
+
+class SearchService:
+    """A resident search service on the current device (ss_service_*): a small kernel that stays on the GPU and takes one search
+    at a time from a pinned mailbox - no launch per search.  ``search_in(searcher, haystack)`` has the semantics of
+    ``searcher.search_in(haystack)`` for a device haystack whose bytes are COMPLETE (the service is not ordered behind pending
+    stream work); ``set_default()`` routes qualifying ``search_in`` calls of every searcher on this device through it."""
+
+    def __init__(self, workgroups=0, lease_ms=0.0):
+        self._h = ctypes.c_void_p()
+        _check(lib().ss_service_start(int(workgroups), float(lease_ms), ctypes.byref(self._h)))
+
+    def search_in(self, searcher, haystack):
+        found = ctypes.c_int(0)
+        ptr, n = (haystack.data_ptr(), haystack.numel()) if hasattr(haystack, "data_ptr") else haystack
+        _check(lib().ss_service_search(self._h, searcher._h, ptr if n else None, n, ctypes.byref(found)))
+        return bool(found.value)
+
+    def set_default(self, enabled=True):
+        _check(lib().ss_service_set_default(self._h, 1 if enabled else 0))
+
+    def counters(self):
+        """(requests served, kernel launches): a burst of requests shares one residency of the kernel."""
+        r, k = _u64(0), _u64(0)
+        _check(lib().ss_service_counters(self._h, ctypes.byref(r), ctypes.byref(k)))
+        return r.value, k.value
+
+    def stop(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.ss_service_stop(self._h)
+            self._h = None
+
+    close = stop
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.stop()
+
+    def __del__(self):
+        try:
+            self.stop()
+        except Exception:
+            pass
+
+
+def mailbox_round_trip_us(iters=2000):
+    """(median, minimum) microseconds of a host -> resident device lane -> host round trip through pinned memory."""
+    med, mn = ctypes.c_double(0), ctypes.c_double(0)
+    _check(lib().ss_mailbox_round_trip_us(iters, ctypes.byref(med), ctypes.byref(mn)))
+    return med.value, mn.value
 
 
 def _ranges(off, begin, end):

@@ -29,7 +29,7 @@ def _c_class(t):
     if "*" in t or "[" in t:
         return "ptr"
     t = re.sub(r"\bconst\b", "", t).strip()
-    return {"int": "i32", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "float": "f32", "void": "void"}[t]
+    return {"int": "i32", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "float": "f32", "double": "f64", "void": "void"}[t]
 
 
 def header_prototypes():
@@ -57,7 +57,7 @@ def _rust_class(t):
     t = t.strip()
     if t.startswith("*"):
         return "ptr"
-    return {"c_int": "i32", "usize": "usize", "u64": "u64", "u32": "u32", "c_float": "f32"}[t]
+    return {"c_int": "i32", "usize": "usize", "u64": "u64", "u32": "u32", "c_float": "f32", "f64": "f64"}[t]
 
 
 def rust_prototypes():
@@ -108,7 +108,8 @@ def test_ctypes_table_matches_the_header():
             return "void"
         if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or isinstance(t, type(ctypes.POINTER(ctypes.c_int))):
             return "ptr"
-        return {ctypes.c_int: "i32", ctypes.c_size_t: "usize", ctypes.c_uint64: "u64", ctypes.c_uint32: "u32", ctypes.c_float: "f32"}[t]
+        return {ctypes.c_int: "i32", ctypes.c_size_t: "usize", ctypes.c_uint64: "u64", ctypes.c_uint32: "u32", ctypes.c_float: "f32",
+                ctypes.c_double: "f64"}[t]
     for name, (res, args) in ss.searcher.ABI.items():
         got = (cls(res), [cls(a) for a in args])
         want = c[name]

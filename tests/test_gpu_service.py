@@ -1,0 +1,161 @@
+"""The resident search service (ss_service_*): the same booleans as the launch path and the oracle, the lease that bounds its
+residency, the routing of ss_search_device through it.  Every wait in the service is bounded on both sides; the tests carry
+a timeout all the same."""
+import os
+import random
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import sliceslice_rs_amd as m
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle as m
+    return m
+
+
+def test_service_answers_like_the_launch_path_and_the_oracle(ss, O):
+    rng = random.Random(7)
+    ln = (4 << 20) + 333
+    buf = torch.empty(ln + 32, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(buf, 0xC0FFEE)
+    torch.cuda.synchronize()
+    with ss.SearchService() as sv:
+        for mis in (0, 1, 7, 15):
+            t = buf[mis:mis + ln]
+            host = t.cpu().numpy()
+            hb = host.tobytes()
+            cases = [b"", b"\xff", hb[:1], hb[ln - 1:], hb[:16], hb[ln - 16:], hb[12345:12345 + 7], hb[ln // 2:ln // 2 + 33], hb[100:100 + 1500]]
+            for n in (2, 3, 5, 8, 13, 16, 17, 31, 64, 200):
+                at = rng.randrange(ln - n)
+                cases.append(hb[at:at + n])
+                miss = bytearray(hb[at:at + n])
+                miss[rng.randrange(n)] = 0xFF                   # 0xFF never occurs in the generated haystack
+                cases.append(bytes(miss))
+            for nd in cases:
+                s = ss.DynamicHipSearcher.new(nd)
+                want = O.OracleSearcher(nd).search_in(host)
+                assert sv.search_in(s, t) == want, (mis, len(nd), "service")
+                assert s.search_in(t) == want, (mis, len(nd), "launch path")
+            # every prefix length around the tile / piece edges, needle at the very end of the slice
+            for cut in (1, 15, 16, 17, 1023, 1024, 1025, 16383, 16384, 16385, 65536 + 5, ln):
+                sl = t[:cut]
+                for nd in (hb[max(0, cut - 16):cut], hb[:min(cut, 3)], b"\xff\x01"):
+                    s = ss.DynamicHipSearcher.new(nd)
+                    assert sv.search_in(s, sl) == O.OracleSearcher(nd).search_in(host[:cut]), (mis, cut, len(nd))
+        requests, launches = sv.counters()
+        assert requests > 300 and 1 <= launches <= 1 + requests // 2
+        # with_position and every position of a short needle
+        t = buf[:ln]
+        host = t.cpu().numpy()
+        nd = host[5000:5012].tobytes()
+        for pos in range(len(nd)):
+            s = ss.DynamicHipSearcher.with_position(nd, pos)
+            assert sv.search_in(s, t) is True
+        # a filter pair 16 or more apart belongs to the launch path
+        long_nd = host[777:777 + 100].tobytes()
+        s = ss.DynamicHipSearcher.new(long_nd)
+        s.set_filter(0, 99)
+        with pytest.raises(ss.SlicesliceError) as e:
+            sv.search_in(s, t)
+        assert e.value.code == ss.SS_ERR_ARGUMENT
+
+
+def test_service_sees_haystack_bytes_written_between_requests(ss):
+    """The kernel stays resident across requests, so nothing is invalidated for it by a kernel boundary: bytes written to the
+    haystack between two requests (by a copy that has completed) must be seen by the next request all the same."""
+    ln = 1 << 20
+    t = torch.zeros(ln, dtype=torch.uint8, device="cuda")
+    needle = bytes(range(1, 17))
+    pn = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+    s = ss.DynamicHipSearcher.new(needle)
+    rng = random.Random(3)
+    with ss.SearchService(workgroups=32) as sv:
+        assert sv.search_in(s, t) is False
+        for it in range(200):
+            at = rng.choice([0, ln - 16, rng.randrange(ln - 16)])
+            t[at:at + 16] = pn
+            torch.cuda.current_stream().synchronize()
+            assert sv.search_in(s, t) is True, (it, at)
+            t[at:at + 16] = 0
+            torch.cuda.current_stream().synchronize()
+            assert sv.search_in(s, t) is False, (it, at)
+
+
+def test_service_lease_bounds_the_residency(ss):
+    """Without requests the kernel leaves after its lease, so a device-wide wait cannot hang on it; the next request starts a new
+    residency (one more launch) and is answered like any other."""
+    t = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    t[-3:] = torch.tensor([7, 8, 9], dtype=torch.uint8)
+    torch.cuda.synchronize()
+    s = ss.DynamicHipSearcher.new(bytes([7, 8, 9]))
+    with ss.SearchService(workgroups=16, lease_ms=2.0) as sv:
+        assert sv.search_in(s, t) is True
+        assert sv.counters() == (1, 1)
+        t0 = time.perf_counter()
+        torch.cuda.synchronize()                             # waits for the service kernel too: at most the lease
+        assert time.perf_counter() - t0 < 1.0
+        time.sleep(0.05)
+        for it in range(20):
+            assert sv.search_in(s, t) is True
+            if it % 5 == 4:
+                time.sleep(0.02)                             # > lease: the kernel has left again
+        requests, launches = sv.counters()
+        assert requests == 21 and 4 <= launches <= 21, (requests, launches)
+        # a burst shares one residency
+        before = sv.counters()[1]
+        for _ in range(500):
+            assert sv.search_in(s, t) is True
+        assert sv.counters()[1] - before <= 2
+
+
+def test_default_service_routes_ss_search_device(ss, O):
+    ln = 1 << 20
+    t = torch.empty(ln, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(t, 0xFACADE)
+    torch.cuda.synchronize()
+    host = t.cpu().numpy()
+    present, absent = host[4321:4321 + 16].tobytes(), bytes([255] * 16)
+    with ss.SearchService() as sv:
+        sv.set_default(True)
+        sp, sa = ss.DynamicHipSearcher.new(present), ss.DynamicHipSearcher.new(absent)
+        for _ in range(50):
+            assert sp.search_in(t) is True and sa.search_in(t) is False
+        assert sv.counters()[0] == 100
+        # what does not qualify takes the launch path and is still right: a long haystack, a wide pair, a timed search
+        big = torch.zeros(32 << 20, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        assert sa.search_in(big) is False
+        wide = ss.DynamicHipSearcher.new(host[100:200].tobytes())
+        wide.set_filter(0, 99)
+        assert wide.search_in(t) is True
+        sp.set_timing(True)
+        assert sp.search_in(t) is True and sp.last_kernel_ms() > 0
+        assert sv.counters()[0] == 100
+        sv.set_default(False)
+        assert sa.search_in(t) is False and sv.counters()[0] == 100
+
+
+def test_parity_suites_in_service_mode():
+    """SLICESLICE_SERVICE=1: the library starts a service by itself and routes every qualifying ss_search_device call through it.
+    The known-answer, boundary and candidate-heavy suites must pass unchanged that way."""
+    env = dict(os.environ, SLICESLICE_SERVICE="1", SLICESLICE_SERVICE_LEASE_MS="5")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "kat or boundary or empty or memchr or candidate or beyond or flush or constructor or position"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
