@@ -136,6 +136,8 @@ static int latency(int calls)
                 "\"empty_kernel_plus_stream_sync\": %.2f, \"empty_kernel_launch_only\": %.2f, "
                 "\"mailbox_round_trip\": %.2f, \"mailbox_round_trip_min\": %.2f, \"rows\": [", calls, floor_us, launch_only_us, box_med, box_min);
     bool first = true;
+    ss_service *sv = nullptr;
+    CK(ss_service_start(0, 0.0, &sv));
     for (size_t len : sizes) {
         for (int w = 0; w < 200; ++w) rc |= ss_search_device(s, d_hay, len, st, &found);
         const double dev_absent = median_us(calls, [&] { rc |= ss_search_device(s, d_hay, len, st, &found); });
@@ -146,19 +148,26 @@ static int latency(int calls)
         const uint64_t p0 = pos;
         const double find_present = median_us(calls, [&] { rc |= ss_find_device(sp, d_hay, len, st, &pos); });
         const uint64_t p1 = pos;
+        for (int w = 0; w < 200; ++w) rc |= ss_service_search(sv, s, d_hay, len, &found);
+        const double svc_absent = median_us(calls, [&] { rc |= ss_service_search(sv, s, d_hay, len, &found); });
+        const int f2 = found;
+        const double svc_present = median_us(calls, [&] { rc |= ss_service_search(sv, sp, d_hay, len, &found); });
+        const int f3 = found;
         for (int w = 0; w < 50; ++w) rc |= ss_search_host(s, h_hay.data(), len, &found);
         const double host_absent = median_us(std::max(200, calls / 4), [&] { rc |= ss_search_host(s, h_hay.data(), len, &found); });
-        if (rc != 0 || f0 != 0 || f1 != 1 || p0 != SS_NPOS || p1 != 0) {
+        if (rc != 0 || f0 != 0 || f1 != 1 || f2 != 0 || f3 != 1 || p0 != SS_NPOS || p1 != 0) {
             std::fprintf(stderr, "latency: wrong answer (rc %d, found %d/%d, pos %llu/%llu): %s\n", rc, f0, f1,
                          (unsigned long long)p0, (unsigned long long)p1, ss_last_error());
             return 1;
         }
         std::printf("%s{\"haystack_bytes\": %zu, \"search_device_absent\": %.2f, \"search_device_present_at_0\": %.2f, "
-                    "\"find_device_absent\": %.2f, \"find_device_present_at_0\": %.2f, \"search_host_absent\": %.2f}",
-                    first ? "" : ", ", len, dev_absent, dev_present, find_absent, find_present, host_absent);
+                    "\"find_device_absent\": %.2f, \"find_device_present_at_0\": %.2f, \"search_host_absent\": %.2f, "
+                    "\"service_absent\": %.2f, \"service_present_at_0\": %.2f}",
+                    first ? "" : ", ", len, dev_absent, dev_present, find_absent, find_present, host_absent, svc_absent, svc_present);
         first = false;
     }
     std::printf("]}\n");
+    ss_service_stop(sv);
     ss_searcher_free(s);
     ss_searcher_free(sp);
     (void)hipStreamDestroy(st);
@@ -206,6 +215,32 @@ static int config1(const char *hay_path, const char *words_path, int iters)
         for (ss_searcher *s : searchers) CK(ss_search_device(s, d_hay, hay.size(), st, &found));
     const double per_call_ms = seconds_since(t0) / iters * 1e3;
 
+    // the same per-needle loop through the resident search service: no launch per search (ss_service_search), and once more
+    // through ss_search_device with the service installed as the device's default (adds the idle check of the caller's stream)
+    ss_service *sv = nullptr;
+    CK(ss_service_start(0, 0.0, &sv));
+    size_t svc_hits = 0;
+    for (ss_searcher *s : searchers) {                  // warm-up pass (starts the residency)
+        CK(ss_service_search(sv, s, d_hay, hay.size(), &found));
+        svc_hits += found != 0;
+    }
+    const auto ts = clk::now();
+    for (int it = 0; it < iters; ++it)
+        for (ss_searcher *s : searchers) CK(ss_service_search(sv, s, d_hay, hay.size(), &found));
+    const double service_ms = seconds_since(ts) / iters * 1e3;
+    CK(ss_service_set_default(sv, 1));
+    size_t routed_hits = 0;
+    const auto tr = clk::now();
+    for (int it = 0; it < iters; ++it)
+        for (ss_searcher *s : searchers) {
+            CK(ss_search_device(s, d_hay, hay.size(), st, &found));
+            routed_hits += found != 0;
+        }
+    const double routed_ms = seconds_since(tr) / iters * 1e3;
+    uint64_t svc_requests = 0, svc_launches = 0;
+    CK(ss_service_counters(sv, &svc_requests, &svc_launches));
+    ss_service_stop(sv);
+
     // the same loop as ONE launch: every needle range against the one haystack range
     const size_t W = words.size();
     std::vector<uint64_t> hb(W, 0), he(W, hay.size()), nb(W), ne(W);
@@ -238,16 +273,21 @@ static int config1(const char *hay_path, const char *words_path, int iters)
     for (int f : flags) bhits += f == 1;
     std::printf("{\"mode\": \"config1\", \"haystack_bytes\": %zu, \"needles\": %zu, \"hits\": %zu, \"batched_hits\": %zu, "
                 "\"per_call_ms_per_iteration\": %.3f, \"per_call_us_per_search\": %.3f, "
+                "\"service_ms_per_iteration\": %.3f, \"service_us_per_search\": %.3f, \"service_hits\": %zu, "
+                "\"service_routed_ms_per_iteration\": %.3f, \"service_requests\": %llu, \"service_kernel_launches\": %llu, "
                 "\"batched_ms_per_iteration\": %.4f, \"reference_published_ms\": 35.181, "
-                "\"note\": \"per-call = one ss_search_device (launch + stream wait + flag) per needle, natively; batched = one "
-                "ss_search_batched launch + flag read-back for all needles\"}\n",
-                hay.size(), W, hits, bhits, per_call_ms, per_call_ms * 1e3 / (double)W, batched_ms);
+                "\"note\": \"per-call = one ss_search_device (launch + completion word) per needle, natively; service = the same loop "
+                "through the resident search service (ss_service_search: no launch per search), routed = ss_search_device with that service "
+                "as the device's default; batched = one ss_search_batched launch + flag read-back for all needles\"}\n",
+                hay.size(), W, hits, bhits, per_call_ms, per_call_ms * 1e3 / (double)W, service_ms, service_ms * 1e3 / (double)W, svc_hits,
+                routed_ms, (unsigned long long)svc_requests, (unsigned long long)svc_launches, batched_ms);
     for (ss_searcher *s : searchers) ss_searcher_free(s);
     (void)hipFree(d_found);
     (void)hipFree(d_rng);
     (void)hipFree(d_words);
     (void)hipFree(d_hay);
     (void)hipStreamDestroy(st);
+    if (svc_hits != W || routed_hits != W * (size_t)iters) return 1;
     return (hits == W && bhits == W) ? 0 : 1;           // every word of words.txt occurs in i386.txt (tests/i386.rs:61-70)
 }
 
