@@ -1837,20 +1837,22 @@ __global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best)
 //   * the host writes the request - a whole Problem - into a 256-byte mailbox in pinned memory: four 64-byte lines, each 15
 //     payload dwords + the request's sequence number as its LAST dword.  A line read over PCIe is one snapshot, and x86
 //     stores become visible in order, so a line that shows the new number holds the new payload;
-//   * wave 0 of EVERY workgroup polls the mailbox itself - 64 lanes x 4 bytes, one instruction - and when all four lines
-//     show the next number makes the workgroup's caches forget what they hold of earlier requests' haystacks (one agent-scope
-//     acquire per workgroup), puts the payload into LDS and releases the other waves from the barrier they wait at.  (A first
-//     cut had one leader wave poll and hand the request to the others through device memory: two more memory round trips
-//     and a release / acquire pair per request - 8.3 us per search instead of the launch path's 8.2.)
-//   * workgroup b scans tiles b, b + grid, ... of the haystack with the same scan_tiles<> as every other kernel and stores
-//     sequence << 1 | found to ITS OWN 8-byte answer slot in pinned memory (a posted write: nothing on the device waits for
-//     it); the host has the answer when a slot says "found", or when all slots carry the request's number.
-// Residency is a LEASE: without a request for `idle_ticks` (100 MHz s_memrealtime) the leader (workgroup 0) stores "gone" to
-// the pinned state word and leaves; the others see that word with their next poll and leave too (a request that arrives
-// in that window may be scanned by some workgroups and not by others: the host, which watches the state word while it waits,
-// starts a new residency with the same request - a slot that carries the request's number is right whichever residency wrote
-// it).  Nothing that waits for the whole device - hipDeviceSynchronize, hipMalloc, hipFree - can therefore wait longer than
-// the lease.  Every spin in here is bounded.
+//   * ONE wave (the leader: wave 0 of workgroup 0) polls the mailbox - 64 lanes x 4 bytes, one instruction - and when all
+//     four lines show the next number hands the payload to the others through device memory (agent-scope 4-byte stores, a
+//     release fence, then the sequence word they all poll);
+//   * every workgroup scans tiles b, b + grid, ... of the haystack with the same scan_tiles<> as every other kernel, counts
+//     itself out exactly like a completion-word launch of scan_kernel, and the workgroup that completes the count stores
+//     found-count << 32 | sequence << 1 | found to the pinned answer word the host spins on.
+// Measured (tools/native_bench latency, profiles/r03/service_experiments.md): a search of a 1 KiB haystack costs 8.2-8.8 us through a
+// launch and 7.7-8.3 us through this service - the mailbox round trip is 1.5 us, but handing the request from the leader to the
+// workgroups (device-memory hop), the per-request acquire (2 us: without it - wrong in general - 6.0 us) and the count-out add
+// up to what the command processor costs.  Letting EVERY workgroup poll the pinned mailbox itself and answer into a slot of
+// its own (no device-side hop at all) was worse: 32 pollers on the PCIe link made a search 16 us.
+// Residency is a LEASE: without a request for `idle_ticks` (100 MHz s_memrealtime) the leader announces that it is leaving,
+// looks at the mailbox once more (a request posted meanwhile is served; host and device each write their word before
+// reading the other's), tells the others and the kernel ends; the host starts it again with its next request.  Nothing that
+// waits for the whole device - hipDeviceSynchronize, hipFree - can therefore wait longer than the lease.  Every spin in here
+// is bounded.
 struct ServiceRequest {
     Problem pr;
     uint32_t q;            // dword window of the second filter byte (the kernels' template parameter Q)
@@ -1859,73 +1861,84 @@ struct ServiceRequest {
     uint32_t pad_;
 };
 static_assert(sizeof(ServiceRequest) <= 240 && sizeof(ServiceRequest) % 8 == 0, "four mailbox lines of 60 payload bytes");
-constexpr uint32_t kSvcRunning = 1, kSvcGone = 3;
+constexpr uint32_t kSvcRunning = 1, kSvcLeaving = 2, kSvcExited = 3;
+constexpr unsigned long long kSvcStopSeq = ~0ull;
 
 template <int U>
 __global__ void __launch_bounds__(kBlock)
-service_kernel(const uint32_t *h_req, uint32_t *h_state, unsigned long long *h_slots, int *d_found, uint32_t first_seq,
-               unsigned long long idle_ticks, uint32_t generation)
+service_kernel(const uint32_t *h_req, uint32_t *h_status, unsigned long long *h_answer, uint32_t *d_box, unsigned long long *d_seq,
+               unsigned long long *d_done, int *d_found, uint32_t first_seq, unsigned long long idle_ticks)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
-    __shared__ __attribute__((aligned(16))) uint32_t s_req[64];
-    __shared__ int s_wg_found, s_go;
-    __shared__ uint32_t s_next;
+    __shared__ int s_wg_found;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const bool leader = blockIdx.x == 0;
-    constexpr unsigned long long kWorkerPatience = 300000000ull;           // 3 s of s_memrealtime: nobody waits longer than lease + this
-    // the state word is written by the leaders only, as generation << 2 | state: a workgroup of residency g leaves when it reads
-    // "g has gone" or anything of a later residency (the host never writes the word, so no reset can hide that from it)
-    if (leader && threadIdx.x == 0) __hip_atomic_store(h_state, (generation << 2) | kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool leader = blockIdx.x == 0 && wave == 0;
+    constexpr unsigned long long kWorkerPatience = 300000000ull;           // 3 s of s_memrealtime: a worker never waits longer
+    if (leader && lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (uint32_t next = first_seq;; ++next) {
-        // ---- 1. wave 0 waits for request `next` ---------------------------------------------------------------------------
-        if (wave == 0) {
-            int go = 0;
+        // ---- 1. the leader fetches request `next` and publishes it --------------------------------------------------
+        if (leader) {
+            auto poll = [&](uint32_t *v) {          // lane i <- dword i of the mailbox; true when all four lines carry `next`
+                *v = __hip_atomic_load(h_req + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return (uint32_t)__builtin_amdgcn_readlane((int)*v, 15) == next && (uint32_t)__builtin_amdgcn_readlane((int)*v, 31) == next &&
+                       (uint32_t)__builtin_amdgcn_readlane((int)*v, 47) == next && (uint32_t)__builtin_amdgcn_readlane((int)*v, 63) == next;
+            };
+            uint32_t v = 0;
+            bool have = false;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                // lane i <- dword i of the mailbox; the state word rides along (lane 0)
-                const uint32_t v = __hip_atomic_load(h_req + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const uint32_t st = lane == 0 ? __hip_atomic_load(h_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
-                // A workgroup that was dispatched late may find a NEWER request than the one it expects (the host moves on as soon
-                // as one slot says "found"): whatever lies between has been answered without it, so it joins at the current one.
-                const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
-                const bool have = (int32_t)(cur - next) >= 0 && (uint32_t)__builtin_amdgcn_readlane((int)v, 31) == cur &&
-                                  (uint32_t)__builtin_amdgcn_readlane((int)v, 47) == cur && (uint32_t)__builtin_amdgcn_readlane((int)v, 63) == cur;
-                if (have) {
-                    next = cur;
-                    // the haystack may have been rewritten since the previous request, and no kernel boundary has invalidated
-                    // anything for this kernel: one agent-scope acquire per workgroup
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    s_req[lane] = v;
-                    go = 1;
+            while (!(have = poll(&v))) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) {
+                    // the lease is over: say so, THEN look once more (the host posts its request, THEN reads this word)
+                    if (lane == 0) __hip_atomic_store(h_status, kSvcLeaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+                    have = poll(&v);
+                    if (have && lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
-                const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t0;
-                const uint32_t stu = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
-                const bool told = stu == ((generation << 2) | kSvcGone) || (int32_t)((stu >> 2) - generation) > 0;
-                if (leader ? waited > idle_ticks : (told || waited > idle_ticks + kWorkerPatience))
-                    break;                                                 // the lease is over / the leader has said so
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (lane == 0) {
-                __hip_atomic_store(&s_go, go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&s_next, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the stop flag travels in the payload (dword 50 + 50/15 = mailbox dword 53 of a 200-byte Problem + q + one_byte)
+            constexpr int kStopPayloadDword = (int)(offsetof(ServiceRequest, stop) / 4);
+            constexpr int kStopLane = kStopPayloadDword + kStopPayloadDword / 15;
+            const bool stop = !have || __builtin_amdgcn_readlane((int)v, kStopLane) != 0;
+            if (!stop) {
+                if ((lane & 15) != 15) __hip_atomic_store(d_box + (lane - (lane >> 4)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // agent-scope atomic stores are performed beyond the XCD's L2 and acknowledged when they are: waiting for the
+                // acknowledgements orders them in front of the sequence word (a release fence - an L2 write-back on top - does
+                // the same for 0.1-0.6 us more per request)
+                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (lane == 0)
+                __hip_atomic_store(d_seq, stop ? kSvcStopSeq : (unsigned long long)next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- 2. everybody waits for the sequence word ------------------------------------------------------------------
+        unsigned long long seen;
+        {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                seen = uniform64(__hip_atomic_load(d_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen == kSvcStopSeq || (uint32_t)seen == next) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks + kWorkerPatience) {
+                    seen = kSvcStopSeq;                                  // the leader is gone: leave, do not hang
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
             }
         }
-        __syncthreads();
-        if (__hip_atomic_load(&s_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) break;
-        next = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&s_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        // ---- 2. the request, out of LDS into scalar registers (mailbox dword j + j/15 holds payload dword j) -----------------
+        if (seen == kSvcStopSeq) break;
+        // ---- 3. the request, out of device memory into scalar registers ------------------------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         constexpr int kDwords = (int)(sizeof(ServiceRequest) / 4);
+        const uint32_t mine = lane < kDwords ? __hip_atomic_load(d_box + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         union {
             ServiceRequest rq;
             uint32_t w[kDwords];
         } u;
 #pragma unroll
-        for (int k = 0; k < kDwords; ++k) u.w[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_req[k + k / 15]);
+        for (int k = 0; k < kDwords; ++k) u.w[k] = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
         const ServiceRequest &rq = u.rq;
-        if (rq.stop) break;
-        // ---- 3. scan: workgroup b takes tiles b, b + grid, ... -------------------------------------------------------------
+        // ---- 4. scan: workgroup b takes tiles b, b + grid, ... -------------------------------------------------------------
         if (threadIdx.x == 0) __hip_atomic_store(&s_wg_found, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         const uint64_t ntiles = (rq.pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
@@ -1940,14 +1953,21 @@ service_kernel(const uint32_t *h_req, uint32_t *h_state, unsigned long long *h_s
             default: scan_tiles<3, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
             }
         }
-        // ---- 4. this workgroup's answer: a posted write to its own pinned slot --------------------------------------------------
+        // ---- 5. count out; the workgroup that completes the count answers (scan_kernel's completion word) ---------------
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long f = (unsigned long long)__hip_atomic_load(&s_wg_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(h_slots + blockIdx.x, ((unsigned long long)next << 1) | (f ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long one = 1ull + (f << 32);
+            const unsigned long long total = __hip_atomic_fetch_add(d_done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + one;
+            if ((uint32_t)total == rq.pr.done_target) {
+                const uint32_t hi = (uint32_t)(total >> 32);
+                __hip_atomic_store(h_answer, ((unsigned long long)hi << 32) | ((unsigned long long)next << 1) | (hi != rq.pr.done_hi ? 1ull : 0ull),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
+        __syncthreads();
     }
-    if (leader && threadIdx.x == 0) __hip_atomic_store(h_state, (generation << 2) | kSvcGone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (leader && lane == 0) __hip_atomic_store(h_status, kSvcExited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Mailbox round trip (ss_mailbox_round_trip_us): ONE lane answers `iters` requests posted by the host to pinned memory -

@@ -1949,36 +1949,40 @@ struct ss_service {
     int workgroups = 0;
     unsigned long long idle_ticks = 0;
     hipStream_t stream = nullptr;
-    uint32_t *h_box = nullptr;              // pinned: request (4 lines of 64 bytes) | state (1 line) | one 8-byte answer slot per workgroup
-    int *d_found = nullptr;                 // device flag the scan polls (never set: the answer travels in the slots)
+    uint32_t *h_box = nullptr;              // pinned, 6 lines of 64 bytes: request (4) | status | answer
+    uint8_t *d_mem = nullptr;               // device: box (256 B) | seq | done counter | found flag
     uint32_t seq = 0;                       // last request posted
-    uint32_t generation = 0;                // residencies started so far (< 2^30: one per lease at most)
+    uint32_t done_low = 0, done_hi = 0;     // the never-reset completion counter, as the host knows it
     uint64_t requests = 0, launches = 0;
     std::mutex mu;
-    volatile uint32_t *state() const { return h_box + 64; }
-    volatile unsigned long long *slots() const { return reinterpret_cast<volatile unsigned long long *>(h_box + 80); }
-    size_t box_bytes() const { return 320 + (size_t)workgroups * 8; }
+    volatile uint32_t *status() const { return h_box + 64; }
+    volatile unsigned long long *answer() const { return reinterpret_cast<volatile unsigned long long *>(h_box + 80); }
+    uint32_t *d_box() const { return reinterpret_cast<uint32_t *>(d_mem); }
+    unsigned long long *d_seq() const { return reinterpret_cast<unsigned long long *>(d_mem + 256); }
+    unsigned long long *d_done() const { return reinterpret_cast<unsigned long long *>(d_mem + 264); }
+    int *d_found() const { return reinterpret_cast<int *>(d_mem + 272); }
 };
 
 namespace {
 
-constexpr int kServiceDefaultWorkgroups = 32;
+constexpr int kServiceDefaultWorkgroups = 64;
 constexpr double kServiceDefaultLeaseMs = 20.0;
 std::atomic<ss_service *> g_default_service[kMaxDevices];
 
 int service_launch(ss_service *sv, uint32_t first_seq)
 {
-    ++sv->generation;                                                   // (the state word is the kernel's to write: see service_kernel)
+    __atomic_store_n(sv->status(), 0u, __ATOMIC_RELAXED);
+    HIP_TRY(hipMemsetAsync(sv->d_seq(), 0, sizeof(unsigned long long), sv->stream));   // (ordered behind the previous residency's end)
     ss::service_kernel<4><<<dim3((unsigned)sv->workgroups), dim3(ss::kBlock), 0, sv->stream>>>(
-        sv->h_box, const_cast<uint32_t *>(sv->state()), const_cast<unsigned long long *>(sv->slots()), sv->d_found, first_seq, sv->idle_ticks,
-        sv->generation);
+        sv->h_box, const_cast<uint32_t *>(sv->status()), const_cast<unsigned long long *>(sv->answer()), sv->d_box(), sv->d_seq(), sv->d_done(),
+        sv->d_found(), first_seq, sv->idle_ticks);
     HIP_TRY(hipGetLastError());
     ++sv->launches;
     return SS_OK;
 }
 
-// Posts one request and waits for its answer (a stop request: for the kernel to say it has gone).
-int service_post(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq, int *found)
+// Posts one request and waits for its answer word (or, for a stop request, for the kernel to say it has left).
+int service_post(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq, unsigned long long *answer)
 {
     uint32_t payload[60] = {0};
     memcpy(payload, &rq, sizeof rq);
@@ -1987,41 +1991,32 @@ int service_post(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq, int
         for (int j = 0; j < 15; ++j) __atomic_store_n(m + line * 16 + j, payload[line * 15 + j], __ATOMIC_RELAXED);
         __atomic_store_n(m + line * 16 + 15, seq, __ATOMIC_RELEASE);      // a line that shows `seq` holds this request's payload
     }
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    uint32_t st = __atomic_load_n(sv->state(), __ATOMIC_ACQUIRE);
-    if (sv->launches == 0) {
-        if (rq.stop) return SS_OK;                                       // never started: nothing to stop
-        if (int rc = service_launch(sv, seq)) return rc;                 // first request of this service
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);                              // the request first, THEN the kernel's state (see service_kernel)
+    uint32_t st = __atomic_load_n(sv->status(), __ATOMIC_ACQUIRE);
+    if (rq.stop && (st == 0 || st == ss::kSvcExited) && sv->launches == 0) return SS_OK;   // never started: nothing to stop
+    bool launched_now = false;
+    if (st == 0 && sv->launches == 0) {                                  // first request of this service
+        if (int rc = service_launch(sv, seq)) return rc;
+        launched_now = true;
     }
-    const int W = sv->workgroups;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         if (!rq.stop) {
-            // "found" in ANY slot of this request is the answer; "not found" needs every slot
-            int done = 0;
-            for (int w = 0; w < W; ++w) {
-                const unsigned long long a = __atomic_load_n(sv->slots() + w, __ATOMIC_ACQUIRE);
-                if ((uint32_t)(a >> 1) != seq) continue;
-                if (a & 1) {
-                    *found = 1;
-                    return SS_OK;
-                }
-                ++done;
-            }
-            if (done == W) {
-                *found = 0;
+            const unsigned long long a = __atomic_load_n(sv->answer(), __ATOMIC_ACQUIRE);
+            if ((uint32_t)((a >> 1) & 0x7FFFFFFFu) == seq) {
+                *answer = a;
                 return SS_OK;
             }
         }
-        st = __atomic_load_n(sv->state(), __ATOMIC_ACQUIRE);
-        if (st == ((sv->generation << 2) | ss::kSvcGone)) {
+        st = __atomic_load_n(sv->status(), __ATOMIC_ACQUIRE);
+        if (st == ss::kSvcExited) {
             if (rq.stop) return SS_OK;
-            // the lease ran out before (all of) the kernel saw this request: a new residency starts with it.  Slots that already
-            // carry this request's number stay valid - same tiles, same bytes.
+            // the lease ran out before the kernel saw this request: a new residency starts with it
             if (int rc = service_launch(sv, seq)) return rc;
+            launched_now = true;
         }
         cpu_relax();
-        if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(launched_now ? 20 : 10))
             return fail(SS_ERR_HIP, "search service: no answer to request %u (kernel state %u)", seq, st);
     }
 }
@@ -2033,7 +2028,7 @@ void service_free(ss_service *sv)
         (void)hipStreamDestroy(sv->stream);
     }
     (void)hipHostFree(sv->h_box);
-    (void)hipFree(sv->d_found);
+    (void)hipFree(sv->d_mem);
     delete sv;
 }
 
@@ -2060,10 +2055,10 @@ int ss_service_start(int workgroups, double lease_ms, ss_service **out)
     sv->workgroups = workgroups;
     sv->idle_ticks = (unsigned long long)(lease_ms * 1e5);             // s_memrealtime: 100 MHz
     hipError_t e = hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&sv->h_box, sv->box_bytes(), hipHostMallocPortable | hipHostMallocMapped);
-    if (e == hipSuccess) memset(sv->h_box, 0, sv->box_bytes());
-    if (e == hipSuccess) e = hipMalloc((void **)&sv->d_found, 64);
-    if (e == hipSuccess) e = hipMemset(sv->d_found, 0, 64);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sv->h_box, 6 * 64, hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) memset(sv->h_box, 0, 6 * 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&sv->d_mem, 512);
+    if (e == hipSuccess) e = hipMemset(sv->d_mem, 0, 512);
     if (e != hipSuccess) {
         service_free(sv);
         return fail(SS_ERR_HIP, "search service set-up: %s", hipGetErrorString(e));
@@ -2092,26 +2087,30 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
     rq.q = (uint32_t)((ps.position % 16) / 4);
     rq.one_byte = ps.one_byte ? 1u : 0u;
     std::lock_guard<std::mutex> lock(sv->mu);
-    if (sv->seq >= 0x7FFFFF00u) {
-        // sequence numbers (31 bits in the answer slots) about to run out: a fresh start
+    if (sv->seq >= 0x7FFFFF00u || sv->done_low > kDoneLowMax) {
+        // sequence numbers (31 bits in the answer word) or the workgroup count about to run out: a fresh start
         ss::ServiceRequest bye;
         memset(&bye, 0, sizeof bye);
         bye.stop = 1;
-        int ignored = 0;
+        unsigned long long ignored = 0;
         if (int rc = service_post(sv, bye, ++sv->seq, &ignored)) return rc;
         HIP_TRY(hipStreamSynchronize(sv->stream));
-        memset(sv->h_box, 0, sv->box_bytes());
-        sv->seq = 0;
+        HIP_TRY(hipMemset(sv->d_mem, 0, 512));
+        memset(sv->h_box, 0, 6 * 64);
+        sv->seq = sv->done_low = sv->done_hi = 0;
         sv->launches = 0;
-        sv->generation = 0;
     }
     const uint32_t seq = ++sv->seq;
     rq.pr.epoch = (int)seq;
-    rq.pr.flags = ss::kProblemCounted;                      // small-grid behaviour: the workgroup's LDS flag, no device flag, no peeks
-    int f = 0;
-    if (int rc = service_post(sv, rq, seq, &f)) return rc;
+    rq.pr.flags = ss::kProblemCounted;
+    rq.pr.done_target = sv->done_low + (uint32_t)sv->workgroups;
+    rq.pr.done_hi = sv->done_hi;
+    unsigned long long a = 0;
+    if (int rc = service_post(sv, rq, seq, &a)) return rc;
+    sv->done_low = rq.pr.done_target;
+    sv->done_hi = (uint32_t)(a >> 32);
     ++sv->requests;
-    *found = f;
+    *found = (int)(a & 1);
     return SS_OK;
 }
 
@@ -2181,7 +2180,7 @@ void ss_service_stop(ss_service *sv)
         ss::ServiceRequest bye;
         memset(&bye, 0, sizeof bye);
         bye.stop = 1;
-        int ignored = 0;
+        unsigned long long ignored = 0;
         (void)service_post(sv, bye, ++sv->seq, &ignored);      // (a kernel that does not answer leaves when its lease runs out)
         service_free(sv);
     }

@@ -135,9 +135,15 @@ def test_default_service_routes_ss_search_device(ss, O):
     with ss.SearchService() as sv:
         sv.set_default(True)
         sp, sa = ss.DynamicHipSearcher.new(present), ss.DynamicHipSearcher.new(absent)
-        for _ in range(50):
-            assert sp.search_in(t) is True and sa.search_in(t) is False
+        # the service is used only when the caller's stream is idle (it cannot be ordered behind pending work); the legacy default
+        # stream never reports idle while another kernel - the service itself - is running, so the callers here bring a stream
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(50):
+                assert sp.search_in(t) is True and sa.search_in(t) is False
         assert sv.counters()[0] == 100
+        for _ in range(5):                                   # default stream: launch path, same answers
+            assert sp.search_in(t) is True and sa.search_in(t) is False
         # what does not qualify takes the launch path and is still right: a long haystack, a wide pair, a timed search
         big = torch.zeros(32 << 20, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
