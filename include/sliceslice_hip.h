@@ -149,6 +149,10 @@ int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t le
  * set that lives for the rest of the process and is lent to one call at a time (a concurrent call on the
  * same device builds and frees a private set), so a small haystack costs tens of microseconds per call. */
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
+/* The same over SEVERAL GPUs, from one process, without a collective: the host slice is range-partitioned (ss_shard_range, n-1
+ * bytes of overlap) and every listed device uploads and scans its own range over its own PCIe link (one host thread per
+ * device running ss_search_host); the booleans are OR-ed on the host.  devs == NULL: devices 0 .. ndev-1. */
+int ss_search_host_all(const ss_searcher *s, const uint8_t *haystack, size_t len, int ndev, const int *devs, int *found);
 /* Slices of up to 64 KiB take a shorter road (ss_find_host too): the CPU copies them into a pinned, device-visible
  * buffer of the calling thread and the kernel reads them over PCIe - no upload command (10-12 us per call instead of
  * 16-24; SLICESLICE_HOST_ZERO_COPY=0 switches it off). */
@@ -185,6 +189,13 @@ int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256]
 int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
                       const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
                       const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
+
+/* Row f1 for a whole batch: the LEFTMOST offset of needle i in haystack i (SS_NPOS: absent; the empty needle: 0) - the
+ * `Option<usize>` shape of bench/sse4-strstr/src/lib.rs:4-15 for many problems in one call.  Same ranges, same plan kernel and
+ * scan grid as ss_search_batched (the `new` position for every problem); d_position: `count` uint64 in device memory. */
+int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                    const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                    size_t count, void *hip_stream, uint64_t *d_position);
 
 /* Same contract, one LANE per problem: the reference's short-haystack workload
  * (bench/benches/i386.rs:118-129: 10,513,405 word-in-word searches of <= 24 bytes).  Use it when the

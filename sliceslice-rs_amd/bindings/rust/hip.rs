@@ -103,6 +103,9 @@ extern "C" {
     pub fn ss_debug_set_completion_state(s: *mut ss_searcher, workgroups: u32, found_workgroups: u32, find_key: u32) -> c_int;
     pub fn ss_debug_set_comm_epoch(c: *mut ss_comm, set: *mut ss_comm_set, value: c_int) -> c_int;
     pub fn ss_debug_fail_next_scans(s: *mut ss_searcher, count: c_int) -> c_int;
+    pub fn ss_find_batched(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
+                           d_needle_begin: *const u64, d_needle_end: *const u64, count: usize, hip_stream: *mut c_void, d_position: *mut u64) -> c_int;
+    pub fn ss_search_host_all(s: *const ss_searcher, haystack: *const u8, len: usize, ndev: c_int, devs: *const c_int, found: *mut c_int) -> c_int;
     pub fn ss_mailbox_round_trip_us(iters: c_int, median_us: *mut f64, min_us: *mut f64) -> c_int;
     pub fn ss_service_start(workgroups: c_int, lease_ms: f64, out: *mut *mut ss_service) -> c_int;
     pub fn ss_service_search(sv: *mut ss_service, s: *const ss_searcher, d_haystack: *const c_void, len: usize, found: *mut c_int) -> c_int;

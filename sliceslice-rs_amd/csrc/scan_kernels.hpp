@@ -1257,7 +1257,8 @@ struct BatchArgs {
     const uint8_t *needles;
     const uint64_t *needle_begin, *needle_end;
     const uint64_t *position;   // may be null: n_i - 1
-    int *found;
+    int *found;                 // search: one int32 flag per problem
+    uint64_t *best;             // find (ss_find_batched): one uint64 leftmost offset per problem (all ones = absent); else null
 };
 constexpr int kBadPosition = -1;   // SS_BATCH_BAD_POSITION: flag of a problem whose position breaks the with_position rules
 
@@ -1533,7 +1534,8 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         eff = eff < nslices ? (eff ? eff : 1) : nslices;
         d.per = (eff << 32) | ((ntiles + eff - 1) / eff);
     }
-    a.found[prob] = flag;
+    if (a.best) a.best[prob] = n == 0 ? 0ull : ~0ull;      // the empty needle matches at offset 0 of every haystack
+    else a.found[prob] = flag;
     descs[prob] = d;
 }
 
@@ -1580,7 +1582,9 @@ struct ColdInDesc {
 //     (1,024 x 1 MiB: 150 us instead of 162, kernel time) - and when one of them finds the needle the others are at the same
 //     depth and stop at their next poll.
 constexpr uint32_t kPlanSliceMajorMax = 8;
-template <int U>
+// FIND: the sink is the problem's uint64 (leftmost offset, atomicMin); a workgroup skips only what lies right of the best so far
+// (scan_tiles does that tile by tile, so the slice-major entry poll is not needed).
+template <int U, bool FIND = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock)
 scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices)
 {
@@ -1595,11 +1599,12 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         prob = w / nslices;
         slice = w - prob * nslices;
     }
-    int *found = a.found + prob;
+    int *found = FIND ? nullptr : a.found + prob;
+    void *sink = FIND ? static_cast<void *>(a.best + prob) : static_cast<void *>(found);
     const BatchDesc *dp = descs + prob;
     // slice-major, later slices: the problem's flag (one coherent load) is requested together with the descriptor (one scalar
     // load, s_load_dwordx16) - one round trip decides whether and what to scan
-    const int seen = slice_major && slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int seen = !FIND && slice_major && slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const BatchDesc d = *dp;
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
@@ -1636,14 +1641,14 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     pr.flags = 0;
     const ColdInDesc cold = {dp, a.needles};
     if ((d.bytes >> 24) & 1) {
-        scan_tiles<0, 0, true, U, 1, false, false, true>(pr, cold, s_needle, t0, step, te, found);
+        scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink);
         return;
     }
     switch ((d.shifts >> 6) & 3) {                  // single stream, non-temporal loads
-    case 0: scan_tiles<0, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, step, te, found); break;
-    case 1: scan_tiles<1, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, step, te, found); break;
-    case 2: scan_tiles<2, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, step, te, found); break;
-    default: scan_tiles<3, 0, false, U, 1, false, false, true>(pr, cold, s_needle, t0, step, te, found); break;
+    case 0: scan_tiles<0, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
+    case 1: scan_tiles<1, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
+    case 2: scan_tiles<2, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
+    default: scan_tiles<3, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
     }
 }
 
@@ -1789,44 +1794,37 @@ __global__ void __launch_bounds__(kBlock) byte_histogram_kernel(const uint8_t *h
     }
 }
 
-// Stream-ordered behind a scan (and the all-reduce of a sharded search): the answer word - epoch << 1 | found - for a host
-// that spins on pinned memory instead of waiting for the stream's completion signal (some 30 us quicker on this stack).
-__global__ void signal_flag_kernel(const int *d_flag, int epoch, long long *h_word)
+// Stream-ordered behind a scan (and the all-reduce of a sharded search): the answer word for a host that spins on pinned memory
+// instead of waiting for the stream's completion signal (some 30 us quicker on this stack).  pair == 0: epoch << 1 | found.
+// pair != 0 (behind the all-reduce(MAX) of a sharded search, whose flag is a PAIR - {found, a rank failed its local part}, both
+// epoch-valued): epoch << 2 | failed << 1 | found.
+__global__ void signal_flag_kernel(const int *d_flag, int epoch, long long *h_word, int pair)
 {
-    const int f = __hip_atomic_load(d_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-    __hip_atomic_store(h_word, (long long)(((unsigned long long)(uint32_t)epoch << 1) | (unsigned long long)f), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long f = __hip_atomic_load(d_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    unsigned long long w = ((unsigned long long)(uint32_t)epoch << 1) | f;
+    if (pair) {
+        const unsigned long long e = __hip_atomic_load(d_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+        w = ((unsigned long long)(uint32_t)epoch << 2) | (e << 1) | f;
+    }
+    __hip_atomic_store(h_word, (long long)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// The same behind the all-reduce(MAX) of a sharded search, whose flag is a PAIR - {found, a rank failed its local part},
-// both epoch-valued: epoch << 2 | failed << 1 | found.
-__global__ void signal_shard_kernel(const int *d_pair, int epoch, long long *h_word)
-{
-    const unsigned long long f = __hip_atomic_load(d_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-    const unsigned long long e = __hip_atomic_load(d_pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-    __hip_atomic_store(h_word, (long long)(((unsigned long long)(uint32_t)epoch << 2) | (e << 1) | f), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// ... and behind the all-reduce(MIN) of a sharded find: {leftmost offset, all ones unless a rank failed}.  The status word
-// first, the offset - the word the host spins on - behind it with release ordering.
-__global__ void publish_shard_best_kernel(const uint64_t *d_pair, uint64_t *h_pair)
-{
-    const uint64_t v = __hip_atomic_load(d_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t ok = __hip_atomic_load(d_pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(h_pair + 1, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(h_pair, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// find(): hands the final minimum to the host through its pinned mirror (one system-scope store), stream-ordered
-// behind the scan - the read-back of ss_find_device without a device-to-host copy command - and re-arms the
-// slot (all ones) for its next user.  Re-arm FIRST, publish second: the host releases the slot the moment the pinned
-// word changes, and the next find() on the slot may run on another stream - its atomicMin must never meet a re-arm store
-// that is still in flight (the release ordering of the system-scope store waits for the re-arm).
-__global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best)
+// find(): hands the final minimum to the host through its pinned mirror (one system-scope store), stream-ordered behind the scan
+// - the read-back of ss_find_device without a device-to-host copy command.
+// pair == 0 (ss_find_device): the slot is re-armed (all ones) for its next user - re-arm FIRST, publish second: the host releases
+//   the slot the moment the pinned word changes, and the next find() on the slot may run on another stream; its atomicMin must
+//   never meet a re-arm store that is still in flight (the release ordering of the system-scope store waits for the re-arm).
+// pair != 0 (behind the all-reduce(MIN) of a sharded find): {leftmost offset, all ones unless a rank failed}; nothing to re-arm
+//   (the pair is the communicator's scratch); the status word first, the offset - the word the host spins on - behind it.
+__global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best, int pair)
 {
     const uint64_t v = __hip_atomic_load(d_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v != ~0ull) __hip_atomic_store(d_best, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pair) {
+        const uint64_t ok = __hip_atomic_load(d_best + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(h_best + 1, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (v != ~0ull) {
+        __hip_atomic_store(d_best, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __hip_atomic_store(h_best, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -25,6 +25,7 @@
 #include <unistd.h>
 #include <deque>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -1014,7 +1015,7 @@ bool spin_for_word(const long long *word, int epoch, double estimate_us, int *fo
     }
 }
 
-// The answer word of a sharded search (signal_shard_kernel): epoch << 2 | "a rank failed" << 1 | found.
+// The answer word of a sharded search (signal_flag_kernel (pair form)): epoch << 2 | "a rank failed" << 1 | found.
 bool spin_for_shard_word(const long long *word, int epoch, double estimate_us, int *found, int *failed)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -1102,7 +1103,7 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     }
     if (rc == SS_OK && !used_done && spin_ok && scan_estimate_us(len) <= kSpinMaxEstimateUs) {
         // larger grid: the word is written by a one-lane kernel behind the scan
-        ss::signal_flag_kernel<<<1, 1, 0, st>>>(pd->d_flags + k, epoch, pd->h_done + k);
+        ss::signal_flag_kernel<<<1, 1, 0, st>>>(pd->d_flags + k, epoch, pd->h_done + k, 0);
         if (hipGetLastError() == hipSuccess && spin_for_word(pd->h_done + k, epoch, scan_estimate_us(len), found)) {
             answered = true;
             if ((epoch & 255) == 0) (void)hipStreamSynchronize(st);
@@ -1189,7 +1190,7 @@ int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, voi
         // by spinning (see spin_for_word) is: the one-lane kernel's store ends the wait
         constexpr uint64_t kPending = ~0ull - 1;
         __atomic_store_n(pd->h_best + k, kPending, __ATOMIC_RELAXED);
-        ss::publish_best_kernel<<<1, 1, 0, st>>>(pd->d_best + k, pd->h_best + k);
+        ss::publish_best_kernel<<<1, 1, 0, st>>>(pd->d_best + k, pd->h_best + k, 0);
         hipError_t e = hipGetLastError();
         bool have = false;
         if (e == hipSuccess && spin_ok && scan_estimate_us(len) <= kSpinMaxEstimateUs) {
@@ -1379,6 +1380,49 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     release_slot(s, pd, k);
     if (rc == SS_OK) *found = result;
     return rc;
+}
+
+// The literal search_in(&[u8]) (src/x86.rs:523) for a HOST slice over several GPUs: the slice is range-partitioned (n-1 bytes of
+// overlap, ss_shard_range) and every device uploads and scans ITS range over ITS OWN PCIe link - one host thread per device,
+// each running ss_search_host on its range with that device current - and the booleans are OR-ed on the host.  No
+// collective: nothing but the found flag is combined, and all of it happens in this process.  PCIe-bound like
+// ss_search_host, G links wide: on an 8-GPU node ~8 x 55 GB/s, above what all cores of the host reach with the reference's
+// own AVX2 path (bench.py cpu_baseline: 300-580 GB/s on 2 x EPYC 9575F).  devs == NULL: devices 0 .. ndev-1; a device may be
+// listed more than once (its ranges are then uploaded through private staging sets).
+int ss_search_host_all(const ss_searcher *s, const uint8_t *haystack, size_t len, int ndev, const int *devs, int *found)
+{
+    if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (len && !haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    if (s->n == 0) { *found = 1; return SS_OK; }
+    if (len < s->n) { *found = 0; return SS_OK; }
+    int visible = 0;
+    HIP_TRY(hipGetDeviceCount(&visible));
+    if (ndev < 1 || ndev > 64) return fail(SS_ERR_ARGUMENT, "1 .. 64 devices");
+    for (int g = 0; g < ndev; ++g) {
+        const int d = devs ? devs[g] : g;
+        if (d < 0 || d >= visible) return fail(SS_ERR_ARGUMENT, "device %d out of range (%d visible)", d, visible);
+    }
+    SearchGate gate(s);
+    std::vector<int> rcs((size_t)ndev, SS_OK), flags((size_t)ndev, 0);
+    std::vector<std::string> msgs((size_t)ndev);
+    std::vector<std::thread> pool;
+    for (int g = 0; g < ndev; ++g)
+        pool.emplace_back([&, g]() {
+            size_t b = 0, e = 0;
+            int rc = ss_shard_range(len, s->n, ndev, g, &b, &e);
+            if (rc == SS_OK && hipSetDevice(devs ? devs[g] : g) != hipSuccess) rc = fail(SS_ERR_HIP, "hipSetDevice(%d) failed", devs ? devs[g] : g);
+            if (rc == SS_OK && e - b >= s->n) rc = ss_search_host(s, haystack + b, e - b, &flags[(size_t)g]);
+            rcs[(size_t)g] = rc;
+            if (rc != SS_OK) msgs[(size_t)g] = g_err;          // (the message lives in the worker thread's buffer)
+        });
+    for (auto &t : pool) t.join();
+    int any = 0;
+    for (int g = 0; g < ndev; ++g) {
+        if (rcs[(size_t)g] != SS_OK) return fail(rcs[(size_t)g], "device %d: %s", devs ? devs[g] : g, msgs[(size_t)g].c_str());
+        any |= flags[(size_t)g];
+    }
+    *found = any;
+    return SS_OK;
 }
 
 // find() for a host haystack: the chunked upload of ss_search_host with the uint64 best-offset sink.
@@ -1681,8 +1725,7 @@ static int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint
                            const uint64_t *d_hay_end, const void *d_needles, const uint64_t *d_needle_begin,
                            const uint64_t *d_needle_end, const uint64_t *d_position, int *d_found)
 {
-    if (!d_hay_begin || !d_hay_end || !d_needle_begin || !d_needle_end || !d_found)
-        return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (!d_hay_begin || !d_hay_end || !d_needle_begin || !d_needle_end) return fail(SS_ERR_ARGUMENT, "NULL argument");
     a->haystacks = static_cast<const uint8_t *>(d_haystacks);
     a->hay_begin = d_hay_begin;
     a->hay_end = d_hay_end;
@@ -1691,19 +1734,41 @@ static int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint
     a->needle_end = d_needle_end;
     a->position = d_position;
     a->found = d_found;
+    a->best = nullptr;
     return SS_OK;
 }
+
+static int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st);
 
 int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
                       const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
                       const uint64_t *d_position, size_t count, void *hip_stream, int *d_found)
 {
     if (count == 0) return SS_OK;
+    if (!d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
     ss::BatchArgs a;
     if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end,
                                  d_position, d_found))
         return rc;
-    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    return launch_batched(a, count, static_cast<hipStream_t>(hip_stream));
+}
+
+/* Row f1 for many problems: the leftmost offset per problem (SS_NPOS: absent), the `Option<usize>` shape of
+ * bench/sse4-strstr/src/lib.rs:4-15 for a whole batch - same plan kernel, same scan grid, FIND instantiation. */
+int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end, const void *d_needles,
+                    const uint64_t *d_needle_begin, const uint64_t *d_needle_end, size_t count, void *hip_stream, uint64_t *d_position)
+{
+    if (count == 0) return SS_OK;
+    if (!d_position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    ss::BatchArgs a;
+    if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end, nullptr, nullptr))
+        return rc;
+    a.best = d_position;
+    return launch_batched(a, count, static_cast<hipStream_t>(hip_stream));
+}
+
+static int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
+{
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     DeviceInfo di;
@@ -1733,8 +1798,11 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
                                                                                       min_tiles, ss::kWavesPerBlock * 4);
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) {
-                ss::scan_batched_plan_kernel<4><<<dim3((unsigned)((uint64_t)count * slices)), dim3(ss::kBlock), batch_lds_pad(), st>>>(
-                    a, descs, (uint32_t)count, (uint32_t)slices);
+                const dim3 grid((unsigned)((uint64_t)count * slices));
+                if (a.best)
+                    ss::scan_batched_plan_kernel<4, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, (uint32_t)slices);
+                else
+                    ss::scan_batched_plan_kernel<4, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, (uint32_t)slices);
                 e = hipGetLastError();
             }
             ps->mu.unlock();
@@ -1748,7 +1816,8 @@ int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, cons
 #ifndef SS_TUNING_VARIANTS
     return fail(SS_ERR_ARGUMENT, "SLICESLICE_BATCH_PLAN=0 selects the single-kernel form, which is part of the tuning build only");
 #else
-    HIP_TRY(hipMemsetAsync(d_found, 0, count * sizeof(int), st));
+    if (a.best) return fail(SS_ERR_ARGUMENT, "ss_find_batched has the planned form only");
+    HIP_TRY(hipMemsetAsync(a.found, 0, count * sizeof(int), st));
     // Single-kernel form (tuning build: the reference point of tools/batch_tune.py).  The haystack lengths live on the device,
     // so the grid is chosen from the problem count alone: 96 workgroups per CU in total; every workgroup rebuilds its problem's
     // descriptor from the range arrays (a chain of three dependent round trips in front of its first haystack load).
@@ -1771,6 +1840,7 @@ int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const 
                     const uint64_t *d_position, size_t count, void *hip_stream, int *d_found)
 {
     if (count == 0) return SS_OK;
+    if (!d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
     ss::BatchArgs a;
     if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end,
                                  d_position, d_found))
@@ -2278,7 +2348,7 @@ struct ss_comm {
     int *d_recv = nullptr;      // int[2]: all-reduce(MAX) result
     int *h_flag = nullptr;      // pinned int[2]: read-back
     int *h_err = nullptr;       // pinned: source of the copy that raises d_flag[1]
-    long long *h_word = nullptr;// pinned answer word of signal_shard_kernel (spinning read-back)
+    long long *h_word = nullptr;// pinned answer word of signal_flag_kernel (pair form) (spinning read-back)
     unsigned finds = 0;         // ss_find_sharded calls (every 256th still waits for the stream)
     uint64_t *d_best = nullptr; // uint64[2] scratch of ss_find_sharded: [0] = offset (MIN), [1] = all ones unless a rank failed
     uint64_t *h_best = nullptr; // pinned uint64[2]
@@ -2482,7 +2552,7 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
         // the answer word behind the all-reduce, and a bounded spin on it (see spin_for_word); ranks that arrive late in
         // the collective make the others' spins run out, which costs those nothing but the stream wait they had before
         __atomic_store_n(c->h_word, 0ll, __ATOMIC_RELAXED);
-        ss::signal_shard_kernel<<<1, 1, 0, st>>>(c->d_recv, epoch, c->h_word);
+        ss::signal_flag_kernel<<<1, 1, 0, st>>>(c->d_recv, epoch, c->h_word, 1);
         HIP_TRY(hipGetLastError());
         int failed = 0;
         if (spin_for_shard_word(c->h_word, epoch, estimate, found, &failed)) {
@@ -2536,7 +2606,7 @@ int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len,
         // pair (and re-arms nothing: d_best is this communicator's scratch, set to all ones at the top of every call)
         constexpr uint64_t kPending = ~0ull - 1;
         __atomic_store_n(c->h_best, kPending, __ATOMIC_RELAXED);
-        ss::publish_shard_best_kernel<<<1, 1, 0, st>>>(c->d_best, c->h_best);
+        ss::publish_best_kernel<<<1, 1, 0, st>>>(c->d_best, c->h_best, 1);
         HIP_TRY(hipGetLastError());
         const auto t0 = std::chrono::steady_clock::now();
         const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
@@ -2712,7 +2782,7 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
             launched = hipSetDevice(set->devs[g]) == hipSuccess;
             if (launched) {
                 ss::signal_flag_kernel<<<1, 1, 0, set->streams[g]>>>(set->combine == SS_COMBINE_RCCL ? set->d_recv[g] : set->d_flag[g],
-                                                                     epoch, set->h_words + g);
+                                                                     epoch, set->h_words + g, 0);
                 launched = hipGetLastError() == hipSuccess;
             }
         }

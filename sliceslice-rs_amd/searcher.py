@@ -62,6 +62,8 @@ ABI = {
     "ss_choose_position": (_int, [_vp, _sz, _vp, ctypes.POINTER(_sz)]),
     "ss_search_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_search_pairs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ss_find_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ss_search_host_all": (_int, [_vp, _vp, _sz, _int, _pint, _pint]),
     "ss_searcher_set_timing": (_int, [_vp, _int]),
     "ss_searcher_last_kernel_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "ss_searcher_set_variant": (_int, [_vp, _int]),
@@ -695,6 +697,28 @@ def search_batched(haystacks, hay_off, needles, needle_off, position=None, strea
     _check(fn(haystacks.data_ptr(), hb, he, needles.data_ptr(), nb, ne,
               position.data_ptr() if position is not None else None, count, st, found.data_ptr()))
     return found
+
+
+def find_batched(haystacks, hay_off, needles, needle_off, stream=None, hay_ranges=None, needle_ranges=None):
+    """Leftmost offset of needle i in haystack i for many problems in one call (ss_find_batched); -1 where absent.  Arguments as
+    search_batched.  Returns an int64 device tensor."""
+    import torch
+    hb, he, count = _ranges(hay_off, *(hay_ranges or (None, None)))
+    nb, ne, ncount = _ranges(needle_off, *(needle_ranges or (None, None)))
+    assert count == ncount
+    pos = torch.empty(count, dtype=torch.int64, device=haystacks.device)
+    st = stream if stream is not None else _current_stream_handle()
+    _check(lib().ss_find_batched(haystacks.data_ptr(), hb, he, needles.data_ptr(), nb, ne, count, st, pos.data_ptr()))
+    return pos                                      # SS_NPOS (all ones) reads as -1
+
+
+def search_host_all(searcher, haystack, devices):
+    """search_in for a HOST buffer over several GPUs (ss_search_host_all): every device uploads and scans its own range."""
+    buf = np.frombuffer(haystack, dtype=np.uint8) if not isinstance(haystack, np.ndarray) else np.ascontiguousarray(haystack, dtype=np.uint8)
+    devs = (ctypes.c_int * len(devices))(*devices)
+    found = ctypes.c_int(0)
+    _check(lib().ss_search_host_all(searcher._h, buf.ctypes.data if buf.size else None, buf.size, len(devices), devs, ctypes.byref(found)))
+    return bool(found.value)
 
 
 def search_file(searcher, path):

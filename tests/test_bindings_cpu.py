@@ -271,7 +271,7 @@ def test_kernels_the_library_launches_by_default_keep_four_waves_per_simd():
     rows = build.kernel_resources()
     names = [r["name"] for r in rows]
     assert len(rows) <= 40, len(rows)
-    assert any("scan_batched_plan_kernel<4>" in n for n in names) and any("scan_pairs_kernel" in n for n in names)
+    assert any("scan_batched_plan_kernel<4, false>" in n for n in names) and any("scan_pairs_kernel" in n for n in names)
     scans = set()
     for r in rows:
         m = re.match(r"void ss::scan_kernel<(\d), (\d), (true|false), (\d), (\d), (true|false), (true|false)>", r["name"])
