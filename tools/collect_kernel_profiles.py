@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/<tag>_<case>_{kt,pmc,sq} (tools/profile_kernels.sh) -> profiles/<round>/kernels.json + kernels.md:
-per case the dominant kernel's name, rocprofv3 average duration, achieved GB/s and fraction of the 8 TB/s peak,
+per case the dominant kernel's name, rocprofv3 duration of the MEASURED launches (the last `launches` rows of the kernel in the
+trace - the 50 ms spin in front of them is excluded: median, min, mean), achieved GB/s by the median and fraction of the 8 TB/s peak,
 HBM bytes fetched per launch (FETCH_SIZE x 2 x 1024: the gfx950 correction and KiB unit of
 MI355X_MICROARCH.md's HBM section) over the algorithmic bytes, and the SQ instruction mix per KiB piece."""
 import csv
@@ -45,9 +46,17 @@ for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
     k = stats[0]
     alg = line["algorithmic_bytes_per_launch"]
     avg_ns = float(k["AverageNs"])
-    row = {"case": case, "kernel": k["Name"], "calls": int(k["Calls"]), "rocprof_avg_ms": round(avg_ns / 1e6, 4),
-           "hipevent_median_ms": line["ms"], "algorithmic_bytes_per_launch": alg,
-           "gbps": round(alg / avg_ns, 1), "frac_of_8tbps": round(alg / avg_ns / 8000, 4), "filter_bytes": line.get("filter_bytes")}
+    # the measured launches: the last `launches` rows of this kernel in the trace (what the hipEvent median covers)
+    tr = [r for r in csv.DictReader(open(os.path.join(kt, "r_kernel_trace.csv"))) if r["Kernel_Name"] == k["Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr[-int(line["launches"]):]]
+    med_ns, min_ns, mean_ns = statistics.median(durs), min(durs), statistics.mean(durs)
+    row = {"case": case, "kernel": k["Name"], "calls_in_trace": int(k["Calls"]), "measured_launches": len(durs),
+           "rocprof_median_ms": round(med_ns / 1e6, 4), "rocprof_min_ms": round(min_ns / 1e6, 4), "rocprof_mean_ms": round(mean_ns / 1e6, 4),
+           "rocprof_avg_ms_all_calls_incl_spin": round(avg_ns / 1e6, 4),
+           "hipevent_median_ms": line["ms"], "hipevent_min_ms": line.get("ms_min"), "algorithmic_bytes_per_launch": alg,
+           "gbps": round(alg / med_ns, 1), "frac_of_8tbps": round(alg / med_ns / 8000, 4), "gbps_best": round(alg / min_ns, 1),
+           "filter_bytes": line.get("filter_bytes")}
     pmc = os.path.join(src, f"{tag}_{case}_pmc", "r_counter_collection.csv")
     if os.path.exists(pmc):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(pmc)) if want in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
@@ -79,11 +88,11 @@ for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
         shutil.copy(os.path.join(kt, "r_kernel_stats.csv"), os.path.join(dst, "kernel_stats", f"{case}_kernel_stats.csv"))
 json.dump(rows, open(os.path.join(dst, "kernels.json"), "w"), indent=1)
 with open(os.path.join(dst, "kernels.md"), "w") as fh:
-    fh.write("| case | kernel | rocprofv3 avg ms | GB/s | frac of 8 TB/s | fetched / algorithmic | VGPRs allocated (waves per SIMD) | VALU / SALU / LDS / VMEM per KiB | wait |\n|---|---|---|---|---|---|---|---|---|\n")
+    fh.write("| case | kernel | rocprofv3 median / min / mean ms (measured launches) | GB/s (median) | frac of 8 TB/s | fetched / algorithmic | VGPRs allocated (waves per SIMD) | VALU / SALU / LDS / VMEM per KiB | wait |\n|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
         sqk = r.get("sq_per_kib", {})
-        fh.write("| %s | `%s` | %.4f | %.0f | %.3f | %s | %s | %s / %s / %s / %s | %s |\n" % (
-            r["case"], r["kernel"].replace("void ", "")[:70], r["rocprof_avg_ms"], r["gbps"], r["frac_of_8tbps"],
+        fh.write("| %s | `%s` | %.4f / %.4f / %.4f | %.0f | %.3f | %s | %s | %s / %s / %s / %s | %s |\n" % (
+            r["case"], r["kernel"].replace("void ", "")[:70], r["rocprof_median_ms"], r["rocprof_min_ms"], r["rocprof_mean_ms"], r["gbps"], r["frac_of_8tbps"],
             r.get("fetched_over_algorithmic", "-"), "%s (%s)" % (r.get("vgpr", "-"), r.get("waves_per_simd", "-")), sqk.get("valu", "-"), sqk.get("salu", "-"), sqk.get("lds", "-"),
             sqk.get("vmem_rd", "-"), r.get("wait_fraction", "-")))
 print(open(os.path.join(dst, "kernels.md")).read())
