@@ -1648,7 +1648,12 @@ int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256]
 }
 
 // ss_search_batched, planned form: tuning constants and the one-time set-up of the stream-ordered allocator.
-constexpr unsigned kPlanWgsPerCu = 256;     // total workgroups aimed at, per CU (tools/batch_shape_probe.py)
+// Total workgroups aimed at, per CU.  Measured in one process on one buffer (tools/batch_tune.py, profiles/r03/batch_tune_*.jsonl;
+// kernel time: tools/shape_trace.py under rocprofv3): 96 per CU is best or within 1 % of the best on every shape at 1 GiB in
+// total (1 / 64 / 256 / 1,024 problems: 149-151 us = 7.1-7.2 TB/s of kernel time; 160 per CU 150-153 us, 256 per CU 161-163 us,
+// 512 per CU 190 us - surplus workgroups cost 0.3-0.4 us of a slot each) and for the i386 loop (0.151 ms; 160: 0.17, 256: 0.77);
+// at 4 GiB in 4,096 problems 256 per CU is 2 % faster (583 vs 597 us), which is not worth the rest.
+constexpr unsigned kPlanWgsPerCu = 96;
 constexpr uint32_t kPlanMinTiles = 2;       // shortest slice worth a workgroup, in 16 KiB tiles
 
 // Descriptor scratch of the planned form: one grow-only device buffer per (device, stream), kept for the life of the process.
