@@ -397,7 +397,14 @@ static int soak(long calls)
     const long rss0 = rss_kib();
     const auto t0 = clk::now();
     long wrong = 0;
+    ss_service *sv = nullptr;
+    CK(ss_service_start(0, 0.0, &sv));
     for (long k = 0; k < calls; ++k) {
+        if (k % 5 == 4) {                                 // every fifth call goes through the resident search service
+            rc |= ss_service_search(sv, (k & 8) ? sp : s, d_hay, len, &found);
+            wrong += found != ((k & 8) ? 1 : 0);
+            continue;
+        }
         switch (k & 3) {
         case 0: rc |= ss_search_device(s, d_hay, len, nullptr, &found); wrong += found != 0; break;
         case 1: rc |= ss_search_device(sp, d_hay, len, nullptr, &found); wrong += found != 1; break;
@@ -406,12 +413,17 @@ static int soak(long calls)
         }
     }
     const double secs = seconds_since(t0);
+    uint64_t svc_requests = 0, svc_launches = 0;
+    CK(ss_service_counters(sv, &svc_requests, &svc_launches));
+    ss_service_stop(sv);
     HK(hipDeviceSynchronize());
     HK(hipMemGetInfo(&free1, &tot));
     const long rss1 = rss_kib();
     std::printf("{\"mode\": \"soak\", \"calls\": %ld, \"seconds\": %.1f, \"us_per_call\": %.2f, \"rc\": %d, \"wrong_answers\": %ld, "
+                "\"service_requests\": %llu, \"service_kernel_launches\": %llu, "
                 "\"rss_kib_before\": %ld, \"rss_kib_after\": %ld, \"device_free_before\": %zu, \"device_free_after\": %zu}\n",
-                calls, secs, secs / (double)calls * 1e6, rc, wrong, rss0, rss1, free0, free1);
+                calls, secs, secs / (double)calls * 1e6, rc, wrong, (unsigned long long)svc_requests, (unsigned long long)svc_launches, rss0, rss1,
+                free0, free1);
     ss_searcher_free(s);
     ss_searcher_free(sp);
     (void)hipFree(d_hay);
