@@ -91,7 +91,8 @@ size_t ss_searcher_position(const ss_searcher *s);
  *   ss_searcher_set_filter overrides the pair and drops the third byte (a plain two-byte filter; a pair 16 or
  *     more apart - e.g. the reference's (0, n-1) for a long needle - runs on the cross-lane or two-stream kernels);
  *     ss_searcher_set_filter3 sets all three.  Tests, tuning, or a caller with corpus statistics (see
- *     ss_byte_histogram_device).  SS_ERR_POSITION if out of range.  Not thread-safe against running searches. */
+ *     ss_byte_histogram_device).  SS_ERR_POSITION if out of range; SS_ERR_ARGUMENT while any search is in flight on the
+ *     searcher (the triple is only rewritten when nothing can be reading it). */
 int ss_searcher_filter(const ss_searcher *s, size_t *first, size_t *second);
 int ss_searcher_filter3(const ss_searcher *s, size_t *first, size_t *second, size_t *third);
 int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second);
@@ -113,7 +114,11 @@ int ss_choose_filter_triple_hist(const uint8_t *needle, size_t n, const uint64_t
 
 /* DynamicAvx2Searcher::search_in (src/x86.rs:523-525) on a haystack ALREADY RESIDENT in device
  * memory (any alignment, any length up to the device's memory).  Enqueues on `hip_stream`
- * (a hipStream_t; NULL = the default stream), waits for that stream, writes 0/1 to *found. */
+ * (a hipStream_t; NULL = the default stream) and returns when the ANSWER has arrived, writing 0/1 to *found.  For scans of
+ * up to ~20 ms the answer is a pinned word the scan's last workgroup (or a one-lane kernel behind the scan) stores and the
+ * caller spins on - the stream itself may still be retiring the command for a few microseconds when the call returns (every
+ * 256th call does wait for the stream); a caller that needs the stream idle - to destroy it, to read its own hipEvent
+ * timings - synchronises it itself.  Longer scans, and SLICESLICE_SPIN_WAIT=0, wait for the stream.  ss_find_device: the same. */
 int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,
                      int *found);
 
@@ -210,7 +215,10 @@ int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const 
 int ss_searcher_set_timing(ss_searcher *s, int enabled);
 int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);   /* of the CALLING THREAD's latest scan through s */
 
-/* Kernel-variant override for tuning/tests: variant = 1000*LAYOUT + 100*MODE + 10*U + NT; LAYOUT 0 =
+/* Kernel-variant override for tuning/tests (the default library holds the kernels the constructors and ss_searcher_set_filter* can
+ * select - U = 4, non-temporal loads except for the two-stream kernels, the 8-byte phase for one-byte needles; a variant that names
+ * another kernel makes the search return SS_ERR_ARGUMENT there and runs in the tuning build, libsliceslice_hip_tuning.so):
+ * variant = 1000*LAYOUT + 100*MODE + 10*U + NT; LAYOUT 0 =
  * automatic, 1 = 16 bytes per lane, 2 = 8-bytes-per-lane first phase (position < 16 only); U in {4,8} pieces (KiB)
  * per wave per tile; NT in {0,1} (plain / non-temporal loads); MODE 0 = automatic, 1 = second load
  * stream, 2 = cross-lane position flags (filter pairs 16 or more apart only); 0 = automatic.  Two more decimal digits
@@ -266,7 +274,8 @@ int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len,
  * leftmost offset (uint64, ncclMin; shard_begins[g] = global offset of shard g).
  * SS_COMBINE_HOST skips the collective: the host ORs the G pinned mirrors (possible only in this
  * single-process form; the difference between the two is the cost of the collective).
- * One search at a time per set (the set's streams and flags are its scratch). */
+ * One search at a time per set (the set's streams and flags are its scratch): a second concurrent call is refused with
+ * SS_ERR_ARGUMENT.  The same holds for ss_search_sharded / ss_find_sharded on one communicator. */
 typedef struct ss_comm_set ss_comm_set;
 #define SS_COMBINE_RCCL 0
 #define SS_COMBINE_HOST 1
