@@ -3,11 +3,13 @@ contract names; guards against an accidental change of the output shape.  CPU on
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-
-def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r02", "bench64g.json")) as fh:
+@pytest.mark.parametrize("rnd", ["r02", "r03"])
+def test_committed_bench_line_has_the_contract_fields(rnd):
+    with open(os.path.join(ROOT, "profiles", rnd, "bench64g.json")) as fh:
         d = json.loads(fh.read())
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
@@ -23,7 +25,15 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "GB/s" and c["cores"] >= 1 and "sample" in c and c["value"] > 0
     assert c["cores"] == c["threads_used"] <= c["host_hardware_threads"] and c["host_physical_cores"] >= 1
-    assert r["traffic_source"].startswith("stored ratio") and d["config"]["ranks"] == d["n_gpus"] == 1
+    assert d["config"]["ranks"] == d["n_gpus"] == 1
+    if rnd == "r02":
+        assert r["traffic_source"].startswith("stored ratio")
+    else:                       # since round 3 the counter pass runs inside the bench run, and the launch time is the median
+        assert r["traffic_source"].startswith("measured in this run") and 1.0 <= r["traffic_per_algorithmic_byte"] < 1.02
+        assert r["kernel_ms_stat"].startswith("median") and r["kernel_ms_min"] <= r["kernel_ms"]
+        assert d["config"]["prewarm_ms"] >= 100 and d["config"]["launcher"]
+        for row in ("1_short", "3", "5", "5_shapes", "text", "adversarial", "latency_us"):
+            assert row in d["configs"], row
     # whole-job value and kernel-only roofline agree within the launch/sync overhead
     assert 0.9 * r["achieved"] <= d["value"] <= 1.001 * r["achieved"]
 

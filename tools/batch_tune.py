@@ -8,7 +8,10 @@ One JSON line per (shape, setting), plan kernel / memset included, by events on 
 bracketed on an otherwise idle stream (median of 15; this includes the HOST's launch path - some 15-20 us of Python, ctypes and
 runtime between the first event and the first kernel - during which the GPU waits), `steady_ms` = calls issued back to back, per
 call (the launch path overlaps the previous call's kernels: what a pipeline of batches sees).  Plus the config-1 loop as one launch
-(4,585 needles x i386.txt) per setting.  Kernel-only durations: tools/shape_trace.py under rocprofv3."""
+(4,585 needles x i386.txt) per setting.  Kernel-only durations: tools/shape_trace.py under rocprofv3.
+
+The single-kernel form (SLICESLICE_BATCH_PLAN=0) lives in the tuning build only: run with
+SLICESLICE_HIP_LIB=sliceslice-rs_amd/csrc/libsliceslice_hip_tuning.so, or pass --default-only for the shipped library."""
 import argparse
 import json
 import os
