@@ -312,13 +312,22 @@ int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *
  *       no variant / grid override, no kernel timing, and only when the caller's stream is idle (hipStreamQuery).
  *       SLICESLICE_SERVICE=1 in the environment does the same with a service the library starts itself on first use
  *       (SLICESLICE_SERVICE_WORKGROUPS, SLICESLICE_SERVICE_LEASE_MS).
- *   ss_service_counters  requests served / kernel launches so far (a burst of requests shares one residency).
+ *   ss_service_bind(sv, d_haystack, len)  the caller vouches that [d_haystack, d_haystack + len) stays UNCHANGED until
+ *       ss_service_unbind / the next bind (the reference's bench shape: one text, thousands of needles).  A kernel that never
+ *       ends sees no kernel boundary, so by default every request drops the caches' copy of whatever it is about to read
+ *       (2 us of a request's 8); inside a bound range only the first request does, and so does any request whose searcher
+ *       was uploaded to the device after the latest such acquire.  Writing to a bound range without re-binding: stale reads.
+ *   ss_service_counters  requests served / kernel launches so far (a burst of requests shares one residency);
+ *   ss_service_settled_requests  how many of them skipped the acquire.
  *   ss_service_stop      asks the kernel to leave, waits for it, frees everything. */
 typedef struct ss_service ss_service;
 int ss_service_start(int workgroups, double lease_ms, ss_service **out);
 int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haystack, size_t len, int *found);
 int ss_service_set_default(ss_service *sv, int enabled);
+int ss_service_bind(ss_service *sv, const void *d_haystack, size_t len);
+int ss_service_unbind(ss_service *sv);
 int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches);
+int ss_service_settled_requests(ss_service *sv, uint64_t *settled);
 void ss_service_stop(ss_service *sv);
 
 /* Measurement: median (and minimum) microseconds of a host -> device -> host round trip through pinned memory against ONE

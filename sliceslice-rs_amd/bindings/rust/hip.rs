@@ -110,7 +110,10 @@ extern "C" {
     pub fn ss_service_start(workgroups: c_int, lease_ms: f64, out: *mut *mut ss_service) -> c_int;
     pub fn ss_service_search(sv: *mut ss_service, s: *const ss_searcher, d_haystack: *const c_void, len: usize, found: *mut c_int) -> c_int;
     pub fn ss_service_set_default(sv: *mut ss_service, enabled: c_int) -> c_int;
+    pub fn ss_service_bind(sv: *mut ss_service, d_haystack: *const c_void, len: usize) -> c_int;
+    pub fn ss_service_unbind(sv: *mut ss_service) -> c_int;
     pub fn ss_service_counters(sv: *mut ss_service, requests: *mut u64, kernel_launches: *mut u64) -> c_int;
+    pub fn ss_service_settled_requests(sv: *mut ss_service, settled: *mut u64) -> c_int;
     pub fn ss_service_stop(sv: *mut ss_service);
 }
 

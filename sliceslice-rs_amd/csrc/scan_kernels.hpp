@@ -1856,7 +1856,8 @@ struct ServiceRequest {
     uint32_t q;            // dword window of the second filter byte (the kernels' template parameter Q)
     uint32_t one_byte;
     uint32_t stop;         // != 0: no search - the service ends
-    uint32_t pad_;
+    uint32_t settled;      // != 0: every byte this request reads was last written before an earlier request's acquire (or the
+                           // kernel's start) - a bound haystack (ss_service_bind), a needle uploaded earlier: no acquire
 };
 static_assert(sizeof(ServiceRequest) <= 240 && sizeof(ServiceRequest) % 8 == 0, "four mailbox lines of 60 payload bytes");
 constexpr uint32_t kSvcRunning = 1, kSvcLeaving = 2, kSvcExited = 3;
@@ -1926,7 +1927,7 @@ service_kernel(const uint32_t *h_req, uint32_t *h_status, unsigned long long *h_
         }
         if (seen == kSvcStopSeq) break;
         // ---- 3. the request, out of device memory into scalar registers ------------------------------------------------
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (agent-scope atomic loads: performed beyond the L2, they need no acquire of their own)
         constexpr int kDwords = (int)(sizeof(ServiceRequest) / 4);
         const uint32_t mine = lane < kDwords ? __hip_atomic_load(d_box + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         union {
@@ -1936,6 +1937,10 @@ service_kernel(const uint32_t *h_req, uint32_t *h_status, unsigned long long *h_
 #pragma unroll
         for (int k = 0; k < kDwords; ++k) u.w[k] = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
         const ServiceRequest &rq = u.rq;
+        // A kernel that never ends sees no kernel boundary: haystack or needle bytes written since it last looked (a copy, another
+        // kernel) may still sit in this XCD's L2 / this CU's vector cache in their old state.  The acquire drops them - 2 us of
+        // the request's 8 - unless the host vouches that nothing this request reads has changed (ServiceRequest::settled).
+        if (!rq.settled) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         // ---- 4. scan: workgroup b takes tiles b, b + grid, ... -------------------------------------------------------------
         if (threadIdx.x == 0) __hip_atomic_store(&s_wg_found, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();

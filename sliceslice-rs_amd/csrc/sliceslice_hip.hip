@@ -114,7 +114,9 @@ struct PerDevice {
     uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax
     uint64_t free_mask = 0;
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
+    uint64_t upload_ticket = 0; // g_upload_ticket when d_needle had been written (a resident service acquires what is newer)
 };
+std::atomic<uint64_t> g_upload_ticket{0};
 constexpr int kSlots = 64;
 constexpr uint32_t kFindTagMax = (1u << (64 - ss::kFindOffsetBits)) - 2;   // keys tag << kFindOffsetBits stay below all-ones
 constexpr uint32_t kDoneLowMax = 0x7FFF0000u;                               // start over before the low half could carry
@@ -224,6 +226,7 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         hipError_t e;
         if ((e = hipMalloc((void **)&p.d_needle, s->n ? s->n : 1)) != hipSuccess) return e;
         if (s->n && (e = hipMemcpy(p.d_needle, s->needle.data(), s->n, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        p.upload_ticket = g_upload_ticket.fetch_add(1, std::memory_order_acq_rel) + 1;
         if ((e = hipMalloc((void **)&p.d_flags, kSlots * sizeof(int))) != hipSuccess) return e;
         if ((e = hipMemset(p.d_flags, 0, kSlots * sizeof(int))) != hipSuccess) return e;
         if ((e = hipHostMalloc((void **)&p.h_flags, kSlots * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
@@ -2028,7 +2031,12 @@ struct ss_service {
     uint8_t *d_mem = nullptr;               // device: box (256 B) | seq | done counter | found flag
     uint32_t seq = 0;                       // last request posted
     uint32_t done_low = 0, done_hi = 0;     // the never-reset completion counter, as the host knows it
-    uint64_t requests = 0, launches = 0;
+    uint64_t requests = 0, launches = 0, settled_requests = 0;
+    // ss_service_bind: a device range the caller vouches for (unchanged until unbound), `bound_settled` once a request has
+    // acquired it; `settled_ticket`: needles uploaded up to this ticket were in memory before the latest acquire
+    const uint8_t *bound_lo = nullptr, *bound_hi = nullptr;
+    bool bound_settled = false;
+    uint64_t settled_ticket = 0;
     std::mutex mu;
     volatile uint32_t *status() const { return h_box + 64; }
     volatile unsigned long long *answer() const { return reinterpret_cast<volatile unsigned long long *>(h_box + 80); }
@@ -2180,12 +2188,45 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
     rq.pr.flags = ss::kProblemCounted;
     rq.pr.done_target = sv->done_low + (uint32_t)sv->workgroups;
     rq.pr.done_hi = sv->done_hi;
+    // Inside a bound range that an earlier request has acquired, with a needle that was in device memory by then: nothing this
+    // request reads has changed, the workgroups skip their acquire (2 us of a request's 8).
+    const uint8_t *lo = static_cast<const uint8_t *>(d_haystack);
+    const bool in_bound = sv->bound_lo && lo >= sv->bound_lo && lo + len <= sv->bound_hi;
+    rq.settled = in_bound && sv->bound_settled && pd->upload_ticket <= sv->settled_ticket ? 1u : 0u;
+    const uint64_t ticket_now = g_upload_ticket.load(std::memory_order_acquire);     // uploads are synchronous: all in memory by now
     unsigned long long a = 0;
     if (int rc = service_post(sv, rq, seq, &a)) return rc;
+    if (!rq.settled) {
+        sv->settled_ticket = ticket_now;
+        if (in_bound) sv->bound_settled = true;
+    } else {
+        ++sv->settled_requests;
+    }
     sv->done_low = rq.pr.done_target;
     sv->done_hi = (uint32_t)(a >> 32);
     ++sv->requests;
     *found = (int)(a & 1);
+    return SS_OK;
+}
+
+int ss_service_bind(ss_service *sv, const void *d_haystack, size_t len)
+{
+    if (!sv) return fail(SS_ERR_ARGUMENT, "service is NULL");
+    if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
+    std::lock_guard<std::mutex> lock(sv->mu);
+    sv->bound_lo = len ? static_cast<const uint8_t *>(d_haystack) : nullptr;
+    sv->bound_hi = sv->bound_lo ? sv->bound_lo + len : nullptr;
+    sv->bound_settled = false;                          // the next request inside the range acquires it, the ones after that do not
+    return SS_OK;
+}
+
+int ss_service_unbind(ss_service *sv) { return ss_service_bind(sv, nullptr, 0); }
+
+int ss_service_settled_requests(ss_service *sv, uint64_t *settled)
+{
+    if (!sv || !settled) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(sv->mu);
+    *settled = sv->settled_requests;
     return SS_OK;
 }
 

@@ -99,6 +99,9 @@ ABI = {
     "ss_service_search": (_int, [_vp, _vp, _vp, _sz, _pint]),
     "ss_service_set_default": (_int, [_vp, _int]),
     "ss_service_counters": (_int, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
+    "ss_service_bind": (_int, [_vp, _vp, _sz]),
+    "ss_service_unbind": (_int, [_vp]),
+    "ss_service_settled_requests": (_int, [_vp, ctypes.POINTER(_u64)]),
     "ss_service_stop": (None, [_vp]),
 }
 
@@ -640,6 +643,20 @@ class SearchService:
 
     def set_default(self, enabled=True):
         _check(lib().ss_service_set_default(self._h, 1 if enabled else 0))
+
+    def bind(self, haystack):
+        """The caller vouches that this device range stays unchanged until ``unbind()`` / the next ``bind``: searches inside it
+        skip the per-request cache acquire (all but the first, and those whose searcher was uploaded after it)."""
+        ptr, n = (haystack.data_ptr(), haystack.numel()) if hasattr(haystack, "data_ptr") else haystack
+        _check(lib().ss_service_bind(self._h, ptr if n else None, n))
+
+    def unbind(self):
+        _check(lib().ss_service_unbind(self._h))
+
+    def settled_requests(self):
+        v = _u64(0)
+        _check(lib().ss_service_settled_requests(self._h, ctypes.byref(v)))
+        return v.value
 
     def counters(self):
         """(requests served, kernel launches): a burst of requests shares one residency of the kernel."""

@@ -98,6 +98,61 @@ def test_service_sees_haystack_bytes_written_between_requests(ss):
             assert sv.search_in(s, t) is False, (it, at)
 
 
+def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O):
+    """ss_service_bind: the caller vouches for a range; requests inside it skip the cache acquire - all but the first, and those
+    whose needle reached device memory after the latest acquire.  The answers are the launch path's and the oracle's; after
+    unbind, bytes written between requests are seen again."""
+    rng = random.Random(11)
+    raw = open(os.path.join(ROOT, "tests", "golden", "data", "i386.txt"), "rb").read()
+    words = [w for w in open(os.path.join(ROOT, "tests", "golden", "data", "words.txt"), "rb").read().split(b"\n") if w]
+    t = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    sample = rng.sample(words, 300) + [b"no such phrase in the manual", b"\x00\x01", raw[-40:], raw[:3], raw[1000:1300]]
+    searchers = [ss.DynamicHipSearcher.new(w) for w in sample]
+    for s in searchers[:8]:
+        s.search_in(t)                                        # (the launch path uploads the needle)
+    with ss.SearchService() as sv:
+        sv.bind(t)
+        assert sv.settled_requests() == 0
+        got = [sv.search_in(s, t) for s in searchers]
+        assert got == [w in raw for w in sample]
+        # the first request acquired the range and every needle uploaded by then; needles uploaded later acquire once more
+        n1 = sv.settled_requests()
+        assert 0 < n1 < len(sample)
+        got = [sv.search_in(s, t[5:-7]) for s in searchers]   # sub-ranges of the bound range count as bound
+        assert got == [w in raw[5:-7] for w in sample]
+        assert sv.settled_requests() == n1 + len(sample)
+        late = ss.DynamicHipSearcher.new(b"descriptor")       # built while the range is bound: its first request is not settled
+        assert sv.search_in(late, t) is True and sv.settled_requests() == n1 + len(sample)
+        assert sv.search_in(late, t) is True and sv.settled_requests() == n1 + len(sample) + 1
+        other = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        before = sv.settled_requests()
+        assert sv.search_in(late, other) is False and sv.settled_requests() == before      # outside the range: acquires
+        sv.unbind()
+        plant = torch.from_numpy(np.frombuffer(b"descriptor", dtype=np.uint8).copy()).cuda()
+        for it in range(50):
+            at = rng.randrange(4096 - 10)
+            other[at:at + 10] = plant
+            torch.cuda.current_stream().synchronize()
+            assert sv.search_in(late, other) is True, it
+            other[at:at + 10] = 0
+            torch.cuda.current_stream().synchronize()
+            assert sv.search_in(late, other) is False, it
+        assert sv.settled_requests() == before
+        # re-binding after a write: the first request of the new binding acquires
+        t2 = t.clone()
+        torch.cuda.synchronize()
+        sv.bind(t2)
+        assert sv.search_in(late, t2) is True
+        sv.bind(None if False else (0, 0))                    # an empty range unbinds
+        t2[:] = 0
+        torch.cuda.current_stream().synchronize()
+        sv.bind(t2)
+        assert sv.search_in(late, t2) is False
+        assert sv.search_in(late, t2) is False
+
+
 def test_service_lease_bounds_the_residency(ss):
     """Without requests the kernel leaves after its lease, so a device-wide wait cannot hang on it; the next request starts a new
     residency (one more launch) and is answered like any other."""

@@ -153,17 +153,27 @@ static int latency(int calls)
         const int f2 = found;
         const double svc_present = median_us(calls, [&] { rc |= ss_service_search(sv, sp, d_hay, len, &found); });
         const int f3 = found;
+        // the haystack bound (ss_service_bind: the caller vouches that it does not change): no acquire per request
+        rc |= ss_service_bind(sv, d_hay, len);
+        for (int w = 0; w < 50; ++w) rc |= ss_service_search(sv, s, d_hay, len, &found);
+        const double bound_absent = median_us(calls, [&] { rc |= ss_service_search(sv, s, d_hay, len, &found); });
+        const int f4 = found;
+        const double bound_present = median_us(calls, [&] { rc |= ss_service_search(sv, sp, d_hay, len, &found); });
+        const int f5 = found;
+        rc |= ss_service_unbind(sv);
         for (int w = 0; w < 50; ++w) rc |= ss_search_host(s, h_hay.data(), len, &found);
         const double host_absent = median_us(std::max(200, calls / 4), [&] { rc |= ss_search_host(s, h_hay.data(), len, &found); });
-        if (rc != 0 || f0 != 0 || f1 != 1 || f2 != 0 || f3 != 1 || p0 != SS_NPOS || p1 != 0) {
+        if (rc != 0 || f0 != 0 || f1 != 1 || f2 != 0 || f3 != 1 || f4 != 0 || f5 != 1 || p0 != SS_NPOS || p1 != 0) {
             std::fprintf(stderr, "latency: wrong answer (rc %d, found %d/%d, pos %llu/%llu): %s\n", rc, f0, f1,
                          (unsigned long long)p0, (unsigned long long)p1, ss_last_error());
             return 1;
         }
         std::printf("%s{\"haystack_bytes\": %zu, \"search_device_absent\": %.2f, \"search_device_present_at_0\": %.2f, "
                     "\"find_device_absent\": %.2f, \"find_device_present_at_0\": %.2f, \"search_host_absent\": %.2f, "
-                    "\"service_absent\": %.2f, \"service_present_at_0\": %.2f}",
-                    first ? "" : ", ", len, dev_absent, dev_present, find_absent, find_present, host_absent, svc_absent, svc_present);
+                    "\"service_absent\": %.2f, \"service_present_at_0\": %.2f, \"service_bound_absent\": %.2f, "
+                    "\"service_bound_present_at_0\": %.2f}",
+                    first ? "" : ", ", len, dev_absent, dev_present, find_absent, find_present, host_absent, svc_absent, svc_present,
+                    bound_absent, bound_present);
         first = false;
     }
     std::printf("]}\n");
@@ -228,6 +238,20 @@ static int config1(const char *hay_path, const char *words_path, int iters)
     for (int it = 0; it < iters; ++it)
         for (ss_searcher *s : searchers) CK(ss_service_search(sv, s, d_hay, hay.size(), &found));
     const double service_ms = seconds_since(ts) / iters * 1e3;
+    // the reference's loop reads ONE text: bound to the service (the caller vouches that it does not change), no acquire per request
+    CK(ss_service_bind(sv, d_hay, hay.size()));
+    size_t bound_hits = 0;
+    for (ss_searcher *s : searchers) {
+        CK(ss_service_search(sv, s, d_hay, hay.size(), &found));
+        bound_hits += found != 0;
+    }
+    const auto tb = clk::now();
+    for (int it = 0; it < iters; ++it)
+        for (ss_searcher *s : searchers) CK(ss_service_search(sv, s, d_hay, hay.size(), &found));
+    const double bound_ms = seconds_since(tb) / iters * 1e3;
+    uint64_t settled = 0;
+    CK(ss_service_settled_requests(sv, &settled));
+    CK(ss_service_unbind(sv));
     CK(ss_service_set_default(sv, 1));
     size_t routed_hits = 0;
     const auto tr = clk::now();
@@ -274,20 +298,23 @@ static int config1(const char *hay_path, const char *words_path, int iters)
     std::printf("{\"mode\": \"config1\", \"haystack_bytes\": %zu, \"needles\": %zu, \"hits\": %zu, \"batched_hits\": %zu, "
                 "\"per_call_ms_per_iteration\": %.3f, \"per_call_us_per_search\": %.3f, "
                 "\"service_ms_per_iteration\": %.3f, \"service_us_per_search\": %.3f, \"service_hits\": %zu, "
+                "\"service_bound_ms_per_iteration\": %.3f, \"service_bound_us_per_search\": %.3f, \"service_bound_hits\": %zu, "
+                "\"service_settled_requests\": %llu, "
                 "\"service_routed_ms_per_iteration\": %.3f, \"service_requests\": %llu, \"service_kernel_launches\": %llu, "
                 "\"batched_ms_per_iteration\": %.4f, \"reference_published_ms\": 35.181, "
                 "\"note\": \"per-call = one ss_search_device (launch + completion word) per needle, natively; service = the same loop "
-                "through the resident search service (ss_service_search: no launch per search), routed = ss_search_device with that service "
+                "through the resident search service (ss_service_search: no launch per search), bound = the same with the text bound to the service "
+                "(ss_service_bind: no cache acquire per request), routed = ss_search_device with that service "
                 "as the device's default; batched = one ss_search_batched launch + flag read-back for all needles\"}\n",
                 hay.size(), W, hits, bhits, per_call_ms, per_call_ms * 1e3 / (double)W, service_ms, service_ms * 1e3 / (double)W, svc_hits,
-                routed_ms, (unsigned long long)svc_requests, (unsigned long long)svc_launches, batched_ms);
+                bound_ms, bound_ms * 1e3 / (double)W, bound_hits, (unsigned long long)settled, routed_ms, (unsigned long long)svc_requests, (unsigned long long)svc_launches, batched_ms);
     for (ss_searcher *s : searchers) ss_searcher_free(s);
     (void)hipFree(d_found);
     (void)hipFree(d_rng);
     (void)hipFree(d_words);
     (void)hipFree(d_hay);
     (void)hipStreamDestroy(st);
-    if (svc_hits != W || routed_hits != W * (size_t)iters) return 1;
+    if (svc_hits != W || bound_hits != W || routed_hits != W * (size_t)iters) return 1;
     return (hits == W && bhits == W) ? 0 : 1;           // every word of words.txt occurs in i386.txt (tests/i386.rs:61-70)
 }
 
