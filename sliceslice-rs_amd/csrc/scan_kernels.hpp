@@ -100,9 +100,11 @@ struct Problem {
     uint64_t order_val[2];    //   byte, rarest first, 1 byte each - entry t: word t/8, bits 8(t%8)..) and needle[K] in that order
     uint32_t norder;          //   how many (<= 15)
     // Exact in-register verification (the reference's const-length compare for SIZE = Some(1..=16), lib.rs:222-241):
-    // when the needle ends at most 16 bytes behind the first filter byte, tail16 holds needle[first .. n) (zero padded)
-    // and exact_len = n - first; a candidate that survives the second level is then compared against these four dwords
-    // in registers - no LDS staging, no re-read of the haystack.  exact_len == 0: the memory compare decides.
+    // when the needle ends at most 16 bytes behind the first filter byte, tail16 holds the L <= 16 needle bytes
+    // needle[first - back .. n) (zero padded; back = as many of the bytes in front of the first filter byte as sixteen leave
+    // room for - all of them for a needle of up to 16 bytes) and exact_len = L | back << 8; a candidate that survives the
+    // second level is then compared against these four dwords in registers - no LDS staging, no re-read of the haystack
+    // (exact_verify_piece).  exact_len == 0: the memory compare decides.
     uint32_t exact_len;
     uint32_t tail16[4];
     int *host_flag;           // optional pinned-host mirror of the found flag (saves the D2H copy); may be null
@@ -191,6 +193,37 @@ __device__ __forceinline__ bool verify_candidate(const uint8_t *hay, const uint8
     for (; k < n; ++k)
         if (h[k] != needle[k]) return false;
     return true;
+}
+
+// h[0 .. count) == nd[0 .. count), both in global memory, for the few candidates the exact in-register compare hands over.
+// Never a byte-by-byte loop - that is one dependent memory round trip per byte, half a microsecond each, which a text full of
+// true matches paid in some wave of nearly every search: a dword per round trip, the last dword of a range OVERLAPPING the one
+// before it so that no load reaches past either range (at most four round trips for up to sixteen bytes).
+// (hb and nd are wave-uniform pointers, `off` the lane's 32-bit offset from hb: scalar base + vector offset addressing, one
+// address register per lane instead of a 64-bit pointer per load - this sits inside kernels that live on 80 vector registers)
+__device__ __forceinline__ bool same_bytes(const uint8_t *hb, uint32_t off, const uint8_t *nd, uint32_t count)
+{
+    auto u32 = [](const uint8_t *p, uint32_t o) { return reinterpret_cast<const UnalignedU32 *>(p + o)->v; };
+    // 4 <= len <= 16 bytes from `at` on: the first and the last dword (all of a range of up to 8 bytes), then the two in
+    // between; one load per side in flight - two pairs at once cost the kernels two vector registers they do not have
+    auto group = [&](uint32_t at, uint32_t len) {
+        const uint32_t o3 = at + len - 4;
+        if (u32(hb, off + at) != u32(nd, at)) return false;
+        if (u32(hb, off + o3) != u32(nd, o3)) return false;
+        if (len <= 8) return true;
+        const uint32_t o1 = at + 4, o2 = at + len - 8;
+        if (u32(hb, off + o1) != u32(nd, o1)) return false;
+        return u32(hb, off + o2) == u32(nd, o2);
+    };
+    if (count < 4) {                                    // 0 .. 3 bytes: first, middle, last
+        if (count == 0) return true;
+        const uint32_t mid = count >> 1, last = count - 1;
+        return (uint32_t)((hb[off] ^ nd[0]) | (hb[off + mid] ^ nd[mid]) | (hb[off + last] ^ nd[last])) == 0;
+    }
+    for (uint32_t k = 0; k + 16 < count; k += 16)
+        if (!group(k, 16)) return false;
+    const uint32_t base = count > 16 ? count - 16 : 0;  // the last 4 .. 16 bytes (overlapping the group in front of them)
+    return group(base, count - base);
 }
 
 // The filters work on raw byte DIFFERENCES: x ^ splat(b) has a zero byte exactly where the haystack byte
@@ -301,6 +334,11 @@ constexpr uint32_t kFarFirst = 10;
 #ifndef SS_REFINE_BYTES_PER_BALLOT
 #define SS_REFINE_BYTES_PER_BALLOT 1
 #endif
+#ifndef SS_EXACT_REFINE_STEPS
+#define SS_EXACT_REFINE_STEPS 2
+#endif
+constexpr uint32_t kExactRefineSteps = SS_EXACT_REFINE_STEPS;     // schedule bytes in front of the exact in-register compare
+constexpr uint32_t kExactSparseLanes = 24;                        // ... none at all with this few candidate lanes in a tile
 constexpr uint32_t kRefineBytesPerBallot = SS_REFINE_BYTES_PER_BALLOT;   // schedule bytes applied between two wave ballots
 
 __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, uint64_t n, uint64_t position,
@@ -433,7 +471,8 @@ struct RefineOrder {
 // on random bytes the extra pieces cost ~2 VALU per KiB on average.  Returns false when no lane of the wave
 // has a candidate left in any piece.
 template <int U, int MODE>
-__device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H, const RefineOrder &ro, uint32_t (&G)[U][4])
+__device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H, const RefineOrder &ro, uint32_t (&G)[U][4],
+                                            uint32_t max_steps)
 {
     auto any_left = [&]() {
         uint32_t o = 0;
@@ -456,11 +495,12 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
     // buffer, profiles/r03/ab_refine_bytes_per_ballot.jsonl): with two, the reference's pair (0, n-1) on text - every tile
     // dense with chance hits - ran at 5.4 TB/s instead of 6.1-6.8, with three at 4.6: the first byte clears most tiles, and
     // the dozen VALU operations per piece of a second one cost more than the ballot -> compare -> branch chain they save.
+    const uint32_t steps = ro.n < max_steps ? ro.n : max_steps;
     uint32_t t = 0;
 #pragma unroll 1
-    while (t < ro.n && any) {
+    while (t < steps && any) {
 #pragma unroll 1
-        for (uint32_t k = 0; k < kRefineBytesPerBallot && t < ro.n; ++k, ++t) {
+        for (uint32_t k = 0; k < kRefineBytesPerBallot && t < steps; ++k, ++t) {
             const uint32_t sh = 8 * (t & 7);
             const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
             const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);
@@ -556,16 +596,28 @@ __device__ __forceinline__ uint32_t flag_nibble(uint32_t g)
 }
 
 // Exact verification of one lane's surviving flags WITHOUT touching memory (MODE 0 kernels, needles that end at most 16
-// bytes behind the first filter byte - every needle of up to 16 bytes whose filter starts at byte 0): the 16 stream bytes
-// behind a candidate lie in this lane's chunk and the next lane's (raw dwords, one DPP hop - lane 63 takes lane 0 of the
-// wave's next piece or the halo chunk), are brought to the candidate's byte offset with v_alignbyte and compared with the
-// needle's dwords under a length mask.  The flags are walked lowest first (lib.rs:220-247), so `where` is the lane's leftmost
-// match.  What the filter stream cannot see - needle bytes IN FRONT of the first filter byte (filters chosen by rarity may
-// start later) - is compared in memory, for exact survivors only.
-__device__ __forceinline__ bool exact_verify_piece(const u32x4 &A, const NextPiece &np, const uint32_t g[4], uint64_t chunk,
-                                                   const Problem &pr, const VerifyArgs &va, const uint32_t tail16[4],
-                                                   uint32_t exact_len, uint64_t &where)
+// bytes behind the first filter byte).  `exact` = L | back << 8: the compare covers the L <= 16 needle bytes needle[first - back
+// .. first - back + L) held in cmp16 - the bytes from the first filter byte on plus as many of the `back` bytes IN FRONT of it
+// (filters chosen by rarity may start inside the needle) as sixteen allow; a needle of up to 16 bytes is covered whole.
+// A lane holds the 32 stream bytes of its own chunk and the next lane's (raw dwords, one DPP hop - lane 63 takes lane 0 of the
+// wave's next piece or the halo chunk).  A candidate at byte b of a chunk needs the bytes from b - back on: with b >= back
+// they lie in that window; a candidate with b < back starts in the PREVIOUS lane's chunk, so its FLAG moves to that lane (one
+// more DPP hop, of a 16-bit flag word), whose window holds all of it.  Only lane 0 has nobody in front of it: its first `back`
+// flags are settled in memory (same_bytes; one candidate in ~170 on average.  Comparing them against lane 63's chunk of the
+// wave's previous piece, held in scalar registers, was tried: five more vector registers at the kernels' peak, i.e. a wave of
+// occupancy).  The window is brought to the candidate's byte offset with v_alignbyte and compared with cmp16 under a length
+// mask.  Flags are walked lowest first (lib.rs:220-247) - a lane's own before those handed to it, which lie further right -
+// so `where_off` is the lane's leftmost match and lanes stay in address order.  Needle bytes further in front than `back`
+// (needles of more than 16 bytes) are compared in memory, for exact survivors only.
+__device__ __forceinline__ bool exact_verify_piece(const u32x4 &A, const NextPiece &np, const uint32_t g[4], uint64_t chunk_wave,
+                                                   int lane, const Problem &pr, const VerifyArgs &va, const uint32_t cmp16[4],
+                                                   uint32_t exact, uint32_t &where_off)
 {
+    // index of the needle's first byte for a candidate at stream byte t of this lane's window: ubase (wave-uniform; wraps for
+    // chunks in front of the haystack) + 16 * lane + t
+    const uint64_t ubase = chunk_wave * 16 - pr.mis;
+    const uint8_t *hb = va.hay + ubase;
+    const uint32_t exact_len = exact & 0xFFu, back = (exact >> 8) & 0xFFu;          // wave-uniform
     // (named scalars, not an array: a select between array ELEMENTS becomes a select between addresses, and the window
     // ends up in scratch memory behind a dynamic index)
     auto hop = [&](uint32_t nword, uint32_t own) {
@@ -579,30 +631,42 @@ __device__ __forceinline__ bool exact_verify_piece(const u32x4 &A, const NextPie
         const int rem = (int)exact_len - 4 * j;
         M[j] = rem >= 4 ? ~0u : (rem <= 0 ? 0u : (1u << (8 * rem)) - 1u);
     }
+    // bit t: a candidate whose first filter byte is stream byte t of {own chunk, next lane's chunk}
     uint32_t flags = flag_nibble(g[0]) | (flag_nibble(g[1]) << 4) | (flag_nibble(g[2]) << 8) | (flag_nibble(g[3]) << 12);
-    const uint64_t anchor = (uint64_t)((pr.base + pr.mis) - va.hay);     // needle bytes in front of the filter stream
+    if (back != 0) {
+        const uint32_t low = flags & ((1u << back) - 1u);
+        flags = (lane == 0 ? flags : flags & ~low) | (from_next_lane_or(0u, low) << 16);
+    }
+    const uint64_t anchor = (uint64_t)((pr.base + pr.mis) - va.hay);     // index of the first filter byte in the needle
+    const uint32_t front = (uint32_t)(anchor - back);                    // needle bytes in front of the register window
     bool hit = false;
     while (flags != 0 && !hit) {
-        const int b = __ffs((int)flags) - 1;            // lowest flagged byte first (tzcnt, lib.rs:221)
+        const int t = __ffs((int)flags) - 1;            // lowest flagged byte first (tzcnt, lib.rs:221)
         flags &= flags - 1;                             // clear lowest set bit        (lib.rs:247)
-        const uint64_t i = chunk * 16 + (uint64_t)b - pr.mis;   // wraps for bytes in front of the haystack
+        const uint32_t off = 16u * (uint32_t)lane + (uint32_t)t;
+        const uint64_t i = ubase + off;                 // wraps for bytes in front of the haystack
         if (i >= va.end) continue;
-        const int q = b >> 2;
-        const uint32_t r = (uint32_t)(b & 3);
-        auto pick = [&](uint32_t a, uint32_t b1, uint32_t c, uint32_t d) {
-            const uint32_t lo = q & 1 ? b1 : a, hi = q & 1 ? d : c;
-            return q & 2 ? hi : lo;
-        };
-        const uint32_t sw[5] = {pick(w0, w1, w2, w3), pick(w1, w2, w3, w4), pick(w2, w3, w4, w5), pick(w3, w4, w5, w6),
-                                pick(w4, w5, w6, w7)};
-        uint32_t diff = 0;
+        uint32_t in_memory = front;                     // needle bytes this candidate still has to match in memory
+        if ((uint32_t)t < back) {
+            // lane 0: the bytes in front of this candidate lie in a chunk the wave may not hold - the whole needle, in memory
+            in_memory = (uint32_t)va.n;
+        } else {
+            const int start = t - (int)back;            // byte offset of needle[first - back] in the window: 0 .. 15
+            const int q = start >> 2;
+            const uint32_t r = (uint32_t)(start & 3);
+            auto pick = [&](uint32_t a, uint32_t b1, uint32_t c, uint32_t d) {
+                const uint32_t lo = q & 1 ? b1 : a, hi = q & 1 ? d : c;
+                return q & 2 ? hi : lo;
+            };
+            const uint32_t sw[5] = {pick(w0, w1, w2, w3), pick(w1, w2, w3, w4), pick(w2, w3, w4, w5), pick(w3, w4, w5, w6),
+                                    pick(w4, w5, w6, w7)};
+            uint32_t diff = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) diff |= (__builtin_amdgcn_alignbyte(sw[j + 1], sw[j], r) ^ tail16[j]) & M[j];
-        if (diff != 0) continue;
-        bool same = true;
-        for (uint64_t k = 0; k < anchor && same; ++k) same = va.hay[i + k] == va.needle[k];
-        hit = same;
-        where = i;                                      // lowest match of this lane when hit
+            for (int j = 0; j < 4; ++j) diff |= (__builtin_amdgcn_alignbyte(sw[j + 1], sw[j], r) ^ cmp16[j]) & M[j];
+            if (diff != 0) continue;
+        }
+        hit = in_memory == 0 || same_bytes(hb, off, va.needle, in_memory);
+        where_off = off;                                // lowest match of this lane when hit: index ubase + off
     }
     return hit;
 }
@@ -1003,8 +1067,12 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         ro.val[t] = uniform64(ro.val[t]);
                     }
                     if (EXACT_OK && va.n - anchor <= 16) {
-                        exact_len = (uint32_t)(va.n - anchor);
-                        const uint32_t nbv = (uint32_t)lane < exact_len ? (uint32_t)va.needle[anchor + lane] : 0u;
+                        // the bytes from the first filter byte on, plus what sixteen leave room for of those in front of it
+                        const uint32_t behind = (uint32_t)(va.n - anchor);
+                        const uint32_t back = (uint32_t)(anchor < 16 - behind ? anchor : 16 - behind);
+                        const uint32_t el = behind + back;
+                        exact_len = el | (back << 8);
+                        const uint32_t nbv = (uint32_t)lane < el ? (uint32_t)va.needle[anchor - back + lane] : 0u;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             tail16[j] = ((uint32_t)__builtin_amdgcn_readlane((int)nbv, 4 * j) & 0xFF) |
@@ -1037,18 +1105,31 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
             // paid once per needle byte instead of once per piece and byte.
             uint32_t pm = (1u << U) - 1;
             bool per_piece = !TILE_WIDE;
+            uint32_t cand_lanes = 0;                    // lanes of the tile that hold a candidate
             if (!ONE_BYTE && TILE_WIDE) {
                 pm = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (__ballot(((G[u][0] | G[u][1] | G[u][2] | G[u][3]) & 0x80808080u) != 0) != 0) pm |= 1u << u;
+                for (int u = 0; u < U; ++u) {
+                    const uint64_t bl = __ballot(((G[u][0] | G[u][1] | G[u][2] | G[u][3]) & 0x80808080u) != 0);
+                    if (bl != 0) pm |= 1u << u;
+                    cand_lanes += (uint32_t)__builtin_popcountll(bl);
+                }
 #ifdef SS_NO_SPARSE_REFINE       // A/B builds only
                 per_piece = false;
 #else
                 per_piece = __builtin_popcount(pm) <= 2;
 #endif
                 if (!per_piece) {
-                    if (!refine_tile<U, MODE>(A, H, ro, G)) continue;
+                    // With the needle's dwords at hand (exact mode) the byte-wise schedule only has to thin out CHANCE hits - two
+                    // bytes do that - because the exact compare settles whatever is left, many candidates per lane or few; a true
+                    // match survives every step of the schedule, and a text full of them (the reference's bench: words of the
+                    // manual searched in the manual) paid for all of its up to 15 ballot rounds in every tile: 5.7 us per search
+                    // for a rare word, 10-11 us for 'instruction' (profiles/r03/service_experiments.md).
+                    // ... and with few candidate lanes in the tile (every piece of this text holds a true match or two) not
+                    // even those: the compare costs a lane ~40 operations per candidate, a schedule byte ~24 per PIECE.
+                    const bool exact = EXACT_OK && exact_len != 0;
+                    const uint32_t max_steps = exact ? (cand_lanes <= kExactSparseLanes ? 0u : kExactRefineSteps) : 15u;
+                    if (max_steps != 0 && !refine_tile<U, MODE>(A, H, ro, G, max_steps)) continue;
                 }
             }
             bool hit = false;
@@ -1075,12 +1156,16 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     NextPiece np;
                     np.N = u + 1 < U ? A[u + 1] : H;
                     np.kind = u + 1 < U ? 1 : 0;                // MODE 0: the halo chunk sits in lane 63
-                    h = exact_verify_piece(A[u], np, g, chunk0 + 64 * u + lane, pr, va, tail16, exact_len, where);
+                    uint32_t where_off = 0;
+                    h = exact_verify_piece(A[u], np, g, chunk0 + 64 * u, lane, pr, va, tail16, exact_len, where_off);
+                    if (FIND) where = (chunk0 + 64 * u) * 16 - pr.mis + where_off;
                 } else {
                     stage_once();
                     h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, va, s_needle, where);
                 }
                 hit |= h;
+                // search_in: the first piece with a match settles the wave (a text full of matches holds one in every piece)
+                if (!FIND && __ballot(h) != 0) break;
                 if (FIND) {
                     const uint64_t m = __ballot(h);
                     if (m != 0) {                       // lanes are in address order: lowest lane = leftmost
@@ -1830,27 +1915,29 @@ __global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best, int pair
 
 // ---- resident search service (ss_service_*) ---------------------------------------------------------------
 // The launch path costs a search 8-10 us whatever its size: doorbell, command processor, dispatch, completion.  A host <->
-// device round trip through pinned memory against a kernel that is ALREADY running costs 1.4-1.6 us (mailbox_echo_kernel
-// below).  The service is that kernel: `gridDim.x` workgroups that stay on the device and take one request at a time:
-//   * the host writes the request - a whole Problem - into a 256-byte mailbox in pinned memory: four 64-byte lines, each 15
-//     payload dwords + the request's sequence number as its LAST dword.  A line read over PCIe is one snapshot, and x86
-//     stores become visible in order, so a line that shows the new number holds the new payload;
-//   * ONE wave (the leader: wave 0 of workgroup 0) polls the mailbox - 64 lanes x 4 bytes, one instruction - and when all
-//     four lines show the next number hands the payload to the others through device memory (agent-scope 4-byte stores, a
-//     release fence, then the sequence word they all poll);
+// device round trip against a kernel that is ALREADY running costs 1.5-2.5 us (mailbox_echo_kernel below, tools/
+// vram_mailbox_probe.hip).  The service is that kernel: `gridDim.x` workgroups that stay on the device and take one request
+// at a time:
+//   * the mailbox is 256 bytes of DEVICE memory that the host writes through the PCIe BAR (every MI300-class part exposes
+//     all of its memory to the CPU): four 64-byte lines, each 15 payload dwords + the request's sequence number as its LAST
+//     dword.  The host writes the payload, fences, then the four sequence dwords: posted writes arrive in order, so a line
+//     that shows the new number holds the new payload;
+//   * EVERY wave of every workgroup polls the mailbox itself - 64 lanes x 4 bytes, one instruction, served by the device's own
+//     memory - and takes the request straight out of the polled registers: no leader, no hop between workgroups.  (Round 3
+//     began with the mailbox in pinned HOST memory: every poll crossed PCIe, so only one wave could poll and had to hand
+//     the request on through device memory - 64 pollers made a round trip 13 us, tools/vram_mailbox_probe.hip; with the
+//     mailbox on the device's side of the link 64 workgroups answer in 3.4 us.)
 //   * every workgroup scans tiles b, b + grid, ... of the haystack with the same scan_tiles<> as every other kernel, counts
 //     itself out exactly like a completion-word launch of scan_kernel, and the workgroup that completes the count stores
 //     found-count << 32 | sequence << 1 | found to the pinned answer word the host spins on.
-// Measured (tools/native_bench latency, profiles/r03/service_experiments.md): a search of a 1 KiB haystack costs 8.2-8.8 us through a
-// launch and 7.7-8.3 us through this service - the mailbox round trip is 1.5 us, but handing the request from the leader to the
-// workgroups (device-memory hop), the per-request acquire (2 us: without it - wrong in general - 6.0 us) and the count-out add
-// up to what the command processor costs.  Letting EVERY workgroup poll the pinned mailbox itself and answer into a slot of
-// its own (no device-side hop at all) was worse: 32 pollers on the PCIe link made a search 16 us.
-// Residency is a LEASE: without a request for `idle_ticks` (100 MHz s_memrealtime) the leader announces that it is leaving,
-// looks at the mailbox once more (a request posted meanwhile is served; host and device each write their word before
-// reading the other's), tells the others and the kernel ends; the host starts it again with its next request.  Nothing that
-// waits for the whole device - hipDeviceSynchronize, hipFree - can therefore wait longer than the lease.  Every spin in here
-// is bounded.
+// Measured: profiles/r03/service_experiments.md.
+// Residency is a LEASE: without a request for `idle_ticks` (100 MHz s_memrealtime) the keeper (wave 0 of workgroup 0)
+// announces that it is leaving, looks at the mailbox once more (a request posted meanwhile is served; host and device each
+// write their word before reading the other's), sets the stop word the others poll beside the mailbox, and the kernel ends;
+// the host starts it again with its next request.  A request that arrives while the stop word spreads may be taken by some
+// waves and not by others: its count never completes, the host sees the kernel gone, waits for the stream, resets the
+// counter and posts the request again to a new residency.  Nothing that waits for the whole device - hipDeviceSynchronize,
+// hipFree - can wait longer than the lease.  Every spin in here is bounded.
 struct ServiceRequest {
     Problem pr;
     uint32_t q;            // dword window of the second filter byte (the kernels' template parameter Q)
@@ -1858,105 +1945,108 @@ struct ServiceRequest {
     uint32_t stop;         // != 0: no search - the service ends
     uint32_t settled;      // != 0: every byte this request reads was last written before an earlier request's acquire (or the
                            // kernel's start) - a bound haystack (ss_service_bind), a needle uploaded earlier: no acquire
+    uint32_t active;       // workgroups 0 .. active-1 scan (tiles b, b + active, ...) and count out; the others only watch
+    uint32_t pad_;
 };
 static_assert(sizeof(ServiceRequest) <= 240 && sizeof(ServiceRequest) % 8 == 0, "four mailbox lines of 60 payload bytes");
 constexpr uint32_t kSvcRunning = 1, kSvcLeaving = 2, kSvcExited = 3;
 constexpr unsigned long long kSvcStopSeq = ~0ull;
 
+#ifndef SS_SERVICE_NT
+#define SS_SERVICE_NT 0
+#endif
 template <int U>
 __global__ void __launch_bounds__(kBlock)
-service_kernel(const uint32_t *h_req, uint32_t *h_status, unsigned long long *h_answer, uint32_t *d_box, unsigned long long *d_seq,
-               unsigned long long *d_done, int *d_found, uint32_t first_seq, unsigned long long idle_ticks)
+service_kernel(const uint32_t *d_req, uint32_t *h_status, unsigned long long *h_answer, uint32_t *d_stop, unsigned long long *d_done,
+               int *d_found, uint32_t first_seq, unsigned long long idle_ticks)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
     __shared__ int s_wg_found;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const bool leader = blockIdx.x == 0 && wave == 0;
-    constexpr unsigned long long kWorkerPatience = 300000000ull;           // 3 s of s_memrealtime: a worker never waits longer
-    if (leader && lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool keeper = blockIdx.x == 0 && wave == 0;                      // the wave that watches the lease
+    constexpr unsigned long long kWorkerPatience = 300000000ull;           // 3 s of s_memrealtime: no wave ever waits longer
+    constexpr int kDwords = (int)(sizeof(ServiceRequest) / 4);
+    constexpr int kStopPayloadDword = (int)(offsetof(ServiceRequest, stop) / 4);
+    constexpr int kStopLane = kStopPayloadDword + kStopPayloadDword / 15;
+    if (keeper && lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (uint32_t next = first_seq;; ++next) {
-        // ---- 1. the leader fetches request `next` and publishes it --------------------------------------------------
-        if (leader) {
-            auto poll = [&](uint32_t *v) {          // lane i <- dword i of the mailbox; true when all four lines carry `next`
-                *v = __hip_atomic_load(h_req + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                return (uint32_t)__builtin_amdgcn_readlane((int)*v, 15) == next && (uint32_t)__builtin_amdgcn_readlane((int)*v, 31) == next &&
-                       (uint32_t)__builtin_amdgcn_readlane((int)*v, 47) == next && (uint32_t)__builtin_amdgcn_readlane((int)*v, 63) == next;
+        // ---- 1. EVERY wave polls the mailbox: device memory the host writes through the BAR ----------------------------------
+        // lane i <- dword i of the mailbox (one instruction, four lines); agent-scope loads are performed beyond the L2, where
+        // the host's stores arrive.  A line that shows `next` in its last dword holds this request's payload (the host writes
+        // the payload, fences, THEN the four sequence dwords).
+        uint32_t v = 0;
+        bool leave = false;
+        {
+            auto issue = [&]() { return __hip_atomic_load(d_req + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            auto shows_next = [&](uint32_t x) {
+                return (uint32_t)__builtin_amdgcn_readlane((int)x, 15) == next && (uint32_t)__builtin_amdgcn_readlane((int)x, 31) == next &&
+                       (uint32_t)__builtin_amdgcn_readlane((int)x, 47) == next && (uint32_t)__builtin_amdgcn_readlane((int)x, 63) == next;
             };
-            uint32_t v = 0;
-            bool have = false;
+            // TWO polls in flight, issued half a memory latency apart and each re-issued as it returns: the mailbox is sampled
+            // twice per latency instead of once, a request waits a quarter of a latency less to be seen.  The stop word and the
+            // lease are looked at every 32nd round only.
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (!(have = poll(&v))) {
-                if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks) {
+            uint32_t pa = issue();
+            __builtin_amdgcn_s_sleep(10);
+            uint32_t pb = issue();
+            for (unsigned round = 1;; ++round) {
+                if (shows_next(pa)) { v = pa; break; }
+                pa = issue();
+                if (shows_next(pb)) { v = pb; break; }
+                pb = issue();
+                if ((round & 31) != 0) continue;
+                const uint32_t stopw = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(d_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (stopw != 0) { leave = true; break; }
+                const unsigned long long waited = __builtin_amdgcn_s_memrealtime() - t0;
+                if (keeper && waited > idle_ticks) {
                     // the lease is over: say so, THEN look once more (the host posts its request, THEN reads this word)
                     if (lane == 0) __hip_atomic_store(h_status, kSvcLeaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
-                    have = poll(&v);
-                    if (have && lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    v = issue();
+                    if (shows_next(v)) {
+                        if (lane == 0) __hip_atomic_store(h_status, kSvcRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    if (lane == 0) __hip_atomic_store(d_stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    leave = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            // the stop flag travels in the payload (dword 50 + 50/15 = mailbox dword 53 of a 200-byte Problem + q + one_byte)
-            constexpr int kStopPayloadDword = (int)(offsetof(ServiceRequest, stop) / 4);
-            constexpr int kStopLane = kStopPayloadDword + kStopPayloadDword / 15;
-            const bool stop = !have || __builtin_amdgcn_readlane((int)v, kStopLane) != 0;
-            if (!stop) {
-                if ((lane & 15) != 15) __hip_atomic_store(d_box + (lane - (lane >> 4)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // agent-scope atomic stores are performed beyond the XCD's L2 and acknowledged when they are: waiting for the
-                // acknowledgements orders them in front of the sequence word (a release fence - an L2 write-back on top - does
-                // the same for 0.1-0.6 us more per request)
-                __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            if (lane == 0)
-                __hip_atomic_store(d_seq, stop ? kSvcStopSeq : (unsigned long long)next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- 2. everybody waits for the sequence word ------------------------------------------------------------------
-        unsigned long long seen;
-        {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                seen = uniform64(__hip_atomic_load(d_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (seen == kSvcStopSeq || (uint32_t)seen == next) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks + kWorkerPatience) {
-                    seen = kSvcStopSeq;                                  // the leader is gone: leave, do not hang
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
+                if (!keeper && waited > idle_ticks + kWorkerPatience) { leave = true; break; }   // the keeper is gone: leave, do not hang
             }
         }
-        if (seen == kSvcStopSeq) break;
-        // ---- 3. the request, out of device memory into scalar registers ------------------------------------------------
-        // (agent-scope atomic loads: performed beyond the L2, they need no acquire of their own)
-        constexpr int kDwords = (int)(sizeof(ServiceRequest) / 4);
-        const uint32_t mine = lane < kDwords ? __hip_atomic_load(d_box + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        if (leave || __builtin_amdgcn_readlane((int)v, kStopLane) != 0) break;
+        // ---- 2. the request, out of the polled registers into scalar registers ---------------------------------------------
         union {
             ServiceRequest rq;
             uint32_t w[kDwords];
         } u;
 #pragma unroll
-        for (int k = 0; k < kDwords; ++k) u.w[k] = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
+        for (int k = 0; k < kDwords; ++k) u.w[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, k + k / 15);
         const ServiceRequest &rq = u.rq;
         // A kernel that never ends sees no kernel boundary: haystack or needle bytes written since it last looked (a copy, another
         // kernel) may still sit in this XCD's L2 / this CU's vector cache in their old state.  The acquire drops them - 2 us of
-        // the request's 8 - unless the host vouches that nothing this request reads has changed (ServiceRequest::settled).
+        // a request - unless the host vouches that nothing this request reads has changed (ServiceRequest::settled).
+        // A small request is not worth every workgroup's count: the host names how many take part (one per tile at most).
+        if (blockIdx.x >= rq.active) continue;
         if (!rq.settled) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        // ---- 4. scan: workgroup b takes tiles b, b + grid, ... -------------------------------------------------------------
+        // ---- 3. scan: workgroup b takes tiles b, b + active, ... -----------------------------------------------------------
         if (threadIdx.x == 0) __hip_atomic_store(&s_wg_found, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         const uint64_t ntiles = (rq.pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
         const ColdInRegisters cold = {&rq.pr};
         if (rq.one_byte) {
-            scan_tiles<0, 0, true, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found);
+            scan_tiles<0, 0, true, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found);
         } else {
             switch (rq.q) {
-            case 0: scan_tiles<0, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
-            case 1: scan_tiles<1, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
-            case 2: scan_tiles<2, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
-            default: scan_tiles<3, 0, false, U, 1, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, gridDim.x, ntiles, d_found, &s_wg_found); break;
+            case 0: scan_tiles<0, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
+            case 1: scan_tiles<1, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
+            case 2: scan_tiles<2, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
+            default: scan_tiles<3, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
             }
         }
-        // ---- 5. count out; the workgroup that completes the count answers (scan_kernel's completion word) ---------------
+        // ---- 4. count out; the workgroup that completes the count answers (scan_kernel's completion word) ---------------
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long f = (unsigned long long)__hip_atomic_load(&s_wg_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1970,7 +2060,7 @@ service_kernel(const uint32_t *h_req, uint32_t *h_status, unsigned long long *h_
         }
         __syncthreads();
     }
-    if (leader && lane == 0) __hip_atomic_store(h_status, kSvcExited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (keeper && lane == 0) __hip_atomic_store(h_status, kSvcExited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Mailbox round trip (ss_mailbox_round_trip_us): ONE lane answers `iters` requests posted by the host to pinned memory -

@@ -8,6 +8,7 @@
 //                                len < n -> false / len == n -> equality x86.rs:357-359)
 // The scan itself lives in scan_kernels.hpp.  There is no CPU search path in this file.
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -472,9 +473,11 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.exact_len = 0;
     pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
     if (!one_byte && pr.d == 0 && n - fa <= 16) {
-        pr.exact_len = (uint32_t)(n - fa);
+        // ... plus as many of the fa bytes in front of it as sixteen leave room for: a needle of up to 16 bytes is compared whole
+        const size_t behind = n - fa, back = std::min(fa, 16 - behind), el = behind + back;
+        pr.exact_len = (uint32_t)(el | (back << 8));
         uint8_t t16[16] = {0};
-        memcpy(t16, s->needle.data() + fa, n - fa);
+        memcpy(t16, s->needle.data() + fa - back, el);
         memcpy(pr.tail16, t16, 16);
     }
     shape->position = position;
@@ -2027,8 +2030,8 @@ struct ss_service {
     int workgroups = 0;
     unsigned long long idle_ticks = 0;
     hipStream_t stream = nullptr;
-    uint32_t *h_box = nullptr;              // pinned, 6 lines of 64 bytes: request (4) | status | answer
-    uint8_t *d_mem = nullptr;               // device: box (256 B) | seq | done counter | found flag
+    uint32_t *h_box = nullptr;              // pinned, 2 lines of 64 bytes: status | answer (written by the device)
+    uint8_t *d_mem = nullptr;               // device: mailbox (256 B, written by the HOST through the BAR) | stop word | done counter | found flag
     uint32_t seq = 0;                       // last request posted
     uint32_t done_low = 0, done_hi = 0;     // the never-reset completion counter, as the host knows it
     uint64_t requests = 0, launches = 0, settled_requests = 0;
@@ -2038,12 +2041,12 @@ struct ss_service {
     bool bound_settled = false;
     uint64_t settled_ticket = 0;
     std::mutex mu;
-    volatile uint32_t *status() const { return h_box + 64; }
-    volatile unsigned long long *answer() const { return reinterpret_cast<volatile unsigned long long *>(h_box + 80); }
-    uint32_t *d_box() const { return reinterpret_cast<uint32_t *>(d_mem); }
-    unsigned long long *d_seq() const { return reinterpret_cast<unsigned long long *>(d_mem + 256); }
-    unsigned long long *d_done() const { return reinterpret_cast<unsigned long long *>(d_mem + 264); }
-    int *d_found() const { return reinterpret_cast<int *>(d_mem + 272); }
+    volatile uint32_t *status() const { return h_box; }
+    volatile unsigned long long *answer() const { return reinterpret_cast<volatile unsigned long long *>(h_box + 16); }
+    volatile uint32_t *mailbox() const { return reinterpret_cast<volatile uint32_t *>(d_mem); }   // the host's view = the device's address
+    uint32_t *d_stop() const { return reinterpret_cast<uint32_t *>(d_mem + 256); }
+    unsigned long long *d_done() const { return reinterpret_cast<unsigned long long *>(d_mem + 320); }
+    int *d_found() const { return reinterpret_cast<int *>(d_mem + 384); }
 };
 
 namespace {
@@ -2052,34 +2055,73 @@ constexpr int kServiceDefaultWorkgroups = 64;
 constexpr double kServiceDefaultLeaseMs = 20.0;
 std::atomic<ss_service *> g_default_service[kMaxDevices];
 
+// The request, into the mailbox in device memory: payload first (16-byte stores: a write-combining mapping merges them into
+// line writes, an uncached one sends each as it is), a store fence, then the four sequence dwords - posted writes reach the
+// device in order, so a line that shows `seq` holds this request's payload.
+void service_write_mailbox(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq)
+{
+    alignas(16) uint32_t img[64];
+    uint32_t payload[60] = {0};
+    memcpy(payload, &rq, sizeof rq);
+    for (int line = 0; line < 4; ++line) {
+        for (int j = 0; j < 15; ++j) img[line * 16 + j] = payload[line * 15 + j];
+        img[line * 16 + 15] = seq - 1;                  // (the previous request's number: what the line shows already)
+    }
+    volatile uint32_t *m = sv->mailbox();
+    static const bool dbg = getenv("SLICESLICE_SERVICE_DEBUG") != nullptr;
+    const auto w0 = dbg ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    for (int k = 0; k < 16; ++k)
+        _mm_store_si128(reinterpret_cast<__m128i *>(const_cast<uint32_t *>(m)) + k, _mm_load_si128(reinterpret_cast<const __m128i *>(img) + k));
+    _mm_sfence();
+    for (int line = 0; line < 4; ++line) m[line * 16 + 15] = seq;
+    _mm_sfence();
+    if (dbg) {
+        static double total_us = 0;
+        static unsigned long n = 0;
+        total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
+        if ((++n & 0x3FFF) == 0) fprintf(stderr, "[service] mailbox write: %.3f us average over %lu requests\n", total_us / n, n);
+    }
+}
+
 int service_launch(ss_service *sv, uint32_t first_seq)
 {
     __atomic_store_n(sv->status(), 0u, __ATOMIC_RELAXED);
-    HIP_TRY(hipMemsetAsync(sv->d_seq(), 0, sizeof(unsigned long long), sv->stream));   // (ordered behind the previous residency's end)
+    HIP_TRY(hipMemsetAsync(sv->d_stop(), 0, sizeof(uint32_t), sv->stream));   // (ordered behind the previous residency's end)
     ss::service_kernel<4><<<dim3((unsigned)sv->workgroups), dim3(ss::kBlock), 0, sv->stream>>>(
-        sv->h_box, const_cast<uint32_t *>(sv->status()), const_cast<unsigned long long *>(sv->answer()), sv->d_box(), sv->d_seq(), sv->d_done(),
-        sv->d_found(), first_seq, sv->idle_ticks);
+        const_cast<const uint32_t *>(reinterpret_cast<uint32_t *>(sv->d_mem)), const_cast<uint32_t *>(sv->status()),
+        const_cast<unsigned long long *>(sv->answer()), sv->d_stop(), sv->d_done(), sv->d_found(), first_seq, sv->idle_ticks);
     HIP_TRY(hipGetLastError());
     ++sv->launches;
     return SS_OK;
 }
 
-// Posts one request and waits for its answer word (or, for a stop request, for the kernel to say it has left).
-int service_post(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq, unsigned long long *answer)
+// A residency has ended (lease, or never begun) with request `seq` unanswered: some of its waves may have taken the request
+// before they saw the stop word and counted themselves out - a count that can no longer complete.  Wait for the kernel to be
+// gone, start the counter over, name the new target in the request, post it again and start a new residency with it.
+int service_restart_with(ss_service *sv, ss::ServiceRequest &rq, uint32_t seq)
 {
-    uint32_t payload[60] = {0};
-    memcpy(payload, &rq, sizeof rq);
-    volatile uint32_t *m = sv->h_box;
-    for (int line = 0; line < 4; ++line) {
-        for (int j = 0; j < 15; ++j) __atomic_store_n(m + line * 16 + j, payload[line * 15 + j], __ATOMIC_RELAXED);
-        __atomic_store_n(m + line * 16 + 15, seq, __ATOMIC_RELEASE);      // a line that shows `seq` holds this request's payload
+    HIP_TRY(hipStreamSynchronize(sv->stream));
+    HIP_TRY(hipMemsetAsync(sv->d_done(), 0, sizeof(unsigned long long), sv->stream));
+    sv->done_low = sv->done_hi = 0;
+    if (!rq.stop) {
+        rq.pr.done_target = rq.active;
+        rq.pr.done_hi = 0;
+        rq.settled = 0;                                 // (a new kernel starts with clean caches anyway)
     }
+    service_write_mailbox(sv, rq, seq);
+    return service_launch(sv, seq);
+}
+
+// Posts one request and waits for its answer word (or, for a stop request, for the kernel to say it has left).
+int service_post(ss_service *sv, ss::ServiceRequest &rq, uint32_t seq, unsigned long long *answer)
+{
+    service_write_mailbox(sv, rq, seq);
     __atomic_thread_fence(__ATOMIC_SEQ_CST);                              // the request first, THEN the kernel's state (see service_kernel)
     uint32_t st = __atomic_load_n(sv->status(), __ATOMIC_ACQUIRE);
-    if (rq.stop && (st == 0 || st == ss::kSvcExited) && sv->launches == 0) return SS_OK;   // never started: nothing to stop
+    if (rq.stop && (st == 0 || st == ss::kSvcExited)) return SS_OK;       // not resident: nothing to stop
     bool launched_now = false;
-    if (st == 0 && sv->launches == 0) {                                  // first request of this service
-        if (int rc = service_launch(sv, seq)) return rc;
+    if (st == 0 && sv->launches == 0) {                                   // first request of this service
+        if (int rc = service_restart_with(sv, rq, seq)) return rc;
         launched_now = true;
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -2094,8 +2136,8 @@ int service_post(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq, uns
         st = __atomic_load_n(sv->status(), __ATOMIC_ACQUIRE);
         if (st == ss::kSvcExited) {
             if (rq.stop) return SS_OK;
-            // the lease ran out before the kernel saw this request: a new residency starts with it
-            if (int rc = service_launch(sv, seq)) return rc;
+            // the lease ran out before (all of) the kernel saw this request: a new residency starts with it
+            if (int rc = service_restart_with(sv, rq, seq)) return rc;
             launched_now = true;
         }
         cpu_relax();
@@ -2132,6 +2174,11 @@ int ss_service_start(int workgroups, double lease_ms, ss_service **out)
     if (workgroups < 1 || workgroups > di.cus) return fail(SS_ERR_ARGUMENT, "1 .. %d service workgroups (one per compute unit at most)", di.cus);
     if (lease_ms == 0) lease_ms = kServiceDefaultLeaseMs;
     if (!(lease_ms >= 0.05 && lease_ms <= 10000.0)) return fail(SS_ERR_ARGUMENT, "lease of 0.05 .. 10000 ms");
+    // the mailbox lives in device memory and is written by the CPU: every byte of an MI300-class part's memory is behind its
+    // PCIe BAR; a platform that hides it cannot run the service (searches take the launch path, as ever)
+    int large_bar = 0;
+    HIP_TRY(hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev));
+    if (!large_bar) return fail(SS_ERR_NO_DEVICE, "device %d does not expose its memory to the CPU (no large BAR): no search service", dev);
     ss_service *sv = new (std::nothrow) ss_service;
     if (!sv) return fail(SS_ERR_NOMEM, "out of memory");
     sv->dev = dev;
@@ -2156,6 +2203,8 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
     if (len && !d_haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
     if (s->n == 0) { *found = 1; return SS_OK; }        // x86.rs:500
     if (len < s->n) { *found = 0; return SS_OK; }       // x86.rs:357-359
+    static const bool dbg = getenv("SLICESLICE_SERVICE_DEBUG") != nullptr;
+    const auto c0 = dbg ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != sv->dev) return fail(SS_ERR_ARGUMENT, "the service runs on device %d, the current device is %d", sv->dev, dev);
@@ -2186,7 +2235,10 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
     const uint32_t seq = ++sv->seq;
     rq.pr.epoch = (int)seq;
     rq.pr.flags = ss::kProblemCounted;
-    rq.pr.done_target = sv->done_low + (uint32_t)sv->workgroups;
+    // one workgroup per tile at most: the count-out of a 1 KiB search is one atomic, not sixty-four
+    const uint64_t tiles = (rq.pr.npieces + ss::kWavesPerBlock * 4 - 1) / (ss::kWavesPerBlock * 4);
+    rq.active = (uint32_t)std::min<uint64_t>((uint64_t)sv->workgroups, std::max<uint64_t>(tiles, 1));
+    rq.pr.done_target = sv->done_low + rq.active;
     rq.pr.done_hi = sv->done_hi;
     // Inside a bound range that an earlier request has acquired, with a needle that was in device memory by then: nothing this
     // request reads has changed, the workgroups skip their acquire (2 us of a request's 8).
@@ -2195,7 +2247,16 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
     rq.settled = in_bound && sv->bound_settled && pd->upload_ticket <= sv->settled_ticket ? 1u : 0u;
     const uint64_t ticket_now = g_upload_ticket.load(std::memory_order_acquire);     // uploads are synchronous: all in memory by now
     unsigned long long a = 0;
+    const auto c1 = dbg ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (int rc = service_post(sv, rq, seq, &a)) return rc;
+    if (dbg) {
+        static double prep_us = 0, post_us = 0;
+        static unsigned long n = 0;
+        const auto c2 = std::chrono::steady_clock::now();
+        prep_us += std::chrono::duration<double, std::micro>(c1 - c0).count();
+        post_us += std::chrono::duration<double, std::micro>(c2 - c1).count();
+        if ((++n & 0x3FFF) == 0) fprintf(stderr, "[service] per request: %.3f us before the post, %.3f us post + wait (%lu requests)\n", prep_us / n, post_us / n, n);
+    }
     if (!rq.settled) {
         sv->settled_ticket = ticket_now;
         if (in_bound) sv->bound_settled = true;
@@ -2273,7 +2334,12 @@ ss_service *default_service(int dev)
     double lease = 0;
     if (const char *e = getenv("SLICESLICE_SERVICE_WORKGROUPS")) workgroups = atoi(e);
     if (const char *e = getenv("SLICESLICE_SERVICE_LEASE_MS")) lease = atof(e);
-    if (ss_service_start(workgroups, lease, &sv) != SS_OK) return nullptr;
+    static bool refused[kMaxDevices];                   // (no large BAR, out of memory ...: asked once, not per search)
+    if (refused[dev]) return nullptr;
+    if (ss_service_start(workgroups, lease, &sv) != SS_OK) {
+        refused[dev] = true;
+        return nullptr;
+    }
     g_default_service[dev].store(sv, std::memory_order_release);
     return sv;
 }

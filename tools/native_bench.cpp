@@ -251,6 +251,53 @@ static int config1(const char *hay_path, const char *words_path, int iters)
     const double bound_ms = seconds_since(tb) / iters * 1e3;
     uint64_t settled = 0;
     CK(ss_service_settled_requests(sv, &settled));
+    if (std::getenv("NATIVE_BENCH_PER_NEEDLE")) {
+        // where the bound loop's time goes: the fastest of `iters` timings per needle, against its length and the offset of
+        // its first occurrence in the text (stderr; not part of the JSON line)
+        std::vector<double> best(words.size(), 1e9);
+        for (int it = 0; it < std::max(iters, 5); ++it)
+            for (size_t w = 0; w < words.size(); ++w) {
+                const auto a = clk::now();
+                CK(ss_service_search(sv, searchers[w], d_hay, hay.size(), &found));
+                best[w] = std::min(best[w], std::chrono::duration<double, std::micro>(clk::now() - a).count());
+            }
+        std::vector<size_t> idx(words.size());
+        for (size_t w = 0; w < idx.size(); ++w) idx[w] = w;
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return best[a] < best[b]; });
+        auto first_at = [&](size_t w) {
+            const uint8_t *nd = wordsblob.data() + words[w].first;
+            const size_t n = words[w].second - words[w].first;
+            const void *p = memmem(hay.data(), hay.size(), nd, n);
+            return p ? (size_t)((const uint8_t *)p - hay.data()) : hay.size();
+        };
+        std::fprintf(stderr, "per needle (bound service, best of %d): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f us\n", std::max(iters, 5),
+                     best[idx[idx.size() / 10]], best[idx[idx.size() / 2]], best[idx[idx.size() * 9 / 10]], best[idx[idx.size() * 99 / 100]],
+                     best[idx.back()]);
+        double by_len[4] = {0}, by_pos[4] = {0};
+        size_t n_len[4] = {0}, n_pos[4] = {0};
+        for (size_t w = 0; w < words.size(); ++w) {
+            const size_t n = words[w].second - words[w].first, at = first_at(w);
+            const int lb = n <= 4 ? 0 : n <= 8 ? 1 : n <= 16 ? 2 : 3, pb = at < 16384 ? 0 : at < 131072 ? 1 : at < 524288 ? 2 : 3;
+            by_len[lb] += best[w]; ++n_len[lb];
+            by_pos[pb] += best[w]; ++n_pos[pb];
+        }
+        std::fprintf(stderr, "mean us by needle length  <=4: %.2f (%zu)  5-8: %.2f (%zu)  9-16: %.2f (%zu)  >16: %.2f (%zu)\n",
+                     by_len[0] / std::max<size_t>(n_len[0], 1), n_len[0], by_len[1] / std::max<size_t>(n_len[1], 1), n_len[1],
+                     by_len[2] / std::max<size_t>(n_len[2], 1), n_len[2], by_len[3] / std::max<size_t>(n_len[3], 1), n_len[3]);
+        std::fprintf(stderr, "mean us by first occurrence  <16K: %.2f (%zu)  <128K: %.2f (%zu)  <512K: %.2f (%zu)  later: %.2f (%zu)\n",
+                     by_pos[0] / std::max<size_t>(n_pos[0], 1), n_pos[0], by_pos[1] / std::max<size_t>(n_pos[1], 1), n_pos[1],
+                     by_pos[2] / std::max<size_t>(n_pos[2], 1), n_pos[2], by_pos[3] / std::max<size_t>(n_pos[3], 1), n_pos[3]);
+        for (size_t k = 0; k < 8; ++k) {
+            const size_t w = idx[idx.size() - 1 - k];
+            std::fprintf(stderr, "  slow: %.2f us  '%.*s'  first at %zu\n", best[w], (int)(words[w].second - words[w].first),
+                         (const char *)wordsblob.data() + words[w].first, first_at(w));
+        }
+        for (size_t k = 0; k < 4; ++k) {
+            const size_t w = idx[k];
+            std::fprintf(stderr, "  fast: %.2f us  '%.*s'  first at %zu\n", best[w], (int)(words[w].second - words[w].first),
+                         (const char *)wordsblob.data() + words[w].first, first_at(w));
+        }
+    }
     CK(ss_service_unbind(sv));
     CK(ss_service_set_default(sv, 1));
     size_t routed_hits = 0;

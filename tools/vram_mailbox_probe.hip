@@ -1,14 +1,15 @@
 // Can the host store straight into device memory (large BAR), and what does a host -> resident lane -> host round trip cost when the
 // REQUEST word lives in device memory (the lane polls locally) instead of pinned host memory (the lane polls over PCIe)?
 //   hipcc --offload-arch=gfx950 -O2 -o /tmp/vram_mailbox_probe tools/vram_mailbox_probe.hip && /tmp/vram_mailbox_probe
-// Prints one JSON line.  The host-store test runs in a forked child first: a part without CPU-visible VRAM faults there, not here.
+// Prints one JSON line.  The host-store test catches the fault of a part without CPU-visible VRAM.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <sys/wait.h>
+#include <csetjmp>
+#include <csignal>
 #include <unistd.h>
 #include <vector>
 #include <x86intrin.h>
@@ -61,19 +62,26 @@ __global__ void echo_slots_kernel(const unsigned long long *req, unsigned *resp_
 
 static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
+// (not in a forked child: the driver's mappings are not inherited across fork(), a child faults whatever the parent may do)
+static sigjmp_buf g_jmp;
+static void on_fault(int) { siglongjmp(g_jmp, 1); }
 static bool host_can_store(void *p)
 {
-    fflush(stdout);
-    pid_t c = fork();
-    if (c == 0) {
+    struct sigaction sa, old_segv, old_bus;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = on_fault;
+    sigaction(SIGSEGV, &sa, &old_segv);
+    sigaction(SIGBUS, &sa, &old_bus);
+    bool ok = false;
+    if (sigsetjmp(g_jmp, 1) == 0) {
         volatile unsigned *q = (volatile unsigned *)p;
         q[0] = 0xABCD1234u;
         _mm_sfence();
-        _exit(q[0] == 0xABCD1234u ? 0 : 1);
+        ok = q[0] == 0xABCD1234u;
     }
-    int st = 0;
-    waitpid(c, &st, 0);
-    return WIFEXITED(st) && WEXITSTATUS(st) == 0;
+    sigaction(SIGSEGV, &old_segv, nullptr);
+    sigaction(SIGBUS, &old_bus, nullptr);
+    return ok;
 }
 
 int main()
@@ -89,7 +97,6 @@ int main()
     CHECK(hipMalloc((void **)&d_done, 64));
     const bool fine_ok = hipExtMallocWithFlags((void **)&d_fine, 4096, hipDeviceMallocFinegrained) == hipSuccess;
     (void)hipGetLastError();
-    // NB: fork() after the runtime is up: the child only stores through an existing mapping and _exit()s
     const bool coarse_host = host_can_store(d_req);
     const bool fine_host = fine_ok && host_can_store(d_fine);
     printf("{\"host_store_to_hipMalloc\": %s, \"host_store_to_finegrained\": %s", coarse_host ? "true" : "false",
