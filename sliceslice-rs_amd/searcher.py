@@ -627,7 +627,8 @@ class NodeSearcher:
 
 class SearchService:
     """A resident search service on the current device (ss_service_*): a small kernel that stays on the GPU and takes one search
-    at a time from a pinned mailbox - no launch per search.  ``search_in(searcher, haystack)`` has the semantics of
+    at a time from a mailbox in device memory that the host writes through the PCIe BAR - no launch per search (5 us instead
+    of 8.5-9.5; ``bind`` a haystack that does not change between searches).  ``search_in(searcher, haystack)`` has the semantics of
     ``searcher.search_in(haystack)`` for a device haystack whose bytes are COMPLETE (the service is not ordered behind pending
     stream work); ``set_default()`` routes qualifying ``search_in`` calls of every searcher on this device through it."""
 

@@ -116,15 +116,17 @@ def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O):
         assert sv.settled_requests() == 0
         got = [sv.search_in(s, t) for s in searchers]
         assert got == [w in raw for w in sample]
-        # the first request acquired the range and every needle uploaded by then; needles uploaded later acquire once more
+        # the first request acquired the range (the needles were uploaded when the searchers were built); a request that starts a
+        # new residency (the lease ran out while Python was busy) acquires by itself
         n1 = sv.settled_requests()
-        assert 0 < n1 < len(sample)
+        assert len(sample) // 2 < n1 < len(sample)
         got = [sv.search_in(s, t[5:-7]) for s in searchers]   # sub-ranges of the bound range count as bound
         assert got == [w in raw[5:-7] for w in sample]
-        assert sv.settled_requests() == n1 + len(sample)
-        late = ss.DynamicHipSearcher.new(b"descriptor")       # built while the range is bound: its first request is not settled
-        assert sv.search_in(late, t) is True and sv.settled_requests() == n1 + len(sample)
-        assert sv.search_in(late, t) is True and sv.settled_requests() == n1 + len(sample) + 1
+        n2 = sv.settled_requests()
+        assert n1 + len(sample) - 3 <= n2 <= n1 + len(sample)
+        late = ss.DynamicHipSearcher.new(b"descriptor")       # uploaded AFTER the latest acquire: its first request is not settled
+        assert sv.search_in(late, t) is True and sv.settled_requests() == n2
+        assert sv.search_in(late, t) is True and sv.settled_requests() == n2 + 1
         other = torch.zeros(4096, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
         before = sv.settled_requests()
