@@ -295,3 +295,43 @@ mod tests {
         assert!(DynamicHipSearcher::new(*b"ipsum").search_in(hay));
     }
 }
+
+/// A resident search service on the current device (`ss_service_*`): a kernel that stays on the GPU and answers one
+/// `search_in` at a time without a launch - 5 us per search instead of 8.5-9.5.  The shape of the reference's own bench
+/// loop (bench/benches/i386.rs:246-256): build the searchers FIRST (building allocates, and allocation waits for the
+/// service's lease to run out), `bind` the text if it does not change between searches, then one `search_in` per needle.
+pub struct SearchService { handle: *mut ss_service }
+
+unsafe impl Send for SearchService {}
+unsafe impl Sync for SearchService {}     // requests queue on a mutex inside the library
+
+impl SearchService {
+    /// `workgroups` = 0: 64; `lease_ms` = 0.0: 20 ms without a request, then the kernel leaves until the next one.
+    pub fn start(workgroups: i32, lease_ms: f64) -> Self {
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { ss_service_start(workgroups as c_int, lease_ms, &mut handle) });
+        Self { handle }
+    }
+    /// The semantics of `DynamicHipSearcher::search_in_device` for a haystack that is COMPLETE in device memory.
+    pub fn search_in<N: Needle>(&self, searcher: &DynamicHipSearcher<N>, haystack: DeviceSlice) -> bool {
+        let mut found = 0;
+        check(unsafe { ss_service_search(self.handle, searcher.handle(), haystack.ptr, haystack.len, &mut found) });
+        found != 0
+    }
+    /// The caller vouches that `haystack` stays unchanged until `unbind` / the next `bind`.
+    pub fn bind(&self, haystack: DeviceSlice) { check(unsafe { ss_service_bind(self.handle, haystack.ptr, haystack.len) }) }
+    pub fn unbind(&self) { check(unsafe { ss_service_unbind(self.handle) }) }
+    /// Routes qualifying `search_in_device` calls of every searcher on this device through the service.
+    pub fn set_default(&self, enabled: bool) { check(unsafe { ss_service_set_default(self.handle, enabled as c_int) }) }
+    /// (requests served, kernel launches, requests that skipped the cache acquire)
+    pub fn counters(&self) -> (u64, u64, u64) {
+        let (mut r, mut k, mut s) = (0u64, 0u64, 0u64);
+        check(unsafe { ss_service_counters(self.handle, &mut r, &mut k) });
+        check(unsafe { ss_service_settled_requests(self.handle, &mut s) });
+        (r, k, s)
+    }
+}
+
+impl Drop for SearchService {
+    fn drop(&mut self) { unsafe { ss_service_stop(self.handle) } }
+}

@@ -1920,8 +1920,8 @@ __global__ void publish_best_kernel(uint64_t *d_best, uint64_t *h_best, int pair
 // at a time:
 //   * the mailbox is 256 bytes of DEVICE memory that the host writes through the PCIe BAR (every MI300-class part exposes
 //     all of its memory to the CPU): four 64-byte lines, each 15 payload dwords + the request's sequence number as its LAST
-//     dword.  The host writes the payload, fences, then the four sequence dwords: posted writes arrive in order, so a line
-//     that shows the new number holds the new payload;
+//     dword.  The host writes the payload with ZERO in the number's place, fences, then the four numbers: posted writes arrive in
+//     order, so a line that shows a number holds that request's payload, whichever request a wave is waiting for;
 //   * EVERY wave of every workgroup polls the mailbox itself - 64 lanes x 4 bytes, one instruction, served by the device's own
 //     memory - and takes the request straight out of the polled registers: no leader, no hop between workgroups.  (Round 3
 //     began with the mailbox in pinned HOST memory: every poll crossed PCIe, so only one wave could poll and had to hand
@@ -1979,9 +1979,17 @@ service_kernel(const uint32_t *d_req, uint32_t *h_status, unsigned long long *h_
         bool leave = false;
         {
             auto issue = [&]() { return __hip_atomic_load(d_req + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            // A request is there when all four lines show the SAME number m >= next (never 0: that is what the lines show while the
+            // host writes a payload).  m > next: this wave never saw the requests in between - possible only for requests its
+            // workgroup took no part in (a request completes when every ACTIVE workgroup has counted out; the others may lag),
+            // so they are skipped.
             auto shows_next = [&](uint32_t x) {
-                return (uint32_t)__builtin_amdgcn_readlane((int)x, 15) == next && (uint32_t)__builtin_amdgcn_readlane((int)x, 31) == next &&
-                       (uint32_t)__builtin_amdgcn_readlane((int)x, 47) == next && (uint32_t)__builtin_amdgcn_readlane((int)x, 63) == next;
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)x, 15);
+                if (m == 0 || m < next || (uint32_t)__builtin_amdgcn_readlane((int)x, 31) != m ||
+                    (uint32_t)__builtin_amdgcn_readlane((int)x, 47) != m || (uint32_t)__builtin_amdgcn_readlane((int)x, 63) != m)
+                    return false;
+                next = m;
+                return true;
             };
             // TWO polls in flight, issued half a memory latency apart and each re-issued as it returns: the mailbox is sampled
             // twice per latency instead of once, a request waits a quarter of a latency less to be seen.  The stop word and the

@@ -2055,9 +2055,9 @@ constexpr int kServiceDefaultWorkgroups = 64;
 constexpr double kServiceDefaultLeaseMs = 20.0;
 std::atomic<ss_service *> g_default_service[kMaxDevices];
 
-// The request, into the mailbox in device memory: payload first (16-byte stores: a write-combining mapping merges them into
-// line writes, an uncached one sends each as it is), a store fence, then the four sequence dwords - posted writes reach the
-// device in order, so a line that shows `seq` holds this request's payload.
+// The request, into the mailbox in device memory: payload first, with zero where the sequence number goes (16-byte stores: a
+// write-combining mapping merges them into line writes, an uncached one sends each as it is), a store fence, then the four
+// sequence dwords - posted writes reach the device in order, so a line that shows a number holds that request's payload.
 void service_write_mailbox(ss_service *sv, const ss::ServiceRequest &rq, uint32_t seq)
 {
     alignas(16) uint32_t img[64];
@@ -2065,7 +2065,7 @@ void service_write_mailbox(ss_service *sv, const ss::ServiceRequest &rq, uint32_
     memcpy(payload, &rq, sizeof rq);
     for (int line = 0; line < 4; ++line) {
         for (int j = 0; j < 15; ++j) img[line * 16 + j] = payload[line * 15 + j];
-        img[line * 16 + 15] = seq - 1;                  // (the previous request's number: what the line shows already)
+        img[line * 16 + 15] = 0;                        // no request's number: a line in this state is nobody's
     }
     volatile uint32_t *m = sv->mailbox();
     static const bool dbg = getenv("SLICESLICE_SERVICE_DEBUG") != nullptr;

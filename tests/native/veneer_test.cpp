@@ -128,6 +128,24 @@ int main()
         CHECK(other.find(shards.data(), begins.data()) == DynamicHipSearcher::npos);
         for (int g = 0; g < ndev; ++g) (void)hipFree(bufs[g]);
     }
+    {   // SearchService: the shape of the reference's bench loop - searchers first, the text bound, one search per needle
+        const std::string text = "the quick brown fox jumps over the lazy dog; pack my box with five dozen liquor jugs";
+        uint8_t *dt = nullptr;
+        CHECK(hipMalloc((void **)&dt, text.size()) == hipSuccess);
+        CHECK(hipMemcpy(dt, text.data(), text.size(), hipMemcpyHostToDevice) == hipSuccess);
+        const char *words[] = {"quick", "lazy dog", "liquor jugs", "the", "x", "fox jumps over", "cat", "jugz", "dozens"};
+        const bool expect[] = {true, true, true, true, true, true, false, false, false};
+        std::vector<DynamicHipSearcher> ss;
+        for (const char *w : words) ss.push_back(DynamicHipSearcher::new_(w));
+        sliceslice::hip::SearchService service;
+        service.bind(DeviceSlice{dt, text.size()});
+        for (int round = 0; round < 3; ++round)
+            for (size_t k = 0; k < ss.size(); ++k) CHECK(service.search_in(ss[k], DeviceSlice{dt, text.size()}) == expect[k]);
+        CHECK(service.requests() == 3 * ss.size() && service.settled_requests() >= 2 * ss.size());
+        service.unbind();
+        CHECK(service.search_in(ss[0], DeviceSlice{dt + 4, text.size() - 4}));
+        (void)hipFree(dt);
+    }
     std::puts("veneer_test ok");
     return 0;
 }
