@@ -116,6 +116,8 @@ struct PerDevice {
     uint64_t free_mask = 0;
     int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
     uint64_t upload_ticket = 0; // g_upload_ticket when d_needle had been written (a resident service acquires what is newer)
+    uint32_t block = ~0u;       // control block of the device's pool (BlockPool): everything above points into it ...
+    bool needle_own = false;    // ... except a needle too long for the block, which has an allocation of its own
 };
 std::atomic<uint64_t> g_upload_ticket{0};
 constexpr int kSlots = 64;
@@ -174,6 +176,7 @@ struct ss_searcher {
     // (SS_ERR_ARGUMENT) while a search runs instead of letting it read a half-written triple.
     mutable std::atomic<int> gate{0};
     mutable std::atomic<int> debug_fail_scans{0};       // test hook: the next k enqueue_scan calls fail (ss_debug_fail_next_scans)
+    mutable std::atomic<bool> used_async{false};        // an *_async entry point may have left work behind (ss_searcher_free waits)
     mutable std::mutex mu;
     mutable std::condition_variable slot_cv;    // signalled when a flag slot is released
     mutable std::deque<PerDevice> per;          // deque: PerDevice pointers handed out stay valid as devices are added
@@ -207,6 +210,74 @@ struct BusyGuard {
     BusyGuard &operator=(const BusyGuard &) = delete;
 };
 
+// ---- control blocks ---------------------------------------------------------------------------------------------------
+// A searcher needs, per device, 1.8 KB of device memory (flag / minimum / completion slots), 1.3 KB of pinned host memory
+// (their mirrors) and its needle.  Allocated one by one that was five hipMalloc, three hipHostMalloc, four hipMemset and a
+// hipMemcpy per `new` - the better part of a millisecond for a constructor that costs the reference tens of nanoseconds, and
+// every one of those calls waits for the whole device (a resident search service: for its lease).  Blocks come from slabs
+// instead (256 blocks of 4 KiB device + 2 KiB pinned memory per slab, kept until the process ends), and a block is
+// initialised by the CPU THROUGH THE PCIe BAR (every byte of an MI300-class part's memory is CPU-visible): `new` makes no
+// runtime call at all once a slab exists.  Posted writes stay in order with the doorbell write of the next launch, and a
+// kernel's start drops the caches' copy of the block; a resident service kernel acquires what was uploaded after its last
+// look (upload tickets).  Without a large BAR (or with SLICESLICE_NO_BAR_WRITES=1) the image goes by one hipMemcpy.
+constexpr size_t kBlockDevBytes = 4096, kBlockHostBytes = 2048, kBlockNeedleOff = 2048, kBlockNeedleMax = 2048;
+constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kCtlBytes = 1792;
+constexpr uint32_t kBlocksPerSlab = 256;
+
+struct BlockPool {
+    std::mutex mu;
+    std::vector<uint8_t *> d_slabs, h_slabs;
+    std::vector<uint32_t> free_blocks;          // slab << 8 | index
+    int bar = -1;                               // 1: the CPU writes device memory directly
+};
+BlockPool g_pools[64];
+
+int pool_acquire(int dev, uint32_t *id, uint8_t **d, uint8_t **h, bool *bar)
+{
+    BlockPool &bp = g_pools[dev];
+    std::lock_guard<std::mutex> lock(bp.mu);
+    if (bp.bar < 0) {
+        int large = 0;
+        const char *off = getenv("SLICESLICE_NO_BAR_WRITES");
+        if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { large = 0; (void)hipGetLastError(); }
+        bp.bar = large && !(off && off[0] == '1') ? 1 : 0;
+    }
+    if (bp.free_blocks.empty()) {
+        uint8_t *ds = nullptr, *hs = nullptr;
+        hipError_t e = hipMalloc((void **)&ds, kBlocksPerSlab * kBlockDevBytes);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&hs, kBlocksPerSlab * kBlockHostBytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipFree(ds);
+            return fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "control-block slab: %s", hipGetErrorString(e));
+        }
+        const uint32_t slab = (uint32_t)bp.d_slabs.size();
+        bp.d_slabs.push_back(ds);
+        bp.h_slabs.push_back(hs);
+        for (uint32_t k = kBlocksPerSlab; k-- > 0;) bp.free_blocks.push_back(slab << 8 | k);
+    }
+    *id = bp.free_blocks.back();
+    bp.free_blocks.pop_back();
+    *d = bp.d_slabs[*id >> 8] + (size_t)(*id & 255) * kBlockDevBytes;
+    *h = bp.h_slabs[*id >> 8] + (size_t)(*id & 255) * kBlockHostBytes;
+    *bar = bp.bar == 1;
+    return SS_OK;
+}
+
+void pool_release(int dev, uint32_t id)
+{
+    BlockPool &bp = g_pools[dev];
+    std::lock_guard<std::mutex> lock(bp.mu);
+    bp.free_blocks.push_back(id);
+}
+
+// `bytes` (a multiple of 16) from host memory into device memory through the BAR
+void bar_write(uint8_t *d_dst, const uint8_t *src, size_t bytes)
+{
+    for (size_t k = 0; k < bytes; k += 16)
+        _mm_store_si128(reinterpret_cast<__m128i *>(d_dst + k), _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k)));
+    _mm_sfence();
+}
+
 int get_per_device(const ss_searcher *s, PerDevice **out)
 {
     int dev = 0;
@@ -223,40 +294,44 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
         return fail(SS_ERR_NO_DEVICE, "HIP device %d is not a gfx950 (MI355X-class) device", dev);
     PerDevice p;
     p.dev = dev;
-    auto alloc = [&]() -> hipError_t {
-        hipError_t e;
-        if ((e = hipMalloc((void **)&p.d_needle, s->n ? s->n : 1)) != hipSuccess) return e;
-        if (s->n && (e = hipMemcpy(p.d_needle, s->needle.data(), s->n, hipMemcpyHostToDevice)) != hipSuccess) return e;
-        p.upload_ticket = g_upload_ticket.fetch_add(1, std::memory_order_acq_rel) + 1;
-        if ((e = hipMalloc((void **)&p.d_flags, kSlots * sizeof(int))) != hipSuccess) return e;
-        if ((e = hipMemset(p.d_flags, 0, kSlots * sizeof(int))) != hipSuccess) return e;
-        if ((e = hipHostMalloc((void **)&p.h_flags, kSlots * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
-        memset(p.h_flags, 0, kSlots * sizeof(int));   // pinned memory is recycled: a stale value must not equal an epoch
-        if ((e = hipMalloc((void **)&p.d_best, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
-        if ((e = hipMemset(p.d_best, 0xFF, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
-        if ((e = hipHostMalloc((void **)&p.h_best, kSlots * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipMalloc((void **)&p.d_done, kSlots * sizeof(unsigned long long))) != hipSuccess) return e;
-        if ((e = hipMemset(p.d_done, 0, kSlots * sizeof(unsigned long long))) != hipSuccess) return e;
-        if ((e = hipMalloc((void **)&p.d_best_done, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
-        if ((e = hipMemset(p.d_best_done, 0xFF, kSlots * sizeof(uint64_t))) != hipSuccess) return e;
-        for (int k = 0; k < kSlots; ++k) p.find_tag[k] = kFindTagMax;
-        if ((e = hipHostMalloc((void **)&p.h_done, kSlots * sizeof(long long), hipHostMallocDefault)) != hipSuccess) return e;
-        memset(p.h_done, 0, kSlots * sizeof(long long));
-        return hipSuccess;
-    };
-    const hipError_t e = alloc();
+    uint8_t *db = nullptr, *hb = nullptr;
+    bool bar = false;
+    if (int rc = pool_acquire(dev, &p.block, &db, &hb, &bar)) return rc;
+    p.d_flags = reinterpret_cast<int *>(db + kOffFlags);
+    p.d_best = reinterpret_cast<uint64_t *>(db + kOffBest);
+    p.d_done = reinterpret_cast<unsigned long long *>(db + kOffDone);
+    p.d_best_done = reinterpret_cast<uint64_t *>(db + kOffBestDone);
+    p.h_flags = reinterpret_cast<int *>(hb + 0);
+    p.h_best = reinterpret_cast<uint64_t *>(hb + 256);
+    p.h_done = reinterpret_cast<long long *>(hb + 768);
+    memset(hb, 0, kBlockHostBytes);                    // blocks are recycled: a stale value must not equal an epoch
+    for (int k = 0; k < kSlots; ++k) p.find_tag[k] = kFindTagMax;
+    // the block's image: flags 0 | minima all ones | completion counters 0 | keyed minima all ones | the needle
+    const bool inside = s->n <= kBlockNeedleMax;
+    alignas(16) uint8_t img[kBlockDevBytes];
+    memset(img, 0, sizeof img);
+    memset(img + kOffBest, 0xFF, kOffDone - kOffBest);
+    memset(img + kOffBestDone, 0xFF, kCtlBytes - kOffBestDone);
+    if (inside && s->n) memcpy(img + kBlockNeedleOff, s->needle.data(), s->n);
+    const size_t img_bytes = inside ? kBlockNeedleOff + ((s->n + 15) & ~(size_t)15) : kCtlBytes;
+    hipError_t e = hipSuccess;
+    if (bar) bar_write(db, img, img_bytes);
+    else e = hipMemcpy(db, img, img_bytes, hipMemcpyHostToDevice);
+    p.d_needle = db + kBlockNeedleOff;
+    if (e == hipSuccess && !inside) {                   // a needle too long for the block
+        p.d_needle = nullptr;
+        if ((e = hipMalloc((void **)&p.d_needle, s->n)) == hipSuccess) {
+            p.needle_own = true;
+            e = hipMemcpy(p.d_needle, s->needle.data(), s->n, hipMemcpyHostToDevice);
+        }
+    }
     if (e != hipSuccess) {                             // nothing half-built is left behind
-        (void)hipFree(p.d_needle);
-        (void)hipFree(p.d_flags);
-        (void)hipHostFree(p.h_flags);
-        (void)hipFree(p.d_best);
-        (void)hipHostFree(p.h_best);
-        (void)hipFree(p.d_done);
-        (void)hipFree(p.d_best_done);
-        (void)hipHostFree(p.h_done);
+        if (p.needle_own) (void)hipFree(p.d_needle);
+        pool_release(dev, p.block);
         return fail(e == hipErrorNoDevice ? SS_ERR_NO_DEVICE : (e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP),
                     "per-device setup: %s", hipGetErrorString(e));
     }
+    p.upload_ticket = g_upload_ticket.fetch_add(1, std::memory_order_acq_rel) + 1;
     p.free_mask = ~0ull;
     s->per.push_back(p);
     *out = &s->per.back();
@@ -887,15 +962,15 @@ void ss_searcher_free(ss_searcher *s)
     int cur = 0;
     (void)hipGetDevice(&cur);
     for (auto &p : s->per) {
-        (void)hipSetDevice(p.dev);
-        (void)hipFree(p.d_needle);
-        (void)hipFree(p.d_flags);
-        (void)hipHostFree(p.h_flags);
-        (void)hipFree(p.d_best);
-        (void)hipHostFree(p.h_best);
-        (void)hipFree(p.d_done);
-        (void)hipFree(p.d_best_done);
-        (void)hipHostFree(p.h_done);
+        // A block goes back to its pool and may be handed out - and rewritten - at once: nothing of this searcher may still be
+        // running.  The synchronous entry points have returned with their kernels' last stores made; only the *_async ones
+        // leave work behind, and a searcher that used them waits for its device here (hipFree did, implicitly, for all).
+        if (s->used_async.load(std::memory_order_acquire) || p.needle_own) {
+            (void)hipSetDevice(p.dev);
+            if (s->used_async.load(std::memory_order_acquire)) (void)hipDeviceSynchronize();
+            if (p.needle_own) (void)hipFree(p.d_needle);
+        }
+        pool_release(p.dev, p.block);
     }
     (void)hipSetDevice(cur);
     if (g_timer.owner == s) g_timer.owner = nullptr;
@@ -990,6 +1065,7 @@ int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t 
         return SS_OK;
     }
     if (len < s->n) return SS_OK;                       // cannot occur; flag untouched
+    s->used_async.store(true, std::memory_order_release);
     return enqueue_scan(s, pd, d_haystack, len, st, d_found);
 }
 
@@ -1142,6 +1218,7 @@ int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t le
         HIP_TRY(hipMemcpyAsync(d_best, &zero, sizeof zero, hipMemcpyHostToDevice, st));
         return SS_OK;
     }
+    s->used_async.store(true, std::memory_order_release);
     return enqueue_scan(s, pd, d_haystack, len, st, d_best, true, base_offset);
 }
 

@@ -8,6 +8,7 @@
 //   native_bench sharded  [GiB=8] [steps=50]      the multi-GPU entry points on every visible GPU: per-search overhead
 //   native_bench soak     [calls=2000000]         small searches through every per-call entry point; RSS / VRAM before and after
 //   native_bench config1  <i386.txt> <words.txt> [iters=5]
+//   native_bench construct [searchers=2000]     what `new` costs (and with a search service resident)
 //        BASELINE.json configs[0] on the GPU: one ss_search_device call per needle over the resident text - the
 //        literal drop-in shape of bench/benches/i386.rs:246-256 - next to ONE ss_search_batched launch.
 #include <hip/hip_runtime.h>
@@ -504,8 +505,66 @@ static int soak(long calls)
     return (rc == 0 && wrong == 0) ? 0 : 1;
 }
 
+// What `DynamicAvx2Searcher::new` costs on this side (x86.rs:454-459: tens of nanoseconds for the reference): ss_searcher_new
+// builds the searcher and puts its needle and control block on the current device.  Also with a search service resident,
+// where every runtime call that waits for the device waits for the service's lease.
+int construct(int count)
+{
+    std::vector<std::string> needles(count);
+    for (int k = 0; k < count; ++k) needles[k] = "needle #" + std::to_string(k) + " of the run";
+    std::vector<ss_searcher *> ss(count, nullptr);
+    uint8_t *d_hay = nullptr;
+    const size_t len = 1 << 16;
+    HK(hipMalloc((void **)&d_hay, len));
+    HK(hipMemset(d_hay, 'x', len));
+    HK(hipMemcpy(d_hay + 1000, needles[count / 2].data(), needles[count / 2].size(), hipMemcpyHostToDevice));
+    HK(hipDeviceSynchronize());
+    ss_searcher *warm = nullptr;
+    CK(ss_searcher_new((const uint8_t *)"warm-up", 7, &warm));
+    int found = 0;
+    CK(ss_search_device(warm, d_hay, len, nullptr, &found));
+    auto t0 = clk::now();
+    for (int k = 0; k < count; ++k) CK(ss_searcher_new((const uint8_t *)needles[k].data(), needles[k].size(), &ss[k]));
+    const double new_us = seconds_since(t0) / count * 1e6;
+    int hits = 0;
+    t0 = clk::now();
+    for (int k = 0; k < count; ++k) { CK(ss_search_device(ss[k], d_hay, len, nullptr, &found)); hits += found; }
+    const double first_search_us = seconds_since(t0) / count * 1e6;
+    t0 = clk::now();
+    for (int k = 0; k < count; ++k) ss_searcher_free(ss[k]);
+    const double free_us = seconds_since(t0) / count * 1e6;
+    // once more with a service resident (lease 20 ms): build, search through the service, free
+    ss_service *sv = nullptr;
+    CK(ss_service_start(0, 0.0, &sv));
+    CK(ss_service_search(sv, warm, d_hay, len, &found));
+    const int n2 = std::min(count, 200);
+    t0 = clk::now();
+    int svc_hits = 0;
+    for (int k = 0; k < n2; ++k) {
+        CK(ss_searcher_new((const uint8_t *)needles[k].data(), needles[k].size(), &ss[k]));
+        CK(ss_service_search(sv, ss[k], d_hay, len, &found));
+        svc_hits += found;
+        ss_searcher_free(ss[k]);
+    }
+    const double resident_us = seconds_since(t0) / n2 * 1e6;
+    uint64_t rq = 0, launches = 0;
+    CK(ss_service_counters(sv, &rq, &launches));
+    ss_service_stop(sv);
+    ss_searcher_free(warm);
+    (void)hipFree(d_hay);
+    std::printf("{\"mode\": \"construct\", \"searchers\": %d, \"new_us\": %.2f, \"first_search_us\": %.2f, \"free_us\": %.2f, "
+                "\"hits\": %d, \"with_service_resident_new_search_free_us\": %.2f, \"service_hits\": %d, \"service_kernel_launches\": %llu, "
+                "\"note\": \"new = ss_searcher_new (needle + control block on the device); first_search = the first ss_search_device of "
+                "each; with a service resident: new + ss_service_search + free per needle (a runtime call that waits for the device "
+                "would wait for the 20 ms lease)\"}\n",
+                count, new_us, first_search_us, free_us, hits, resident_us, svc_hits, (unsigned long long)launches);
+    const int want2 = n2 > count / 2 ? 1 : 0;
+    return hits == 1 && svc_hits == want2 ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "construct") return construct(argc > 2 ? std::atoi(argv[2]) : 2000);
     const std::string mode = argc > 1 ? argv[1] : "headline";
     if (mode == "latency") return latency(argc > 2 ? std::atoi(argv[2]) : 2000);
     if (mode == "config1") {
