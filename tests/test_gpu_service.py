@@ -224,3 +224,51 @@ def test_parity_suites_in_service_mode():
                          capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def test_building_searchers_does_not_wait_for_a_resident_service(ss):
+    """Searchers take their device memory from slabs and initialise it through the PCIe BAR: `new` makes no runtime call that
+    waits for the device, so a resident service (here with a lease of half a second) does not stall it - with one allocation per
+    searcher every `new` below waited out the lease."""
+    t = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    t[1000:1004] = torch.tensor([9, 8, 7, 6], dtype=torch.uint8)
+    torch.cuda.synchronize()
+    warm = [ss.DynamicHipSearcher.new(bytes([1, 2, 3, k])) for k in range(300)]      # (more than one slab's worth)
+    with ss.SearchService(lease_ms=500.0) as sv:
+        assert sv.search_in(warm[0], t) is False
+        t0 = time.perf_counter()
+        for k in range(40):
+            s = ss.DynamicHipSearcher.new(bytes([9, 8, 7, 6]) if k % 2 else bytes([9, 8, 7, 5, k]))
+            assert sv.search_in(s, t) is bool(k % 2), k
+            del s
+        assert time.perf_counter() - t0 < 5.0
+        assert sv.counters()[1] == 1                       # one residency throughout
+
+
+def test_control_blocks_without_bar_writes():
+    """SLICESLICE_NO_BAR_WRITES=1: the control block and the needle travel by hipMemcpy (what a platform without a large BAR
+    gets); same answers."""
+    code = r'''
+import os, random, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import sliceslice_rs_amd as ss
+raw = open(os.path.join(%r, "tests", "golden", "data", "i386.txt"), "rb").read()[:300000]
+t = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda()
+rng = random.Random(5)
+for _ in range(300):
+    n = rng.choice([1, 2, 3, 7, 16, 17, 40, 300, 2500])
+    at = rng.randrange(len(raw) - n)
+    nd = bytearray(raw[at:at + n])
+    if rng.random() < 0.4:
+        nd[rng.randrange(n)] ^= 0x80
+    nd = bytes(nd)
+    s = ss.DynamicHipSearcher.new(nd)
+    want = raw.find(nd)
+    assert s.search_in(t) is (want >= 0), (nd, want)
+    assert s.find(t) == (want if want >= 0 else None), (nd, want)
+print("ok")
+''' % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SLICESLICE_NO_BAR_WRITES="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
