@@ -60,7 +60,9 @@ typedef enum ss_status {
  * `VectorHash` (src/lib.rs:165-176). */
 typedef struct ss_searcher ss_searcher;
 
-/* DynamicAvx2Searcher::new (src/x86.rs:454-459): position = n - 1 (wrapping for n == 0). */
+/* DynamicAvx2Searcher::new (src/x86.rs:454-459): position = n - 1 (wrapping for n == 0).
+ * Also places the needle and the searcher's control block on the CURRENT device (other devices: on first use there): a block
+ * of a per-device slab, written by the CPU through the PCIe BAR - about 2 us, no HIP runtime call once a slab exists. */
 int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out);
 
 /* DynamicAvx2Searcher::with_position (src/x86.rs:468-493).
@@ -69,6 +71,8 @@ int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out);
  * caller keeps ownership of its buffer (the reference copies n in 2..=16 too, x86.rs:476-490). */
 int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out);
 
+/* No search of `s` may be running.  The synchronous entry points have finished when they return; work left behind by
+ * ss_search_device_async / ss_find_device_async is waited for here (hipDeviceSynchronize on the devices it used). */
 void ss_searcher_free(ss_searcher *s);
 
 size_t ss_searcher_needle_len(const ss_searcher *s);
