@@ -215,24 +215,25 @@ struct BusyGuard {
 // (their mirrors) and its needle.  Allocated one by one that was five hipMalloc, three hipHostMalloc, four hipMemset and a
 // hipMemcpy per `new` - the better part of a millisecond for a constructor that costs the reference tens of nanoseconds, and
 // every one of those calls waits for the whole device (a resident search service: for its lease).  Blocks come from slabs
-// instead (256 blocks of 4 KiB device + 2 KiB pinned memory per slab, kept until the process ends), and a block is
+// instead (512 blocks of 4 KiB device + 2 KiB pinned memory per slab, kept until the process ends), and a block is
 // initialised by the CPU THROUGH THE PCIe BAR (every byte of an MI300-class part's memory is CPU-visible): `new` makes no
-// runtime call at all once a slab exists.  Posted writes stay in order with the doorbell write of the next launch, and a
-// kernel's start drops the caches' copy of the block; a resident service kernel acquires what was uploaded after its last
+// runtime call at all once a slab exists.  The writes are pushed through the device's host data path and waited for (bar_write);
+// a kernel's start drops the caches' copy of the block; a resident service kernel acquires what was uploaded after its last
 // look (upload tickets).  Without a large BAR (or with SLICESLICE_NO_BAR_WRITES=1) the image goes by one hipMemcpy.
 constexpr size_t kBlockDevBytes = 4096, kBlockHostBytes = 2048, kBlockNeedleOff = 2048, kBlockNeedleMax = 2048;
 constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kCtlBytes = 1792;
-constexpr uint32_t kBlocksPerSlab = 256;
+constexpr uint32_t kBlocksPerSlab = 512;        // 2 MiB of device memory per slab: one page-table fragment
 
 struct BlockPool {
     std::mutex mu;
     std::vector<uint8_t *> d_slabs, h_slabs;
-    std::vector<uint32_t> free_blocks;          // slab << 8 | index
+    std::vector<uint32_t> free_blocks;          // slab << 16 | index
     int bar = -1;                               // 1: the CPU writes device memory directly
+    volatile uint32_t *hdp_flush = nullptr;     // the device's HDP_MEM_COHERENCY_FLUSH_CNTL register (CPU-visible), or null
 };
 BlockPool g_pools[64];
 
-int pool_acquire(int dev, uint32_t *id, uint8_t **d, uint8_t **h, bool *bar)
+int pool_acquire(int dev, uint32_t *id, uint8_t **d, uint8_t **h, bool *bar, volatile uint32_t **hdp_flush)
 {
     BlockPool &bp = g_pools[dev];
     std::lock_guard<std::mutex> lock(bp.mu);
@@ -241,6 +242,9 @@ int pool_acquire(int dev, uint32_t *id, uint8_t **d, uint8_t **h, bool *bar)
         const char *off = getenv("SLICESLICE_NO_BAR_WRITES");
         if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { large = 0; (void)hipGetLastError(); }
         bp.bar = large && !(off && off[0] == '1') ? 1 : 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) bp.hdp_flush = prop.hdpMemFlushCntl;
+        else (void)hipGetLastError();
     }
     if (bp.free_blocks.empty()) {
         uint8_t *ds = nullptr, *hs = nullptr;
@@ -253,13 +257,14 @@ int pool_acquire(int dev, uint32_t *id, uint8_t **d, uint8_t **h, bool *bar)
         const uint32_t slab = (uint32_t)bp.d_slabs.size();
         bp.d_slabs.push_back(ds);
         bp.h_slabs.push_back(hs);
-        for (uint32_t k = kBlocksPerSlab; k-- > 0;) bp.free_blocks.push_back(slab << 8 | k);
+        for (uint32_t k = kBlocksPerSlab; k-- > 0;) bp.free_blocks.push_back(slab << 16 | k);
     }
     *id = bp.free_blocks.back();
     bp.free_blocks.pop_back();
-    *d = bp.d_slabs[*id >> 8] + (size_t)(*id & 255) * kBlockDevBytes;
-    *h = bp.h_slabs[*id >> 8] + (size_t)(*id & 255) * kBlockHostBytes;
+    *d = bp.d_slabs[*id >> 16] + (size_t)(*id & 0xFFFF) * kBlockDevBytes;
+    *h = bp.h_slabs[*id >> 16] + (size_t)(*id & 0xFFFF) * kBlockHostBytes;
     *bar = bp.bar == 1;
+    *hdp_flush = bp.hdp_flush;
     return SS_OK;
 }
 
@@ -270,12 +275,22 @@ void pool_release(int dev, uint32_t id)
     bp.free_blocks.push_back(id);
 }
 
-// `bytes` (a multiple of 16) from host memory into device memory through the BAR
-void bar_write(uint8_t *d_dst, const uint8_t *src, size_t bytes)
+// `bytes` (a multiple of 16) from host memory into device memory through the BAR, complete before anything the caller does
+// next can reach the device: CPU writes into device memory pass through the device's host data path (HDP), which may hold
+// them back; writing its flush register pushes them out, and reading the register back waits until that write - and with
+// it, in order, everything in front of it - has arrived (what the HIP runtime does for kernel arguments it places in device
+// memory).  One PCIe read round trip: the microsecond of a `new`'s two.
+void bar_write(uint8_t *d_dst, const uint8_t *src, size_t bytes, volatile uint32_t *hdp_flush)
 {
     for (size_t k = 0; k < bytes; k += 16)
         _mm_store_si128(reinterpret_cast<__m128i *>(d_dst + k), _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k)));
     _mm_sfence();
+    if (hdp_flush) {
+        *hdp_flush = 1u;
+        (void)*hdp_flush;
+    } else {
+        (void)*reinterpret_cast<volatile uint32_t *>(d_dst);    // no register at hand: read what was written first back
+    }
 }
 
 int get_per_device(const ss_searcher *s, PerDevice **out)
@@ -296,7 +311,8 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
     p.dev = dev;
     uint8_t *db = nullptr, *hb = nullptr;
     bool bar = false;
-    if (int rc = pool_acquire(dev, &p.block, &db, &hb, &bar)) return rc;
+    volatile uint32_t *hdp_flush = nullptr;
+    if (int rc = pool_acquire(dev, &p.block, &db, &hb, &bar, &hdp_flush)) return rc;
     p.d_flags = reinterpret_cast<int *>(db + kOffFlags);
     p.d_best = reinterpret_cast<uint64_t *>(db + kOffBest);
     p.d_done = reinterpret_cast<unsigned long long *>(db + kOffDone);
@@ -315,7 +331,7 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
     if (inside && s->n) memcpy(img + kBlockNeedleOff, s->needle.data(), s->n);
     const size_t img_bytes = inside ? kBlockNeedleOff + ((s->n + 15) & ~(size_t)15) : kCtlBytes;
     hipError_t e = hipSuccess;
-    if (bar) bar_write(db, img, img_bytes);
+    if (bar) bar_write(db, img, img_bytes, hdp_flush);
     else e = hipMemcpy(db, img, img_bytes, hipMemcpyHostToDevice);
     p.d_needle = db + kBlockNeedleOff;
     if (e == hipSuccess && !inside) {                   // a needle too long for the block
@@ -2110,6 +2126,7 @@ struct ss_service {
     uint32_t *h_box = nullptr;              // pinned, 2 lines of 64 bytes: status | answer (written by the device)
     uint8_t *d_mem = nullptr;               // device: mailbox (256 B, written by the HOST through the BAR) | stop word | done counter | found flag
     uint32_t seq = 0;                       // last request posted
+    volatile uint32_t *hdp_flush = nullptr; // the device's HDP flush register: pushes the mailbox writes out of the host data path
     uint32_t done_low = 0, done_hi = 0;     // the never-reset completion counter, as the host knows it
     uint64_t requests = 0, launches = 0, settled_requests = 0;
     // ss_service_bind: a device range the caller vouches for (unchanged until unbound), `bound_settled` once a request has
@@ -2152,6 +2169,7 @@ void service_write_mailbox(ss_service *sv, const ss::ServiceRequest &rq, uint32_
     _mm_sfence();
     for (int line = 0; line < 4; ++line) m[line * 16 + 15] = seq;
     _mm_sfence();
+    if (sv->hdp_flush) *sv->hdp_flush = 1u;               // (no read-back: the kernel polls, nothing is ordered behind this)
     if (dbg) {
         static double total_us = 0;
         static unsigned long n = 0;
@@ -2260,6 +2278,12 @@ int ss_service_start(int workgroups, double lease_ms, ss_service **out)
     if (!sv) return fail(SS_ERR_NOMEM, "out of memory");
     sv->dev = dev;
     sv->workgroups = workgroups;
+    {
+        static const bool flush = []() { const char *v = getenv("SLICESLICE_SERVICE_HDP_FLUSH"); return !(v && v[0] == '0'); }();
+        hipDeviceProp_t prop;
+        if (flush && hipGetDeviceProperties(&prop, dev) == hipSuccess) sv->hdp_flush = prop.hdpMemFlushCntl;
+        else (void)hipGetLastError();
+    }
     sv->idle_ticks = (unsigned long long)(lease_ms * 1e5);             // s_memrealtime: 100 MHz
     hipError_t e = hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&sv->h_box, 6 * 64, hipHostMallocPortable | hipHostMallocMapped);
