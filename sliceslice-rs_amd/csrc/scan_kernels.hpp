@@ -2058,12 +2058,19 @@ service_kernel(const uint32_t *d_req, uint32_t *h_status, unsigned long long *h_
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long f = (unsigned long long)__hip_atomic_load(&s_wg_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned long long one = 1ull + (f << 32);
-            const unsigned long long total = __hip_atomic_fetch_add(d_done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + one;
-            if ((uint32_t)total == rq.pr.done_target) {
-                const uint32_t hi = (uint32_t)(total >> 32);
-                __hip_atomic_store(h_answer, ((unsigned long long)hi << 32) | ((unsigned long long)next << 1) | (hi != rq.pr.done_hi ? 1ull : 0ull),
+            if (rq.active == 1) {
+                // the only workgroup of this request: nobody to count with - the answer goes out a memory round trip earlier
+                // (the counter and the host's copy of it stay as they are)
+                __hip_atomic_store(h_answer, ((unsigned long long)rq.pr.done_hi << 32) | ((unsigned long long)next << 1) | f,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                const unsigned long long one = 1ull + (f << 32);
+                const unsigned long long total = __hip_atomic_fetch_add(d_done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + one;
+                if ((uint32_t)total == rq.pr.done_target) {
+                    const uint32_t hi = (uint32_t)(total >> 32);
+                    __hip_atomic_store(h_answer, ((unsigned long long)hi << 32) | ((unsigned long long)next << 1) | (hi != rq.pr.done_hi ? 1ull : 0ull),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
         __syncthreads();

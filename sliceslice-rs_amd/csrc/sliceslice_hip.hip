@@ -2127,6 +2127,7 @@ struct ss_service {
     uint8_t *d_mem = nullptr;               // device: mailbox (256 B, written by the HOST through the BAR) | stop word | done counter | found flag
     uint32_t seq = 0;                       // last request posted
     volatile uint32_t *hdp_flush = nullptr; // the device's HDP flush register: pushes the mailbox writes out of the host data path
+    volatile uint32_t *hdp_reg = nullptr;   // the same register, whatever SLICESLICE_SERVICE_HDP_FLUSH says (set-up writes)
     uint32_t done_low = 0, done_hi = 0;     // the never-reset completion counter, as the host knows it
     uint64_t requests = 0, launches = 0, settled_requests = 0;
     // ss_service_bind: a device range the caller vouches for (unchanged until unbound), `bound_settled` once a request has
@@ -2178,6 +2179,16 @@ void service_write_mailbox(ss_service *sv, const ss::ServiceRequest &rq, uint32_
     }
 }
 
+// Mailbox, stop word, counter and flag start as zeros - written by the CPU through the BAR and waited for, like everything
+// else the host puts there: a hipMemset is asynchronous to the host and would be free to run AFTER the first request has
+// been written into the mailbox (it did, now and then: the kernel never saw that request, left when its lease was over, and
+// the request was answered by a second residency).
+void service_zero_device_memory(ss_service *sv)
+{
+    alignas(16) static const uint8_t zeros[512] = {0};
+    bar_write(sv->d_mem, zeros, sizeof zeros, sv->hdp_reg);
+}
+
 int service_launch(ss_service *sv, uint32_t first_seq)
 {
     __atomic_store_n(sv->status(), 0u, __ATOMIC_RELAXED);
@@ -2199,7 +2210,7 @@ int service_restart_with(ss_service *sv, ss::ServiceRequest &rq, uint32_t seq)
     HIP_TRY(hipMemsetAsync(sv->d_done(), 0, sizeof(unsigned long long), sv->stream));
     sv->done_low = sv->done_hi = 0;
     if (!rq.stop) {
-        rq.pr.done_target = rq.active;
+        rq.pr.done_target = rq.active == 1 ? 0u : rq.active;
         rq.pr.done_hi = 0;
         rq.settled = 0;                                 // (a new kernel starts with clean caches anyway)
     }
@@ -2281,15 +2292,19 @@ int ss_service_start(int workgroups, double lease_ms, ss_service **out)
     {
         static const bool flush = []() { const char *v = getenv("SLICESLICE_SERVICE_HDP_FLUSH"); return !(v && v[0] == '0'); }();
         hipDeviceProp_t prop;
-        if (flush && hipGetDeviceProperties(&prop, dev) == hipSuccess) sv->hdp_flush = prop.hdpMemFlushCntl;
-        else (void)hipGetLastError();
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            sv->hdp_reg = prop.hdpMemFlushCntl;
+            if (flush) sv->hdp_flush = prop.hdpMemFlushCntl;
+        } else {
+            (void)hipGetLastError();
+        }
     }
     sv->idle_ticks = (unsigned long long)(lease_ms * 1e5);             // s_memrealtime: 100 MHz
     hipError_t e = hipStreamCreateWithFlags(&sv->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&sv->h_box, 6 * 64, hipHostMallocPortable | hipHostMallocMapped);
     if (e == hipSuccess) memset(sv->h_box, 0, 6 * 64);
     if (e == hipSuccess) e = hipMalloc((void **)&sv->d_mem, 512);
-    if (e == hipSuccess) e = hipMemset(sv->d_mem, 0, 512);
+    if (e == hipSuccess) service_zero_device_memory(sv);
     if (e != hipSuccess) {
         service_free(sv);
         return fail(SS_ERR_HIP, "search service set-up: %s", hipGetErrorString(e));
@@ -2328,7 +2343,7 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
         unsigned long long ignored = 0;
         if (int rc = service_post(sv, bye, ++sv->seq, &ignored)) return rc;
         HIP_TRY(hipStreamSynchronize(sv->stream));
-        HIP_TRY(hipMemset(sv->d_mem, 0, 512));
+        service_zero_device_memory(sv);
         memset(sv->h_box, 0, 6 * 64);
         sv->seq = sv->done_low = sv->done_hi = 0;
         sv->launches = 0;
@@ -2339,7 +2354,7 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
     // one workgroup per tile at most: the count-out of a 1 KiB search is one atomic, not sixty-four
     const uint64_t tiles = (rq.pr.npieces + ss::kWavesPerBlock * 4 - 1) / (ss::kWavesPerBlock * 4);
     rq.active = (uint32_t)std::min<uint64_t>((uint64_t)sv->workgroups, std::max<uint64_t>(tiles, 1));
-    rq.pr.done_target = sv->done_low + rq.active;
+    rq.pr.done_target = sv->done_low + (rq.active == 1 ? 0u : rq.active);     // a single workgroup answers without the counter
     rq.pr.done_hi = sv->done_hi;
     // Inside a bound range that an earlier request has acquired, with a needle that was in device memory by then: nothing this
     // request reads has changed, the workgroups skip their acquire (2 us of a request's 8).
