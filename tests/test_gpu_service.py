@@ -192,15 +192,16 @@ def test_default_service_routes_ss_search_device(ss, O):
     with ss.SearchService() as sv:
         sv.set_default(True)
         sp, sa = ss.DynamicHipSearcher.new(present), ss.DynamicHipSearcher.new(absent)
-        # the service is used only when the caller's stream is idle (it cannot be ordered behind pending work); the legacy default
-        # stream never reports idle while another kernel - the service itself - is running, so the callers here bring a stream
+        # the service is used only when the caller's stream is idle (it cannot be ordered behind pending work)
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             for _ in range(50):
                 assert sp.search_in(t) is True and sa.search_in(t) is False
         assert sv.counters()[0] == 100
-        for _ in range(5):                                   # default stream: launch path, same answers
+        for _ in range(5):                                   # the default stream: whichever road it takes, the same answers
             assert sp.search_in(t) is True and sa.search_in(t) is False
+        assert 100 <= sv.counters()[0] <= 110
+        base = sv.counters()[0]
         # what does not qualify takes the launch path and is still right: a long haystack, a wide pair, a timed search
         big = torch.zeros(32 << 20, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
@@ -210,9 +211,9 @@ def test_default_service_routes_ss_search_device(ss, O):
         assert wide.search_in(t) is True
         sp.set_timing(True)
         assert sp.search_in(t) is True and sp.last_kernel_ms() > 0
-        assert sv.counters()[0] == 100
+        assert sv.counters()[0] == base
         sv.set_default(False)
-        assert sa.search_in(t) is False and sv.counters()[0] == 100
+        assert sa.search_in(t) is False and sv.counters()[0] == base
 
 
 def test_parity_suites_in_service_mode():
