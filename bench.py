@@ -847,6 +847,14 @@ def main():
         }
         if ceiling is not None:
             out["roofline"]["read_ceiling_gbps"] = round(ceiling, 2)
+            # a diagnosis, not a correction: the scan normally runs at 0.975-0.992 of what a plain streaming read of the same
+            # buffer reaches in the same process; far below that the buffer sits badly (a previous process's tens of GiB were
+            # still being reclaimed when it was allocated: DESIGN.md section 6)
+            out["roofline"]["frac_of_read_ceiling"] = round(out["roofline"]["achieved"] / ceiling, 4)
+            if out["roofline"]["achieved"] < 0.96 * ceiling:
+                out["roofline"]["placement_note"] = ("the scan kernel reached only %.3f of this buffer's plain-read rate (normally 0.975-0.992): "
+                                                     "the haystack was allocated while the driver was still reclaiming another process's memory"
+                                                     % (out["roofline"]["achieved"] / ceiling))
         if world == 1 and not args.no_configs:
             cfg = other_configs(ss, shard)
             room = torch.cuda.mem_get_info()[0] > total + (8 << 30)          # a second haystack of the same size fits
