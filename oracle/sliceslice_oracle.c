@@ -447,20 +447,65 @@ static void pin_to_share(int t, int threads)
     if (CPU_COUNT(&both) > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof both, &both);
 }
 
+/* The threads are a POOL that lives from one call to the next (re-built when the thread count changes): created per call, 256
+ * threads cost several milliseconds of pthread_create / sysfs reads / affinity calls - as much as the 10 ms scan they were
+ * created for, which made the rates at 64 threads and more come out BELOW those at 32 ("what's weak" 9).  Workers
+ * park on a barrier; a call sets their shares, releases them, waits on a second barrier and ORs their booleans. */
+static struct {
+    int threads;
+    pthread_t *tid;
+    mt_arg *arg;
+    pthread_barrier_t start, done;
+    int quit;
+} g_pool;
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+
 static void *mt_worker(void *p)
 {
     mt_arg *a = (mt_arg *)p;
     pin_to_share(a->t, a->threads);
-    a->found = oracle_search_in(a->s, a->hay, a->len);
+    for (;;) {
+        pthread_barrier_wait(&g_pool.start);
+        if (g_pool.quit) break;
+        a->found = oracle_search_in(a->s, a->hay, a->len);
+        pthread_barrier_wait(&g_pool.done);
+    }
     return NULL;
+}
+
+static void pool_resize(int threads)
+{
+    if (g_pool.threads == threads) return;
+    if (g_pool.threads > 0) {
+        g_pool.quit = 1;
+        pthread_barrier_wait(&g_pool.start);
+        for (int t = 0; t < g_pool.threads; ++t) pthread_join(g_pool.tid[t], NULL);
+        pthread_barrier_destroy(&g_pool.start);
+        pthread_barrier_destroy(&g_pool.done);
+        free(g_pool.tid);
+        free(g_pool.arg);
+        g_pool.threads = 0;
+        g_pool.quit = 0;
+    }
+    if (threads <= 0) return;
+    g_pool.tid = (pthread_t *)calloc((size_t)threads, sizeof *g_pool.tid);
+    g_pool.arg = (mt_arg *)calloc((size_t)threads, sizeof *g_pool.arg);
+    pthread_barrier_init(&g_pool.start, NULL, (unsigned)threads + 1);
+    pthread_barrier_init(&g_pool.done, NULL, (unsigned)threads + 1);
+    g_pool.threads = threads;
+    for (int t = 0; t < threads; ++t) {
+        g_pool.arg[t].t = t;
+        g_pool.arg[t].threads = threads;
+        pthread_create(&g_pool.tid[t], NULL, mt_worker, &g_pool.arg[t]);
+    }
 }
 
 int oracle_search_in_mt(const oracle_searcher *s, const uint8_t *hay, size_t len, int threads)
 {
     if (threads <= 1 || s->n == 0 || len < s->n * 2 || len < (size_t)threads * 4096)
         return oracle_search_in(s, hay, len);
-    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof *tid);
-    mt_arg *arg = (mt_arg *)calloc((size_t)threads, sizeof *arg);
+    pthread_mutex_lock(&g_pool_mu);
+    pool_resize(threads);
     const size_t shard = (len + (size_t)threads - 1) / (size_t)threads;
     int found = 0;
     for (int t = 0; t < threads; ++t) {
@@ -468,19 +513,15 @@ int oracle_search_in_mt(const oracle_searcher *s, const uint8_t *hay, size_t len
         size_t e = b + shard + s->n - 1;
         if (b > len) b = len;
         if (e > len) e = len;
-        arg[t].s = s;
-        arg[t].hay = hay + b;
-        arg[t].len = e - b;
-        arg[t].t = t;
-        arg[t].threads = threads;
-        pthread_create(&tid[t], NULL, mt_worker, &arg[t]);
+        g_pool.arg[t].s = s;
+        g_pool.arg[t].hay = hay + b;
+        g_pool.arg[t].len = e - b;
+        g_pool.arg[t].found = 0;
     }
-    for (int t = 0; t < threads; ++t) {
-        pthread_join(tid[t], NULL);
-        found |= arg[t].found;
-    }
-    free(tid);
-    free(arg);
+    pthread_barrier_wait(&g_pool.start);
+    pthread_barrier_wait(&g_pool.done);
+    for (int t = 0; t < threads; ++t) found |= g_pool.arg[t].found;
+    pthread_mutex_unlock(&g_pool_mu);
     return found;
 }
 
