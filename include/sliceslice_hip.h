@@ -62,7 +62,7 @@ typedef struct ss_searcher ss_searcher;
 
 /* DynamicAvx2Searcher::new (src/x86.rs:454-459): position = n - 1 (wrapping for n == 0).
  * Also places the needle and the searcher's control block on the CURRENT device (other devices: on first use there): a block
- * of a per-device slab, written by the CPU through the PCIe BAR - about 2 us, no HIP runtime call once a slab exists. */
+ * of a per-device slab, written by the CPU through the PCIe BAR - about 3 us, no HIP runtime call once a slab exists. */
 int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out);
 
 /* DynamicAvx2Searcher::with_position (src/x86.rs:468-493).

@@ -299,3 +299,41 @@ def test_service_restarts_under_a_lease_as_short_as_a_search(ss):
                     pass
         requests, launches = sv.counters()
         assert requests == 4000 and launches > 100, (requests, launches)
+
+
+def test_service_is_shared_by_threads(ss):
+    """One request at a time per service: callers from several threads queue on the service's mutex and each gets ITS answer
+    (ctypes releases the GIL, so the calls do overlap in the library)."""
+    import threading
+    rng = random.Random(31)
+    raw = open(os.path.join(ROOT, "tests", "golden", "data", "i386.txt"), "rb").read()[:400000]
+    t = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    needles = []
+    for _ in range(64):
+        n = rng.choice([2, 5, 9, 16, 17, 33])
+        at = rng.randrange(len(raw) - n)
+        nd = bytearray(raw[at:at + n])
+        if rng.random() < 0.5:
+            nd[rng.randrange(n)] ^= 0x40
+        needles.append(bytes(nd))
+    searchers = [ss.DynamicHipSearcher.new(nd) for nd in needles]
+    want = [nd in raw for nd in needles]
+    wrong = []
+    with ss.SearchService() as sv:
+        sv.bind(t)
+
+        def worker(k):
+            torch.cuda.set_device(0)
+            for rep in range(300):
+                i = (k * 17 + rep * 5) % len(searchers)
+                if sv.search_in(searchers[i], t) is not want[i]:
+                    wrong.append((k, rep, i))
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not wrong, wrong[:5]
+        assert sv.counters()[0] == 4 * 300
