@@ -278,6 +278,9 @@ int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len,
  * leftmost offset (uint64, ncclMin; shard_begins[g] = global offset of shard g).
  * SS_COMBINE_HOST skips the collective: the host ORs the G pinned mirrors (possible only in this
  * single-process form; the difference between the two is the cost of the collective).
+ * ss_search_sharded_all ends every device's scan at the first match on ANY device: the host relays the finding device's flag
+ * into the others' through their PCIe BARs while it waits (SLICESLICE_CROSS_EXIT=0 turns that off; needs CPU-visible device
+ * memory, else each device runs its scan to the end as before).
  * One search at a time per set (the set's streams and flags are its scratch): a second concurrent call is refused with
  * SS_ERR_ARGUMENT.  The same holds for ss_search_sharded / ss_find_sharded on one communicator. */
 typedef struct ss_comm_set ss_comm_set;

@@ -2598,6 +2598,11 @@ struct ss_comm_set {
     long long *h_words = nullptr;                       // pinned: ndev answer words of signal_flag_kernel (spinning read-back)
     uint64_t *h_best = nullptr;                         // pinned: ndev offsets (host combine) / [0] = all-reduce result
     std::atomic<bool> busy{false};                      // one search at a time per set: a second concurrent call is refused
+    // Cross-device early exit of ss_search_sharded_all: the host, which waits for the answer words anyway, watches the pinned
+    // mirrors the finding waves write and stores the epoch into every OTHER device's flag through that device's PCIe BAR;
+    // their workgroups see it at their next poll and leave.  Possible when every device's memory is CPU-visible.
+    bool relay_ok = false;
+    std::vector<volatile uint32_t *> hdp_flush;         // per device: HDP flush register (pushes the store out of the host data path)
 };
 
 namespace {
@@ -2926,6 +2931,20 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
         free_comm_set(set);
         return fail(SS_ERR_HIP, "communicator set scratch: %s", hipGetErrorString(e));
     }
+    {
+        const char *off = getenv("SLICESLICE_CROSS_EXIT");
+        set->relay_ok = !(off && off[0] == '0');
+        set->hdp_flush.assign((size_t)ndev, nullptr);
+        for (int g = 0; g < ndev; ++g) {
+            int large = 0;
+            hipDeviceProp_t prop;
+            if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, set->devs[g]) != hipSuccess || !large) set->relay_ok = false;
+            if (hipGetDeviceProperties(&prop, set->devs[g]) == hipSuccess) set->hdp_flush[g] = prop.hdpMemFlushCntl;
+            (void)hipGetLastError();
+            (void)hipSetDevice(set->devs[g]);
+            (void)hipDeviceSynchronize();               // the memsets above are asynchronous to the host: done before anyone stores there
+        }
+    }
     *out = set;
     return SS_OK;
 }
@@ -3015,11 +3034,40 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
             }
         }
         if (launched) {
+            // Collect the G answer words; meanwhile - cross-device early exit - watch the pinned mirrors: the first device that
+            // reports a match has its epoch stored into every other device's flag through the BAR, so that THEIR grids stop
+            // scanning too (a match in shard 0 of a 64 GiB haystack over eight devices otherwise costs the full 1.2 ms scan of
+            // the seven others).  The flag only ever means "found somewhere": the OR of the answers is unchanged.
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
+            uint64_t got = 0;
+            bool relayed = !set->relay_ok || G < 2;
             spun = true;
-            for (int g = 0; g < G && spun; ++g) {
-                int f = 0;
-                spun = spin_for_word(set->h_words + g, epoch, estimate, &f);
-                any_word |= f;
+            for (unsigned spins = 0; got != (G >= 64 ? ~0ull : (1ull << G) - 1); ++spins) {
+                for (int g = 0; g < G; ++g) {
+                    if ((got >> g) & 1) continue;
+                    const long long v = __atomic_load_n(set->h_words + g, __ATOMIC_ACQUIRE);
+                    if (((uint32_t)v >> 1) == (uint32_t)epoch) {
+                        any_word |= (int)(v & 1);
+                        got |= 1ull << g;
+                    }
+                }
+                if (!relayed) {
+                    for (int g = 0; g < G; ++g) {
+                        if (__atomic_load_n(set->h_flag[g], __ATOMIC_ACQUIRE) != epoch) continue;
+                        for (int o = 0; o < G; ++o) {
+                            if (o == g || ((got >> o) & 1) || shard_lens[o] < s->n) continue;
+                            *reinterpret_cast<volatile int *>(set->d_flag[o]) = epoch;
+                        }
+                        _mm_sfence();
+                        for (int o = 0; o < G; ++o)
+                            if (o != g && set->hdp_flush[o]) *set->hdp_flush[o] = 1u;
+                        relayed = true;
+                        break;
+                    }
+                }
+                cpu_relax();
+                if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) { spun = false; break; }
             }
             if (spun && (epoch & 255) != 0) {
                 *found = any_word;

@@ -284,3 +284,47 @@ def test_comm_set_bookkeeping_with_three_and_eight_shards_on_one_gpu():
             absent.close()
     finally:
         del os.environ["SLICESLICE_COMM_SET_NO_RCCL"]
+
+
+def test_cross_device_early_exit_of_the_single_process_search():
+    """A match on ONE device ends the other devices' scans too: the host, which waits for the answer words anyway, sees the
+    finding wave's pinned mirror and stores the epoch into the other devices' flags through the BAR.  Three shards of 3 GiB on
+    one GPU (a test set), the needle at the start of shard 0 only: with the relay the call returns long before the other two
+    shards have been read; without it (SLICESLICE_CROSS_EXIT=0) it takes their full scans.  The answers do not change."""
+    import time
+    import numpy as np
+    import torch
+    import sliceslice_rs_amd as ss
+    os.environ["SLICESLICE_COMM_SET_NO_RCCL"] = "1"
+    try:
+        G, each = 3, 3 << 30
+        needle = bytes(range(200, 216))
+        pn = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+        sh = []
+        for g in range(G):
+            t = torch.empty(each, dtype=torch.uint8, device="cuda")
+            ss.fill_random_device(t, 0x5EED0100 + g)
+            sh.append(t)
+        sh[0][4096:4096 + 16] = pn
+        torch.cuda.synchronize()
+        times = {}
+        for relay in ("1", "0"):
+            os.environ["SLICESLICE_CROSS_EXIT"] = relay
+            node = ss.NodeSearcher(needle, devices=[0] * G)
+            for _ in range(5):
+                assert node.search_in(sh) is True
+            t0 = time.perf_counter()
+            for _ in range(20):
+                assert node.search_in(sh) is True
+            times[relay] = (time.perf_counter() - t0) / 20
+            node.close()
+        # absent: nothing to relay, same answer either way
+        sh[0][4096:4096 + 16] = 0
+        torch.cuda.synchronize()
+        node = ss.NodeSearcher(needle, devices=[0] * G)
+        assert node.search_in(sh) is False
+        node.close()
+        assert times["1"] < 0.6 * times["0"], times
+    finally:
+        del os.environ["SLICESLICE_COMM_SET_NO_RCCL"]
+        os.environ.pop("SLICESLICE_CROSS_EXIT", None)
