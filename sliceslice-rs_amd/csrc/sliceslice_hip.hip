@@ -1429,7 +1429,26 @@ const uint8_t *small_host_copy(const uint8_t *haystack, size_t len, hipStream_t 
 
 }  // namespace
 
+}  // extern "C"
+
+namespace {
+// ss_search_host, with a word shared by the threads of ss_search_host_all: a thread that has found the needle says so, and the
+// others stop issuing chunks (the answer is an OR: theirs no longer matters).
+int search_host_impl(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found, std::atomic<int> *somebody_found);
+}  // namespace
+
+extern "C" {
+
 int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found)
+{
+    return search_host_impl(s, haystack, len, found, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+int search_host_impl(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found, std::atomic<int> *somebody_found)
 {
     if (!s || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
     if (len && !haystack) return fail(SS_ERR_ARGUMENT, "haystack is NULL");
@@ -1459,6 +1478,7 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
     int result = 0;
     size_t idx = 0;
     for (size_t off = 0; off < len && rc == SS_OK && !result; off += C, ++idx) {
+        if (somebody_found && somebody_found->load(std::memory_order_acquire)) break;   // another device's range holds the needle
         const int b = (int)(idx % nbuf);
         const size_t lead = off == 0 ? 0 : carry;
         const size_t bytes = (len - off < C ? len - off : C) + lead;
@@ -1477,9 +1497,16 @@ int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, in
         if (st[b]) (void)hipStreamSynchronize(st[b]);
     if (rc == SS_OK && !result) result = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
     release_slot(s, pd, k);
-    if (rc == SS_OK) *found = result;
+    if (rc == SS_OK) {
+        *found = result;
+        if (result && somebody_found) somebody_found->store(1, std::memory_order_release);
+    }
     return rc;
 }
+
+}  // namespace
+
+extern "C" {
 
 // The literal search_in(&[u8]) (src/x86.rs:523) for a HOST slice over several GPUs: the slice is range-partitioned (n-1 bytes of
 // overlap, ss_shard_range) and every device uploads and scans ITS range over ITS OWN PCIe link - one host thread per device,
@@ -1505,12 +1532,13 @@ int ss_search_host_all(const ss_searcher *s, const uint8_t *haystack, size_t len
     std::vector<int> rcs((size_t)ndev, SS_OK), flags((size_t)ndev, 0);
     std::vector<std::string> msgs((size_t)ndev);
     std::vector<std::thread> pool;
+    std::atomic<int> somebody_found{0};                  // early exit across the devices: checked by every thread between chunks
     for (int g = 0; g < ndev; ++g)
         pool.emplace_back([&, g]() {
             size_t b = 0, e = 0;
             int rc = ss_shard_range(len, s->n, ndev, g, &b, &e);
             if (rc == SS_OK && hipSetDevice(devs ? devs[g] : g) != hipSuccess) rc = fail(SS_ERR_HIP, "hipSetDevice(%d) failed", devs ? devs[g] : g);
-            if (rc == SS_OK && e - b >= s->n) rc = ss_search_host(s, haystack + b, e - b, &flags[(size_t)g]);
+            if (rc == SS_OK && e - b >= s->n) rc = search_host_impl(s, haystack + b, e - b, &flags[(size_t)g], &somebody_found);
             rcs[(size_t)g] = rc;
             if (rc != SS_OK) msgs[(size_t)g] = g_err;          // (the message lives in the worker thread's buffer)
         });

@@ -121,3 +121,28 @@ def test_search_host_all_stripes_a_host_slice_over_devices(ss):
     assert ss.search_host_all(s, host[:10], [0, 0]) is False
     with pytest.raises(ss.SlicesliceError):
         ss.search_host_all(s, host, [n_dev + 5])
+
+
+def test_search_host_all_stops_the_other_devices_at_the_first_match(ss):
+    """The threads of ss_search_host_all share one word: the device whose range holds the needle says so, and the others stop
+    issuing chunks.  1.5 GiB host slice as three ranges on one GPU, the needle at the start of the first range: far quicker than
+    the absent search, which uploads everything."""
+    import time
+    total = (3 << 29) + 12345
+    host = ss.fill_random_host(total, 0x5EED0200).copy()
+    needle = bytes(range(180, 200))
+    s = ss.DynamicHipSearcher.new(needle)
+    devices = [0, 0, 0]
+    assert ss.search_host_all(s, host, devices) is False          # (also warms the staging buffers)
+    t0 = time.perf_counter()
+    assert ss.search_host_all(s, host, devices) is False
+    absent = time.perf_counter() - t0
+    host[5000:5000 + len(needle)] = np.frombuffer(needle, dtype=np.uint8)
+    t0 = time.perf_counter()
+    assert ss.search_host_all(s, host, devices) is True
+    present = time.perf_counter() - t0
+    assert present < 0.5 * absent, (present, absent)
+    # the needle in the LAST range only: still found
+    host[5000:5000 + len(needle)] = 0
+    host[total - 30:total - 30 + len(needle)] = np.frombuffer(needle, dtype=np.uint8)
+    assert ss.search_host_all(s, host, devices) is True
