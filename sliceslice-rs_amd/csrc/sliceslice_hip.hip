@@ -286,8 +286,10 @@ void bar_write(uint8_t *d_dst, const uint8_t *src, size_t bytes, volatile uint32
         _mm_store_si128(reinterpret_cast<__m128i *>(d_dst + k), _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k)));
     _mm_sfence();
     if (hdp_flush) {
-        *hdp_flush = 1u;
-        (void)*hdp_flush;
+        // (atomic accesses: several threads - building searchers, posting service requests - write this register concurrently;
+        // any write to it means "flush")
+        __atomic_store_n(hdp_flush, 1u, __ATOMIC_RELAXED);
+        (void)__atomic_load_n(hdp_flush, __ATOMIC_RELAXED);
     } else {
         (void)*reinterpret_cast<volatile uint32_t *>(d_dst);    // no register at hand: read what was written first back
     }
@@ -2198,7 +2200,7 @@ void service_write_mailbox(ss_service *sv, const ss::ServiceRequest &rq, uint32_
     _mm_sfence();
     for (int line = 0; line < 4; ++line) m[line * 16 + 15] = seq;
     _mm_sfence();
-    if (sv->hdp_flush) *sv->hdp_flush = 1u;               // (no read-back: the kernel polls, nothing is ordered behind this)
+    if (sv->hdp_flush) __atomic_store_n(sv->hdp_flush, 1u, __ATOMIC_RELAXED);   // (no read-back: the kernel polls, nothing is ordered behind this)
     if (dbg) {
         static double total_us = 0;
         static unsigned long n = 0;
@@ -2499,17 +2501,17 @@ void ss_service_stop(ss_service *sv)
         ss_service *expect = sv;
         g_default_service[sv->dev].compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel);
     }
+    DeviceGuard guard;
+    (void)hipSetDevice(sv->dev);
     {
-        std::lock_guard<std::mutex> lock(sv->mu);
-        DeviceGuard guard;
-        (void)hipSetDevice(sv->dev);
+        std::lock_guard<std::mutex> lock(sv->mu);               // (a search still in its wait loop finishes first)
         ss::ServiceRequest bye;
         memset(&bye, 0, sizeof bye);
         bye.stop = 1;
         unsigned long long ignored = 0;
         (void)service_post(sv, bye, ++sv->seq, &ignored);      // (a kernel that does not answer leaves when its lease runs out)
-        service_free(sv);
     }
+    service_free(sv);                                           // outside the lock: the mutex is part of what is freed
 }
 
 // DPP / alignbyte self-test used by the GPU tests: out must hold 320 uint32 (host memory).
@@ -3089,7 +3091,7 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
                         }
                         _mm_sfence();
                         for (int o = 0; o < G; ++o)
-                            if (o != g && set->hdp_flush[o]) *set->hdp_flush[o] = 1u;
+                            if (o != g && set->hdp_flush[o]) __atomic_store_n(set->hdp_flush[o], 1u, __ATOMIC_RELAXED);
                         relayed = true;
                         break;
                     }

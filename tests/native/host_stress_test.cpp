@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,7 @@ static std::atomic<int> g_failures{0};
 
 int main(int argc, char **argv)
 {
+    std::setvbuf(stdout, nullptr, _IONBF, 0);           // (a sanitizer abort must not swallow the progress lines)
     const int nthreads = argc > 1 ? std::atoi(argv[1]) : 128;
     const int iterations = argc > 2 ? std::atoi(argv[2]) : 16;
     const size_t len = 2u << 20;
@@ -278,6 +280,46 @@ int main(int argc, char **argv)
         CHECK(ss_searcher_set_filter3(s, 0, 6, 5) == SS_OK);          // nothing in flight now
         CHECK(ss_searcher_filter3(s, &a, &b, &c3) == SS_OK && a == 0 && b == 6 && c3 == 5);
         std::printf("set_filter against 4 searching threads: %d accepted, %d refused\n", accepted.load(), refused.load());
+    }
+
+    // The resident search service from several threads (requests queue on its mutex), searchers built and dropped while it is
+    // resident (control blocks from the slab pool, written through the BAR), bind / unbind, a lease short enough to end the
+    // residency now and then - and the stop: the service's memory, its mutex included, is freed OUTSIDE its own lock.
+    if (!std::getenv("HST_SKIP_SERVICE")) {
+        ss_service *sv = nullptr;
+        const double lease = std::getenv("HST_SVC_LEASE_MS") ? std::atof(std::getenv("HST_SVC_LEASE_MS")) : 1.0;
+        const bool build_inside = !std::getenv("HST_SVC_NO_NEW");
+        CHECK(ss_service_start(32, lease, &sv) == SS_OK);
+        CHECK(ss_service_bind(sv, d_yes, len) == SS_OK);
+        std::vector<std::thread> callers;
+        for (int t = 0; t < 4; ++t)
+            callers.emplace_back([&, t]() {
+                for (int it = 0; it < 400; ++it) {
+                    int found = -1;
+                    TCHECK(ss_service_search(sv, s, (it & 1) ? d_yes : d_no, len, &found) == SS_OK && found == (it & 1));
+                    if (build_inside && (it & 63) == 17) {
+                        const uint8_t other[5] = {9, 9, 8, 8, (uint8_t)t};
+                        ss_searcher *tmp = nullptr;
+                        TCHECK(ss_searcher_new(other, 5, &tmp) == SS_OK);
+                        TCHECK(ss_service_search(sv, tmp, d_yes, len, &found) == SS_OK && found == 0);
+                        ss_searcher_free(tmp);
+                    }
+                    if ((it & 127) == 100) std::this_thread::sleep_for(std::chrono::milliseconds(2));    // > lease
+                }
+            });
+        for (auto &t : callers) t.join();
+        std::puts("service callers joined");
+        CHECK(g_failures == 0);
+        uint64_t requests = 0, launches = 0, settled = 0;
+        CHECK(ss_service_counters(sv, &requests, &launches) == SS_OK && requests >= 1600 && launches >= 1);
+        CHECK(ss_service_settled_requests(sv, &settled) == SS_OK && settled > 0);
+        CHECK(ss_service_unbind(sv) == SS_OK);
+        int found = -1;
+        CHECK(ss_service_search(sv, s, d_yes, len, &found) == SS_OK && found == 1);
+        ss_service_stop(sv);
+        std::puts("service stopped");
+        std::printf("service from 4 threads: %llu requests, %llu residencies, %llu without an acquire\n", (unsigned long long)requests,
+                    (unsigned long long)launches, (unsigned long long)settled);
     }
 
     ss_searcher_free(s);
