@@ -988,7 +988,9 @@ void ss_searcher_free(ss_searcher *s)
             if (s->used_async.load(std::memory_order_acquire)) (void)hipDeviceSynchronize();
             if (p.needle_own) (void)hipFree(p.d_needle);
         }
-        pool_release(p.dev, p.block);
+        // (once exit() has begun the pools - function-scope-free statics - may already be gone: a searcher dropped by a thread
+        // that outlives main keeps its block)
+        if (!process_exiting()) pool_release(p.dev, p.block);
     }
     (void)hipSetDevice(cur);
     if (g_timer.owner == s) g_timer.owner = nullptr;
