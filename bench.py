@@ -731,8 +731,8 @@ def main():
                                                   "process instead" % (repr(e)[:200],))
             return
     transport = args.transport
-    if share and world > 1 and transport == "rccl":
-        transport = "torch"                                    # RCCL refuses two ranks on one device
+    if share and world > 1 and transport == "rccl" and not os.environ.get("SLICESLICE_RCCL_LIB"):
+        transport = "torch"                                    # RCCL refuses two ranks on one device (a stand-in named by SLICESLICE_RCCL_LIB does not)
 
     import sliceslice_rs_amd as ss
     ss.lib()

@@ -1,5 +1,5 @@
 /*
- * sliceslice_hip.h - C ABI of the MI355X (gfx950) substring searcher.
+ * sliceslice_hip.h - C ABI of the MI355X (gfx950) substring searcher: the reference-facing entry points.
  *
  * This is the drop-in boundary for ONE hot path of cloudflare/sliceslice-rs:
  * `DynamicAvx2Searcher::{new, with_position, search_in}` -> bool.  The reference
@@ -9,6 +9,7 @@
  * style - pointer + length pairs, integer status - follows the reference's only
  * FFI precedent, bench/sse4-strstr/src/wrapper.h:7
  *     size_t avx2_strstr_v2(const char* s, size_t n, const char* needle, size_t k);
+ * Benchmark / tuning helpers and the test hooks are in sliceslice_hip_tuning.h.
  *
  * All citations are paths under /root/reference (sliceslice-rs @ 2024_08_07).
  *
@@ -30,6 +31,11 @@
  *
  * No CPU fallback exists: every ss_search_* that has to look at haystack bytes
  * launches a HIP kernel, and fails with SS_ERR_NO_DEVICE / SS_ERR_HIP otherwise.
+ *
+ * Environment (read once per process; everything else is an argument):
+ *     SLICESLICE_SPIN_WAIT=0      wait for the stream instead of spinning on the pinned answer word
+ *     SLICESLICE_NO_BAR_WRITES=1  never write device memory from the CPU (control blocks go by hipMemcpy; no service, no relay)
+ *     SLICESLICE_RCCL_LIB=<path>  the RCCL library to dlopen instead of librccl.so.1 / librccl.so
  */
 #ifndef SLICESLICE_HIP_H
 #define SLICESLICE_HIP_H
@@ -40,6 +46,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define SS_API __attribute__((visibility("default")))
 
 typedef enum ss_status {
     SS_OK = 0,
@@ -55,66 +63,59 @@ typedef enum ss_status {
 } ss_status;
 
 /* Opaque searcher: owns a host copy and a device copy of the needle, `position`,
- * and the two filter bytes (needle[0], needle[position]) - the counterpart of
- * `DynamicAvx2Searcher<N>` (src/x86.rs:405-442) and of the pre-splatted
- * `VectorHash` (src/lib.rs:165-176). */
+ * and the filter bytes - the counterpart of `DynamicAvx2Searcher<N>` (src/x86.rs:405-442)
+ * and of the pre-splatted `VectorHash` (src/lib.rs:165-176). */
 typedef struct ss_searcher ss_searcher;
 
 /* DynamicAvx2Searcher::new (src/x86.rs:454-459): position = n - 1 (wrapping for n == 0).
  * Also places the needle and the searcher's control block on the CURRENT device (other devices: on first use there): a block
  * of a per-device slab, written by the CPU through the PCIe BAR - about 3 us, no HIP runtime call once a slab exists. */
-int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out);
+SS_API int ss_searcher_new(const uint8_t *needle, size_t n, ss_searcher **out);
 
 /* DynamicAvx2Searcher::with_position (src/x86.rs:468-493).
  *   n == 0: any position accepted (N0);  n == 1: position must be 0;  n >= 2: position < n.
  * Violations return SS_ERR_POSITION (the reference panics).  The needle bytes are copied; the
  * caller keeps ownership of its buffer (the reference copies n in 2..=16 too, x86.rs:476-490). */
-int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out);
+SS_API int ss_searcher_with_position(const uint8_t *needle, size_t n, size_t position, ss_searcher **out);
 
 /* No search of `s` may be running.  The synchronous entry points have finished when they return; work left behind by
  * ss_search_device_async / ss_find_device_async is waited for here (hipDeviceSynchronize on the devices it used). */
-void ss_searcher_free(ss_searcher *s);
+SS_API void ss_searcher_free(ss_searcher *s);
 
-size_t ss_searcher_needle_len(const ss_searcher *s);
-size_t ss_searcher_position(const ss_searcher *s);
+/* needle().len() and the `position` the searcher was built with (`new`: n - 1).  Either pointer may be NULL. */
+SS_API int ss_searcher_info(const ss_searcher *s, size_t *needle_len, size_t *position);
 
-/* The needle bytes the device filter tests: needle[first], needle[second] (first <= second < n) and, in the
- * single-stream kernels (second - first <= 15), a third byte needle[third] with first < third <= first + 15
- * (third == second: none).  The reference tests needle[0] and needle[position] (src/x86.rs:297-316) and proves
- * with its own tests that the result does not depend on `position` (src/lib.rs:375-378); every further byte
- * is one more necessary condition of a match, so it cannot change a result either.
+/* The needle bytes the filter tests: needle[first], needle[second] (first <= second < n) and, when second - first <= 15,
+ * a third byte needle[third] with first < third <= first + 15 (third == second: none).  The reference tests needle[0] and
+ * needle[position] (src/x86.rs:297-316) and proves with its own tests that the result does not depend on `position`
+ * (src/lib.rs:375-378); every further byte is one more necessary condition of a match, so it cannot change a result either.
  *   ss_searcher_with_position always tests the caller's byte needle[position].  Up to position 15 its partner is the
  *     reference's needle[0], plus the rarest other byte of needle[1..15] as the third; from position 16 the partner is a
- *     byte at most 15 in front of `position` (see ss_choose_filter_for_position), so that every constructor-built
- *     searcher runs on the single-stream kernels.  ss_searcher_position() reports `position` either way.
+ *     byte at most 15 in front of `position`, so that one 16-byte load serves all three.
  *   ss_searcher_new - whose caller did not choose - picks all three by a static rarity ranking of the needle's
  *     bytes (first byte + the two rarest of the 15 bytes behind it, over the first 1024 needle bytes), so that
- *     text-like haystacks rarely pass the filter and long needles stay on the single-stream kernels;
- *     ss_searcher_position() still reports n-1.  SLICESLICE_AUTO_FILTER=0 in the environment makes both
- *     constructors test the reference's pair (needle[0], needle[position]) at any distance.
- *   ss_searcher_set_filter overrides the pair and drops the third byte (a plain two-byte filter; a pair 16 or
- *     more apart - e.g. the reference's (0, n-1) for a long needle - runs on the cross-lane or two-stream kernels);
- *     ss_searcher_set_filter3 sets all three.  Tests, tuning, or a caller with corpus statistics (see
- *     ss_byte_histogram_device).  SS_ERR_POSITION if out of range; SS_ERR_ARGUMENT while any search is in flight on the
+ *     text-like haystacks rarely pass the filter.  ss_searcher_info still reports position n-1.
+ *   ss_searcher_set_filter3 sets the triple verbatim (third == second: a plain two-byte filter, e.g. the reference's own
+ *     pair (0, n-1)).  A pair 16 or more apart has no third byte and runs on the cross-lane kernels; beyond 16 * 63 bytes
+ *     apart the device filters with `first` and two bytes close behind it and tests the caller's `second` first thing when a
+ *     candidate reaches memory.  SS_ERR_POSITION if out of range; SS_ERR_ARGUMENT while any search is in flight on the
  *     searcher (the triple is only rewritten when nothing can be reading it). */
-int ss_searcher_filter(const ss_searcher *s, size_t *first, size_t *second);
-int ss_searcher_filter3(const ss_searcher *s, size_t *first, size_t *second, size_t *third);
-int ss_searcher_set_filter(ss_searcher *s, size_t first, size_t second);
-int ss_searcher_set_filter3(ss_searcher *s, size_t first, size_t second, size_t third);
-/* What ss_searcher_new would pick for this needle (pure host functions, no device needed). */
-int ss_choose_filter_pair(const uint8_t *needle, size_t n, size_t *first, size_t *second);
-int ss_choose_filter_triple(const uint8_t *needle, size_t n, size_t *first, size_t *second, size_t *third);
-/* What ss_searcher_with_position would pick: `second` == position always; position < 16: first == 0 (the reference's pair,
- * x86.rs:297-316) plus the rarest other byte of needle[1..15] as `third`; position >= 16: `first` is a byte at most 15 in
- * front of `position` and `third` one of the 15 behind `first`, so that one 16-byte load serves all three - the result never
- * depends on which bytes are tested (lib.rs:375-378).  ss_searcher_set_filter(s, 0, position) restores the reference's pair
- * at any distance.  SS_ERR_POSITION as the constructor. */
-int ss_choose_filter_for_position(const uint8_t *needle, size_t n, size_t position, size_t *first, size_t *second, size_t *third);
-/* The same choice driven by a byte histogram of (a sample of) the haystack - ss_byte_histogram_device - instead of the
- * static ranking (hist == NULL: the static ranking): cost of a byte = log2(count + 1), so sums compare products of
- * frequencies.  Apply with ss_searcher_set_filter3.  Row f3 of SURVEY.md 8f for the three-byte filter. */
-int ss_choose_filter_triple_hist(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *first, size_t *second,
-                                 size_t *third);
+SS_API int ss_searcher_filter3(const ss_searcher *s, size_t *first, size_t *second, size_t *third);
+SS_API int ss_searcher_set_filter3(ss_searcher *s, size_t first, size_t second, size_t third);
+
+/* Row f3: a `position` policy.  The reference leaves `position` to the caller and defaults to the last byte
+ * (src/x86.rs:252-255, 285).  ss_byte_histogram_device counts byte values of a device haystack (every
+ * ceil(len/sample_bytes)-th 16-byte chunk; sample_bytes = 0 -> all) into hist[256] (host memory).
+ * ss_choose_position returns the index (>= 1) of the needle byte that is rarest under `hist` - ties to the later byte;
+ * hist == NULL -> n-1, the reference default - for ss_searcher_with_position.  ss_choose_filter_triple is the same choice for
+ * all three filter bytes (what ss_searcher_new picks; hist == NULL: its static ranking, else cost of a byte = log2(count + 1),
+ * so sums compare products of frequencies) for ss_searcher_set_filter3.  Pure host functions.  The result of a search never
+ * depends on the choice (src/lib.rs:375-378); only how often candidates are verified does. */
+SS_API int ss_byte_histogram_device(const void *d_haystack, size_t len, size_t sample_bytes, void *hip_stream,
+                                    uint64_t hist[256]);
+SS_API int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *position);
+SS_API int ss_choose_filter_triple(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *first, size_t *second,
+                                   size_t *third);
 
 /* DynamicAvx2Searcher::search_in (src/x86.rs:523-525) on a haystack ALREADY RESIDENT in device
  * memory (any alignment, any length up to the device's memory).  Enqueues on `hip_stream`
@@ -123,15 +124,12 @@ int ss_choose_filter_triple_hist(const uint8_t *needle, size_t n, const uint64_t
  * caller spins on - the stream itself may still be retiring the command for a few microseconds when the call returns (every
  * 256th call does wait for the stream); a caller that needs the stream idle - to destroy it, to read its own hipEvent
  * timings - synchronises it itself.  Longer scans, and SLICESLICE_SPIN_WAIT=0, wait for the stream.  ss_find_device: the same. */
-int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,
-                     int *found);
+SS_API int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, int *found);
 
 /* Same scan without the host round trip: ORs the result into the caller's device flag
  * (`*d_found`, int32, caller-zeroed) and returns after enqueueing.  This is the building block of
- * the range-sharded multi-GPU search: each rank scans its shard, then ONE all-reduce(MAX) of the
- * flag combines them (ss_comm_allreduce_flag or torch.distributed). */
-int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t len,
-                           void *hip_stream, int *d_found);
+ * a range-sharded multi-GPU search with the caller's own collective (torch.distributed: searcher.py). */
+SS_API int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, int *d_found);
 
 /* ---- row f1: position-returning find ------------------------------------------- */
 /* Offset of the LEFTMOST occurrence, or SS_NPOS - the `Option<usize>` shape every competitor in the
@@ -141,47 +139,31 @@ int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t 
  * n == 0 -> 0.  Same kernels as search_in with the flag replaced by an atomicMin'ed uint64; a wave
  * only skips work that lies to the right of the best match so far. */
 #define SS_NPOS UINT64_MAX
-int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,
-                   uint64_t *position);
+SS_API int ss_find_device(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream, uint64_t *position);
 /* The same for a HOST haystack (chunked upload, n-1 byte carry, stops issuing chunks after the first
  * chunk that reports a match). */
-int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint64_t *position);
+SS_API int ss_find_host(const ss_searcher *s, const uint8_t *haystack, size_t len, uint64_t *position);
 /* Enqueue-only form: atomicMin's base_offset + local offset into *d_best (uint64 in device memory,
  * caller-initialised to SS_NPOS).  With base_offset = the shard's begin, an all-reduce(MIN) over the
  * ranks' d_best gives the global leftmost match of a range-sharded haystack. */
-int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t len, uint64_t base_offset,
-                         void *hip_stream, uint64_t *d_best);
+SS_API int ss_find_device_async(const ss_searcher *s, const void *d_haystack, size_t len, uint64_t base_offset,
+                                void *hip_stream, uint64_t *d_best);
 
 /* Drop-in form of search_in(&[u8]) for a HOST haystack: uploads the bytes in double-buffered chunks of up
  * to 64 MiB (needle_len-1 bytes of carry between chunks) and scans them on the device.  PCIe-bound by
  * construction; never used for roofline numbers.  The device buffers and streams come from a per-device
  * set that lives for the rest of the process and is lent to one call at a time (a concurrent call on the
- * same device builds and frees a private set), so a small haystack costs tens of microseconds per call. */
-int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
-/* The same over SEVERAL GPUs, from one process, without a collective: the host slice is range-partitioned (ss_shard_range, n-1
- * bytes of overlap) and every listed device uploads and scans its own range over its own PCIe link (one host thread per
- * device running ss_search_host); the booleans are OR-ed on the host.  devs == NULL: devices 0 .. ndev-1. */
-int ss_search_host_all(const ss_searcher *s, const uint8_t *haystack, size_t len, int ndev, const int *devs, int *found);
-/* Slices of up to 64 KiB take a shorter road (ss_find_host too): the CPU copies them into a pinned, device-visible
- * buffer of the calling thread and the kernel reads them over PCIe - no upload command (10-12 us per call instead of
- * 16-24; SLICESLICE_HOST_ZERO_COPY=0 switches it off). */
+ * same device builds and frees a private set), so a small haystack costs tens of microseconds per call.
+ * Slices of up to 64 KiB take a shorter road (ss_find_host too): the CPU copies them into a pinned, device-visible
+ * buffer of the calling thread and the kernel reads them over PCIe - no upload command (10-12 us per call instead of 16-24). */
+SS_API int ss_search_host(const ss_searcher *s, const uint8_t *haystack, size_t len, int *found);
 
 /* Row f2: the host-file front end of examples/grep.rs:42-56 (open the file, one
  * search_in) as a pipeline: reader threads pread() 64 MiB chunks into pinned buffers while earlier
  * chunks are uploading and being scanned on their own streams; n-1 bytes are carried across chunk
  * edges.  Bound by the file read / PCIe, never by the scan.  Uses the same cached per-device staging set
  * (plus pinned host buffers) as ss_search_host. */
-int ss_search_file(const ss_searcher *s, const char *path, int *found);
-
-/* Row f3: data for a `position` policy.  The reference leaves `position` to the caller
- * and defaults to the last byte (src/x86.rs:252-255, 285).  ss_byte_histogram_device counts byte values
- * of a device haystack (every ceil(len/sample_bytes)-th 16-byte chunk; sample_bytes = 0 -> all) into
- * hist[256] (host memory); ss_choose_position returns the index (>= 1) of the needle byte that is rarest
- * under `hist` - ties to the later byte; hist == NULL -> n-1, the reference default.  The result of a
- * search never depends on the choice (src/lib.rs:375-378); only the verify load does. */
-int ss_byte_histogram_device(const void *d_haystack, size_t len, size_t sample_bytes, void *hip_stream,
-                             uint64_t hist[256]);
-int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256], size_t *position);
+SS_API int ss_search_file(const ss_searcher *s, const char *path, int *found);
 
 /* Batched search, one launch (BASELINE.json config 5): problem i searches the needle
  * d_needles[needle_begin[i] .. needle_end[i]) in the haystack d_haystacks[hay_begin[i] .. hay_end[i]).
@@ -189,84 +171,79 @@ int ss_choose_position(const uint8_t *needle, size_t n, const uint64_t hist[256]
  * pass (off, off + 1); ranges may alias, e.g. 4,585 needles against ONE haystack - the loop of
  * bench/benches/i386.rs:252-256 as a single launch.  position[i] follows the with_position rules
  * (NULL = the `new` default n_i - 1) and is always one of the bytes the device tests; its partner bytes are picked on
- * the device by the rule of ss_choose_filter_for_position (coarser ranking).  Writes `count` int32 flags to d_found (device), each with the
- * semantics of ss_search_device for its problem; a problem whose position breaks those rules - where the
+ * the device by the rule of ss_searcher_with_position (coarser ranking).  Writes `count` int32 flags to d_found (device), each
+ * with the semantics of ss_search_device for its problem; a problem whose position breaks those rules - where the
  * reference panics while building the searcher, src/x86.rs:300,473 - gets SS_BATCH_BAD_POSITION instead
  * (a device array cannot be validated on the host without a read-back).  One workgroup (or more) per
- * problem: meant for haystacks of KiBs to GiBs. */
+ * problem: meant for haystacks of KiBs to GiBs.  Not capturable into a hipGraph (SS_ERR_ARGUMENT on a capturing stream: the
+ * call keeps per-stream scratch that a later call may reallocate) - a graph takes an ss_batch_plan. */
 #define SS_BATCH_BAD_POSITION (-1)
-int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
-                      const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
-                      const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
+SS_API int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                             const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                             const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
 
 /* Row f1 for a whole batch: the LEFTMOST offset of needle i in haystack i (SS_NPOS: absent; the empty needle: 0) - the
  * `Option<usize>` shape of bench/sse4-strstr/src/lib.rs:4-15 for many problems in one call.  Same ranges, same plan kernel and
  * scan grid as ss_search_batched (the `new` position for every problem); d_position: `count` uint64 in device memory. */
-int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
-                    const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
-                    size_t count, void *hip_stream, uint64_t *d_position);
+SS_API int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                           const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                           size_t count, void *hip_stream, uint64_t *d_position);
 
-/* Same contract, one LANE per problem: the reference's short-haystack workload
+/* Plan once, search many: the reference builds its 4,585 searchers ONCE and times only the searches
+ * (bench/benches/i386.rs:246-256).  ss_batch_plan_create does for a batch what the constructors do for one needle: it reads
+ * the range arrays and the NEEDLE bytes (on `hip_stream`, and waits for it) and keeps one descriptor per problem in memory of
+ * its own; ss_batch_plan_run is then a single scan launch that also re-arms the outputs - no plan kernel, no scratch
+ * acquire, nothing allocated, capturable into a hipGraph.  `find` != 0: the plan answers leftmost offsets (d_out = `count`
+ * uint64, as ss_find_batched), else flags (d_out = `count` int32, as ss_search_batched).  The caller vouches that ranges,
+ * needle bytes and the haystacks' ADDRESSES are unchanged between create and the last run; haystack CONTENTS may change
+ * freely.  ONE run at a time per plan (the plan's state words are the run's scratch; the last workgroup of every problem
+ * puts them back to idle): runs must be ordered one behind the other - the same stream, or events.  d_out needs no
+ * initialisation.  No run may be in flight when the plan is freed. */
+typedef struct ss_batch_plan ss_batch_plan;
+SS_API int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                                const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                                const uint64_t *d_position, size_t count, int find, void *hip_stream, ss_batch_plan **out);
+SS_API int ss_batch_plan_run(const ss_batch_plan *plan, void *hip_stream, void *d_out);
+SS_API void ss_batch_plan_free(ss_batch_plan *plan);
+
+/* Same contract as ss_search_batched, one LANE per problem: the reference's short-haystack workload
  * (bench/benches/i386.rs:118-129: 10,513,405 word-in-word searches of <= 24 bytes).  Use it when the
  * haystacks are tens of bytes; any length is correct but long haystacks belong to ss_search_batched. */
-int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
-                    const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
-                    const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
+SS_API int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                           const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                           const uint64_t *d_position, size_t count, void *hip_stream, int *d_found);
 
-/* Kernel timing hook for bench.py's roofline line: when enabled, every scan launched through `s`
- * is bracketed by hipEvents ON THE LAUNCH STREAM; ss_searcher_last_kernel_ms returns the elapsed
- * time of the most recent completed scan kernel (milliseconds). */
-int ss_searcher_set_timing(ss_searcher *s, int enabled);
-int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);   /* of the CALLING THREAD's latest scan through s */
-
-/* Kernel-variant override for tuning/tests (the default library holds the kernels the constructors and ss_searcher_set_filter* can
- * select - U = 4, non-temporal loads except for the two-stream kernels, the 8-byte phase for one-byte needles; a variant that names
- * another kernel makes the search return SS_ERR_ARGUMENT there and runs in the tuning build, libsliceslice_hip_tuning.so):
- * variant = 1000*LAYOUT + 100*MODE + 10*U + NT; LAYOUT 0 =
- * automatic, 1 = 16 bytes per lane, 2 = 8-bytes-per-lane first phase (position < 16 only); U in {4,8} pieces (KiB)
- * per wave per tile; NT in {0,1} (plain / non-temporal loads); MODE 0 = automatic, 1 = second load
- * stream, 2 = cross-lane position flags (filter pairs 16 or more apart only); 0 = automatic.  Two more decimal digits
- * on top are launch-shape experiments: + 10000*OCC (at most OCC workgroups per CU) + 100000*B (workgroup
- * size: 1 = 128, 2 = 256, 3 = 512 threads).  See DESIGN.md "Kernels". */
-int ss_searcher_set_variant(ss_searcher *s, int variant);
-/* Grid override: blocks > 0 = that many persistent workgroups (grid-stride over tiles); blocks < 0 =
- * -blocks tiles per short-lived workgroup; 0 = automatic. */
-int ss_searcher_set_grid(ss_searcher *s, int blocks);
-
-/* Synthetic haystack generator (not part of the reference):
- *   byte(i) = (splitmix64(splitmix64(seed) ^ (i >> 3)) >> (8 * (i & 7))) & 0xFF, then 0xFF -> 0x00,
- * with i = global_offset + k the GLOBAL byte index, so that range shards on different GPUs hold
- * slices of one logical haystack.  Device and host versions are bit-identical. */
-int ss_fill_random_device(void *d_dst, uint64_t global_offset, size_t len, uint64_t seed,
-                          void *hip_stream);
-int ss_fill_random_host(uint8_t *dst, uint64_t global_offset, size_t len, uint64_t seed);
-
-/* Plain streaming read of `len` bytes (sum-reduced so it cannot be elided): the empirical
- * "achievable HBM read" ceiling printed next to the scan's GB/s.  ms = kernel time by hipEvents. */
-int ss_read_ceiling(const void *d_src, size_t len, void *hip_stream, int reps, float *ms_per_rep);
+/* Kernel timing: when enabled, every scan launched through `s` is bracketed by hipEvents ON THE LAUNCH STREAM;
+ * ss_searcher_last_kernel_ms returns the elapsed time of the CALLING THREAD's most recent completed scan through s
+ * (milliseconds) - what a roofline figure for the scan kernel is computed from (bench.py). */
+SS_API int ss_searcher_set_timing(ss_searcher *s, int enabled);
+SS_API int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);
 
 /* ---- multi-GPU: one process per GPU, native RCCL ------------------------------------------- */
+/* Range partition used by every sharded caller (SURVEY.md 8e): rank r of G scans bytes
+ * [r*S, min(len, (r+1)*S + n-1)) with S = ceil(len/G): an overlap of n-1 bytes, so a match that
+ * straddles a boundary is seen by exactly the left rank. */
+SS_API int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *begin, size_t *end);
+
 /* The found flag of a range-sharded search is combined by ONE ncclAllReduce(int32, ncclMax)
  * (OR over {0,1} == MAX; RCCL has no bitwise-OR op).  librccl is dlopen()ed on first use. */
 typedef struct ss_comm ss_comm;
 #define SS_UNIQUE_ID_BYTES 128
-int ss_comm_unique_id(uint8_t id[SS_UNIQUE_ID_BYTES]);                       /* rank 0, then broadcast */
-int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank, ss_comm **out);
-void ss_comm_free(ss_comm *c);
-int ss_comm_count(const ss_comm *c, int *nranks);                            /* ncclCommCount: what RCCL itself sees */
-/* In-place all-reduce(MAX) of one int32 device flag on `hip_stream`, then (if found != NULL)
- * stream-synchronise and copy the combined flag to *found. */
-int ss_comm_allreduce_flag(ss_comm *c, int *d_flag, void *hip_stream, int *found);
+SS_API int ss_comm_unique_id(uint8_t id[SS_UNIQUE_ID_BYTES]);                       /* rank 0, then broadcast */
+SS_API int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank, ss_comm **out);
+SS_API void ss_comm_free(ss_comm *c);
+SS_API int ss_comm_count(const ss_comm *c, int *nranks);                            /* ncclCommCount: what RCCL itself sees */
 /* Scan + all-reduce + read-back on one stream: the whole sharded search_in.  The communicator's flag is
  * never cleared - "found" is the call's epoch (every rank makes the same sequence of calls on a communicator,
- * so the epochs agree) - which saves the memset launch per search.  Collective: every rank must call it. */
-int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, ss_comm *c,
-                      void *hip_stream, int *found);
-
+ * so the epochs agree) - which saves the memset launch per search.  Collective: every rank must call it, and a rank whose
+ * local part fails still takes part (it returns its own error, every other rank SS_ERR_PEER; the next search finds all
+ * ranks in step).  One search at a time per communicator: a second concurrent call is refused with SS_ERR_ARGUMENT. */
+SS_API int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, ss_comm *c,
+                             void *hip_stream, int *found);
 /* The same for the leftmost offset: ss_find_device_async with base_offset = shard_begin, then ONE
  * ncclAllReduce(uint64, ncclMin); *position = SS_NPOS when no rank has a match. */
-int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, uint64_t shard_begin,
-                    ss_comm *c, void *hip_stream, uint64_t *position);
+SS_API int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, uint64_t shard_begin,
+                           ss_comm *c, void *hip_stream, uint64_t *position);
 
 /* ---- multi-GPU inside ONE process (ncclCommInitAll) --------------------------------------------------- */
 /* The form a drop-in `search_in(&self, haystack) -> bool` (src/x86.rs:523) over all GPUs of a node needs: no
@@ -279,27 +256,19 @@ int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len,
  * SS_COMBINE_HOST skips the collective: the host ORs the G pinned mirrors (possible only in this
  * single-process form; the difference between the two is the cost of the collective).
  * ss_search_sharded_all ends every device's scan at the first match on ANY device: the host relays the finding device's flag
- * into the others' through their PCIe BARs while it waits (SLICESLICE_CROSS_EXIT=0 turns that off; needs CPU-visible device
- * memory, else each device runs its scan to the end as before).
- * One search at a time per set (the set's streams and flags are its scratch): a second concurrent call is refused with
- * SS_ERR_ARGUMENT.  The same holds for ss_search_sharded / ss_find_sharded on one communicator. */
+ * into the others' through their PCIe BARs while it waits (needs CPU-visible device memory, else each device runs its scan
+ * to the end).  One search at a time per set (the set's streams and flags are its scratch): a second concurrent call is
+ * refused with SS_ERR_ARGUMENT. */
 typedef struct ss_comm_set ss_comm_set;
 #define SS_COMBINE_RCCL 0
 #define SS_COMBINE_HOST 1
-int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out);
-void ss_comm_set_free(ss_comm_set *set);
-int ss_comm_set_size(const ss_comm_set *set);
-int ss_comm_set_device(const ss_comm_set *set, int index, int *device);
-int ss_comm_set_combine(ss_comm_set *set, int combine);
-int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
-                          ss_comm_set *set, int *found);
-int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
-                        const uint64_t *shard_begins, ss_comm_set *set, uint64_t *position);
-
-/* Range partition used by every sharded caller (SURVEY.md 8e): rank r of G scans bytes
- * [r*S, min(len, (r+1)*S + n-1)) with S = ceil(len/G): an overlap of n-1 bytes, so a match that
- * straddles a boundary is seen by exactly the left rank. */
-int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *begin, size_t *end);
+SS_API int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out);
+SS_API void ss_comm_set_free(ss_comm_set *set);
+SS_API int ss_comm_set_combine(ss_comm_set *set, int combine);
+SS_API int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
+                                 ss_comm_set *set, int *found);
+SS_API int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
+                               const uint64_t *shard_begins, ss_comm_set *set, uint64_t *position);
 
 /* ---- resident search service ------------------------------------------------------------------------------------
  * The reference answers a search of a small haystack in tens of nanoseconds (README.md:38: 10.5 M word-in-word searches in
@@ -307,62 +276,36 @@ int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *
  * costs ss_search_device 8-10 us.  A search service is a small kernel that STAYS on the device and takes requests from a
  * 256-byte mailbox in DEVICE memory that the host writes through the PCIe BAR: no launch, no dispatch, no completion signal -
  * the host writes the request, every wave of the service polls the mailbox in its own memory and scans its share (same kernels'
- * code), the answer arrives in a pinned word the caller spins on: 5.0-5.7 us per search (launch: 8.5-9.5), the reference's
- * 4,585-needle loop in 26-30 ms per iteration (README: 35.181 ms on the CPU).  Needs CPU-visible device memory (large BAR:
- * every MI300-class part; SS_ERR_NO_DEVICE otherwise).
+ * code), the answer arrives in a pinned word the caller spins on: 5.0-5.7 us per search (launch: 8.5-9.5).  That is the floor
+ * of the per-call shape - one PCIe round trip per search; the GPU's answer to the reference's
+ * many-needles loop is the batched call.  Needs CPU-visible device memory (large BAR: every MI300-class part;
+ * SS_ERR_NO_DEVICE otherwise).
  *   ss_service_start(workgroups, lease_ms, &sv)  on the current device; workgroups = 0: 64 (one per 4 compute units), at most
  *       one per compute unit; lease_ms = 0: 20 ms.  The kernel is resident only while requests keep coming: after
- *       `lease_ms` without one it leaves by itself (and is started again by the next request, at the price of one launch),
- *       so nothing that waits for the whole device - hipDeviceSynchronize, hipFree - waits longer than the lease.
+ *       `lease_ms` without one it leaves by itself (and is started again by the next request, at the price of one launch);
+ *       under continuous traffic it leaves all the same once it has been resident for 16 leases (at least 250 ms), so that
+ *       nothing that waits for the whole device - hipDeviceSynchronize, hipFree - waits longer than that.
  *   ss_service_search(sv, s, d_haystack, len, &found)  the semantics of ss_search_device, for searchers whose filter bytes
  *       lie within 16 bytes of each other (every constructor-built searcher; else SS_ERR_ARGUMENT).  The haystack must be
  *       COMPLETE in device memory: the service is not ordered behind work pending on any stream.  One request at a time per
  *       service (callers queue on a mutex); any haystack length is correct, a few MiB and less is what it is for.
- *   ss_service_set_default(sv, 1)  routes qualifying ss_search_device calls on sv's device through sv: haystacks up to 8 MiB,
- *       no variant / grid override, no kernel timing, and only when the caller's stream is idle (hipStreamQuery).
- *       SLICESLICE_SERVICE=1 in the environment does the same with a service the library starts itself on first use
- *       (SLICESLICE_SERVICE_WORKGROUPS, SLICESLICE_SERVICE_LEASE_MS).
  *   ss_service_bind(sv, d_haystack, len)  the caller vouches that [d_haystack, d_haystack + len) stays UNCHANGED until
- *       ss_service_unbind / the next bind (the reference's bench shape: one text, thousands of needles).  A kernel that never
- *       ends sees no kernel boundary, so by default every request drops the caches' copy of whatever it is about to read
+ *       the next bind (len == 0: nothing bound) - the reference's bench shape: one text, thousands of needles.  A kernel that
+ *       never ends sees no kernel boundary, so by default every request drops the caches' copy of whatever it is about to read
  *       (2 us of a request's 8); inside a bound range only the first request does, and so does any request whose searcher
  *       was uploaded to the device after the latest such acquire.  Writing to a bound range without re-binding: stale reads.
- *   ss_service_counters  requests served / kernel launches so far (a burst of requests shares one residency);
- *   ss_service_settled_requests  how many of them skipped the acquire.
- *   ss_service_stop      asks the kernel to leave, waits for it, frees everything. */
+ *   ss_service_stop  asks the kernel to leave, waits for it and for every ss_service_search / _bind that has already
+ *       entered, frees everything.  Calls that ARRIVE after ss_service_stop has been entered are the caller's bug (the
+ *       handle is dead), exactly as with free(). */
 typedef struct ss_service ss_service;
-int ss_service_start(int workgroups, double lease_ms, ss_service **out);
-int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haystack, size_t len, int *found);
-int ss_service_set_default(ss_service *sv, int enabled);
-int ss_service_bind(ss_service *sv, const void *d_haystack, size_t len);
-int ss_service_unbind(ss_service *sv);
-int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches);
-int ss_service_settled_requests(ss_service *sv, uint64_t *settled);
-void ss_service_stop(ss_service *sv);
-
-/* Measurement: median (and minimum) microseconds of a host -> device -> host round trip through pinned memory against ONE
- * resident device lane - the fixed cost per request of a "search service" kernel that would stay on the device instead of
- * being launched per search, to set against ss_search_device's per-call time. */
-int ss_mailbox_round_trip_us(int iters, double *median_us, double *min_us);
+SS_API int ss_service_start(int workgroups, double lease_ms, ss_service **out);
+SS_API int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haystack, size_t len, int *found);
+SS_API int ss_service_bind(ss_service *sv, const void *d_haystack, size_t len);
+SS_API void ss_service_stop(ss_service *sv);
 
 /* Diagnostics */
-const char *ss_last_error(void);      /* thread-local, static storage */
-int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *total_mem);
-const char *ss_version(void);
-/* Device self-test of the cross-lane primitives the scan relies on (DPP wave_shl:1, v_alignbyte):
- * fills out[0..320) (host memory); see tests/test_gpu_parity.py::test_cross_lane_primitives. */
-int ss_selftest_dpp(uint32_t *out);
-/* Test hooks: set the "found"-epoch counters (of every flag slot of `s` on the current device / of a
- * communicator or communicator set) so that a test can cross the 2^31 wrap. */
-int ss_debug_set_epochs(ss_searcher *s, int value);
-/* ... and the completion-word state of every slot of `s` on the current device, device counters and host copies alike:
- * the never-reset count of workgroups (the library starts a slot over before 2^31), the count of workgroups that found
- * the needle (wraps at 2^32) and the decreasing key of find()'s minimum (starts over at 0). */
-int ss_debug_set_completion_state(ss_searcher *s, uint32_t workgroups, uint32_t found_workgroups, uint32_t find_key);
-int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
-/* ... and make the next `count` scans launched through `s` fail before they reach the device (SS_ERR_HIP): how the tests
- * check that a rank-local failure leaves no other rank waiting in the collective of ss_search_sharded / ss_find_sharded. */
-int ss_debug_fail_next_scans(ss_searcher *s, int count);
+SS_API const char *ss_last_error(void);      /* thread-local, static storage */
+SS_API int ss_device_info(char *name, size_t name_cap, int *compute_units, size_t *total_mem);
 
 #ifdef __cplusplus
 }

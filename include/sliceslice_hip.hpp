@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "sliceslice_hip.h"
 
@@ -133,8 +134,18 @@ public:
         return found != 0;
     }
 
-    size_t position() const { return ss_searcher_position(h_); }
-    size_t needle_len() const { return ss_searcher_needle_len(h_); }
+    size_t position() const
+    {
+        size_t p = 0;
+        check(ss_searcher_info(h_, nullptr, &p));
+        return p;
+    }
+    size_t needle_len() const
+    {
+        size_t n = 0;
+        check(ss_searcher_info(h_, &n, nullptr));
+        return n;
+    }
     ss_searcher *handle() const { return h_; }
 
     // The needle bytes the device filter tests (first, second, third; third == second: none).  `with_position`
@@ -149,7 +160,7 @@ public:
         check(ss_searcher_filter3(h_, &f.first, &f.second, &f.third));
         return f;
     }
-    void set_filter(size_t first, size_t second) { check(ss_searcher_set_filter(h_, first, second)); }
+    void set_filter(size_t first, size_t second) { check(ss_searcher_set_filter3(h_, first, second, second)); }   // a plain two-byte filter
     void set_filter(size_t first, size_t second, size_t third) { check(ss_searcher_set_filter3(h_, first, second, third)); }
 
 private:
@@ -207,6 +218,7 @@ public:
     NodeSearcher(const uint8_t *needle, size_t n, int ndev, const int *devices = nullptr)
         : searcher_(DynamicHipSearcher::new_(needle, n)), n_(n), ndev_(ndev)
     {
+        for (int g = 0; g < ndev; ++g) devs_.push_back(devices ? devices[g] : g);
         check(ss_comm_init_all(ndev, devices, &set_));
     }
     NodeSearcher(const std::string &needle, int ndev)
@@ -216,12 +228,7 @@ public:
     ~NodeSearcher() { ss_comm_set_free(set_); }
 
     int devices() const { return ndev_; }
-    int device(int index) const
-    {
-        int d = -1;
-        check(ss_comm_set_device(set_, index, &d));
-        return d;
-    }
+    int device(int index) const { return devs_.at((size_t)index); }
     // byte range [begin, end) of shard `g` of a haystack of `len` bytes
     std::pair<size_t, size_t> shard_range(size_t len, int g) const
     {
@@ -256,6 +263,7 @@ private:
     DynamicHipSearcher searcher_;
     size_t n_;
     int ndev_;
+    std::vector<int> devs_;
     ss_comm_set *set_ = nullptr;
 };
 
@@ -279,21 +287,7 @@ public:
     }
     // the caller vouches that `haystack` stays unchanged until unbind() / the next bind()
     void bind(DeviceSlice haystack) { check(ss_service_bind(sv_, haystack.ptr, haystack.len)); }
-    void unbind() { check(ss_service_unbind(sv_)); }
-    // routes qualifying search_in(DeviceSlice) calls of every searcher on this device through the service
-    void set_default(bool enabled) { check(ss_service_set_default(sv_, enabled ? 1 : 0)); }
-    uint64_t requests() const
-    {
-        uint64_t r = 0, k = 0;
-        check(ss_service_counters(sv_, &r, &k));
-        return r;
-    }
-    uint64_t settled_requests() const
-    {
-        uint64_t v = 0;
-        check(ss_service_settled_requests(sv_, &v));
-        return v;
-    }
+    void unbind() { check(ss_service_bind(sv_, nullptr, 0)); }
 
 private:
     ss_service *sv_ = nullptr;

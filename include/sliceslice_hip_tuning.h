@@ -1,0 +1,85 @@
+/*
+ * sliceslice_hip_tuning.h - NOT the drop-in boundary (that is sliceslice_hip.h): what the benchmark, the tuning tools and the
+ * tests use around it.  Two groups:
+ *
+ *   1. Benchmark helpers, exported by libsliceslice_hip_tools.so (a separate small library: nothing here belongs in a
+ *      product that replaces DynamicAvx2Searcher): the synthetic haystack generator of SURVEY.md 8d, the plain-read
+ *      ceiling, the cross-lane self-test.
+ *   2. Tuning knobs and test hooks, exported only by builds with -DSS_TEST_HOOKS (libsliceslice_hip_tuning.so and the
+ *      sanitizer builds; the product library has neither the symbols nor the code behind them): kernel-variant and grid
+ *      overrides, fault injection, epoch / counter setters, the pure filter-choice helper, service counters.  Hooks builds
+ *      also read a few more environment variables (tuning: SLICESLICE_BATCH_WGS, _BATCH_MIN_TILES, _BATCH_OCC;
+ *      measurement: SLICESLICE_CROSS_EXIT=0, SLICESLICE_SERVICE_HDP_FLUSH=0, SLICESLICE_SERVICE_DEBUG).
+ */
+#ifndef SLICESLICE_HIP_TUNING_H
+#define SLICESLICE_HIP_TUNING_H
+
+#include "sliceslice_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 1. libsliceslice_hip_tools.so ------------------------------------------------------------------------------- */
+
+/* Synthetic haystack generator (not part of the reference):
+ *   byte(i) = (splitmix64(splitmix64(seed) ^ (i >> 3)) >> (8 * (i & 7))) & 0xFF, then 0xFF -> 0x00,
+ * with i = global_offset + k the GLOBAL byte index, so that range shards on different GPUs hold
+ * slices of one logical haystack.  Device and host versions are bit-identical. */
+SS_API int ss_fill_random_device(void *d_dst, uint64_t global_offset, size_t len, uint64_t seed, void *hip_stream);
+SS_API int ss_fill_random_host(uint8_t *dst, uint64_t global_offset, size_t len, uint64_t seed);
+
+/* Plain streaming read of `len` bytes (sum-reduced so it cannot be elided): the empirical
+ * "achievable HBM read" ceiling printed next to the scan's GB/s.  ms = kernel time by hipEvents. */
+SS_API int ss_read_ceiling(const void *d_src, size_t len, void *hip_stream, int reps, float *ms_per_rep);
+
+/* Device self-test of the cross-lane primitives the scan relies on (DPP wave_shl:1, v_alignbyte):
+ * fills out[0..320) (host memory); see tests/test_gpu_parity.py::test_cross_lane_primitives. */
+SS_API int ss_selftest_dpp(uint32_t *out);
+
+SS_API const char *ss_tools_last_error(void);
+
+/* ---- 2. -DSS_TEST_HOOKS builds only ------------------------------------------------------------------------------ */
+
+SS_API const char *ss_version(void);      /* names the build: "... tuning build: every kernel variant, test hooks" */
+
+/* Kernel-variant override (the product library holds the kernels the constructors and ss_searcher_set_filter3 can select -
+ * U = 4, non-temporal loads, the 8-byte phase for one-byte needles; the tuning build has every combination):
+ * variant = 1000*LAYOUT + 100*MODE + 10*U + NT; LAYOUT 0 = automatic, 1 = 16 bytes per lane, 2 = 8-bytes-per-lane first
+ * phase (position < 16 only); U in {4,8} pieces (KiB) per wave per tile; NT in {0,1} (plain / non-temporal loads);
+ * MODE 0 = automatic, 2 = cross-lane position flags (filter pairs 16 or more apart only).  Two more decimal digits
+ * on top are launch-shape experiments: + 10000*OCC (at most OCC workgroups per CU) + 100000*B (workgroup
+ * size: 1 = 128, 2 = 256, 3 = 512 threads).  See DESIGN.md "Kernels". */
+SS_API int ss_searcher_set_variant(ss_searcher *s, int variant);
+/* Grid override: blocks > 0 = that many persistent workgroups (grid-stride over tiles); blocks < 0 =
+ * -blocks tiles per short-lived workgroup; 0 = automatic. */
+SS_API int ss_searcher_set_grid(ss_searcher *s, int blocks);
+
+/* What ss_searcher_with_position would pick (pure host function): `second` == position always; position < 16: first == 0
+ * (the reference's pair, x86.rs:297-316) plus the rarest other byte of needle[1..15] as `third`; position >= 16: `first` is a
+ * byte at most 15 in front of `position` and `third` one of the 15 behind `first`.  SS_ERR_POSITION as the constructor. */
+SS_API int ss_choose_filter_for_position(const uint8_t *needle, size_t n, size_t position, size_t *first, size_t *second,
+                                         size_t *third);
+
+/* Set the "found"-epoch counters (of every flag slot of `s` on the current device / of a
+ * communicator or communicator set) so that a test can cross the 2^31 wrap. */
+SS_API int ss_debug_set_epochs(ss_searcher *s, int value);
+/* ... and the completion-word state of every slot of `s` on the current device, device counters and host copies alike:
+ * the never-reset count of workgroups (the library starts a slot over before 2^31), the count of workgroups that found
+ * the needle (wraps at 2^32) and the decreasing key of find()'s minimum (starts over at 0). */
+SS_API int ss_debug_set_completion_state(ss_searcher *s, uint32_t workgroups, uint32_t found_workgroups, uint32_t find_key);
+SS_API int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
+/* ... and make the next `count` scans launched through `s` fail before they reach the device (SS_ERR_HIP): how the tests
+ * check that a rank-local failure leaves no other rank waiting in the collective of ss_search_sharded / ss_find_sharded. */
+SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
+/* The workgroups-per-CU choice of `s`'s latest scan on the current device (4 or 6) and the candidate-tile rate it was made
+ * from (sampled candidate tiles per 1024 sampled tiles of the scan before it; -1: none yet, the needle's bytes decided). */
+SS_API int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *candidate_tiles_per_1024);
+
+/* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */
+SS_API int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches, uint64_t *settled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLICESLICE_HIP_TUNING_H */

@@ -1,10 +1,16 @@
-"""Builds csrc/ into the in-tree C-ABI library with hipcc for gfx950 (cross-compiles without a GPU).
-The kernel families are separate translation units and are compiled in parallel.
+"""Builds csrc/ into the in-tree C-ABI libraries with hipcc for gfx950 (cross-compiles without a GPU).
 
-Concurrency: every rank of a `torch.distributed.run` job may call build() at once on a fresh clone.  The
-whole build runs under an exclusive fcntl lock, objects and the library are written to temporary names
-and os.replace()d into place, so no process can ever CDLL a half-written file, and the up-to-date check
-compares the library with its objects (a failed link leaves an old .so behind newer .o files)."""
+    libsliceslice_hip.so          the product: include/sliceslice_hip.h and nothing else (-fvisibility=hidden)
+    libsliceslice_hip_tools.so    benchmark helpers (synthetic haystack generator, read ceiling, self-test): ss_tools.hip
+    libsliceslice_hip_tuning.so   the product's sources with -DSS_TUNING_VARIANTS -DSS_TEST_HOOKS: every kernel variant,
+                                  ss_searcher_set_variant / _set_grid, fault injection (tools/, the variant and hook tests)
+    libsliceslice_hip_asan.so / _tsan.so   the host code under sanitizers (with the test hooks), device code untouched
+    tests/native/libfake_rccl.so  the shared-memory RCCL stand-in of the multi-rank tests (test infrastructure)
+
+Every translation unit is compiled in parallel.  Concurrency: every rank of a `torch.distributed.run` job may call build() at
+once on a fresh clone.  Each build runs under an exclusive fcntl lock, objects and libraries are written to temporary names and
+os.replace()d into place, so no process can ever CDLL a half-written file, and the up-to-date check compares the library with
+its objects (a failed link leaves an old .so behind newer .o files)."""
 import fcntl
 import json
 import os
@@ -18,25 +24,44 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_CSRC, "libsliceslice_hip.so")
-# The default library: what the constructors and ss_searcher_set_filter* can select (26 scan kernels, scan_launch.hpp::kernel_built).
-_SOURCES = ["sliceslice_hip.hip", "scan_inst_u4_nt0.hip", "scan_inst_u4_nt1.hip", "scan_inst_find_nt0.hip", "scan_inst_find_nt1.hip"]
-# The tuning build (-DSS_TUNING_VARIANTS): every variant ss_searcher_set_variant can name, incl. the U = 8 families.
-_TUNING_SOURCES = _SOURCES + ["scan_inst_u8_nt0.hip", "scan_inst_u8_nt1.hip"]
-_HEADERS = ["scan_kernels.hpp", "scan_launch.hpp", os.path.join("..", "..", "include", "sliceslice_hip.h")]
-_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
-# Host-side sanitizer build (the reference's guard on its unsafe code is its ASAN CI job,
-# .github/workflows/check.yml:42-58): ASan + UBSan on the HOST code of the same sources, device code untouched.
+_TOOLS_SO = os.path.join(_CSRC, "libsliceslice_hip_tools.so")
+# host-side translation units (ss_internal.hpp lists what each holds) ...
+_HOST_SOURCES = ["ss_core.hip", "ss_scan.hip", "ss_host.hip", "ss_batched.hip", "ss_service.hip", "ss_comm.hip"]
+# ... and the scan kernel family, one explicit-instantiation unit per (U, load flavour, search / find).  The product holds what
+# the constructors and ss_searcher_set_filter3 can select (scan_launch.hpp::kernel_built): U = 4, non-temporal loads.
+_KERNEL_SOURCES = ["scan_inst_u4_nt1.hip", "scan_inst_find_nt1.hip"]
+_SOURCES = _HOST_SOURCES + _KERNEL_SOURCES
+# The tuning build adds every variant ss_searcher_set_variant can name: plain loads, U = 8.
+_TUNING_SOURCES = _SOURCES + ["scan_inst_u4_nt0.hip", "scan_inst_find_nt0.hip", "scan_inst_u8_nt0.hip", "scan_inst_u8_nt1.hip"]
+_HEADERS = ["scan_filters.hpp", "scan_kernels.hpp", "scan_launch.hpp", "batched_kernels.hpp", "service_kernels.hpp", "aux_kernels.hpp",
+            "ss_internal.hpp", os.path.join("..", "..", "include", "sliceslice_hip.h"),
+            os.path.join("..", "..", "include", "sliceslice_hip_tuning.h")]
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-fvisibility=hidden"]
+_HOOK_FLAGS = ["-DSS_TEST_HOOKS=1"]
+# Host-side sanitizer builds (the reference's guard on its unsafe code is its ASAN CI job,
+# .github/workflows/check.yml:42-58): ASan + UBSan / TSan on the HOST code of the same sources, device code untouched.
 _SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"]
+_TSAN_FLAGS = ["-fsanitize=thread", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"]
 _NATIVE_BENCH_SRC = os.path.join(_ROOT, "tools", "native_bench.cpp")
 _NATIVE_BENCH = os.path.join(_ROOT, "tools", "native_bench")
+_FAKE_RCCL_SRC = os.path.join(_ROOT, "tests", "native", "fake_rccl.c")
+_FAKE_RCCL = os.path.join(_ROOT, "tests", "native", "libfake_rccl.so")
 
 
 def library_path():
     return _SO
 
 
+def tools_library_path():
+    return _TOOLS_SO
+
+
 def native_bench_path():
     return _NATIVE_BENCH
+
+
+def fake_rccl_path():
+    return _FAKE_RCCL
 
 
 def _mtime(rel):
@@ -71,22 +96,21 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
-def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host_only=False, sources=None):
-    """host_only: only the API translation unit (sliceslice_hip.hip - all of the host logic) is compiled with
-    `extra_flags`; the kernel-instantiation units come from the regular build (their host side is launch stubs)."""
-    sources = sources or _SOURCES
+def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, sources, own=None, record_resources=False):
+    """Compiles `sources` (those in `own` - default: all - with `extra_flags` into <name><obj_suffix>; the others are taken as the
+    regular build's <name>.o) and links them into `so`."""
+    own = sources if own is None else own
     newest_header = max(_mtime(h) for h in _HEADERS)
-    own = sources[:1] if host_only else sources
     objs = [os.path.join(_CSRC, s[:-4] + (obj_suffix if s in own else ".o")) for s in sources]
     todo = []
     for src, obj in zip(sources, objs):
         if src not in own:
             continue
-        stale = obj_suffix == ".o" and not os.path.exists(obj + ".res")         # objects from before the resource record
+        stale = record_resources and not os.path.exists(obj + ".res")            # objects from before the resource record
         if force or stale or not os.path.exists(obj) or os.path.getmtime(obj) < max(_mtime(src), newest_header):
             todo.append((src, obj))
     if (not todo and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(o) for o in objs) and
-            (obj_suffix != ".o" or os.path.exists(_RESOURCES))):
+            (not record_resources or os.path.exists(_RESOURCES))):
         return so
     hipcc = _hipcc()
     tag = ".tmp%d" % os.getpid()
@@ -94,7 +118,7 @@ def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host
     def compile_one(job):
         src, obj = job
         cmd = [hipcc] + _FLAGS + extra_flags + ["-c", os.path.join(_CSRC, src), "-o", obj + tag]
-        if obj_suffix != ".o":
+        if not record_resources:
             _run(cmd, verbose)
         else:
             # the regular build also records what the register allocator did with every kernel (see _resources)
@@ -113,10 +137,10 @@ def _build_variant(so, obj_suffix, extra_flags, link_flags, force, verbose, host
     if todo:
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1) or 1) as pool:
             list(pool.map(compile_one, todo))
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", so + tag] + link_flags + objs +
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-Bsymbolic-functions", "-o", so + tag] + link_flags + objs +
          ["-ldl", "-pthread"], verbose)
     os.replace(so + tag, so)
-    if obj_suffix == ".o":
+    if record_resources:
         rows = []
         for o in objs:
             if os.path.exists(o + ".res"):
@@ -136,7 +160,8 @@ _RES_KEYS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "Scratch
 def _resources(remarks, tu):
     """-Rpass-analysis=kernel-resource-usage remarks -> one row per kernel.  Kept next to the library
     (csrc/kernel_resources.json, `kernel_resources()`): the scan kernels are fast at four waves per SIMD (<= 128 VGPRs) and
-    14 % slower at three, and which side of 128 the allocator lands on moves with unrelated edits."""
+    14 % slower at three, and which side of 128 the allocator lands on moves with unrelated edits; scalar-register spills
+    (v_writelane traffic in front of every short-lived workgroup's first load) doubled unnoticed in round 3."""
     rows, cur = [], None
     for line in remarks.splitlines():
         m = re.search(r"remark: (?:\s*)([A-Za-z \[\]/]+): (\S+) \[-Rpass-analysis", line)
@@ -157,36 +182,43 @@ def _resources(remarks, tu):
 
 
 def kernel_resources():
-    """Rows of csrc/kernel_resources.json (written by build()): kernel, name, vgprs, waves_per_simd, spills, ..."""
+    """Rows of csrc/kernel_resources.json (written by build()): kernel, name, vgprs, waves_per_simd, spills, ...  Product library
+    only (the tools library's kernels are in csrc/ss_tools.o.res)."""
     build()
     return json.load(open(_RESOURCES))
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> csrc/libsliceslice_hip.so.  Returns the path."""
+    """hipcc --offload-arch=gfx950 -> csrc/libsliceslice_hip.so (+ libsliceslice_hip_tools.so).  Returns the product's path."""
     with _Lock(".build.lock"):
-        return _build_variant(_SO, ".o", [], [], force, verbose)
+        so = _build_variant(_SO, ".o", [], [], force, verbose, _SOURCES, record_resources=True)
+    build_tools(force=force, verbose=verbose)
+    return so
+
+
+def build_tools(force=False, verbose=False):
+    """csrc/ss_tools.hip -> csrc/libsliceslice_hip_tools.so: the benchmark helpers of include/sliceslice_hip_tuning.h, group 1."""
+    with _Lock(".build_toolslib.lock"):
+        return _build_variant(_TOOLS_SO, ".o", [], [], force, verbose, ["ss_tools.hip"])
 
 
 def build_sanitized(force=False, verbose=False):
-    """The host logic (sliceslice_hip.hip) with ASan + UBSan -> csrc/libsliceslice_hip_asan.so (test builds only:
+    """The host logic with ASan + UBSan and the test hooks -> csrc/libsliceslice_hip_asan.so (test builds only:
     load it with SLICESLICE_HIP_LIB=<path> and the ASan runtime preloaded; see tests/test_gpu_native.py)."""
     so = os.path.join(_CSRC, "libsliceslice_hip_asan.so")
     build(verbose=verbose)                                  # the kernel-instantiation objects are shared with the regular build
     with _Lock(".build_asan.lock"):
-        return _build_variant(so, ".asan.o", _SAN_FLAGS, ["-fsanitize=address,undefined", "-shared-libsan"], force, verbose,
-                              host_only=True)
-
-
-_TSAN_FLAGS = ["-fsanitize=thread", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g", "-O1"]
+        return _build_variant(so, ".asan.o", _SAN_FLAGS + _HOOK_FLAGS, ["-fsanitize=address,undefined", "-shared-libsan"], force, verbose,
+                              _SOURCES, own=_HOST_SOURCES)
 
 
 def build_tsan(force=False, verbose=False):
-    """ThreadSanitizer build of the host code -> csrc/libsliceslice_hip_tsan.so (tests/test_gpu_native.py)."""
+    """ThreadSanitizer build of the host code (with the test hooks) -> csrc/libsliceslice_hip_tsan.so (tests/test_gpu_native.py)."""
     so = os.path.join(_CSRC, "libsliceslice_hip_tsan.so")
     build(verbose=verbose)
     with _Lock(".build_tsan.lock"):
-        return _build_variant(so, ".tsan.o", _TSAN_FLAGS, ["-fsanitize=thread", "-shared-libsan"], force, verbose, host_only=True)
+        return _build_variant(so, ".tsan.o", _TSAN_FLAGS + _HOOK_FLAGS, ["-fsanitize=thread", "-shared-libsan"], force, verbose,
+                              _SOURCES, own=_HOST_SOURCES)
 
 
 def tsan_runtime():
@@ -202,17 +234,32 @@ def asan_runtime():
 
 def build_native_bench(force=False, verbose=False):
     """tools/native_bench.cpp -> tools/native_bench: the measurements that must not have Python or torch in the
-    loop (per-call latencies, the config-1 per-needle loop), linked against the in-tree library."""
+    loop (per-call latencies, the config-1 per-needle loop, the multi-rank overheads), linked against the in-tree libraries."""
     so = build(verbose=verbose)
     with _Lock(".build_tools.lock"):
         if (not force and os.path.exists(_NATIVE_BENCH) and
-                os.path.getmtime(_NATIVE_BENCH) >= max(os.path.getmtime(_NATIVE_BENCH_SRC), os.path.getmtime(so))):
+                os.path.getmtime(_NATIVE_BENCH) >= max(os.path.getmtime(_NATIVE_BENCH_SRC), os.path.getmtime(so), os.path.getmtime(_TOOLS_SO))):
             return _NATIVE_BENCH
         tmp = _NATIVE_BENCH + ".tmp%d" % os.getpid()
         _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(_ROOT, "include"), _NATIVE_BENCH_SRC, "-o", tmp,
-              "-L", _CSRC, "-lsliceslice_hip", "-Wl,-rpath,$ORIGIN/../sliceslice-rs_amd/csrc", "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
+              "-L", _CSRC, "-lsliceslice_hip", "-lsliceslice_hip_tools", "-Wl,-rpath,$ORIGIN/../sliceslice-rs_amd/csrc",
+              "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
         os.replace(tmp, _NATIVE_BENCH)
         return _NATIVE_BENCH
+
+
+def build_fake_rccl(force=False, verbose=False):
+    """tests/native/fake_rccl.c -> tests/native/libfake_rccl.so: the shared-memory stand-in that lets the native collective code
+    run with several ranks on ONE GPU (real RCCL refuses that).  Test infrastructure; handed to the library with
+    SLICESLICE_RCCL_LIB=<path>."""
+    with _Lock(".build_fake_rccl.lock"):
+        if not force and os.path.exists(_FAKE_RCCL) and os.path.getmtime(_FAKE_RCCL) >= os.path.getmtime(_FAKE_RCCL_SRC):
+            return _FAKE_RCCL
+        tmp = _FAKE_RCCL + ".tmp%d" % os.getpid()
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-I/opt/rocm/include", _FAKE_RCCL_SRC, "-o", tmp,
+              "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-pthread", "-Wl,-rpath,/opt/rocm/lib"], verbose)
+        os.replace(tmp, _FAKE_RCCL)
+        return _FAKE_RCCL
 
 
 def tuning_library_path():
@@ -220,11 +267,12 @@ def tuning_library_path():
 
 
 def build_tuning(force=False, verbose=False):
-    """Every kernel variant ss_searcher_set_variant can name (-DSS_TUNING_VARIANTS, plus the U = 8 translation units) ->
-    csrc/libsliceslice_hip_tuning.so.  Not the product: tools/ and the variant tests load it with SLICESLICE_HIP_LIB=<path>."""
+    """Every kernel variant ss_searcher_set_variant can name plus the test hooks (-DSS_TUNING_VARIANTS -DSS_TEST_HOOKS, with the plain-load
+    and U = 8 translation units) -> csrc/libsliceslice_hip_tuning.so.  Not the product: tools/ and the variant / hook tests load it
+    with SLICESLICE_HIP_LIB=<path>."""
     so = tuning_library_path()
     with _Lock(".build_tuning.lock"):
-        return _build_variant(so, ".tuning.o", ["-DSS_TUNING_VARIANTS=1"], [], force, verbose, sources=_TUNING_SOURCES)
+        return _build_variant(so, ".tuning.o", ["-DSS_TUNING_VARIANTS=1"] + _HOOK_FLAGS, [], force, verbose, _TUNING_SOURCES)
 
 
 def build_ab(name, defines, force=False, verbose=False):
@@ -232,4 +280,4 @@ def build_ab(name, defines, force=False, verbose=False):
     with SLICESLICE_HIP_LIB=<path>, see tools/ab_compare.py)."""
     so = os.path.join(_CSRC, "libsliceslice_hip_%s.so" % name)
     with _Lock(".build_ab_%s.lock" % name):
-        return _build_variant(so, ".%s.o" % name, ["-D" + d for d in defines], [], force, verbose)
+        return _build_variant(so, ".%s.o" % name, ["-D" + d for d in defines] + _HOOK_FLAGS, [], force, verbose, _SOURCES)

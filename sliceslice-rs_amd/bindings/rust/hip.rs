@@ -17,6 +17,7 @@ use std::os::raw::{c_char, c_float, c_int, c_void};
 #[repr(C)] pub struct ss_comm { _private: [u8; 0] }
 #[repr(C)] pub struct ss_comm_set { _private: [u8; 0] }
 #[repr(C)] pub struct ss_service { _private: [u8; 0] }
+#[repr(C)] pub struct ss_batch_plan { _private: [u8; 0] }
 
 pub const SS_OK: c_int = 0;
 pub const SS_ERR_POSITION: c_int = 1;
@@ -38,16 +39,13 @@ extern "C" {
     pub fn ss_searcher_new(needle: *const u8, n: usize, out: *mut *mut ss_searcher) -> c_int;
     pub fn ss_searcher_with_position(needle: *const u8, n: usize, position: usize, out: *mut *mut ss_searcher) -> c_int;
     pub fn ss_searcher_free(s: *mut ss_searcher);
-    pub fn ss_searcher_needle_len(s: *const ss_searcher) -> usize;
-    pub fn ss_searcher_position(s: *const ss_searcher) -> usize;
-    pub fn ss_searcher_filter(s: *const ss_searcher, first: *mut usize, second: *mut usize) -> c_int;
-    pub fn ss_searcher_set_filter(s: *mut ss_searcher, first: usize, second: usize) -> c_int;
-    pub fn ss_choose_filter_pair(needle: *const u8, n: usize, first: *mut usize, second: *mut usize) -> c_int;
+    pub fn ss_searcher_info(s: *const ss_searcher, needle_len: *mut usize, position: *mut usize) -> c_int;
     pub fn ss_searcher_filter3(s: *const ss_searcher, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
     pub fn ss_searcher_set_filter3(s: *mut ss_searcher, first: usize, second: usize, third: usize) -> c_int;
-    pub fn ss_choose_filter_triple(needle: *const u8, n: usize, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
-    pub fn ss_choose_filter_for_position(needle: *const u8, n: usize, position: usize, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
-    pub fn ss_choose_filter_triple_hist(needle: *const u8, n: usize, hist: *const u64, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
+    // position policy (the reference leaves `position` to its caller, src/x86.rs:252-255)
+    pub fn ss_byte_histogram_device(d_haystack: *const c_void, len: usize, sample_bytes: usize, hip_stream: *mut c_void, hist: *mut u64) -> c_int;
+    pub fn ss_choose_position(needle: *const u8, n: usize, hist: *const u64, position: *mut usize) -> c_int;
+    pub fn ss_choose_filter_triple(needle: *const u8, n: usize, hist: *const u64, first: *mut usize, second: *mut usize, third: *mut usize) -> c_int;
     // search_in (src/x86.rs:498-525)
     pub fn ss_search_device(s: *const ss_searcher, d_haystack: *const c_void, len: usize, hip_stream: *mut c_void, found: *mut c_int) -> c_int;
     pub fn ss_search_device_async(s: *const ss_searcher, d_haystack: *const c_void, len: usize, hip_stream: *mut c_void, d_found: *mut c_int) -> c_int;
@@ -57,64 +55,47 @@ extern "C" {
     pub fn ss_find_device(s: *const ss_searcher, d_haystack: *const c_void, len: usize, hip_stream: *mut c_void, position: *mut u64) -> c_int;
     pub fn ss_find_host(s: *const ss_searcher, haystack: *const u8, len: usize, position: *mut u64) -> c_int;
     pub fn ss_find_device_async(s: *const ss_searcher, d_haystack: *const c_void, len: usize, base_offset: u64, hip_stream: *mut c_void, d_best: *mut u64) -> c_int;
-    // position policy data
-    pub fn ss_byte_histogram_device(d_haystack: *const c_void, len: usize, sample_bytes: usize, hip_stream: *mut c_void, hist: *mut u64) -> c_int;
-    pub fn ss_choose_position(needle: *const u8, n: usize, hist: *const u64, position: *mut usize) -> c_int;
     // many problems, one launch
     pub fn ss_search_batched(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
                              d_needle_begin: *const u64, d_needle_end: *const u64, d_position: *const u64, count: usize,
                              hip_stream: *mut c_void, d_found: *mut c_int) -> c_int;
+    pub fn ss_find_batched(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
+                           d_needle_begin: *const u64, d_needle_end: *const u64, count: usize, hip_stream: *mut c_void, d_position: *mut u64) -> c_int;
+    pub fn ss_batch_plan_create(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
+                                d_needle_begin: *const u64, d_needle_end: *const u64, d_position: *const u64, count: usize, find: c_int,
+                                hip_stream: *mut c_void, out: *mut *mut ss_batch_plan) -> c_int;
+    pub fn ss_batch_plan_run(plan: *const ss_batch_plan, hip_stream: *mut c_void, d_out: *mut c_void) -> c_int;
+    pub fn ss_batch_plan_free(plan: *mut ss_batch_plan);
     pub fn ss_search_pairs(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
                            d_needle_begin: *const u64, d_needle_end: *const u64, d_position: *const u64, count: usize,
                            hip_stream: *mut c_void, d_found: *mut c_int) -> c_int;
-    // measurement / tuning hooks
+    // kernel timing (what a roofline figure is computed from)
     pub fn ss_searcher_set_timing(s: *mut ss_searcher, enabled: c_int) -> c_int;
     pub fn ss_searcher_last_kernel_ms(s: *const ss_searcher, ms: *mut c_float) -> c_int;
-    pub fn ss_searcher_set_variant(s: *mut ss_searcher, variant: c_int) -> c_int;
-    pub fn ss_searcher_set_grid(s: *mut ss_searcher, blocks: c_int) -> c_int;
-    pub fn ss_fill_random_device(d_dst: *mut c_void, global_offset: u64, len: usize, seed: u64, hip_stream: *mut c_void) -> c_int;
-    pub fn ss_fill_random_host(dst: *mut u8, global_offset: u64, len: usize, seed: u64) -> c_int;
-    pub fn ss_read_ceiling(d_src: *const c_void, len: usize, hip_stream: *mut c_void, reps: c_int, ms_per_rep: *mut c_float) -> c_int;
     // multi-GPU, one process per GPU
+    pub fn ss_shard_range(len: usize, needle_len: usize, nranks: c_int, rank: c_int, begin: *mut usize, end: *mut usize) -> c_int;
     pub fn ss_comm_unique_id(id: *mut u8) -> c_int;
     pub fn ss_comm_init_rank(id: *const u8, nranks: c_int, rank: c_int, out: *mut *mut ss_comm) -> c_int;
     pub fn ss_comm_free(c: *mut ss_comm);
     pub fn ss_comm_count(c: *const ss_comm, nranks: *mut c_int) -> c_int;
-    pub fn ss_comm_allreduce_flag(c: *mut ss_comm, d_flag: *mut c_int, hip_stream: *mut c_void, found: *mut c_int) -> c_int;
     pub fn ss_search_sharded(s: *const ss_searcher, d_shard: *const c_void, shard_len: usize, c: *mut ss_comm, hip_stream: *mut c_void, found: *mut c_int) -> c_int;
     pub fn ss_find_sharded(s: *const ss_searcher, d_shard: *const c_void, shard_len: usize, shard_begin: u64, c: *mut ss_comm,
                            hip_stream: *mut c_void, position: *mut u64) -> c_int;
     // multi-GPU inside one process
     pub fn ss_comm_init_all(ndev: c_int, devs: *const c_int, out: *mut *mut ss_comm_set) -> c_int;
     pub fn ss_comm_set_free(set: *mut ss_comm_set);
-    pub fn ss_comm_set_size(set: *const ss_comm_set) -> c_int;
-    pub fn ss_comm_set_device(set: *const ss_comm_set, index: c_int, device: *mut c_int) -> c_int;
     pub fn ss_comm_set_combine(set: *mut ss_comm_set, combine: c_int) -> c_int;
     pub fn ss_search_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, set: *mut ss_comm_set, found: *mut c_int) -> c_int;
     pub fn ss_find_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, shard_begins: *const u64,
                                set: *mut ss_comm_set, position: *mut u64) -> c_int;
-    pub fn ss_shard_range(len: usize, needle_len: usize, nranks: c_int, rank: c_int, begin: *mut usize, end: *mut usize) -> c_int;
+    // resident search service
+    pub fn ss_service_start(workgroups: c_int, lease_ms: f64, out: *mut *mut ss_service) -> c_int;
+    pub fn ss_service_search(sv: *mut ss_service, s: *const ss_searcher, d_haystack: *const c_void, len: usize, found: *mut c_int) -> c_int;
+    pub fn ss_service_bind(sv: *mut ss_service, d_haystack: *const c_void, len: usize) -> c_int;
+    pub fn ss_service_stop(sv: *mut ss_service);
     // diagnostics
     pub fn ss_last_error() -> *const c_char;
     pub fn ss_device_info(name: *mut c_char, name_cap: usize, compute_units: *mut c_int, total_mem: *mut usize) -> c_int;
-    pub fn ss_version() -> *const c_char;
-    pub fn ss_selftest_dpp(out: *mut u32) -> c_int;
-    pub fn ss_debug_set_epochs(s: *mut ss_searcher, value: c_int) -> c_int;
-    pub fn ss_debug_set_completion_state(s: *mut ss_searcher, workgroups: u32, found_workgroups: u32, find_key: u32) -> c_int;
-    pub fn ss_debug_set_comm_epoch(c: *mut ss_comm, set: *mut ss_comm_set, value: c_int) -> c_int;
-    pub fn ss_debug_fail_next_scans(s: *mut ss_searcher, count: c_int) -> c_int;
-    pub fn ss_find_batched(d_haystacks: *const c_void, d_hay_begin: *const u64, d_hay_end: *const u64, d_needles: *const c_void,
-                           d_needle_begin: *const u64, d_needle_end: *const u64, count: usize, hip_stream: *mut c_void, d_position: *mut u64) -> c_int;
-    pub fn ss_search_host_all(s: *const ss_searcher, haystack: *const u8, len: usize, ndev: c_int, devs: *const c_int, found: *mut c_int) -> c_int;
-    pub fn ss_mailbox_round_trip_us(iters: c_int, median_us: *mut f64, min_us: *mut f64) -> c_int;
-    pub fn ss_service_start(workgroups: c_int, lease_ms: f64, out: *mut *mut ss_service) -> c_int;
-    pub fn ss_service_search(sv: *mut ss_service, s: *const ss_searcher, d_haystack: *const c_void, len: usize, found: *mut c_int) -> c_int;
-    pub fn ss_service_set_default(sv: *mut ss_service, enabled: c_int) -> c_int;
-    pub fn ss_service_bind(sv: *mut ss_service, d_haystack: *const c_void, len: usize) -> c_int;
-    pub fn ss_service_unbind(sv: *mut ss_service) -> c_int;
-    pub fn ss_service_counters(sv: *mut ss_service, requests: *mut u64, kernel_launches: *mut u64) -> c_int;
-    pub fn ss_service_settled_requests(sv: *mut ss_service, settled: *mut u64) -> c_int;
-    pub fn ss_service_stop(sv: *mut ss_service);
 }
 
 /// Haystack already resident in device memory (caller-owned `hipMalloc` memory).
@@ -176,7 +157,11 @@ impl<N: Needle> DynamicHipSearcher<N> {
         check(unsafe { ss_find_device(self.handle, haystack.ptr, haystack.len, stream, &mut pos) });
         if pos == SS_NPOS { None } else { Some(pos as usize) }
     }
-    pub fn position(&self) -> usize { unsafe { ss_searcher_position(self.handle) } }
+    pub fn position(&self) -> usize {
+        let mut p = 0usize;
+        check(unsafe { ss_searcher_info(self.handle, std::ptr::null_mut(), &mut p) });
+        p
+    }
     pub fn needle(&self) -> &N { &self.needle }
     pub fn handle(&self) -> *const ss_searcher { self.handle }
 }
@@ -297,9 +282,10 @@ mod tests {
 }
 
 /// A resident search service on the current device (`ss_service_*`): a kernel that stays on the GPU and answers one
-/// `search_in` at a time without a launch - 5 us per search instead of 8.5-9.5.  The shape of the reference's own bench
-/// loop (bench/benches/i386.rs:246-256): build the searchers FIRST (building allocates, and allocation waits for the
-/// service's lease to run out), `bind` the text if it does not change between searches, then one `search_in` per needle.
+/// `search_in` at a time without a launch - 5 us per search instead of 8.5-9.5: the floor of the per-call shape (one PCIe
+/// round trip).  The shape of the reference's own bench loop (bench/benches/i386.rs:246-256): build the searchers FIRST,
+/// `bind` the text if it does not change between searches, then one `search_in` per needle.  The GPU's own answer to that
+/// loop is ONE call for all needles: `ss_batch_plan_create` once (the searchers), `ss_batch_plan_run` per iteration.
 pub struct SearchService { handle: *mut ss_service }
 
 unsafe impl Send for SearchService {}
@@ -320,16 +306,7 @@ impl SearchService {
     }
     /// The caller vouches that `haystack` stays unchanged until `unbind` / the next `bind`.
     pub fn bind(&self, haystack: DeviceSlice) { check(unsafe { ss_service_bind(self.handle, haystack.ptr, haystack.len) }) }
-    pub fn unbind(&self) { check(unsafe { ss_service_unbind(self.handle) }) }
-    /// Routes qualifying `search_in_device` calls of every searcher on this device through the service.
-    pub fn set_default(&self, enabled: bool) { check(unsafe { ss_service_set_default(self.handle, enabled as c_int) }) }
-    /// (requests served, kernel launches, requests that skipped the cache acquire)
-    pub fn counters(&self) -> (u64, u64, u64) {
-        let (mut r, mut k, mut s) = (0u64, 0u64, 0u64);
-        check(unsafe { ss_service_counters(self.handle, &mut r, &mut k) });
-        check(unsafe { ss_service_settled_requests(self.handle, &mut s) });
-        (r, k, s)
-    }
+    pub fn unbind(&self) { check(unsafe { ss_service_bind(self.handle, std::ptr::null(), 0) }) }
 }
 
 impl Drop for SearchService {

@@ -1,0 +1,361 @@
+// batched_kernels.hpp - K4: many (needle, haystack) problems in one grid (ss_search_batched / ss_find_batched / ss_batch_plan_*),
+// and the one-lane-per-problem kernel for short haystacks (ss_search_pairs).  Included by ss_batched.hip only.
+#pragma once
+#include "scan_kernels.hpp"
+
+namespace ss {
+
+// ---- K4: batched, one grid for many (needle, haystack) problems ----------------------------------
+// blockIdx.x = problem, blockIdx.y = slice of that problem's tiles: the workgroups of slice 0 of every
+// problem are dispatched before any of slice 1, so when the needles are present early (the reference's
+// i386 loop: every word occurs in the text) the later slices find the flag set on entry and leave - the
+// sequential scan's early exit survives the slicing.  Per-problem flags, no cross-problem early exit.  The problem descriptor is built per workgroup from the range arrays
+// (begin[i], end[i]) - CSR callers pass (off, off + 1); ranges may alias (many needles, one haystack).
+struct BatchArgs {
+    const uint8_t *haystacks;
+    const uint64_t *hay_begin, *hay_end;
+    const uint8_t *needles;
+    const uint64_t *needle_begin, *needle_end;
+    const uint64_t *position;   // may be null: n_i - 1
+    int *found;                 // search: one int32 flag per problem
+    uint64_t *best;             // find (ss_find_batched): one uint64 leftmost offset per problem (all ones = absent); else null
+};
+constexpr int kBadPosition = -1;   // SS_BATCH_BAD_POSITION: flag of a problem whose position breaks the with_position rules
+
+// ---- K4, planned form: a one-lane-per-problem plan kernel + the scan grid ------------------------------------
+// The kernel above rebuilds its problem descriptor in every workgroup: ranges -> needle bytes -> first haystack load is a
+// chain of three dependent memory round trips (3-4 us under load) in front of every slice, which is why it only does well
+// when a slice is long (4,096 x 1 MiB in ~10-tile slices: 0.88-0.90 of the HBM peak; 1,024 x 1 MiB in 8-tile slices: 0.73).
+// Here the descriptors are built ONCE per problem by batch_plan_kernel (one lane per problem; it also writes the initial
+// flag, so it replaces the memset launch), 64 bytes each, and a scan workgroup starts with ONE scalar load
+// (s_load_dwordx16 of its problem's descriptor, issued together with the entry poll of the problem's flag) before its first
+// haystack load - one round trip more than scan_kernel, whose descriptor travels in the kernel arguments.  With the start-up
+// chain gone, slices can be short (kPlanMinTiles) and the grid generous: surplus slices leave after that one scalar load.
+struct __attribute__((aligned(64))) BatchDesc {
+    const uint8_t *base;       // 16-byte-aligned start of the filter stream: hay + anchor - mis
+    uint64_t end;              // candidate offsets (0: nothing to scan - trivial problem, answered by the plan kernel)
+    uint64_t nchunks_all;
+    uint64_t n;                // needle length
+    uint64_t needle_off;       // offset of the needle in the needle blob
+    uint64_t anchor;           // index of the first filter byte in the needle
+    uint64_t per;              // active slices of the problem << 32 | tiles per slice (both < 2^32: the grid is one-dimensional)
+    uint32_t bytes;            // needle[anchor] | second byte << 8 | third byte << 16 | (one-byte needle) << 24
+    uint32_t shifts;           // mis | r << 4 | Q << 6 | r3 << 8 | q3 << 10
+};
+static_assert(sizeof(BatchDesc) == 64, "one scalar load (s_load_dwordx16) per workgroup");
+
+__host__ __device__ constexpr inline int rarity_class4(uint8_t b)
+{
+    const int r = byte_rarity_rank(b);
+    return r < 64 ? 0 : (r < 128 ? 1 : (r < 192 ? 2 : 3));
+}
+// The four classes as two bit planes of 256 bits each (8 dwords per plane): no table in memory, no branches - the plan kernel
+// fills its LDS table from these constants.
+struct ClassPlanes {
+    uint32_t lo[8], hi[8];
+};
+constexpr ClassPlanes make_class_planes()
+{
+    ClassPlanes p = {};
+    for (int b = 0; b < 256; ++b) {
+        const int c = rarity_class4((uint8_t)b);
+        if (c & 1) p.lo[b >> 5] |= 1u << (b & 31);
+        if (c & 2) p.hi[b >> 5] |= 1u << (b & 31);
+    }
+    return p;
+}
+
+// One LANE per problem.  `nslices` = slices per problem of the scan launch that follows, `min_tiles` = the shortest slice worth a
+// workgroup.  Same rules as scan_batched_kernel: needle[position] is always a first-phase byte; its partner is needle[0]
+// when position < 16, else the rarest (class) byte of the 15 in front of it, closest to `position` among equals; the third
+// byte is the rarest of the 15 behind the anchor, the later one among equals; the two are ordered by dword (q3 <= Q).
+// Written for LATENCY - the scan cannot start before this kernel has ended: the rarity classes come from a 256-entry table
+// in LDS (byte_rarity_rank is a dozen branches), and the needle bytes of a step are fetched by unconditional loads
+// (out-of-range slots re-read byte 0 of the window) that are all in flight together; a first cut with a predicated
+// load-rank loop ran 8-12 us, one memory round trip per byte.
+__global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
+                                                             uint32_t nslices, uint32_t min_tiles, int tile_pieces)
+{
+    __shared__ uint8_t s_class[256];
+    {
+        constexpr ClassPlanes P = make_class_planes();                         // compile-time constants, selected by wave
+        const uint32_t t = threadIdx.x, w = t >> 5;                            // kBlock == 256: one table entry per thread
+        uint32_t lo = P.lo[0], hi = P.hi[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; ++k) {
+            lo = w == k ? P.lo[k] : lo;
+            hi = w == k ? P.hi[k] : hi;
+        }
+        s_class[t] = (uint8_t)(((lo >> (t & 31)) & 1u) | (((hi >> (t & 31)) & 1u) << 1));
+    }
+    const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = prob < count;
+    const uint64_t pi = live ? prob : 0;                                       // (every lane reaches the barrier)
+    const uint64_t h0 = a.hay_begin[pi], h1 = a.hay_end[pi];
+    const uint64_t n0 = a.needle_begin[pi], n1 = a.needle_end[pi];
+    const uint64_t given = a.position ? a.position[pi] : 0;
+    __syncthreads();
+    if (!live) return;
+    const uint64_t len = h1 - h0, n = n1 - n0;
+    const uint64_t position = (a.position && n) ? given : n - 1;
+    BatchDesc d;
+    d.base = nullptr;
+    d.end = d.nchunks_all = 0;
+    d.n = n;
+    d.needle_off = n0;
+    d.anchor = 0;
+    d.per = 0;                                      // no active slice
+    d.bytes = d.shifts = 0;
+    int flag = 0;
+    if (n == 0) {
+        flag = 1;                                   // N0: found everywhere (x86.rs:500)
+    } else if (n == 1 ? position != 0 : position >= n) {
+        flag = kBadPosition;                        // the reference panics building this searcher (x86.rs:300, 473)
+    } else if (len >= n) {
+        const uint8_t *needle = a.needles + n0;
+        uint64_t anchor = 0;
+        if (position >= 16) {
+            uint32_t cls[15];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) cls[k] = needle[position - 15 + k];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) cls[k] = s_class[cls[k]];
+            uint32_t best_cls = 4;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {          // later bytes win ties: the partner closest to `position`
+                const bool better = cls[k] <= best_cls;
+                best_cls = better ? cls[k] : best_cls;
+                anchor = better ? position - 15 + k : anchor;
+            }
+        }
+        uint32_t s2 = (uint32_t)(position - anchor);            // distance between the two filter bytes: 0 .. 15
+        const uint32_t lim = n - anchor < 16 ? (uint32_t)(n - anchor) : 16u;
+        uint32_t fb[16], cls[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) fb[k] = needle[anchor + (k < lim ? k : 0u)];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) cls[k] = s_class[fb[k]];
+        uint32_t p3 = s2, best_cls = 4;
+#pragma unroll
+        for (uint32_t k = 1; k < 16; ++k) {         // the rarest of the 15 bytes behind the anchor, later ones winning ties
+            const bool better = k < lim && k != s2 && cls[k] <= best_cls && n - anchor >= 3;
+            best_cls = better ? cls[k] : best_cls;
+            p3 = better ? k : p3;
+        }
+        if (p3 / 4 > s2 / 4) {                      // the kernels want the third byte's dword not behind the second's
+            const uint32_t t = p3;
+            p3 = s2;
+            s2 = t;
+        }
+        uint32_t b2 = 0, b3 = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {         // fb[s2], fb[p3] without a dynamic index (scratch)
+            b2 = k == s2 ? fb[k] : b2;
+            b3 = k == p3 ? fb[k] : b3;
+        }
+        const uint8_t *hf = a.haystacks + h0 + anchor;
+        const uint32_t mis = (uint32_t)((uintptr_t)hf & 15);
+        d.base = hf - mis;
+        d.end = len - n + 1;
+        d.nchunks_all = (mis + len - anchor + 15) / 16;
+        d.anchor = anchor;
+        d.bytes = fb[0] | (b2 << 8) | (b3 << 16) | (n == 1 ? 1u << 24 : 0u);
+        d.shifts = mis | ((s2 % 4) << 4) | ((s2 / 4) << 6) | ((p3 % 4) << 8) | ((p3 / 4) << 10);
+        const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
+        const uint64_t ntiles = (npieces + tile_pieces - 1) / tile_pieces;
+        uint64_t eff = (ntiles + min_tiles - 1) / min_tiles;
+        eff = eff < nslices ? (eff ? eff : 1) : nslices;
+        d.per = (eff << 32) | ((ntiles + eff - 1) / eff);
+    }
+    if (d.per == 0) d.shifts = (uint32_t)flag;             // no scan: the answer travels in the descriptor too (plan runs)
+    if (a.best) a.best[prob] = n == 0 ? 0ull : ~0ull;      // the empty needle matches at offset 0 of every haystack
+    else if (a.found) a.found[prob] = flag;
+    descs[prob] = d;
+}
+
+// The cold fields of a planned problem, re-read from its descriptor by the waves that need them (scan_tiles' ColdT).
+struct ColdFields {
+    const uint8_t *hay, *needle;
+    uint64_t n, end;
+    uint32_t norder, exact_len;
+    uint64_t order_idx[2], order_val[2];
+    uint32_t tail16[4];
+    int *host_flag;
+    uint64_t far_off;
+    __device__ __forceinline__ const ColdFields *operator->() const { return this; }
+};
+struct ColdInDesc {
+    const BatchDesc *dp;
+    const uint8_t *needles;
+    __device__ __forceinline__ ColdFields operator()() const
+    {
+        const BatchDesc *q = dp;
+        __asm__ volatile("" : "+s"(q));             // opaque: the loads stay in the cold path
+        ColdFields f;
+        f.hay = q->base + (q->shifts & 15) - q->anchor;
+        f.needle = needles + q->needle_off;
+        f.n = q->n;
+        f.end = q->end;
+        f.norder = f.exact_len = 0;                 // LAZY_ORDER: built by the wave
+        f.order_idx[0] = f.order_idx[1] = f.order_val[0] = f.order_val[1] = 0;
+        f.tail16[0] = f.tail16[1] = f.tail16[2] = f.tail16[3] = 0;
+        f.host_flag = nullptr;
+        f.far_off = 0;
+        return f;
+    }
+};
+
+// Grid: ONE dimension, nslices workgroups per problem; two ways of laying them out, chosen by the host from the slice count
+// (the lengths live on the device; the count of problems is all the host knows):
+//   * many problems, few slices each (nslices <= kPlanSliceMajorMax): SLICE-MAJOR, w = slice * count + problem, each slice a
+//     contiguous run of the problem's tiles.  All slice-0 workgroups are dispatched before any slice-1 workgroup, so a needle
+//     that is present early (the reference's i386 loop: every word occurs in the text, most of them in the first tiles) has
+//     set its flag by the time the later slices of its problem start, and those leave at their entry poll - problem-major
+//     layouts start all slices of a problem together and ran that loop at 0.21-0.45 ms instead of 0.15.
+//   * few problems, many slices each: PROBLEM-MAJOR, w = problem * nslices + slice, and the active slices take the problem's
+//     tiles ROUND ROBIN (slice s scans tiles s, s + eff, ...): the workgroups of a problem move through its haystack side
+//     by side - consecutive addresses in flight, where slice-major puts 1,024 separate streams a haystack apart in flight
+//     (1,024 x 1 MiB: 150 us instead of 162, kernel time) - and when one of them finds the needle the others are at the same
+//     depth and stop at their next poll.
+constexpr uint32_t kPlanSliceMajorMax = 8;
+// FIND: the sink is the problem's uint64 (leftmost offset, atomicMin); a workgroup skips only what lies right of the best so far
+// (scan_tiles does that tile by tile, so the slice-major entry poll is not needed).
+// COUNTED (ss_batch_plan_run: descriptors built once, searched many times - the reference builds its searchers once and times
+// the searches, bench/benches/i386.rs:246-256): ONE launch does everything, outputs included, and can be replayed from a
+// hipGraph.  The workgroups of a problem work on the plan's own state word (flag / minimum, `state`), count themselves out on
+// the problem's counter, and the workgroup that completes the count writes the caller's output, then puts state and counter back
+// to their idle values for the next run - nothing is initialised by the host or by another kernel, so nothing races with a
+// workgroup that is already scanning.  Problems without a scan (eff == 0: the empty needle, a bad position, a haystack shorter
+// than the needle) are answered by their slice-0 workgroup from the descriptor.
+template <int U, bool FIND = false, bool COUNTED = false>
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock)
+scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state,
+                         uint32_t *counters)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
+    const uint32_t w = blockIdx.x;
+    const bool slice_major = nslices <= kPlanSliceMajorMax;
+    uint32_t prob, slice;
+    if (slice_major) {
+        slice = w / count;
+        prob = w - slice * count;
+    } else {
+        prob = w / nslices;
+        slice = w - prob * nslices;
+    }
+    int *found = FIND ? nullptr : (COUNTED ? static_cast<int *>(state) + prob : a.found + prob);
+    void *sink = FIND ? static_cast<void *>((COUNTED ? static_cast<uint64_t *>(state) : a.best) + prob) : static_cast<void *>(found);
+    const BatchDesc *dp = descs + prob;
+    // slice-major, later slices: the problem's flag (one coherent load) is requested together with the descriptor (one scalar
+    // load, s_load_dwordx16) - one round trip decides whether and what to scan
+    const int seen = !FIND && slice_major && slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const BatchDesc d = *dp;
+    const uint32_t mis = d.shifts & 15;
+    const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
+    const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
+    const uint32_t eff = (uint32_t)(d.per >> 32), per = (uint32_t)d.per;
+    if (slice >= eff) {                             // surplus slice, or a problem that needs no scan (eff == 0)
+        if (COUNTED && eff == 0 && slice == 0 && threadIdx.x == 0) {
+            if (FIND) a.best[prob] = d.n == 0 ? 0ull : ~0ull;
+            else a.found[prob] = (int)d.shifts;     // the plan kernel's answer: 1 (empty needle), kBadPosition, or 0
+        }
+        return;
+    }
+    uint64_t t0, te, step;
+    bool work = true;
+    if (slice_major) {
+        t0 = (uint64_t)slice * per;
+        te = t0 + per < ntiles ? t0 + per : ntiles;
+        step = 1;
+        work = __builtin_amdgcn_readfirstlane(seen) == 0;        // later slices of a needle that has been found: nothing to do
+    } else {
+        t0 = slice;
+        te = ntiles;
+        step = eff;
+    }
+    work = work && t0 < te;
+    if (!COUNTED && !work) return;
+
+    if (work) {
+        Problem pr;                                 // hot fields only; the cold ones are re-read from the descriptor
+        pr.base = d.base;
+        pr.nchunks_all = d.nchunks_all;
+        pr.npieces = npieces;
+        pr.d = 0;
+        pr.find_base = 0;
+        pr.mis = mis;
+        pr.r = (d.shifts >> 4) & 3;
+        pr.n0x4 = 0x01010101u * (d.bytes & 0xFF);
+        pr.nlx4 = 0x01010101u * ((d.bytes >> 8) & 0xFF);
+        pr.n3x4 = 0x01010101u * ((d.bytes >> 16) & 0xFF);
+        pr.r3 = (d.shifts >> 8) & 3;
+        pr.q3 = (d.shifts >> 10) & 3;
+        pr.epoch = 1;
+        pr.flags = 0;
+        const ColdInDesc cold = {dp, a.needles};
+        if ((d.bytes >> 24) & 1) {
+            scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink);
+        } else {
+            switch ((d.shifts >> 6) & 3) {          // single stream, non-temporal loads
+            case 0: scan_tiles<0, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
+            case 1: scan_tiles<1, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
+            case 2: scan_tiles<2, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
+            default: scan_tiles<3, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
+            }
+        }
+    }
+    if (COUNTED) {
+        // count out (every active slice of the problem gets here, with or without work).  A wave's atomicMin has no return
+        // value and the barrier does not wait for vector memory: every wave drains its own queue first (see scan_kernel).
+        if (FIND) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t c = __hip_atomic_fetch_add(counters + prob, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (c == eff) {                         // the last workgroup of this problem: publish, and back to idle
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (FIND) {
+                    uint64_t *st = static_cast<uint64_t *>(state) + prob;
+                    a.best[prob] = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(st, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    int *st = static_cast<int *>(state) + prob;
+                    a.found[prob] = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                    __hip_atomic_store(st, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(counters + prob, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// ---- short-haystack pairs: one LANE per (needle, haystack) problem ---------------------------------
+// The shape of the reference's short-haystack loop (bench/benches/i386.rs:118-129, tests/i386.rs:46-59:
+// 10.5 M word-in-word searches of <= 24 bytes each): far too small for a workgroup per problem.  Each
+// lane runs the same two-byte filter + compare sequentially over its few candidate offsets.
+__global__ void __launch_bounds__(kBlock) scan_pairs_kernel(const BatchArgs a, uint64_t count)
+{
+    const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (prob >= count) return;
+    const uint64_t h0 = a.hay_begin[prob], n0 = a.needle_begin[prob];
+    const uint64_t len = a.hay_end[prob] - h0, n = a.needle_end[prob] - n0;
+    int result = 0;
+    uint64_t position = (a.position && n) ? a.position[prob] : n - 1;
+    if (n == 0) {
+        result = 1;
+    } else if (n == 1 ? position != 0 : position >= n) {              // x86.rs:300, 473
+        result = kBadPosition;
+    } else if (len >= n) {
+        const uint8_t *h = a.haystacks + h0, *nd = a.needles + n0;
+        const uint8_t first = nd[0], last = nd[position];
+        const uint64_t end = len - n + 1;
+        for (uint64_t i = 0; i < end && !result; ++i) {
+            if (h[i] != first || h[i + position] != last) continue;
+            uint64_t k = 1;
+            while (k < n && h[i + k] == nd[k]) ++k;
+            result = k >= n;
+        }
+    }
+    a.found[prob] = result;
+}
+
+}  // namespace ss

@@ -5,7 +5,7 @@
 
 namespace ss {
 
-// q = (position % 16) / 4, mode = 0/1/2 (see scan_tiles), `sink` = int flag or uint64 best (FIND).
+// q = (position % 16) / 4, mode = 0/2 (see scan_tiles), `sink` = int flag or uint64 best (FIND).
 // l8 = use the 8-bytes-per-lane first phase (mode 0 / one-byte needles, bool result only).
 // Shape = the launch geometry: workgroups, threads per workgroup (128 / 256 / 512), tiles per workgroup
 // (0 = grid-stride), and unused dynamic LDS per workgroup (caps the workgroups resident per CU; tuning only).
@@ -15,21 +15,20 @@ struct Shape {
     uint64_t tpb;
     uint32_t lds_pad;
 };
-// Which kernels a build holds.  The DEFAULT library has what the constructors and ss_searcher_set_filter* can reach - U = 4;
-// non-temporal loads for the single-stream (MODE 0) and cross-lane (MODE 2) kernels, plain loads for the two-stream ones
-// (MODE 1); the 8-byte first phase for one-byte needles only: 26 scan kernels.  -DSS_TUNING_VARIANTS adds every other
-// combination ss_searcher_set_variant can name (U = 8, the other load flavour per mode, the 8-byte phase for two-byte filters,
-// the 16-byte layout for one-byte needles) - tuning residue, 80 more kernels of which 42 ran at three waves per SIMD or fewer:
-// libsliceslice_hip_tuning.so (sliceslice_rs_amd._build.build_tuning), used by tools/ and by the variant tests.
+// Which kernels a build holds.  The PRODUCT library has what the constructors and ss_searcher_set_filter3 can reach - U = 4,
+// non-temporal loads, the single-stream (MODE 0) and cross-lane (MODE 2) kernels, the 8-byte first phase for one-byte needles
+// only: 18 scan kernels (4 Q x 2 modes + one-byte, search and find).  -DSS_TUNING_VARIANTS adds every other combination
+// ss_searcher_set_variant can name (U = 8, plain loads, the 8-byte phase for two-byte filters, the 16-byte layout for one-byte
+// needles) - tuning residue: libsliceslice_hip_tuning.so (sliceslice_rs_amd._build.build_tuning), used by tools/ and by the
+// variant tests.
 constexpr bool kernel_built(int mode, bool one_byte, int U, int NT, bool FIND, bool L8)
 {
 #ifdef SS_TUNING_VARIANTS
     return (void)mode, (void)one_byte, (void)U, (void)NT, (void)FIND, (void)L8, true;
 #else
-    if (U != 4) return false;
-    if (one_byte) return NT == 1 && (FIND ? !L8 : L8);
-    if (L8) return false;
-    return mode == 1 ? NT == 0 : NT == 1;
+    if (U != 4 || NT != 1) return false;
+    if (one_byte) return FIND ? !L8 : L8;
+    return (void)mode, !L8;
 #endif
 }
 
@@ -71,21 +70,21 @@ bool launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Sha
     case (QQ) * 3 + (MM):                                                                          \
         return launch_one<QQ, MM, false, U, NT, FIND, false>(pr, sh, st, flag);
     switch (q * 3 + mode) {
-        SS_CASE(0, 0) SS_CASE(0, 1) SS_CASE(0, 2) SS_CASE(1, 0) SS_CASE(1, 1) SS_CASE(1, 2)
-        SS_CASE(2, 0) SS_CASE(2, 1) SS_CASE(2, 2) SS_CASE(3, 0) SS_CASE(3, 1) SS_CASE(3, 2)
+        SS_CASE(0, 0) SS_CASE(0, 2) SS_CASE(1, 0) SS_CASE(1, 2)
+        SS_CASE(2, 0) SS_CASE(2, 2) SS_CASE(3, 0) SS_CASE(3, 2)
     }
 #undef SS_CASE
     return false;
 }
 #else
-extern template bool launch_scan_un<4, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 extern template bool launch_scan_un<4, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template bool launch_scan_un<4, 1, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 #ifdef SS_TUNING_VARIANTS
+extern template bool launch_scan_un<4, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
+extern template bool launch_scan_un<4, 0, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 extern template bool launch_scan_un<8, 0, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 extern template bool launch_scan_un<8, 1, false>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 #endif
-extern template bool launch_scan_un<4, 0, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
-extern template bool launch_scan_un<4, 1, true>(const Problem &, int, int, bool, const Shape &, hipStream_t, void *, bool);
 #endif
 
 }  // namespace ss

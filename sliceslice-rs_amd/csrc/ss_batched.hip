@@ -1,0 +1,321 @@
+// ss_batched.hip - many (needle, haystack) problems per launch.
+//   ss_search_batched / ss_find_batched   BASELINE.json config 5 (4,096 needles x 1 MiB haystacks as one grid), and the loop of
+//                                         /root/reference/bench/benches/i386.rs:252-256 (4,585 needles, one text) as one call
+//   ss_batch_plan_*                       the same with the per-problem set-up done ONCE (the reference builds its searchers
+//                                         once, i386.rs:246-250, and times only the searches)
+//   ss_search_pairs                       row f4 of SURVEY.md 8f: the short-haystack loop of i386.rs:118-129, one lane per problem
+// Semantics per problem are those of ss_search_device / ss_find_device.  There is no CPU search path in this file.
+#include "ss_internal.hpp"
+
+#include "batched_kernels.hpp"
+
+namespace ssh {
+namespace {
+
+// Total workgroups aimed at, per CU.  Measured in one process on one buffer (tools/batch_tune.py, profiles/r03/batch_tune_*.jsonl;
+// kernel time: tools/shape_trace.py under rocprofv3): 96 per CU is best or within 1 % of the best on every shape at 1 GiB in
+// total (1 / 64 / 256 / 1,024 problems: 149-151 us = 7.1-7.2 TB/s of kernel time; 160 per CU 150-153 us, 256 per CU 161-163 us,
+// 512 per CU 190 us - surplus workgroups cost 0.3-0.4 us of a slot each) and for the i386 loop (0.151 ms; 160: 0.17, 256: 0.77);
+// at 4 GiB in 4,096 problems 256 per CU is 2 % faster (583 vs 597 us), which is not worth the rest.
+constexpr unsigned kPlanWgsPerCu = 96;
+constexpr uint32_t kPlanMinTiles = 2;       // shortest slice worth a workgroup, in 16 KiB tiles
+
+// Descriptor scratch of the unplanned calls: one grow-only device buffer per (device, stream), kept for the life of the process.
+// Launches on one stream execute in order, so a buffer that belongs to the stream can be reused by the next call on that
+// stream without any wait; the entry's mutex keeps the two launches of one call adjacent when several threads share a
+// stream.  (hipMallocAsync / hipFreeAsync per call did the same job at 5-10 us of extra latency per call.)  At most
+// kPlanScratchEntries streams per device are remembered; beyond that the least recently used entry is freed (hipFree waits
+// for the device, so nothing that still reads the buffer can be running).  None of this can be captured into a hipGraph - a
+// graph would bake in a buffer that a later call frees - so a capturing stream is refused; graphs take an ss_batch_plan.
+constexpr int kPlanScratchEntries = 32;
+struct PlanScratch {
+    hipStream_t stream = nullptr;
+    bool used = false;
+    ss::BatchDesc *buf = nullptr;
+    size_t cap = 0;             // descriptors
+    uint64_t stamp = 0;
+    std::mutex mu;              // held across the plan + scan launches of one call
+};
+struct PlanTable {
+    std::mutex mu;
+    PlanScratch entry[kPlanScratchEntries];
+    uint64_t clock = 0;
+};
+PlanTable *plan_tables()        // never destroyed (a call may come from a thread that outlives main)
+{
+    static PlanTable *const t = new PlanTable[kMaxDevices];
+    return t;
+}
+
+// Returns the stream's entry with its mutex LOCKED and room for `count` descriptors, or nullptr (no memory).
+PlanScratch *plan_scratch_acquire(int dev, hipStream_t st, size_t count)
+{
+    if (dev < 0 || dev >= kMaxDevices) return nullptr;
+    PlanTable &tab = plan_tables()[dev];
+    std::unique_lock<std::mutex> table(tab.mu);
+    PlanScratch *e = nullptr, *victim = nullptr;
+    for (auto &c : tab.entry) {
+        if (c.used && c.stream == st) {
+            e = &c;
+            break;
+        }
+        if (!victim || (!c.used && victim->used) || (c.used == victim->used && c.stamp < victim->stamp)) victim = &c;
+    }
+    if (e) {
+        e->mu.lock();            // another thread's call on this stream is between its two launches: brief
+    } else {
+        e = victim;              // an unused entry, else the least recently used one (if a call is between its two launches
+        e->mu.lock();            // on it right now: wait for that - microseconds)
+        if (e->buf) (void)hipFree(e->buf);                      // hipFree waits for the device: nobody reads it any more
+        e->buf = nullptr;
+        e->cap = 0;
+        e->stream = st;
+        e->used = true;
+    }
+    e->stamp = ++tab.clock;
+    table.unlock();
+    if (e->cap < count) {
+        const size_t want = count < 4096 ? 4096 : count + count / 2;
+        if (e->buf) (void)hipFree(e->buf);
+        e->buf = nullptr;
+        e->cap = 0;
+        if (hipMalloc((void **)&e->buf, want * sizeof(ss::BatchDesc)) != hipSuccess) {
+            (void)hipGetLastError();
+            e->buf = nullptr;
+            e->mu.unlock();
+            return nullptr;
+        }
+        e->cap = want;
+    }
+    return e;
+}
+
+// Unused dynamic LDS that leaves room for exactly `occ` workgroups of kBlock threads per CU (160 KiB of LDS; the kernels'
+// needle slices are static LDS).  The batched kernels (73-80 VGPRs) are held to four workgroups per CU like the single-problem
+// scan on random bytes (ss_scan.hip, pick_variant).
+uint32_t batch_lds_pad()
+{
+    int occ = 4;
+#ifdef SS_TEST_HOOKS
+    if (const char *e = getenv("SLICESLICE_BATCH_OCC")) { const int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }
+#endif
+    const uint32_t per = (160u * 1024u) / (uint32_t)occ, fixed = ss::kWavesPerBlock * ss::kNeedleLds;
+    uint32_t pad = per > fixed + 2048 ? ((per - fixed - 1024) & ~1023u) : 0;
+    if (pad > 64u * 1024u - fixed) pad = 64u * 1024u - fixed;
+    return pad;
+}
+
+int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                    const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end, const uint64_t *d_position)
+{
+    if (!d_hay_begin || !d_hay_end || !d_needle_begin || !d_needle_end) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    a->haystacks = static_cast<const uint8_t *>(d_haystacks);
+    a->hay_begin = d_hay_begin;
+    a->hay_end = d_hay_end;
+    a->needles = static_cast<const uint8_t *>(d_needles);
+    a->needle_begin = d_needle_begin;
+    a->needle_end = d_needle_end;
+    a->position = d_position;
+    a->found = nullptr;
+    a->best = nullptr;
+    return SS_OK;
+}
+
+// The grid of a batch: the haystack lengths live on the device, so it is sized from the problem COUNT - kPlanWgsPerCu
+// workgroups per CU in total, i.e. `slices` workgroups per problem.  The price of being wrong is small: a surplus slice costs
+// one scalar round trip, and a slice as short as kPlanMinTiles tiles is worth a workgroup because nothing but that load stands
+// in front of its first haystack byte.
+struct BatchShape {
+    uint32_t slices, min_tiles;
+};
+int batch_shape(int dev, size_t count, BatchShape *out)
+{
+    DeviceInfo di;
+    if (int rc = device_info(dev, &di)) return rc;
+    if (count > 0x3fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
+    uint64_t wg_target = (uint64_t)di.cus * kPlanWgsPerCu;
+    uint32_t min_tiles = kPlanMinTiles;
+#ifdef SS_TEST_HOOKS
+    if (const char *e = getenv("SLICESLICE_BATCH_WGS")) { const long v = atol(e); if (v > 0) wg_target = (uint64_t)v; }
+    if (const char *e = getenv("SLICESLICE_BATCH_MIN_TILES")) { const long v = atol(e); if (v > 0) min_tiles = (uint32_t)v; }
+#endif
+    uint64_t slices = (wg_target + count - 1) / count;
+    if (slices < 1) slices = 1;
+    while (slices > 1 && (uint64_t)count * slices > 0x7fffffffull) --slices;   // gridDim.x
+    out->slices = (uint32_t)slices;
+    out->min_tiles = min_tiles;
+    return SS_OK;
+}
+
+hipError_t launch_plan_kernel(const ss::BatchArgs &a, size_t count, ss::BatchDesc *descs, const BatchShape &sh, hipStream_t st)
+{
+    const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
+    ss::batch_plan_kernel<<<dim3((unsigned)pblocks), dim3(ss::kBlock), 0, st>>>(a, (uint64_t)count, descs, sh.slices, sh.min_tiles,
+                                                                               ss::kWavesPerBlock * 4);
+    return hipGetLastError();
+}
+
+// batch_plan_kernel turns the range arrays into one 64-byte descriptor per problem and writes the initial outputs (no memset
+// launch), the scan grid's workgroups then start with one scalar load.
+int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(SS_ERR_ARGUMENT, "ss_search_batched / ss_find_batched keep per-stream scratch and cannot be captured into a hipGraph: "
+                                     "build an ss_batch_plan outside the capture and capture ss_batch_plan_run");
+    (void)hipGetLastError();
+    BatchShape sh;
+    if (int rc = batch_shape(dev, count, &sh)) return rc;
+    PlanScratch *ps = plan_scratch_acquire(dev, st, count);
+    if (!ps) return fail(SS_ERR_NOMEM, "no device memory for %zu problem descriptors", count);
+    ss::BatchDesc *descs = ps->buf;
+    hipError_t e = launch_plan_kernel(a, count, descs, sh, st);
+    if (e == hipSuccess) {
+        const dim3 grid((unsigned)((uint64_t)count * sh.slices));
+        if (a.best)
+            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
+        else
+            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
+        e = hipGetLastError();
+    }
+    ps->mu.unlock();
+    if (e != hipSuccess) return fail(SS_ERR_HIP, "batched launch: %s", hipGetErrorString(e));
+    return SS_OK;
+}
+
+}  // namespace
+}  // namespace ssh
+
+using namespace ssh;
+
+// One buffer of the plan's own: descriptors | state words (uint64 each; the bool plans use the low int) | counters.
+struct ss_batch_plan {
+    int dev = 0;
+    size_t count = 0;
+    bool find = false;
+    ss::BatchArgs args;
+    BatchShape shape = {1, 1};
+    uint8_t *mem = nullptr;
+    ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
+    void *state() const { return mem + count * sizeof(ss::BatchDesc); }
+    uint32_t *counters() const { return reinterpret_cast<uint32_t *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t))); }
+};
+
+extern "C" {
+
+int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                      const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                      const uint64_t *d_position, size_t count, void *hip_stream, int *d_found)
+{
+    if (count == 0) return SS_OK;
+    if (!d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    ss::BatchArgs a;
+    if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end, d_position)) return rc;
+    a.found = d_found;
+    return launch_batched(a, count, static_cast<hipStream_t>(hip_stream));
+}
+
+/* Row f1 for many problems: the leftmost offset per problem (SS_NPOS: absent), the `Option<usize>` shape of
+ * bench/sse4-strstr/src/lib.rs:4-15 for a whole batch - same plan kernel, same scan grid, FIND instantiation. */
+int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end, const void *d_needles,
+                    const uint64_t *d_needle_begin, const uint64_t *d_needle_end, size_t count, void *hip_stream, uint64_t *d_position)
+{
+    if (count == 0) return SS_OK;
+    if (!d_position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    ss::BatchArgs a;
+    if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end, nullptr)) return rc;
+    a.best = d_position;
+    return launch_batched(a, count, static_cast<hipStream_t>(hip_stream));
+}
+
+int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end, const void *d_needles,
+                         const uint64_t *d_needle_begin, const uint64_t *d_needle_end, const uint64_t *d_position, size_t count,
+                         int find, void *hip_stream, ss_batch_plan **out)
+{
+    if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (count == 0) return fail(SS_ERR_ARGUMENT, "a plan needs at least one problem");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(SS_ERR_ARGUMENT, "ss_batch_plan_create allocates and waits: call it outside the stream capture");
+    (void)hipGetLastError();
+    ss_batch_plan *p = new (std::nothrow) ss_batch_plan;
+    if (!p) return fail(SS_ERR_NOMEM, "out of memory");
+    p->count = count;
+    p->find = find != 0;
+    int rc = fill_batch_args(&p->args, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end, find ? nullptr : d_position);
+    hipError_t e = hipSuccess;
+    if (rc == SS_OK && (e = hipGetDevice(&p->dev)) != hipSuccess) rc = fail(SS_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape);
+    if (rc == SS_OK) {
+        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t) + sizeof(uint32_t));
+        if ((e = hipMalloc((void **)&p->mem, bytes)) != hipSuccess)
+            rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    if (rc == SS_OK) {
+        // idle values: flags 0 / minima all ones, counters 0; then the descriptors (the plan kernel writes no outputs here:
+        // args.found and args.best are both null)
+        e = hipMemsetAsync(p->state(), p->find ? 0xFF : 0, count * sizeof(uint64_t), st);
+        if (e == hipSuccess) e = hipMemsetAsync(p->counters(), 0, count * sizeof(uint32_t), st);
+        if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs(), p->shape, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "plan set-up: %s", hipGetErrorString(e));
+    }
+    if (rc != SS_OK) {
+        (void)hipFree(p->mem);
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return SS_OK;
+}
+
+int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
+{
+    if (!p || !d_out) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != p->dev) return fail(SS_ERR_ARGUMENT, "the plan was made on device %d, the current device is %d", p->dev, dev);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    ss::BatchArgs a = p->args;
+    const dim3 grid((unsigned)((uint64_t)p->count * p->shape.slices));
+    if (p->find) {
+        a.best = static_cast<uint64_t *>(d_out);
+        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices,
+                                                                                                   p->state(), p->counters());
+    } else {
+        a.found = static_cast<int *>(d_out);
+        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices,
+                                                                                                    p->state(), p->counters());
+    }
+    HIP_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+void ss_batch_plan_free(ss_batch_plan *p)
+{
+    if (!p) return;
+    (void)hipFree(p->mem);          // (waits for the device: a run the caller forgot about cannot read freed memory)
+    delete p;
+}
+
+int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
+                    const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
+                    const uint64_t *d_position, size_t count, void *hip_stream, int *d_found)
+{
+    if (count == 0) return SS_OK;
+    if (!d_found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    ss::BatchArgs a;
+    if (int rc = fill_batch_args(&a, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end, d_position)) return rc;
+    a.found = d_found;
+    const uint64_t blocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
+    if (blocks > 0x7fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
+    ss::scan_pairs_kernel<<<dim3((unsigned)blocks), dim3(ss::kBlock), 0, static_cast<hipStream_t>(hip_stream)>>>(a, count);
+    HIP_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,653 @@
+// ss_comm.hip - the range-sharded searches: rank r of G scans bytes [r*S, (r+1)*S + n-1) of the logical haystack,
+// the found flags are combined by ONE ncclAllReduce(MAX) per search (OR over {0,1}; RCCL has no OR), leftmost offsets by ONE
+// ncclAllReduce(MIN).  Two forms: one process per GPU (ss_comm_init_rank / ss_search_sharded / ss_find_sharded) and all GPUs
+// of a node from one process (ss_comm_init_all / ss_search_sharded_all / ss_find_sharded_all: the form a drop-in
+// `search_in(&self, &[u8]) -> bool`, /root/reference/src/x86.rs:523, needs - no launcher, no rendezvous).  librccl is
+// dlopen()ed on first use.  The scans are the same kernels (enqueue_scan, ss_scan.hip); there is no CPU search path here.
+#include "ss_internal.hpp"
+
+#include <dlfcn.h>
+
+using namespace ssh;
+
+namespace {
+
+struct Id128 {
+    char b[128];
+};
+
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128 /* ncclUniqueId, by value */, int) = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        // SLICESLICE_RCCL_LIB names the library to use (a site's own build; the shared-memory stand-in of tests/native/fake_rccl.c,
+        // which lets several ranks share one GPU): RTLD_LOCAL, so that its nccl* symbols never interpose on a librccl that is
+        // already in the process (torch's)
+        if (const char *path = getenv("SLICESLICE_RCCL_LIB")) {
+            if (path[0]) r.h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char *nm : names) {
+                r.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+                if (r.h) break;
+            }
+        }
+        if (!r.h) return;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.h, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.h, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.h, "ncclGroupEnd");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    });
+    if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.CommCount || !r.GroupStart ||
+        !r.GroupEnd || !r.AllReduce)
+        return nullptr;
+    return &r;
+}
+
+constexpr int kNcclInt32 = 2;   // ncclInt32 / ncclInt  (rccl.h ncclDataType_t)
+constexpr int kNcclUint64 = 5;  // ncclUint64
+constexpr int kNcclMax = 2;     // ncclMax              (rccl.h ncclRedOp_t: sum 0, prod 1, max 2, min 3)
+constexpr int kNcclMin = 3;     // ncclMin
+
+int rccl_fail(Rccl *r, int code, const char *what)
+{
+    return fail(SS_ERR_RCCL, "%s: %s", what, r && r->GetErrorString ? r->GetErrorString(code) : "rccl error");
+}
+
+}  // namespace
+
+// One rank's end of a communicator (one process per GPU).  The found flag of a sharded search is never
+// cleared: "found" is the call's epoch - every rank makes the same sequence of collective calls on a
+// communicator, so the ranks' epochs agree - and since a rank's flag only ever holds epochs of earlier
+// calls or of this one, max over the ranks == epoch exactly when some rank found the needle in THIS call.
+struct ss_comm {
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+    int dev = 0;
+    int epoch = 0;
+    // A PAIR of ints goes through the all-reduce(MAX): [0] = this rank's found flag, [1] = "this rank failed its local
+    // part", both epoch-valued and never cleared.  A rank whose scan could not be enqueued still takes part in the
+    // collective (nobody is left waiting in ncclAllReduce, the ranks' epochs stay in step) and every rank learns of it:
+    // the failing rank returns its own error, the others SS_ERR_PEER.
+    int *d_flag = nullptr;      // int[2]
+    int *d_recv = nullptr;      // int[2]: all-reduce(MAX) result
+    int *h_flag = nullptr;      // pinned int[2]: read-back
+    int *h_err = nullptr;       // pinned: source of the copy that raises d_flag[1]
+    long long *h_word = nullptr;// pinned answer word of signal_flag_kernel (pair form) (spinning read-back)
+    unsigned finds = 0;         // ss_find_sharded calls (every 256th still waits for the stream)
+    uint64_t *d_best = nullptr; // uint64[2] scratch of ss_find_sharded: [0] = offset (MIN), [1] = all ones unless a rank failed
+    uint64_t *h_best = nullptr; // pinned uint64[2]
+    std::atomic<bool> busy{false};   // one search at a time per communicator: a second concurrent call is refused
+};
+
+// All ranks of a communicator inside ONE process (ncclCommInitAll): one stream, flag and read-back per device.
+struct ss_comm_set {
+    int ndev = 0;
+    int combine = 0;            // SS_COMBINE_RCCL / SS_COMBINE_HOST
+    int epoch = 0;
+    std::vector<int> devs;
+    std::vector<void *> comms;
+    std::vector<hipStream_t> streams;
+    std::vector<int *> d_flag, d_recv, h_flag;          // h_flag[g]: pinned mirror written by device g's finding wave
+    std::vector<uint64_t *> d_best, d_best_recv;
+    bool no_rccl = false;                               // librccl could not be loaded: no communicators, host combine only
+    int *h_recv = nullptr;                              // pinned: device 0's all-reduce result
+    long long *h_words = nullptr;                       // pinned: ndev answer words of signal_flag_kernel (spinning read-back)
+    uint64_t *h_best = nullptr;                         // pinned: ndev offsets (host combine) / [0] = all-reduce result
+    std::atomic<bool> busy{false};                      // one search at a time per set: a second concurrent call is refused
+    // Cross-device early exit of ss_search_sharded_all: the host, which waits for the answer words anyway, watches the pinned
+    // mirrors the finding waves write and stores the epoch into every OTHER device's flag through that device's PCIe BAR;
+    // their workgroups see it at their next poll and leave.  Possible when every device's memory is CPU-visible.
+    bool relay_ok = false;
+    std::vector<volatile uint32_t *> hdp_flush;         // per device: HDP flush register (pushes the store out of the host data path)
+};
+
+namespace {
+
+int next_comm_epoch(int *epoch, int *const *d_flags, const int *devs, int ndev, int *const *h_flags = nullptr)
+{
+    if (*epoch >= INT_MAX - 1 || *epoch < 0) {          // 2^31 calls: clear the flags so that no stale value equals a new epoch
+        DeviceGuard guard;
+        for (int g = 0; g < ndev; ++g) {
+            (void)hipSetDevice(devs[g]);
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(d_flags[g], 0, 2 * sizeof(int));       // flag + "a rank failed" (every flag word is a pair)
+            if (h_flags) *h_flags[g] = 0;
+        }
+        *epoch = 0;
+    }
+    return ++*epoch;
+}
+
+void free_comm(ss_comm *c)
+{
+    Rccl *r = rccl();
+    if (r && c->comm) r->CommDestroy(c->comm);
+    (void)hipFree(c->d_flag);
+    (void)hipFree(c->d_recv);
+    (void)hipHostFree(c->h_flag);
+    (void)hipHostFree(c->h_err);
+    (void)hipHostFree(c->h_word);
+    (void)hipFree(c->d_best);
+    (void)hipHostFree(c->h_best);
+    delete c;
+}
+
+void free_comm_set(ss_comm_set *set)
+{
+    Rccl *r = rccl();
+    DeviceGuard guard;
+    for (int g = 0; g < set->ndev; ++g) {
+        (void)hipSetDevice(set->devs[g]);
+        if (g < (int)set->streams.size() && set->streams[g]) {
+            (void)hipStreamSynchronize(set->streams[g]);
+            (void)hipStreamDestroy(set->streams[g]);
+        }
+        if (r && g < (int)set->comms.size() && set->comms[g]) r->CommDestroy(set->comms[g]);
+        if (g < (int)set->d_flag.size()) (void)hipFree(set->d_flag[g]);
+        if (g < (int)set->d_recv.size()) (void)hipFree(set->d_recv[g]);
+        if (g < (int)set->h_flag.size()) (void)hipHostFree(set->h_flag[g]);
+        if (g < (int)set->d_best.size()) (void)hipFree(set->d_best[g]);
+        if (g < (int)set->d_best_recv.size()) (void)hipFree(set->d_best_recv[g]);
+    }
+    (void)hipHostFree(set->h_recv);
+    (void)hipHostFree(set->h_words);
+    (void)hipHostFree(set->h_best);
+    delete set;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_comm_unique_id(uint8_t id[SS_UNIQUE_ID_BYTES])
+{
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    static_assert(SS_UNIQUE_ID_BYTES == sizeof(Id128), "ncclUniqueId is 128 bytes");
+    if (int rc = r->GetUniqueId(id)) return rccl_fail(r, rc, "ncclGetUniqueId");
+    return SS_OK;
+}
+
+int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank, ss_comm **out)
+{
+    if (!out || !id) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SS_ERR_ARGUMENT, "bad rank %d of %d", rank, nranks);
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    ss_comm *c = new (std::nothrow) ss_comm;
+    if (!c) return fail(SS_ERR_NOMEM, "out of memory");
+    Id128 uid;
+    memcpy(uid.b, id, sizeof uid);
+    if (int rc = r->CommInitRank(&c->comm, nranks, uid, rank)) {
+        c->comm = nullptr;
+        free_comm(c);
+        return rccl_fail(r, rc, "ncclCommInitRank");
+    }
+    c->nranks = nranks;
+    c->rank = rank;
+    hipError_t e = hipGetDevice(&c->dev);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_recv, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_recv, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_flag, 2 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_word, sizeof(long long), hipHostMallocDefault);
+    if (e == hipSuccess) *c->h_word = 0;
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_best, 2 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_best, 2 * sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) {                               // nothing half-built is left behind (communicator included)
+        free_comm(c);
+        return fail(SS_ERR_HIP, "communicator scratch: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SS_OK;
+}
+
+void ss_comm_free(ss_comm *c)
+{
+    if (c) free_comm(c);
+}
+
+#ifdef SS_TEST_HOOKS
+int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value)
+{
+    if (c) c->epoch = value;
+    if (set) set->epoch = value;
+    return SS_OK;
+}
+#endif
+
+int ss_comm_count(const ss_comm *c, int *nranks)
+{
+    if (!c || !nranks) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    if (int rc = r->CommCount(c->comm, nranks)) return rccl_fail(r, rc, "ncclCommCount");   // what RCCL itself says
+    return SS_OK;
+}
+
+int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, ss_comm *c,
+                      void *hip_stream, int *found)
+{
+    if (!s || !c || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (shard_len && !d_shard) return fail(SS_ERR_ARGUMENT, "shard is NULL");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    if (s->n == 0) { *found = 1; return SS_OK; }            // N0 (x86.rs:500): the same on every rank, nothing to combine
+    BusyGuard busy(&c->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator is in use by another search (one search at a time)");
+    SearchGate gate(s);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const int epoch = next_comm_epoch(&c->epoch, &c->d_flag, &c->dev, 1);
+    // The local part.  Whatever happens here, this rank ENTERS THE COLLECTIVE below: a rank that returned early would
+    // leave the others waiting in ncclAllReduce for good and put the ranks' epochs out of step.
+    int local_rc = SS_OK;
+    char local_msg[512] = "";
+    if (shard_len >= s->n) {                                // a shard shorter than the needle holds no candidate
+        PerDevice *pd = nullptr;
+        local_rc = get_per_device(s, &pd);
+        if (local_rc == SS_OK) local_rc = enqueue_scan(s, pd, d_shard, shard_len, st, c->d_flag, false, 0, nullptr, epoch);
+        if (local_rc != SS_OK) {
+            snprintf(local_msg, sizeof local_msg, "%s", last_error());
+            *c->h_err = epoch;                              // contributes "not found" and raises the pair's second word
+            (void)hipMemcpyAsync(c->d_flag + 1, c->h_err, sizeof(int), hipMemcpyHostToDevice, st);
+        }
+    }
+    auto done = [&](int any_failed) {
+        if (local_rc != SS_OK) return fail(local_rc, "%s", local_msg);
+        if (any_failed) return fail(SS_ERR_PEER, "another rank failed the local part of this sharded search; no answer");
+        return (int)SS_OK;
+    };
+    if (int rc = r->AllReduce(c->d_flag, c->d_recv, 2, kNcclInt32, kNcclMax, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    const bool spin_ok = spin_wait_enabled();
+    const double estimate = scan_estimate_us(shard_len) + 100.0;      // + the collective
+    if (spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(shard_len) >= kSpinMinEstimateUs) {
+        // the answer word behind the all-reduce, and a bounded spin on it (see spin_for_word); ranks that arrive late in
+        // the collective make the others' spins run out, which costs those nothing but the stream wait they had before
+        __atomic_store_n(c->h_word, 0ll, __ATOMIC_RELAXED);
+        HIP_TRY(launch_signal_flag(st, c->d_recv, epoch, c->h_word, 1));
+        int failed = 0;
+        if (spin_for_shard_word(c->h_word, epoch, estimate, found, &failed)) {
+            if ((epoch & 255) == 0) HIP_TRY(hipStreamSynchronize(st));
+            return done(failed);
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!spin_for_shard_word(c->h_word, epoch, 0.0, found, &failed)) return fail(SS_ERR_HIP, "the answer word was not written");
+        return done(failed);
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_flag, c->d_recv, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *found = c->h_flag[0] == epoch;
+    return done(c->h_flag[1] == epoch);
+}
+
+// Sharded find: every rank lowers its uint64 with shard_begin + local offset of its leftmost match, ONE
+// all-reduce(MIN) over a uint64 PAIR gives the global leftmost offset (SS_NPOS = all ones = absent everywhere) and
+// tells every rank whether some rank failed its local part (second word: all ones unless so) - collective-safe the
+// same way as ss_search_sharded.
+int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t shard_len, uint64_t shard_begin, ss_comm *c,
+                    void *hip_stream, uint64_t *position)
+{
+    if (!s || !c || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (shard_len && !d_shard) return fail(SS_ERR_ARGUMENT, "shard is NULL");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    BusyGuard busy(&c->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator is in use by another search (one search at a time)");
+    SearchGate gate(s);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int local_rc = SS_OK;
+    char local_msg[512] = "";
+    hipError_t e0 = hipMemsetAsync(c->d_best, 0xFF, 2 * sizeof(uint64_t), st);
+    if (e0 != hipSuccess) local_rc = fail(SS_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e0));
+    if (local_rc == SS_OK) local_rc = ss_find_device_async(s, d_shard, shard_len, shard_begin, hip_stream, c->d_best);
+    if (local_rc != SS_OK) {                                // still enter the collective: see ss_search_sharded
+        snprintf(local_msg, sizeof local_msg, "%s", last_error());
+        (void)hipMemsetAsync(c->d_best + 1, 0, sizeof(uint64_t), st);
+    }
+    auto done = [&](uint64_t status) {
+        if (local_rc != SS_OK) return fail(local_rc, "%s", local_msg);
+        if (status != ~0ull) return fail(SS_ERR_PEER, "another rank failed the local part of this sharded find; no answer");
+        return (int)SS_OK;
+    };
+    if (int rc = r->AllReduce(c->d_best, c->d_best, 2, kNcclUint64, kNcclMin, c->comm, st)) return rccl_fail(r, rc, "ncclAllReduce");
+    const bool spin_ok = spin_wait_enabled();
+    const double estimate = scan_estimate_us(shard_len) + 100.0;
+    if (spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(shard_len) >= kSpinMinEstimateUs) {
+        // as ss_search_sharded: the pinned mirror starts as "pending", a one-lane kernel behind the all-reduce stores the
+        // pair (and re-arms nothing: d_best is this communicator's scratch, set to all ones at the top of every call)
+        constexpr uint64_t kPending = ~0ull - 1;
+        __atomic_store_n(c->h_best, kPending, __ATOMIC_RELAXED);
+        HIP_TRY(launch_publish_best(st, c->d_best, c->h_best, 1));
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
+        for (unsigned spins = 0;; ++spins) {
+            const uint64_t v = __atomic_load_n(c->h_best, __ATOMIC_ACQUIRE);
+            if (v != kPending) {
+                *position = v;
+                if ((++c->finds & 255) == 0) HIP_TRY(hipStreamSynchronize(st));
+                return done(__atomic_load_n(c->h_best + 1, __ATOMIC_RELAXED));
+            }
+            cpu_relax();
+            if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) break;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        *position = __atomic_load_n(c->h_best, __ATOMIC_ACQUIRE);
+        return done(__atomic_load_n(c->h_best + 1, __ATOMIC_RELAXED));
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_best, c->d_best, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *position = c->h_best[0];
+    return done(c->h_best[1]);
+}
+
+// ---- multi-GPU inside ONE process ---------------------------------------------------------------------
+// What a drop-in `search_in(&self, &[u8]) -> bool` over the 8 GPUs of a node calls (x86.rs:523 has no
+// launcher to lean on): ncclCommInitAll once, then per search one scan per device on that device's stream,
+// the G all-reduces inside ONE ncclGroupStart/End, one read-back.
+int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
+{
+    if (!out) return fail(SS_ERR_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int visible = 0;
+    HIP_TRY(hipGetDeviceCount(&visible));
+    // Without a loadable librccl the set still works: no communicators are created and only the host combine is offered (all
+    // ranks live in this process; the collective is an option here, not a need).  Whether a device may be listed twice is RCCL's
+    // call (ncclCommInitAll refuses; the shared-memory stand-in of the tests, tests/native/fake_rccl.c, allows it).
+    Rccl *r = rccl();
+    const bool no_rccl = r == nullptr;
+    if (ndev < 1 || ndev > kMaxDevices) return fail(SS_ERR_ARGUMENT, "%d devices requested (1 .. %d)", ndev, kMaxDevices);
+    ss_comm_set *set = new (std::nothrow) ss_comm_set;
+    if (!set) return fail(SS_ERR_NOMEM, "out of memory");
+    set->ndev = ndev;
+    set->no_rccl = no_rccl;
+    if (no_rccl) set->combine = SS_COMBINE_HOST;
+    for (int g = 0; g < ndev; ++g) {
+        const int d = devs ? devs[g] : g;
+        if (d < 0 || d >= visible) {
+            delete set;
+            return fail(SS_ERR_ARGUMENT, "device %d out of range (%d visible)", d, visible);
+        }
+        set->devs.push_back(d);
+    }
+    set->comms.assign(ndev, nullptr);
+    set->streams.assign(ndev, nullptr);
+    set->d_flag.assign(ndev, nullptr);
+    set->d_recv.assign(ndev, nullptr);
+    set->h_flag.assign(ndev, nullptr);
+    set->d_best.assign(ndev, nullptr);
+    set->d_best_recv.assign(ndev, nullptr);
+    DeviceGuard guard;
+    if (int rc = no_rccl ? 0 : r->CommInitAll(set->comms.data(), ndev, set->devs.data())) {
+        set->comms.assign(ndev, nullptr);
+        free_comm_set(set);
+        return rccl_fail(r, rc, "ncclCommInitAll");
+    }
+    hipError_t e = hipSuccess;
+    for (int g = 0; g < ndev && e == hipSuccess; ++g) {
+        e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&set->streams[g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_flag[g], 2 * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(set->d_flag[g], 0, 2 * sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_recv[g], sizeof(int));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_flag[g], sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+        if (e == hipSuccess) *set->h_flag[g] = 0;
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_best[g], sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_best_recv[g], sizeof(uint64_t));
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_recv, sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_words, (size_t)ndev * sizeof(long long), hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) memset(set->h_words, 0, (size_t)ndev * sizeof(long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_best, (size_t)ndev * sizeof(uint64_t), hipHostMallocPortable | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        free_comm_set(set);
+        return fail(SS_ERR_HIP, "communicator set scratch: %s", hipGetErrorString(e));
+    }
+    {
+        set->relay_ok = bar_writes_allowed();
+        set->hdp_flush.assign((size_t)ndev, nullptr);
+        for (int g = 0; g < ndev; ++g) {
+            DeviceInfo di;
+            if (device_info(set->devs[g], &di) != SS_OK || !di.large_bar) set->relay_ok = false;
+            else set->hdp_flush[g] = di.hdp_flush;
+            (void)hipSetDevice(set->devs[g]);
+            (void)hipDeviceSynchronize();               // the memsets above are asynchronous to the host: done before anyone stores there
+        }
+    }
+    *out = set;
+    return SS_OK;
+}
+
+void ss_comm_set_free(ss_comm_set *set)
+{
+    if (set) free_comm_set(set);
+}
+
+int ss_comm_set_combine(ss_comm_set *set, int combine)
+{
+    if (!set || (combine != SS_COMBINE_RCCL && combine != SS_COMBINE_HOST)) return fail(SS_ERR_ARGUMENT, "bad combine mode");
+    if (set->no_rccl && combine == SS_COMBINE_RCCL) return fail(SS_ERR_RCCL, "this set was created without communicators (librccl could not be loaded)");
+    set->combine = combine;
+    return SS_OK;
+}
+
+int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens, ss_comm_set *set,
+                          int *found)
+{
+    if (!s || !d_shards || !shard_lens || !set || !found) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (s->n == 0) { *found = 1; return SS_OK; }            // N0 (x86.rs:500)
+    Rccl *r = set->combine == SS_COMBINE_RCCL ? rccl() : nullptr;
+    if (set->combine == SS_COMBINE_RCCL && !r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    const int G = set->ndev;
+    for (int g = 0; g < G; ++g)
+        if (shard_lens[g] && !d_shards[g]) return fail(SS_ERR_ARGUMENT, "shard %d is NULL", g);
+    // the set's epoch, streams, flags and pinned words are ONE search's scratch: a second thread would corrupt both answers
+    BusyGuard busy(&set->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator set is in use by another search (one search at a time per set)");
+    SearchGate gate(s);
+    DeviceGuard guard;
+    const int epoch = next_comm_epoch(&set->epoch, set->d_flag.data(), set->devs.data(), G, set->h_flag.data());
+    int rc = SS_OK;
+    // 1. one scan per device, each on its device's stream; the finding wave also writes the epoch to that device's
+    //    pinned-host mirror
+    for (int g = 0; g < G && rc == SS_OK; ++g) {
+        if (shard_lens[g] < s->n) continue;                 // shorter than the needle: no candidate, flag stays old
+        if (hipSetDevice(set->devs[g]) != hipSuccess) { rc = fail(SS_ERR_HIP, "hipSetDevice(%d) failed", set->devs[g]); break; }
+        PerDevice *pd = nullptr;
+        rc = get_per_device(s, &pd);
+        if (rc == SS_OK) rc = enqueue_scan(s, pd, d_shards[g], shard_lens[g], set->streams[g], set->d_flag[g], false, 0, set->h_flag[g], epoch);
+    }
+    // 2. combine: G all-reduce(MAX) calls as ONE group (the default), or no collective at all - the host ORs the
+    //    G pinned mirrors (possible only because all ranks live in this process)
+    if (rc == SS_OK && set->combine == SS_COMBINE_RCCL) {
+        int nrc = r->GroupStart();
+        for (int g = 0; g < G && nrc == 0; ++g)
+            nrc = r->AllReduce(set->d_flag[g], set->d_recv[g], 1, kNcclInt32, kNcclMax, set->comms[g], set->streams[g]);
+        const int erc = r->GroupEnd();
+        if (nrc == 0) nrc = erc;
+        if (nrc != 0) rc = rccl_fail(r, nrc, "grouped ncclAllReduce");
+        if (rc == SS_OK) {
+            hipError_t e = hipSetDevice(set->devs[0]);
+            if (e == hipSuccess) e = hipMemcpyAsync(set->h_recv, set->d_recv[0], sizeof(int), hipMemcpyDeviceToHost, set->streams[0]);
+            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
+        }
+    }
+    // 3. every stream is drained before the call returns: the haystacks are only borrowed for the call.  Scans short
+    //    enough to be waited for by spinning (spin_for_word) end with a one-lane kernel per device that stores the device's
+    //    answer word - behind the scan and the all-reduce, so a word that has arrived says its stream is done - and the
+    //    host collects the G words; whatever is missing when the spin budget runs out is waited for on the stream.
+    const bool spin_ok = spin_wait_enabled();
+    size_t longest = 0;
+    for (int g = 0; g < G; ++g) longest = shard_lens[g] > longest ? shard_lens[g] : longest;
+    const double estimate = scan_estimate_us(longest) + 100.0;
+    bool spun = false;
+    int any_word = 0;
+    if (rc == SS_OK && spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(longest) >= kSpinMinEstimateUs) {
+        bool launched = true;
+        for (int g = 0; g < G && launched; ++g) {
+            __atomic_store_n(set->h_words + g, 0ll, __ATOMIC_RELAXED);
+            launched = hipSetDevice(set->devs[g]) == hipSuccess;
+            if (launched) {
+                launched = launch_signal_flag(set->streams[g], set->combine == SS_COMBINE_RCCL ? set->d_recv[g] : set->d_flag[g], epoch,
+                                              set->h_words + g, 0) == hipSuccess;
+            }
+        }
+        if (launched) {
+            // Collect the G answer words; meanwhile - cross-device early exit - watch the pinned mirrors: the first device that
+            // reports a match has its epoch stored into every other device's flag through the BAR, so that THEIR grids stop
+            // scanning too (a match in shard 0 of a 64 GiB haystack over eight devices otherwise costs the full 1.2 ms scan of
+            // the seven others).  The flag only ever means "found somewhere": the OR of the answers is unchanged.
+            const auto t0 = std::chrono::steady_clock::now();
+            const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
+            uint64_t got = 0;
+            bool relayed = !set->relay_ok || G < 2 || !cross_exit_enabled();
+            spun = true;
+            for (unsigned spins = 0; got != (G >= 64 ? ~0ull : (1ull << G) - 1); ++spins) {
+                for (int g = 0; g < G; ++g) {
+                    if ((got >> g) & 1) continue;
+                    const long long v = __atomic_load_n(set->h_words + g, __ATOMIC_ACQUIRE);
+                    if (((uint32_t)v >> 1) == (uint32_t)epoch) {
+                        any_word |= (int)(v & 1);
+                        got |= 1ull << g;
+                    }
+                }
+                if (!relayed) {
+                    for (int g = 0; g < G; ++g) {
+                        if (__atomic_load_n(set->h_flag[g], __ATOMIC_ACQUIRE) != epoch) continue;
+                        for (int o = 0; o < G; ++o) {
+                            if (o == g || ((got >> o) & 1) || shard_lens[o] < s->n) continue;
+                            *reinterpret_cast<volatile int *>(set->d_flag[o]) = epoch;
+                        }
+                        _mm_sfence();
+                        // push the stores out of each device's host data path and WAIT for them (read the register back, as
+                        // bar_write does): a posted write still in flight when this call returns could land after the NEXT
+                        // search on the set has moved that flag on to its own epoch, and put it back
+                        for (int o = 0; o < G; ++o) {
+                            if (o == g || ((got >> o) & 1) || shard_lens[o] < s->n) continue;
+                            if (set->hdp_flush[o]) {
+                                __atomic_store_n(set->hdp_flush[o], 1u, __ATOMIC_RELAXED);
+                                (void)__atomic_load_n(set->hdp_flush[o], __ATOMIC_RELAXED);
+                            } else {
+                                (void)*reinterpret_cast<volatile int *>(set->d_flag[o]);
+                            }
+                        }
+                        relayed = true;
+                        break;
+                    }
+                }
+                cpu_relax();
+                if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) { spun = false; break; }
+            }
+            if (spun && (epoch & 255) != 0) {
+                *found = any_word;
+                return SS_OK;
+            }
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+        hipError_t e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipStreamSynchronize(set->streams[g]);
+        if (e != hipSuccess && rc == SS_OK) rc = fail(SS_ERR_HIP, "stream wait on device %d: %s", set->devs[g], hipGetErrorString(e));
+    }
+    if (rc != SS_OK) return rc;
+    if (spun) {
+        *found = any_word;
+        return SS_OK;
+    }
+    int any = 0;
+    if (set->combine == SS_COMBINE_RCCL) {
+        any = *set->h_recv == epoch;
+    } else {
+        for (int g = 0; g < G; ++g) any |= __atomic_load_n(set->h_flag[g], __ATOMIC_ACQUIRE) == epoch;
+    }
+    *found = any;
+    return SS_OK;
+}
+
+int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
+                        const uint64_t *shard_begins, ss_comm_set *set, uint64_t *position)
+{
+    if (!s || !d_shards || !shard_lens || !shard_begins || !set || !position) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    Rccl *r = set->combine == SS_COMBINE_RCCL ? rccl() : nullptr;
+    if (set->combine == SS_COMBINE_RCCL && !r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    const int G = set->ndev;
+    for (int g = 0; g < G; ++g)
+        if (shard_lens[g] && !d_shards[g]) return fail(SS_ERR_ARGUMENT, "shard %d is NULL", g);
+    BusyGuard busy(&set->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator set is in use by another search (one search at a time per set)");
+    SearchGate gate(s);
+    DeviceGuard guard;
+    int rc = SS_OK;
+    for (int g = 0; g < G && rc == SS_OK; ++g) {
+        hipError_t e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipMemsetAsync(set->d_best[g], 0xFF, sizeof(uint64_t), set->streams[g]);
+        if (e != hipSuccess) { rc = fail(SS_ERR_HIP, "device %d: %s", set->devs[g], hipGetErrorString(e)); break; }
+        rc = ss_find_device_async(s, d_shards[g], shard_lens[g], shard_begins[g], set->streams[g], set->d_best[g]);
+    }
+    if (rc == SS_OK && set->combine == SS_COMBINE_RCCL) {
+        int nrc = r->GroupStart();
+        for (int g = 0; g < G && nrc == 0; ++g)
+            nrc = r->AllReduce(set->d_best[g], set->d_best_recv[g], 1, kNcclUint64, kNcclMin, set->comms[g], set->streams[g]);
+        const int erc = r->GroupEnd();
+        if (nrc == 0) nrc = erc;
+        if (nrc != 0) rc = rccl_fail(r, nrc, "grouped ncclAllReduce");
+    }
+    if (rc == SS_OK) {                                       // read-back: the reduced value from device 0, or all G minima
+        const int nread = set->combine == SS_COMBINE_RCCL ? 1 : G;
+        for (int g = 0; g < nread && rc == SS_OK; ++g) {
+            hipError_t e = hipSetDevice(set->devs[g]);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(set->h_best + g, set->combine == SS_COMBINE_RCCL ? set->d_best_recv[g] : set->d_best[g],
+                                   sizeof(uint64_t), hipMemcpyDeviceToHost, set->streams[g]);
+            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "offset read-back: %s", hipGetErrorString(e));
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+        hipError_t e = hipSetDevice(set->devs[g]);
+        if (e == hipSuccess) e = hipStreamSynchronize(set->streams[g]);
+        if (e != hipSuccess && rc == SS_OK) rc = fail(SS_ERR_HIP, "stream wait on device %d: %s", set->devs[g], hipGetErrorString(e));
+    }
+    if (rc != SS_OK) return rc;
+    uint64_t best = set->h_best[0];
+    if (set->combine != SS_COMBINE_RCCL)
+        for (int g = 1; g < G; ++g) best = set->h_best[g] < best ? set->h_best[g] : best;
+    *position = best;
+    return SS_OK;
+}
+
+int ss_shard_range(size_t len, size_t needle_len, int nranks, int rank, size_t *begin, size_t *end)
+{
+    if (!begin || !end || nranks < 1 || rank < 0 || rank >= nranks) return fail(SS_ERR_ARGUMENT, "bad shard arguments");
+    const size_t S = (len + (size_t)nranks - 1) / (size_t)nranks;
+    size_t b = (size_t)rank * S;
+    if (b > len) b = len;
+    const size_t overlap = needle_len ? needle_len - 1 : 0;
+    size_t e = len - b <= S || len - b - S <= overlap ? len : b + S + overlap;
+    *begin = b;
+    *end = e;
+    return SS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// ss_internal.hpp - what the host-side translation units of libsliceslice_hip share (namespace ssh; nothing here is exported:
+// the library is built with -fvisibility=hidden and only the SS_API entry points of include/sliceslice_hip*.h are visible).
+//
+//   ss_core.hip     errors, device info, control-block pools, ss_searcher (constructors, filter-byte choice, accessors)
+//   ss_scan.hip     kernel selection, the Problem of a (searcher, haystack), enqueue_scan, ss_search_device / ss_find_device
+//   ss_host.hip     host-slice and host-file front ends, the byte histogram (rows f2, f3 of SURVEY.md 8f)
+//   ss_batched.hip  batched search / find, batch plans, short-haystack pairs (config 5, row f4)
+//   ss_service.hip  the resident search service
+//   ss_comm.hip     RCCL, the range-sharded searches (one process per GPU and all GPUs from one process), ss_shard_range
+//   ss_tools.hip    benchmark / tuning helpers and the test hooks (sliceslice_hip_tuning.h)
+// The scan kernels live in scan_filters.hpp / scan_kernels.hpp (instantiated in scan_inst_*.hip), the others next to their users.
+// There is no CPU search path in any of them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <emmintrin.h>
+
+#include <atomic>
+#include <chrono>
+#include <climits>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/sliceslice_hip.h"
+#include "../../include/sliceslice_hip_tuning.h"
+#include "scan_filters.hpp"
+
+namespace ssh {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+const char *last_error();               // the calling thread's message buffer (what ss_last_error returns)
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return ssh::fail(e_ == hipErrorNoDevice ? SS_ERR_NO_DEVICE : SS_ERR_HIP, "%s: %s (%s:%d)",  \
+                             #expr, hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
+// restores the calling thread's current device on scope exit
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
+struct DeviceInfo {
+    int cus = 0;
+    bool ok = false;
+    bool gfx950 = false;
+    bool large_bar = false;                     // every byte of the device's memory is CPU-visible through the PCIe BAR
+    volatile uint32_t *hdp_flush = nullptr;     // the device's HDP_MEM_COHERENCY_FLUSH_CNTL register (CPU-visible), or null
+};
+int device_info(int dev, DeviceInfo *out);
+
+constexpr int kSlots = 64;
+constexpr int kMaxDevices = 64;
+constexpr uint32_t kFindTagMax = (1u << (64 - ss::kFindOffsetBits)) - 2;   // keys tag << kFindOffsetBits stay below all-ones
+constexpr uint32_t kDoneLowMax = 0x7FFF0000u;                               // start over before the low half could carry
+constexpr uint64_t kShiftMaxD = 62;      // cross-lane kernels: d + 1 halo chunks must fit one piece (tools/tune.py: wins up to d = 62)
+
+// Per-device state of a searcher: the needle copy and a small pool of found-flag slots so that
+// concurrent ss_search_device calls on one handle never share mutable scratch.
+struct PerDevice {
+    int dev = -1;
+    uint8_t *d_needle = nullptr;
+    int *d_flags = nullptr;     // kSlots ints; "found" is the owning call's epoch, so slots are never cleared
+    int *h_flags = nullptr;     // pinned-host mirror written by the finding wave (no D2H copy per call)
+    uint64_t *d_best = nullptr; // kSlots uint64 for find(): all-ones whenever a slot is free
+    uint64_t *h_best = nullptr; // pinned mirror
+    // Completion word (small grids).  Nothing on the device side is ever reset between calls: the counter's low half
+    // counts workgroups out towards a target the host names per launch, its high half counts the workgroups that found
+    // the needle (the host remembers where it stood), and find() keys its minimum with a per-launch tag that decreases.
+    // The host copies below belong to whoever owns the slot; start_over() resets a slot behind a device synchronise.
+    unsigned long long *d_done = nullptr;   // kSlots counters: found-workgroups << 32 | workgroups
+    long long *h_done = nullptr;            // pinned: the answer word, stored by the workgroup that completes the count
+    uint64_t *d_best_done = nullptr;        // kSlots keyed minima of find()
+    // Candidate-tile statistics of the scans launched through this searcher on this device: a pinned counter the sampled
+    // workgroups of a scan add to (Problem::stats), how far it had got when the latest launch was made, and how many wave-tiles
+    // that launch's sampled workgroups cover - what the NEXT launch's workgroups-per-CU choice goes by (ss_scan.hip).  Racy by
+    // design when several threads search through one handle (a heuristic: any value is a valid choice).
+    unsigned long long *h_stats = nullptr;
+    unsigned long long stats_seen = 0, stats_sampled = 0;    // (accessed with relaxed __atomic builtins)
+    int last_occ = 0, last_rate = -1;                // the latest launch's choice and the rate behind it (ss_debug_last_occupancy)
+    uint32_t done_low[64] = {0}, done_hi[64] = {0};
+    uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax
+    uint64_t free_mask = 0;
+    int epoch[64] = {0};        // per slot: the "found" value of the slot's latest call
+    uint64_t upload_ticket = 0; // g_upload_ticket when d_needle had been written (a resident service acquires what is newer)
+    uint32_t block = ~0u;       // control block of the device's pool (BlockPool): everything above points into it ...
+    bool needle_own = false;    // ... except a needle too long for the block, which has an allocation of its own
+};
+extern std::atomic<uint64_t> g_upload_ticket;
+
+// exit() has begun: thread-local HIP objects and pool blocks are leaked instead of released (see ss_core.hip, ExitMark)
+bool process_exiting();
+
+// `bytes` (a multiple of 16) from host memory into device memory through the BAR, complete before anything the caller does next
+// can reach the device (ss_core.hip).
+void bar_write(uint8_t *d_dst, const uint8_t *src, size_t bytes, volatile uint32_t *hdp_flush);
+bool bar_writes_allowed();              // SLICESLICE_NO_BAR_WRITES != 1
+
+}  // namespace ssh
+
+struct ss_searcher {
+    std::vector<uint8_t> needle;
+    size_t n = 0;
+    size_t position = 0;      // the API position (what ss_searcher_position reports; x86.rs:468)
+    // The needle bytes the filter is SAID to test (ss_searcher_filter3): needle[fa], needle[fb], fa <= fb (fa == fb == 0 for
+    // one-byte needles), and - only when fb - fa <= 15 - a third one, fa < fc <= fa + 15 (== fb: none).  with_position callers
+    // get their byte plus partners (filter_for_position), `new` callers a triple chosen by choose_filter_triple,
+    // ss_searcher_set_filter3 any pair verbatim.  The result of a search never depends on them (src/lib.rs:375-378 asserts that
+    // for every position).  What the DEVICE tests is this triple, except for a pair too far apart for any kernel (see
+    // fill_problem in ss_scan.hip): first byte + two partners close behind it, the caller's far byte checked in memory.
+    size_t fa = 0, fb = 0, fc = 0;
+    size_t da = 0, db = 0, dc = 0;  // the triple the device tests (derive_device_filter): == fa, fb, fc unless the pair is too far apart
+    size_t far = 0;                 // ... then: the caller's far byte (== fb), tested first when a candidate reaches memory; else 0
+    int variant = 0;          // tuning builds only (ss_searcher_set_variant / _set_grid); 0 = automatic
+    int grid = 0;
+    bool timing = false;
+    // Searches in flight (>= 0), or -1 while ss_searcher_set_filter3 rewrites fa / fb / fc: the setter refuses
+    // (SS_ERR_ARGUMENT) while a search runs instead of letting it read a half-written triple.
+    mutable std::atomic<int> gate{0};
+#ifdef SS_TEST_HOOKS
+    mutable std::atomic<int> debug_fail_scans{0};       // the next k enqueue_scan calls fail (ss_debug_fail_next_scans)
+#endif
+    mutable std::atomic<bool> used_async{false};        // an *_async entry point may have left work behind (ss_searcher_free waits)
+    mutable std::mutex mu;
+    mutable std::condition_variable slot_cv;    // signalled when a flag slot is released
+    mutable std::deque<ssh::PerDevice> per;     // deque: PerDevice pointers handed out stay valid as devices are added
+};
+
+namespace ssh {
+
+// One search's hold on the searcher's filter bytes (see ss_searcher::gate).  Counting, so entry points may nest.
+struct SearchGate {
+    const ss_searcher *s;
+    explicit SearchGate(const ss_searcher *s_) : s(s_)
+    {
+        for (;;) {
+            int v = s->gate.load(std::memory_order_acquire);
+            if (v >= 0 && s->gate.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) return;
+            if (v < 0) std::this_thread::yield();       // a setter is writing: a handful of stores
+        }
+    }
+    ~SearchGate() { s->gate.fetch_sub(1, std::memory_order_acq_rel); }
+    SearchGate(const SearchGate &) = delete;
+    SearchGate &operator=(const SearchGate &) = delete;
+};
+
+// "One search at a time" scratch owners (communicators, communicator sets): the second concurrent call is refused.
+struct BusyGuard {
+    std::atomic<bool> *flag;
+    bool mine;
+    explicit BusyGuard(std::atomic<bool> *f) : flag(f), mine(!f->exchange(true, std::memory_order_acq_rel)) {}
+    ~BusyGuard() { if (mine) flag->store(false, std::memory_order_release); }
+    BusyGuard(const BusyGuard &) = delete;
+    BusyGuard &operator=(const BusyGuard &) = delete;
+};
+
+// ---- ss_core.hip ------------------------------------------------------------------------------------------------------
+int get_per_device(const ss_searcher *s, PerDevice **out);      // the searcher's state on the CURRENT device (uploads on first use)
+int acquire_slot(const ss_searcher *s, PerDevice *p);
+void release_slot(const ss_searcher *s, PerDevice *p, int k);
+int next_epoch(PerDevice *p, int k);
+void start_over(PerDevice *p, int k);
+
+// Cost of one filter byte: a static, corpus-free rarity class, or - with a byte histogram of (a sample of) the haystack -
+// 8 * log2(count + 1): summing costs then compares PRODUCTS of frequencies, which is what the candidate rate of a multi-byte
+// filter is (bytes taken as independent).
+struct ByteCost {
+    int cost[256];
+    explicit ByteCost(const uint64_t *hist);
+    int operator()(uint8_t b) const { return cost[b]; }
+};
+size_t choose_third(const uint8_t *needle, size_t n, size_t fa, size_t fb, const ByteCost &cost, size_t other = ~(size_t)0);
+
+// ---- ss_scan.hip ------------------------------------------------------------------------------------------------------
+// What a launch needs to know about a Problem besides the Problem itself.
+struct ProblemShape {
+    size_t position, position3;     // the second / third filter byte, relative to the first (ordered by dword: q3 <= Q)
+    size_t fa;                      // index of the first filter byte
+    bool one_byte;
+};
+// The Problem of (searcher, haystack): everything but the sink-side fields (epoch, host_flag, completion word), which the caller
+// sets.  Preconditions: 1 <= n <= len.
+void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_hay, size_t len, uint64_t find_base, ss::Problem *out,
+                  ProblemShape *shape);
+// Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, set to `epoch` by the wave that
+// finds the needle, never cleared.  find == true: *d_sink is a uint64, atomicMin'ed with find_base + offset of every match the grid
+// sees (the leftmost one survives).  Preconditions: 1 <= n <= len.  done_slot >= 0: the call owns flag slot `done_slot` and would
+// like to wait on the slot's completion word instead of the stream; granted (*used_done = true) for small grids.
+int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find = false,
+                 uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1, int done_slot = -1, bool *used_done = nullptr);
+void timer_forget(const ss_searcher *s);                         // ss_searcher_free: the calling thread's timing record
+
+// Scans too large for the workgroup count of the completion word still answer through a pinned word when the scan is short enough
+// to be waited for by spinning: a one-lane kernel behind the scan (behind the all-reduce, for a sharded search) stores the word.
+constexpr double kSpinMaxEstimateUs = 20000.0;
+constexpr double kSpinMinEstimateUs = 0.5;
+inline double scan_estimate_us(size_t len) { return (double)len / 7.0e6; }          // 7 TB/s
+bool spin_wait_enabled();                                                           // SLICESLICE_SPIN_WAIT != 0
+bool spin_for_word(const long long *word, int epoch, double estimate_us, int *found);
+bool spin_for_shard_word(const long long *word, int epoch, double estimate_us, int *found, int *failed);
+// one-lane kernels behind a scan / an all-reduce (aux_kernels.hpp): answer word epoch << 1 | found (pair: epoch << 2 | failed << 1 |
+// found), and find()'s minimum into its pinned mirror (pair: {offset, status}; else the device word is re-armed)
+hipError_t launch_signal_flag(hipStream_t st, const int *d_flag, int epoch, long long *h_word, int pair);
+hipError_t launch_publish_best(hipStream_t st, uint64_t *d_best, uint64_t *h_best, int pair);
+
+#ifdef SS_TEST_HOOKS
+bool cross_exit_enabled();        // SLICESLICE_CROSS_EXIT != 0 (hooks builds: the relay's effect is measured by a test)
+#else
+inline bool cross_exit_enabled() { return true; }
+#endif
+
+}  // namespace ssh

@@ -36,73 +36,74 @@ _int = ctypes.c_int
 _pint = ctypes.POINTER(ctypes.c_int)
 _pvp = ctypes.POINTER(ctypes.c_void_p)
 
-# every symbol include/sliceslice_hip.h declares: name -> (restype, argtypes)
+_psz = ctypes.POINTER(_sz)
+_pu64 = ctypes.POINTER(_u64)
+
+# every symbol include/sliceslice_hip.h declares (the product library): name -> (restype, argtypes)
 ABI = {
     "ss_searcher_new": (_int, [_vp, _sz, _pvp]),
     "ss_searcher_with_position": (_int, [_vp, _sz, _sz, _pvp]),
     "ss_searcher_free": (None, [_vp]),
-    "ss_searcher_needle_len": (_sz, [_vp]),
-    "ss_searcher_position": (_sz, [_vp]),
-    "ss_searcher_filter": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
-    "ss_searcher_set_filter": (_int, [_vp, _sz, _sz]),
-    "ss_choose_filter_pair": (_int, [_vp, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
-    "ss_searcher_filter3": (_int, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_searcher_info": (_int, [_vp, _psz, _psz]),
+    "ss_searcher_filter3": (_int, [_vp, _psz, _psz, _psz]),
     "ss_searcher_set_filter3": (_int, [_vp, _sz, _sz, _sz]),
-    "ss_choose_filter_triple": (_int, [_vp, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
-    "ss_choose_filter_for_position": (_int, [_vp, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
-    "ss_choose_filter_triple_hist": (_int, [_vp, _sz, _vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_byte_histogram_device": (_int, [_vp, _sz, _sz, _vp, _vp]),
+    "ss_choose_position": (_int, [_vp, _sz, _vp, _psz]),
+    "ss_choose_filter_triple": (_int, [_vp, _sz, _vp, _psz, _psz, _psz]),
     "ss_search_device": (_int, [_vp, _vp, _sz, _vp, _pint]),
     "ss_search_device_async": (_int, [_vp, _vp, _sz, _vp, _vp]),
-    "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
-    "ss_find_device": (_int, [_vp, _vp, _sz, _vp, ctypes.POINTER(_u64)]),
+    "ss_find_device": (_int, [_vp, _vp, _sz, _vp, _pu64]),
+    "ss_find_host": (_int, [_vp, _vp, _sz, _pu64]),
     "ss_find_device_async": (_int, [_vp, _vp, _sz, _u64, _vp, _vp]),
-    "ss_find_host": (_int, [_vp, _vp, _sz, ctypes.POINTER(_u64)]),
+    "ss_search_host": (_int, [_vp, _vp, _sz, _pint]),
     "ss_search_file": (_int, [_vp, ctypes.c_char_p, _pint]),
-    "ss_byte_histogram_device": (_int, [_vp, _sz, _sz, _vp, _vp]),
-    "ss_choose_position": (_int, [_vp, _sz, _vp, ctypes.POINTER(_sz)]),
     "ss_search_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "ss_search_pairs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_find_batched": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "ss_search_host_all": (_int, [_vp, _vp, _sz, _int, _pint, _pint]),
+    "ss_batch_plan_create": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp, _pvp]),
+    "ss_batch_plan_run": (_int, [_vp, _vp, _vp]),
+    "ss_batch_plan_free": (None, [_vp]),
+    "ss_search_pairs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_searcher_set_timing": (_int, [_vp, _int]),
     "ss_searcher_last_kernel_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
-    "ss_searcher_set_variant": (_int, [_vp, _int]),
-    "ss_searcher_set_grid": (_int, [_vp, _int]),
-    "ss_fill_random_device": (_int, [_vp, _u64, _sz, _u64, _vp]),
-    "ss_fill_random_host": (_int, [_vp, _u64, _sz, _u64]),
-    "ss_read_ceiling": (_int, [_vp, _sz, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
+    "ss_shard_range": (_int, [_sz, _sz, _int, _int, _psz, _psz]),
     "ss_comm_unique_id": (_int, [_vp]),
     "ss_comm_init_rank": (_int, [_vp, _int, _int, _pvp]),
     "ss_comm_free": (None, [_vp]),
     "ss_comm_count": (_int, [_vp, _pint]),
+    "ss_search_sharded": (_int, [_vp, _vp, _sz, _vp, _vp, _pint]),
+    "ss_find_sharded": (_int, [_vp, _vp, _sz, _u64, _vp, _vp, _pu64]),
     "ss_comm_init_all": (_int, [_int, _pint, _pvp]),
     "ss_comm_set_free": (None, [_vp]),
-    "ss_comm_set_size": (_int, [_vp]),
-    "ss_comm_set_device": (_int, [_vp, _int, _pint]),
     "ss_comm_set_combine": (_int, [_vp, _int]),
-    "ss_search_sharded_all": (_int, [_vp, _pvp, ctypes.POINTER(_sz), _vp, _pint]),
-    "ss_find_sharded_all": (_int, [_vp, _pvp, ctypes.POINTER(_sz), ctypes.POINTER(_u64), _vp, ctypes.POINTER(_u64)]),
-    "ss_comm_allreduce_flag": (_int, [_vp, _vp, _vp, _pint]),
-    "ss_search_sharded": (_int, [_vp, _vp, _sz, _vp, _vp, _pint]),
-    "ss_find_sharded": (_int, [_vp, _vp, _sz, _u64, _vp, _vp, ctypes.POINTER(_u64)]),
-    "ss_shard_range": (_int, [_sz, _sz, _int, _int, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "ss_search_sharded_all": (_int, [_vp, _pvp, _psz, _vp, _pint]),
+    "ss_find_sharded_all": (_int, [_vp, _pvp, _psz, _pu64, _vp, _pu64]),
+    "ss_service_start": (_int, [_int, ctypes.c_double, _pvp]),
+    "ss_service_search": (_int, [_vp, _vp, _vp, _sz, _pint]),
+    "ss_service_bind": (_int, [_vp, _vp, _sz]),
+    "ss_service_stop": (None, [_vp]),
     "ss_last_error": (ctypes.c_char_p, []),
-    "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, ctypes.POINTER(_sz)]),
-    "ss_version": (ctypes.c_char_p, []),
+    "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, _psz]),
+}
+# include/sliceslice_hip_tuning.h, group 1: libsliceslice_hip_tools.so
+TOOLS_ABI = {
+    "ss_fill_random_device": (_int, [_vp, _u64, _sz, _u64, _vp]),
+    "ss_fill_random_host": (_int, [_vp, _u64, _sz, _u64]),
+    "ss_read_ceiling": (_int, [_vp, _sz, _vp, _int, ctypes.POINTER(ctypes.c_float)]),
     "ss_selftest_dpp": (_int, [_vp]),
+    "ss_tools_last_error": (ctypes.c_char_p, []),
+}
+# ... group 2: builds with -DSS_TEST_HOOKS only (libsliceslice_hip_tuning.so, the sanitizer builds)
+HOOKS_ABI = {
+    "ss_version": (ctypes.c_char_p, []),
+    "ss_searcher_set_variant": (_int, [_vp, _int]),
+    "ss_searcher_set_grid": (_int, [_vp, _int]),
+    "ss_choose_filter_for_position": (_int, [_vp, _sz, _sz, _psz, _psz, _psz]),
     "ss_debug_set_epochs": (_int, [_vp, _int]),
     "ss_debug_set_completion_state": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
-    "ss_mailbox_round_trip_us": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
-    "ss_service_start": (_int, [_int, ctypes.c_double, _pvp]),
-    "ss_service_search": (_int, [_vp, _vp, _vp, _sz, _pint]),
-    "ss_service_set_default": (_int, [_vp, _int]),
-    "ss_service_counters": (_int, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
-    "ss_service_bind": (_int, [_vp, _vp, _sz]),
-    "ss_service_unbind": (_int, [_vp]),
-    "ss_service_settled_requests": (_int, [_vp, ctypes.POINTER(_u64)]),
-    "ss_service_stop": (None, [_vp]),
+    "ss_debug_last_occupancy": (_int, [_vp, _pint, _pint]),
+    "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
 
 
@@ -117,34 +118,93 @@ class PositionError(SlicesliceError, AssertionError):
     src/x86.rs:473 `assert_eq!(position, 0)`)."""
 
 
+def _preload_torch():
+    if "torch" in sys.modules or os.environ.get("SLICESLICE_PRELOAD_TORCH", "1") == "1":
+        # torch wheels bundle their own libamdhip64 (same soname).  Loading torch first makes this
+        # library bind to the SAME HIP runtime, so torch streams/pointers are valid in it.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
+def _bind(L, table, strict):
+    for name, (res, args) in table.items():
+        if not strict and not hasattr(L, name):
+            continue
+        fn = getattr(L, name)          # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def _load(path):
+    """One build of the library: every product symbol must be there; the hooks are bound where the build has them."""
+    _preload_torch()
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    _bind(L, ABI, strict=True)
+    _bind(L, HOOKS_ABI, strict=False)
+    L.has_hooks = hasattr(L, "ss_debug_fail_next_scans")
+    return L
+
+
 def lib():
-    """Loads csrc/libsliceslice_hip.so (building it with hipcc if it is missing).  Fails loudly."""
+    """Loads csrc/libsliceslice_hip.so (building it with hipcc if it is missing).  Fails loudly.
+    SLICESLICE_HIP_LIB=<path> loads another build of the SAME library instead (the tuning build, an A/B build)."""
     global _lib
     if _lib is None:
-        if "torch" in sys.modules or os.environ.get("SLICESLICE_PRELOAD_TORCH", "1") == "1":
-            # torch wheels bundle their own libamdhip64 (same soname).  Loading torch first makes this
-            # library bind to the SAME HIP runtime, so torch streams/pointers are valid in it.
-            try:
-                import torch  # noqa: F401
-            except Exception:
-                pass
-        # SLICESLICE_HIP_LIB: load a specific build of the SAME library (A/B timing of two kernel versions)
-        path = os.environ.get("SLICESLICE_HIP_LIB") or _build.build()
-        L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        for name, (res, args) in ABI.items():
-            if os.environ.get("SLICESLICE_HIP_LIB") and not hasattr(L, name):
-                continue                   # an older build under A/B test may lack newer entry points
-            fn = getattr(L, name)          # AttributeError if the header and the library disagree
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(os.environ.get("SLICESLICE_HIP_LIB") or _build.build())
     return _lib
 
 
-def _check(rc):
+_tools = None
+_tuning = None
+
+
+def tools_lib():
+    """csrc/libsliceslice_hip_tools.so: the benchmark helpers (synthetic haystack generator, read ceiling, self-test)."""
+    global _tools
+    if _tools is None:
+        _build.build()
+        _preload_torch()
+        _tools = _bind(ctypes.CDLL(_build.tools_library_path(), mode=ctypes.RTLD_LOCAL), TOOLS_ABI, strict=True)
+    return _tools
+
+
+class tuning_build:
+    """``with ss.tuning_build():`` - inside the block ``lib()`` is libsliceslice_hip_tuning.so (every kernel variant, the test
+    hooks of include/sliceslice_hip_tuning.h).  Objects remember the library they were made with, so searchers created
+    inside keep working (and are freed by the right library) after the block."""
+
+    def __enter__(self):
+        global _lib, _tuning
+        if _tuning is None:
+            _tuning = _load(_build.build_tuning())
+        self._saved, _lib = _lib, _tuning
+        return _tuning
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+def _hooks(L):
+    if not getattr(L, "has_hooks", False):
+        raise SlicesliceError(SS_ERR_ARGUMENT, "this entry point exists in builds with -DSS_TEST_HOOKS only (libsliceslice_hip_tuning.so: "
+                                               "`with ss.tuning_build():` or SLICESLICE_HIP_LIB=<path>)")
+    return L
+
+
+def _check(rc, L=None):
     if rc != SS_OK:
-        msg = lib().ss_last_error().decode("utf-8", "replace")
+        msg = (L or lib()).ss_last_error().decode("utf-8", "replace")
         raise (PositionError if rc == SS_ERR_POSITION else SlicesliceError)(rc, msg)
+
+
+def _check_tools(rc):
+    if rc != SS_OK:
+        raise SlicesliceError(rc, tools_lib().ss_tools_last_error().decode("utf-8", "replace"))
 
 
 def _host_view(b):
@@ -204,10 +264,14 @@ class DynamicHipSearcher:
         k, addr, n = _host_view(nb)
         self._h = ctypes.c_void_p()
         self._needle = nb
+        L = self._L = lib()                 # the build this searcher belongs to (see tuning_build)
         if position is None:
-            _check(lib().ss_searcher_new(addr, n, ctypes.byref(self._h)))
+            _check(L.ss_searcher_new(addr, n, ctypes.byref(self._h)), L)
         else:
-            _check(lib().ss_searcher_with_position(addr, n, position % (1 << 64), ctypes.byref(self._h)))
+            _check(L.ss_searcher_with_position(addr, n, position % (1 << 64), ctypes.byref(self._h)), L)
+
+    def _ck(self, rc):
+        _check(rc, self._L)
 
     # -- reference-shaped constructors ---------------------------------------------------------------
     @classmethod
@@ -224,7 +288,9 @@ class DynamicHipSearcher:
 
     @property
     def position(self):
-        return lib().ss_searcher_position(self._h)
+        n, pos = _sz(0), _sz(0)
+        self._ck(self._L.ss_searcher_info(self._h, ctypes.byref(n), ctypes.byref(pos)))
+        return pos.value
 
     # -- the hot path ------------------------------------------------------------------------------------
     def search_in(self, haystack, stream=None):
@@ -237,14 +303,14 @@ class DynamicHipSearcher:
                 raise TypeError("device haystack must be a contiguous 1-byte tensor")
             with _on_device_of(haystack):
                 st = stream if stream is not None else _current_stream_handle()
-                _check(lib().ss_search_device(self._h, haystack.data_ptr(), haystack.numel(), st, ctypes.byref(found)))
+                self._ck(self._L.ss_search_device(self._h, haystack.data_ptr(), haystack.numel(), st, ctypes.byref(found)))
         elif isinstance(haystack, tuple):
             ptr, length = haystack
             st = stream if stream is not None else _current_stream_handle()
-            _check(lib().ss_search_device(self._h, ptr, length, st, ctypes.byref(found)))
+            self._ck(self._L.ss_search_device(self._h, ptr, length, st, ctypes.byref(found)))
         else:
             k, addr, n = _host_view(haystack)
-            _check(lib().ss_search_host(self._h, addr, n, ctypes.byref(found)))
+            self._ck(self._L.ss_search_host(self._h, addr, n, ctypes.byref(found)))
         return bool(found.value)
 
     inlined_search_in = search_in       # src/x86.rs:498
@@ -258,66 +324,72 @@ class DynamicHipSearcher:
             ptr, length = haystack if isinstance(haystack, tuple) else (haystack.data_ptr(), haystack.numel())
             with _on_device_of(haystack):
                 st = stream if stream is not None else _current_stream_handle()
-                _check(lib().ss_find_device(self._h, ptr, length, st, ctypes.byref(pos)))
+                self._ck(self._L.ss_find_device(self._h, ptr, length, st, ctypes.byref(pos)))
         else:
             if _is_tensor(haystack):
                 haystack = haystack.numpy()
             k, addr, n = _host_view(haystack)
-            _check(lib().ss_find_host(self._h, addr, n, ctypes.byref(pos)))
+            self._ck(self._L.ss_find_host(self._h, addr, n, ctypes.byref(pos)))
         return None if pos.value == (1 << 64) - 1 else pos.value
 
     def find_async(self, haystack, d_best, base_offset=0, stream=None):
         """Enqueue only: atomicMin base_offset + offset into the uint64 device tensor d_best (init: all ones)."""
         with _on_device_of(haystack):
             st = stream if stream is not None else _current_stream_handle()
-            _check(lib().ss_find_device_async(self._h, haystack.data_ptr(), haystack.numel(), base_offset, st,
+            self._ck(self._L.ss_find_device_async(self._h, haystack.data_ptr(), haystack.numel(), base_offset, st,
                                               d_best.data_ptr()))
 
     def search_in_async(self, haystack, d_flag, stream=None):
         """Enqueue only: OR the result into the int32 device tensor ``d_flag`` (caller-zeroed)."""
         with _on_device_of(haystack):
             st = stream if stream is not None else _current_stream_handle()
-            _check(lib().ss_search_device_async(self._h, haystack.data_ptr(), haystack.numel(), st, d_flag.data_ptr()))
+            self._ck(self._L.ss_search_device_async(self._h, haystack.data_ptr(), haystack.numel(), st, d_flag.data_ptr()))
 
     # -- tuning / measurement hooks ------------------------------------------------------------------
     @property
     def filter(self):
-        """(first, second): indices of the two needle bytes the device filter tests."""
-        a, b = _sz(0), _sz(0)
-        _check(lib().ss_searcher_filter(self._h, ctypes.byref(a), ctypes.byref(b)))
-        return a.value, b.value
+        """(first, second): indices of the first two needle bytes the filter tests."""
+        return self.filter3[:2]
 
     @property
     def filter3(self):
         """(first, second, third): the bytes of the first-phase filter (third == second: a two-byte filter)."""
         a, b, c = _sz(0), _sz(0), _sz(0)
-        _check(lib().ss_searcher_filter3(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        self._ck(self._L.ss_searcher_filter3(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
 
     def set_filter(self, first, second, third=None):
-        if third is None:
-            _check(lib().ss_searcher_set_filter(self._h, first, second))
-        else:
-            _check(lib().ss_searcher_set_filter3(self._h, first, second, third))
+        """ss_searcher_set_filter3; third=None: a plain two-byte filter (third == second)."""
+        self._ck(self._L.ss_searcher_set_filter3(self._h, first, second, second if third is None else third))
 
     def set_timing(self, on=True):
-        _check(lib().ss_searcher_set_timing(self._h, int(on)))
+        self._ck(self._L.ss_searcher_set_timing(self._h, int(on)))
 
     def last_kernel_ms(self):
         ms = ctypes.c_float(0)
-        _check(lib().ss_searcher_last_kernel_ms(self._h, ctypes.byref(ms)))
+        self._ck(self._L.ss_searcher_last_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
 
     def set_variant(self, variant):
-        _check(lib().ss_searcher_set_variant(self._h, int(variant)))
+        """Tuning builds only (ss_searcher_set_variant); 0 - the automatic choice - is accepted by every build."""
+        if int(variant) != 0 or getattr(self._L, "has_hooks", False):
+            self._ck(_hooks(self._L).ss_searcher_set_variant(self._h, int(variant)))
 
     def set_grid(self, blocks):
-        _check(lib().ss_searcher_set_grid(self._h, int(blocks)))
+        if int(blocks) != 0 or getattr(self._L, "has_hooks", False):
+            self._ck(_hooks(self._L).ss_searcher_set_grid(self._h, int(blocks)))
+
+    def last_occupancy(self):
+        """(workgroups per CU of the latest scan, candidate tiles per 1024 it went by or -1) - hooks builds."""
+        w, r = ctypes.c_int(0), ctypes.c_int(0)
+        self._ck(_hooks(self._L).ss_debug_last_occupancy(self._h, ctypes.byref(w), ctypes.byref(r)))
+        return w.value, r.value
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and _lib is not None:
-            _lib.ss_searcher_free(h)
+        L = getattr(self, "_L", None)
+        if h and L is not None and _lib is not None:
+            L.ss_searcher_free(h)
 
 
 class HipSearcher(DynamicHipSearcher):
@@ -391,22 +463,30 @@ class ShardedSearcher:
         self._comm = None
         self._flag = None
         self._flag_next = 0
+        self._L = self._searcher._L if self._searcher is not None else lib()
         if backend == "rccl":
             self._init_rccl()
 
     def shard_range(self, total_len):
         return shard_range(total_len, len(self.needle), self.nranks, self.rank)
 
+    def _ck(self, rc):
+        _check(rc, self._L)
+
+    def fail_next_scans(self, count=1):
+        """Hooks builds: the next `count` scans of this rank fail before they reach the device (ss_debug_fail_next_scans)."""
+        self._ck(_hooks(self._L).ss_debug_fail_next_scans(self._searcher._h, count))
+
     def _init_rccl(self):
         import torch
         uid = (ctypes.c_uint8 * 128)()
         box = [None]
-        if self.rank == 0 and lib().ss_comm_unique_id(uid) == 0:
+        if self.rank == 0 and self._L.ss_comm_unique_id(uid) == 0:
             box = [bytes(uid)]
         self._dist.broadcast_object_list(box, src=0, group=self.group)     # None: rank 0 has no id to offer
         if box[0] is None:
             raise SlicesliceError(SS_ERR_RCCL, "rank 0 could not create an RCCL unique id" +
-                                  (": " + lib().ss_last_error().decode("utf-8", "replace") if self.rank == 0 else ""))
+                                  (": " + self._L.ss_last_error().decode("utf-8", "replace") if self.rank == 0 else ""))
         uid = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
         comm = ctypes.c_void_p()
         # ncclCommInitRank is a collective: a rank on which it fails (or never returns) must not leave the others
@@ -421,8 +501,8 @@ class ShardedSearcher:
             try:
                 if dev is not None:
                     torch.cuda.set_device(dev)
-                result["rc"] = lib().ss_comm_init_rank(uid, self.nranks, self.rank, ctypes.byref(comm))
-                result["err"] = lib().ss_last_error().decode("utf-8", "replace") if result["rc"] else ""
+                result["rc"] = self._L.ss_comm_init_rank(uid, self.nranks, self.rank, ctypes.byref(comm))
+                result["err"] = self._L.ss_last_error().decode("utf-8", "replace") if result["rc"] else ""
             except Exception as e:                                   # pragma: no cover - ctypes / loader failures
                 result["rc"], result["err"] = -1, repr(e)
 
@@ -435,7 +515,7 @@ class ShardedSearcher:
         self._dist.all_reduce(ok, op=self._dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) != 1:
             if mine:
-                lib().ss_comm_free(comm)
+                self._L.ss_comm_free(comm)
             why = "timed out" if t.is_alive() else (result.get("err") or "failed on another rank")
             raise SlicesliceError(SS_ERR_RCCL, "native RCCL communicator not built on every rank (this rank: %s)" % why)
         self._comm = comm
@@ -466,7 +546,7 @@ class ShardedSearcher:
             found = ctypes.c_int(0)
             with _on_device_of(shard):
                 st = stream if stream is not None else _current_stream_handle()
-                _check(lib().ss_search_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), self._comm, st,
+                self._ck(self._L.ss_search_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), self._comm, st,
                                                ctypes.byref(found)))
             return bool(found.value)
         # torch transport: the scan, the flag housekeeping and the all-reduce must all be ordered on ONE stream -
@@ -522,7 +602,7 @@ class ShardedSearcher:
             pos = _u64(0)
             with _on_device_of(shard):
                 st = stream if stream is not None else _current_stream_handle()
-                _check(lib().ss_find_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), shard_begin, self._comm, st,
+                self._ck(self._L.ss_find_sharded(self._searcher._h, shard.data_ptr(), shard.numel(), shard_begin, self._comm, st,
                                              ctypes.byref(pos)))
             return None if pos.value == (1 << 64) - 1 else pos.value
         else:
@@ -557,12 +637,12 @@ class ShardedSearcher:
         if self._comm is None:
             return None
         n = ctypes.c_int(0)
-        _check(lib().ss_comm_count(self._comm, ctypes.byref(n)))
+        self._ck(self._L.ss_comm_count(self._comm, ctypes.byref(n)))
         return n.value
 
     def close(self):
         if self._comm is not None and _lib is not None:
-            _lib.ss_comm_free(self._comm)
+            self._L.ss_comm_free(self._comm)
             self._comm = None
 
 
@@ -581,12 +661,20 @@ class NodeSearcher:
         self.devices = list(devices)
         arr = (ctypes.c_int * len(self.devices))(*self.devices)
         self._set = ctypes.c_void_p()
-        _check(lib().ss_comm_init_all(len(self.devices), arr, ctypes.byref(self._set)))
+        L = self._L = lib()
+        _check(L.ss_comm_init_all(len(self.devices), arr, ctypes.byref(self._set)), L)
         self._searcher = DynamicHipSearcher(needle, position)
         self.needle = bytes(needle)
 
     def set_combine(self, mode):
-        _check(lib().ss_comm_set_combine(self._set, mode))
+        self._ck(self._L.ss_comm_set_combine(self._set, mode))
+
+    def _ck(self, rc):
+        _check(rc, self._L)
+
+    def set_epoch(self, value):
+        """Hooks builds: move the set's "found" epoch (ss_debug_set_comm_epoch) so that a test can cross the 2^31 wrap."""
+        self._ck(_hooks(self._L).ss_debug_set_comm_epoch(None, self._set, value))
 
     def shard_range(self, total_len, g):
         return shard_range(total_len, len(self.needle), len(self.devices), g)
@@ -603,19 +691,19 @@ class NodeSearcher:
     def search_in(self, shards):
         ptrs, lens = self._args(shards)
         found = ctypes.c_int(0)
-        _check(lib().ss_search_sharded_all(self._searcher._h, ptrs, lens, self._set, ctypes.byref(found)))
+        self._ck(self._L.ss_search_sharded_all(self._searcher._h, ptrs, lens, self._set, ctypes.byref(found)))
         return bool(found.value)
 
     def find(self, shards, begins):
         ptrs, lens = self._args(shards)
         b = (_u64 * len(begins))(*begins)
         pos = _u64(0)
-        _check(lib().ss_find_sharded_all(self._searcher._h, ptrs, lens, b, self._set, ctypes.byref(pos)))
+        self._ck(self._L.ss_find_sharded_all(self._searcher._h, ptrs, lens, b, self._set, ctypes.byref(pos)))
         return None if pos.value == (1 << 64) - 1 else pos.value
 
     def close(self):
         if getattr(self, "_set", None) and _lib is not None:
-            _lib.ss_comm_set_free(self._set)
+            self._L.ss_comm_set_free(self._set)
             self._set = None
 
     def __del__(self):
@@ -630,44 +718,41 @@ class SearchService:
     at a time from a mailbox in device memory that the host writes through the PCIe BAR - no launch per search (5 us instead
     of 8.5-9.5; ``bind`` a haystack that does not change between searches).  ``search_in(searcher, haystack)`` has the semantics of
     ``searcher.search_in(haystack)`` for a device haystack whose bytes are COMPLETE (the service is not ordered behind pending
-    stream work); ``set_default()`` routes qualifying ``search_in`` calls of every searcher on this device through it."""
+    stream work)."""
 
     def __init__(self, workgroups=0, lease_ms=0.0):
         self._h = ctypes.c_void_p()
-        _check(lib().ss_service_start(int(workgroups), float(lease_ms), ctypes.byref(self._h)))
+        L = self._L = lib()
+        _check(L.ss_service_start(int(workgroups), float(lease_ms), ctypes.byref(self._h)), L)
+
+    def _ck(self, rc):
+        _check(rc, self._L)
 
     def search_in(self, searcher, haystack):
         found = ctypes.c_int(0)
         ptr, n = (haystack.data_ptr(), haystack.numel()) if hasattr(haystack, "data_ptr") else haystack
-        _check(lib().ss_service_search(self._h, searcher._h, ptr if n else None, n, ctypes.byref(found)))
+        assert searcher._L is self._L, "searcher and service come from different builds of the library"
+        self._ck(self._L.ss_service_search(self._h, searcher._h, ptr if n else None, n, ctypes.byref(found)))
         return bool(found.value)
-
-    def set_default(self, enabled=True):
-        _check(lib().ss_service_set_default(self._h, 1 if enabled else 0))
 
     def bind(self, haystack):
         """The caller vouches that this device range stays unchanged until ``unbind()`` / the next ``bind``: searches inside it
         skip the per-request cache acquire (all but the first, and those whose searcher was uploaded after it)."""
         ptr, n = (haystack.data_ptr(), haystack.numel()) if hasattr(haystack, "data_ptr") else haystack
-        _check(lib().ss_service_bind(self._h, ptr if n else None, n))
+        self._ck(self._L.ss_service_bind(self._h, ptr if n else None, n))
 
     def unbind(self):
-        _check(lib().ss_service_unbind(self._h))
-
-    def settled_requests(self):
-        v = _u64(0)
-        _check(lib().ss_service_settled_requests(self._h, ctypes.byref(v)))
-        return v.value
+        self._ck(self._L.ss_service_bind(self._h, None, 0))
 
     def counters(self):
-        """(requests served, kernel launches): a burst of requests shares one residency of the kernel."""
-        r, k = _u64(0), _u64(0)
-        _check(lib().ss_service_counters(self._h, ctypes.byref(r), ctypes.byref(k)))
-        return r.value, k.value
+        """(requests served, kernel launches, requests that skipped the acquire) - hooks builds (ss_service_counters)."""
+        r, k, t = _u64(0), _u64(0), _u64(0)
+        self._ck(_hooks(self._L).ss_service_counters(self._h, ctypes.byref(r), ctypes.byref(k), ctypes.byref(t)))
+        return r.value, k.value, t.value
 
     def stop(self):
         if getattr(self, "_h", None) and _lib is not None:
-            _lib.ss_service_stop(self._h)
+            self._L.ss_service_stop(self._h)
             self._h = None
 
     close = stop
@@ -685,11 +770,45 @@ class SearchService:
             pass
 
 
-def mailbox_round_trip_us(iters=2000):
-    """(median, minimum) microseconds of a host -> resident device lane -> host round trip through pinned memory."""
-    med, mn = ctypes.c_double(0), ctypes.c_double(0)
-    _check(lib().ss_mailbox_round_trip_us(iters, ctypes.byref(med), ctypes.byref(mn)))
-    return med.value, mn.value
+class BatchPlan:
+    """Plan once, search many (ss_batch_plan_*): the per-problem set-up of ``search_batched`` / ``find_batched`` done once - the
+    reference builds its 4,585 searchers once and times the searches (bench/benches/i386.rs:246-256).  ``run()`` is ONE kernel
+    launch that also re-arms the outputs; it can be captured into a hipGraph.  Arguments as ``search_batched``; the tensors
+    must stay alive (and their ranges / needle bytes unchanged) as long as the plan is used."""
+
+    def __init__(self, haystacks, hay_off, needles, needle_off, position=None, find=False, stream=None, hay_ranges=None,
+                 needle_ranges=None):
+        hb, he, count = _ranges(hay_off, *(hay_ranges or (None, None)))
+        nb, ne, ncount = _ranges(needle_off, *(needle_ranges or (None, None)))
+        assert count == ncount
+        self._keep = (haystacks, hay_off, needles, needle_off, position, hay_ranges, needle_ranges)
+        self.count, self.find, self.device = count, bool(find), haystacks.device
+        self._h = ctypes.c_void_p()
+        L = self._L = lib()
+        st = stream if stream is not None else _current_stream_handle()
+        _check(L.ss_batch_plan_create(haystacks.data_ptr(), hb, he, needles.data_ptr(), nb, ne,
+                                      position.data_ptr() if position is not None else None, count, int(self.find), st,
+                                      ctypes.byref(self._h)), L)
+
+    def run(self, out=None, stream=None):
+        """Enqueues the search; returns the output tensor (int32 flags, or int64 offsets with -1 = absent for find plans)."""
+        import torch
+        if out is None:
+            out = torch.empty(self.count, dtype=torch.int64 if self.find else torch.int32, device=self.device)
+        st = stream if stream is not None else _current_stream_handle()
+        _check(self._L.ss_batch_plan_run(self._h, st, out.data_ptr()), self._L)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            self._L.ss_batch_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _ranges(off, begin, end):
@@ -730,19 +849,10 @@ def find_batched(haystacks, hay_off, needles, needle_off, stream=None, hay_range
     return pos                                      # SS_NPOS (all ones) reads as -1
 
 
-def search_host_all(searcher, haystack, devices):
-    """search_in for a HOST buffer over several GPUs (ss_search_host_all): every device uploads and scans its own range."""
-    buf = np.frombuffer(haystack, dtype=np.uint8) if not isinstance(haystack, np.ndarray) else np.ascontiguousarray(haystack, dtype=np.uint8)
-    devs = (ctypes.c_int * len(devices))(*devices)
-    found = ctypes.c_int(0)
-    _check(lib().ss_search_host_all(searcher._h, buf.ctypes.data if buf.size else None, buf.size, len(devices), devs, ctypes.byref(found)))
-    return bool(found.value)
-
-
 def search_file(searcher, path):
     """examples/grep.rs:42-56: map the file, one search_in (row f2)."""
     found = ctypes.c_int(0)
-    _check(lib().ss_search_file(searcher._h, os.fsencode(path), ctypes.byref(found)))
+    _check(searcher._L.ss_search_file(searcher._h, os.fsencode(path), ctypes.byref(found)), searcher._L)
     return bool(found.value)
 
 
@@ -763,52 +873,48 @@ def choose_position(needle, hist=None):
     return pos.value
 
 
-def choose_filter_pair(needle):
-    """(first, second): the two needle bytes `DynamicHipSearcher.new(needle)` lets the device filter test."""
-    nb = bytes(needle)
-    a, b = _sz(0), _sz(0)
-    _check(lib().ss_choose_filter_pair(nb, len(nb), ctypes.byref(a), ctypes.byref(b)))
-    return a.value, b.value
-
-
 def choose_filter_triple(needle, hist=None):
     """(first, second, third) that `DynamicHipSearcher.new(needle)` lets the device filter test; with `hist` (256
     byte counts of the haystack, `byte_histogram`) the corpus-aware choice to apply with `set_filter`."""
     nb = bytes(needle)
     a, b, c = _sz(0), _sz(0), _sz(0)
-    if hist is None:
-        _check(lib().ss_choose_filter_triple(nb, len(nb), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-    else:
-        h = np.ascontiguousarray(hist, dtype=np.uint64)
-        _check(lib().ss_choose_filter_triple_hist(nb, len(nb), h.ctypes.data, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    h = None if hist is None else np.ascontiguousarray(hist, dtype=np.uint64)
+    _check(lib().ss_choose_filter_triple(nb, len(nb), None if h is None else h.ctypes.data, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
     return a.value, b.value, c.value
+
+
+def choose_filter_pair(needle):
+    """(first, second): the first two of `choose_filter_triple(needle)`."""
+    return choose_filter_triple(needle)[:2]
 
 
 def choose_filter_for_position(needle, position):
     """(first, second, third) that `DynamicHipSearcher.with_position(needle, position)` lets the device filter test:
-    `second == position`; `first == 0` (the reference's pair) when `position < 16`, else a byte at most 15 in front of it."""
+    `second == position`; `first == 0` (the reference's pair) when `position < 16`, else a byte at most 15 in front of it.
+    Hooks builds (a pure host function; a constructed searcher's `filter3` says the same in every build)."""
     nb = bytes(needle)
     a, b, c = _sz(0), _sz(0), _sz(0)
-    _check(lib().ss_choose_filter_for_position(nb, len(nb), position, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    L = _hooks(lib())
+    _check(L.ss_choose_filter_for_position(nb, len(nb), position, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), L)
     return a.value, b.value, c.value
 
 
 def fill_random_device(tensor, seed, global_offset=0, stream=None):
     st = stream if stream is not None else _current_stream_handle()
-    _check(lib().ss_fill_random_device(tensor.data_ptr(), global_offset, tensor.numel(), seed, st))
+    _check_tools(tools_lib().ss_fill_random_device(tensor.data_ptr(), global_offset, tensor.numel(), seed, st))
     return tensor
 
 
 def fill_random_host(length, seed, global_offset=0):
     out = np.empty(length, dtype=np.uint8)
-    _check(lib().ss_fill_random_host(out.ctypes.data, global_offset, length, seed))
+    _check_tools(tools_lib().ss_fill_random_host(out.ctypes.data, global_offset, length, seed))
     return out
 
 
 def read_ceiling_gbps(tensor, reps=10, stream=None):
     ms = ctypes.c_float(0)
     st = stream if stream is not None else _current_stream_handle()
-    _check(lib().ss_read_ceiling(tensor.data_ptr(), tensor.numel(), st, reps, ctypes.byref(ms)))
+    _check_tools(tools_lib().ss_read_ceiling(tensor.data_ptr(), tensor.numel(), st, reps, ctypes.byref(ms)))
     return tensor.numel() / (ms.value * 1e-3) / 1e9
 
 
@@ -817,3 +923,10 @@ def device_info():
     cus, mem = ctypes.c_int(0), _sz(0)
     _check(lib().ss_device_info(name, 256, ctypes.byref(cus), ctypes.byref(mem)))
     return {"name": name.value.decode(), "compute_units": cus.value, "total_mem": mem.value}
+
+
+def selftest_dpp():
+    """320 uint32 of the cross-lane self-test (ss_selftest_dpp; tests/test_gpu_parity.py::test_cross_lane_primitives)."""
+    out = np.zeros(320, dtype=np.uint32)
+    _check_tools(tools_lib().ss_selftest_dpp(out.ctypes.data))
+    return out

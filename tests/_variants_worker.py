@@ -21,8 +21,8 @@ def absent_needle(n):
 
 def main():
     which = sys.argv[1]
-    tuning = b"tuning" in ss.lib().ss_version()
-    assert tuning == (which == "tuning"), (which, ss.lib().ss_version())
+    tuning = ss.lib().has_hooks and b"tuning" in ss.lib().ss_version()
+    assert tuning == (which == "tuning"), which
     ln = (8 << 20) + 777
     t = torch.empty(ln + 16, dtype=torch.uint8, device="cuda")
     ss.fill_random_device(t, 0xABCDEF)
@@ -31,47 +31,46 @@ def main():
     cases = [absent_needle(n) for n in (1, 2, 16, 20, 200, 700, 1200)]
     cases += [host[ln - n:].tobytes() for n in (1, 2, 16, 20, 200, 700, 1200)]
     cases += [host[12345:12345 + n].tobytes() for n in (33, 100, 257, 1000)]
-    # variant = 100000*B + 10000*OCC + 1000*LAYOUT + 100*MODE + 10*U + NT (include/sliceslice_hip.h).  Launch-shape digits
-    # (1xxxxx / 3xxxxx = 128- / 512-thread workgroups, x4xxxx = occupancy cap) on top of U = 4 + non-temporal loads are part
-    # of every build; the other load flavour per mode, U = 8, the 8-byte phase for two-byte filters (2xxx) and the 16-byte
-    # layout for one-byte needles (1xxx) are tuning-build kernels.
-    everywhere = (41, 100041, 300041, 40041)
-    tuning_only = (40, 80, 81, 140, 141, 181, 240, 241, 280, 281, 1040, 1041, 1081, 2040, 2041, 2080, 2081, 100241, 300141, 302041, 130081)
+    # variant = 100000*B + 10000*OCC + 1000*LAYOUT + 100*MODE + 10*U + NT (include/sliceslice_hip_tuning.h), tuning build only:
+    # launch-shape digits (1xxxxx / 3xxxxx = 128- / 512-thread workgroups, x4xxxx = occupancy cap), plain loads, U = 8, the 8-byte
+    # phase for two-byte filters (2xxx) and the 16-byte layout for one-byte needles (1xxx).  The product library launches the
+    # automatic choice only (variant 0, grid 0) and has no entry point to ask for anything else.
+    variants = (41, 100041, 300041, 40041, 40, 80, 81, 240, 241, 280, 281, 1040, 1041, 1081, 2040, 2041, 2080, 2081, 100241, 302041,
+                130081) if tuning else (0,)
     checked = refused = 0
     for nd in cases:
         want = O.OracleSearcher(nd).search_in(host)
-        for variant in everywhere + (tuning_only if tuning else ()):
-            for grid in (0, 1, 7, 4096, -1, -3, -1000):
+        for variant in variants:
+            for grid in ((0, 1, 7, 4096, -1, -3, -1000) if tuning else (0,)):
                 s = ss.DynamicHipSearcher.new(nd)
                 s.set_variant(variant)
                 s.set_grid(grid)
                 assert s.search_in(t) == want, (len(nd), variant, grid)
                 checked += 1
             if len(nd) > 16:
-                # the reference's pair (needle[0], needle[n-1]), which no constructor picks at this distance: the mode digit
-                # (x1xx two streams, x2xx cross-lane up to a distance of 1,007) takes effect only here
-                for grid in (0, 7, -3):
+                # the reference's pair (needle[0], needle[n-1]), which no constructor picks at this distance: cross-lane kernels up
+                # to a distance of 1,007, beyond that the first byte + two partners with the far byte checked in memory
+                for grid in ((0, 7, -3) if tuning else (0,)):
                     s = ss.DynamicHipSearcher.new(nd)
                     s.set_filter(0, len(nd) - 1)
-                    s.set_variant(variant if tuning else 0)
+                    assert s.filter3 == (0, len(nd) - 1, len(nd) - 1)
+                    s.set_variant(variant)
                     s.set_grid(grid)
                     assert s.search_in(t) == want, (len(nd), variant, grid, "reference pair")
                     if (variant // 10) % 10 != 8:                      # find() has the U = 4 kernels only
                         assert s.find(t) == (host.tobytes().find(nd) if want else None), (len(nd), variant, grid, "reference pair, find")
                     checked += 1
         if not tuning:
-            # the default library refuses what it does not hold - loudly, and without launching anything
-            for variant in (81, 2041) if len(nd) > 1 else (81, 1041):
-                s = ss.DynamicHipSearcher.new(nd)
-                s.set_variant(variant)
+            # the product library has no variant / grid override at all - asking is refused loudly, nothing is launched
+            s = ss.DynamicHipSearcher.new(nd)
+            for ask in (lambda: s.set_variant(81), lambda: s.set_grid(7)):
                 try:
-                    s.search_in(t)
-                    raise AssertionError("variant %d ran in the default build" % variant)
+                    ask()
+                    raise AssertionError("the product library took a tuning override")
                 except ss.SlicesliceError as e:
-                    assert e.code == ss.SS_ERR_ARGUMENT and "tuning build" in str(e), e
+                    assert e.code == ss.SS_ERR_ARGUMENT and "SS_TEST_HOOKS" in str(e), e
                     refused += 1
-                s.set_variant(0)
-                assert s.search_in(t) == want
+            assert s.search_in(t) == want
     print("variants ok: %d searches checked, %d refusals" % (checked, refused))
 
 

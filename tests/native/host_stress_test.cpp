@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sliceslice_hip.h"
+#include "sliceslice_hip_tuning.h"      // built against a hooks build (ASan / TSan): fault injection, epoch setters, counters
 
 #define CHECK(cond)                                                                  \
     do {                                                                             \
@@ -76,9 +77,9 @@ int main(int argc, char **argv)
 
     ss_searcher *s = nullptr;
     CHECK(ss_searcher_new(needle, 7, &s) == SS_OK);
-    CHECK(ss_searcher_set_filter(s, 3, 2) == SS_ERR_POSITION && ss_searcher_set_filter(s, 0, 7) == SS_ERR_POSITION);
+    CHECK(ss_searcher_set_filter3(s, 3, 2, 2) == SS_ERR_POSITION && ss_searcher_set_filter3(s, 0, 7, 7) == SS_ERR_POSITION);
     size_t fa = 9, fb = 9;
-    CHECK(ss_searcher_filter(s, &fa, &fb) == SS_OK && fa <= fb && fb < 7);
+    { size_t fc = 0; CHECK(ss_searcher_filter3(s, &fa, &fb, &fc) == SS_OK && fa <= fb && fb < 7); }
     CHECK(ss_searcher_set_timing(s, 1) == SS_OK);
 
     // ---- more concurrent callers than flag slots, all entry points mixed ----
@@ -187,14 +188,12 @@ int main(int argc, char **argv)
         CHECK(hipGetDeviceCount(&ndev) == hipSuccess && ndev >= 1);
         if (ndev > 8) ndev = 8;
         ss_comm_set *set = nullptr;
-        CHECK(ss_comm_init_all(ndev, nullptr, &set) == SS_OK && ss_comm_set_size(set) == ndev);
+        CHECK(ss_comm_init_all(ndev, nullptr, &set) == SS_OK);
         std::vector<uint8_t *> bufs(ndev, nullptr);
         std::vector<const void *> shards(ndev);
         std::vector<size_t> lens(ndev, len);
         std::vector<uint64_t> begins(ndev);
         for (int g = 0; g < ndev; ++g) {
-            int d = -1;
-            CHECK(ss_comm_set_device(set, g, &d) == SS_OK && d == g);
             CHECK(hipSetDevice(g) == hipSuccess && hipMalloc((void **)&bufs[g], len) == hipSuccess);
             CHECK(hipMemcpy(bufs[g], g == ndev - 1 ? h_yes.data() : h_no.data(), len, hipMemcpyHostToDevice) == hipSuccess);
             shards[g] = bufs[g];
@@ -268,7 +267,7 @@ int main(int argc, char **argv)
         while (searched.load() < 64 && g_failures == 0) std::this_thread::yield();      // all four are searching by now
         for (int it = 0; it < 20000 || (refused == 0 && it < 2000000); ++it) {
             const size_t *q = pairs[it & 3];
-            const int rc = (it & 4) ? ss_searcher_set_filter(s, q[0], q[1]) : ss_searcher_set_filter3(s, q[0], q[1], q[2]);
+            const int rc = (it & 4) ? ss_searcher_set_filter3(s, q[0], q[1], q[1]) : ss_searcher_set_filter3(s, q[0], q[1], q[2]);
             if (rc == SS_OK) ++accepted;
             else { CHECK(rc == SS_ERR_ARGUMENT); ++refused; }
         }
@@ -311,15 +310,56 @@ int main(int argc, char **argv)
         std::puts("service callers joined");
         CHECK(g_failures == 0);
         uint64_t requests = 0, launches = 0, settled = 0;
-        CHECK(ss_service_counters(sv, &requests, &launches) == SS_OK && requests >= 1600 && launches >= 1);
-        CHECK(ss_service_settled_requests(sv, &settled) == SS_OK && settled > 0);
-        CHECK(ss_service_unbind(sv) == SS_OK);
+        CHECK(ss_service_counters(sv, &requests, &launches, &settled) == SS_OK && requests >= 1600 && launches >= 1 && settled > 0);
+        CHECK(ss_service_bind(sv, nullptr, 0) == SS_OK);
         int found = -1;
         CHECK(ss_service_search(sv, s, d_yes, len, &found) == SS_OK && found == 1);
         ss_service_stop(sv);
         std::puts("service stopped");
         std::printf("service from 4 threads: %llu requests, %llu residencies, %llu without an acquire\n", (unsigned long long)requests,
                     (unsigned long long)launches, (unsigned long long)settled);
+    }
+
+    // ss_service_stop against callers that are INSIDE the service: one long request holds the service's mutex, three more calls
+    // have entered and wait for it, then the stop arrives.  Whoever gets the mutex before the stop is answered, whoever gets it
+    // after is turned away (SS_ERR_ARGUMENT), and the stop frees the service only when all four have left - a caller blocked on
+    // the mutex at that moment used to wake into freed memory (ASan / TSan builds of this test are the proof).
+    if (!std::getenv("HST_SKIP_SERVICE")) {
+        const size_t big_len = (size_t)4 << 30;
+        uint8_t *d_big = nullptr;
+        CHECK(hipMalloc((void **)&d_big, big_len) == hipSuccess && hipMemset(d_big, 0, big_len) == hipSuccess);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        for (int round = 0; round < 3; ++round) {
+            ss_service *sv = nullptr;
+            CHECK(ss_service_start(8, 5.0, &sv) == SS_OK);
+            int warm = -1;
+            CHECK(ss_service_search(sv, s, d_no, len, &warm) == SS_OK && warm == 0);
+            std::atomic<int> entering{0}, answered{0}, refused{0};
+            std::vector<std::thread> callers;
+            for (int t = 0; t < 4; ++t)
+                callers.emplace_back([&, t]() {
+                    (void)hipSetDevice(0);
+                    int found = -1;
+                    entering.fetch_add(1);
+                    const int rc = t == 0 ? ss_service_search(sv, s, d_big, big_len, &found)        // ~ tens of ms on 8 workgroups
+                                          : ss_service_search(sv, s, (t & 1) ? d_yes : d_no, len, &found);
+                    if (rc == SS_OK) {
+                        TCHECK(found == (t == 0 ? 0 : (t & 1)));
+                        answered.fetch_add(1);
+                    } else {
+                        TCHECK(rc == SS_ERR_ARGUMENT);
+                        refused.fetch_add(1);
+                    }
+                });
+            while (entering.load() < 4) std::this_thread::yield();
+            std::this_thread::sleep_for(std::chrono::milliseconds(3));          // all four are inside ss_service_search by now
+            ss_service_stop(sv);
+            for (auto &t : callers) t.join();
+            CHECK(answered.load() + refused.load() == 4 && answered.load() >= 1);
+            std::printf("stop against 4 callers inside the service: %d answered, %d turned away\n", answered.load(), refused.load());
+        }
+        CHECK(g_failures == 0);
+        (void)hipFree(d_big);
     }
 
     ss_searcher_free(s);

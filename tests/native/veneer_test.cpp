@@ -141,7 +141,6 @@ int main()
         service.bind(DeviceSlice{dt, text.size()});
         for (int round = 0; round < 3; ++round)
             for (size_t k = 0; k < ss.size(); ++k) CHECK(service.search_in(ss[k], DeviceSlice{dt, text.size()}) == expect[k]);
-        CHECK(service.requests() == 3 * ss.size() && service.settled_requests() >= 2 * ss.size());
         service.unbind();
         CHECK(service.search_in(ss[0], DeviceSlice{dt + 4, text.size() - 4}));
         (void)hipFree(dt);

@@ -105,7 +105,9 @@ def test_new_picks_rare_bytes_and_with_position_keeps_the_callers_byte(ss):
     assert ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 7).filter3 == (0, 7, 5)        # + 'q' as the third
     # further apart the caller's byte stays, its partner moves next to it: 'q', ' ' (position 20), 'x'
     w = ss.DynamicHipSearcher.with_position(b" the quick brown fox ", 20)
-    assert w.position == 20 and w.filter3 == ss.choose_filter_for_position(b" the quick brown fox ", 20) == (5, 20, 19)
+    assert w.position == 20 and w.filter3 == (5, 20, 19)
+    with ss.tuning_build():                                  # the pure host form of the same choice (hooks builds)
+        assert ss.choose_filter_for_position(b" the quick brown fox ", 20) == (5, 20, 19)
     w.set_filter(0, 20)                                      # the reference's pair, verbatim (cross-lane kernel)
     assert w.filter3 == (0, 20, 20)
     # a 2000-byte needle: the default position 1999 would need two load streams; `new` and `with_position` stay within 15 bytes
@@ -115,12 +117,45 @@ def test_new_picks_rare_bytes_and_with_position_keeps_the_callers_byte(ss):
     for p in (16, 500, 1007, 1008, 1999):
         a, b, c = ss.DynamicHipSearcher.with_position(long_needle, p).filter3
         assert b == p and p - 15 <= a < p and a < c <= a + 15 and c != p
-    os.environ["SLICESLICE_AUTO_FILTER"] = "0"
-    try:
-        assert ss.DynamicHipSearcher.new(long_needle).filter == (0, 1999)
-        assert ss.DynamicHipSearcher.with_position(long_needle, 1000).filter3 == (0, 1000, 1000)
-    finally:
-        del os.environ["SLICESLICE_AUTO_FILTER"]
+    # the reference's own pair at any distance is one set_filter away
+    far = ss.DynamicHipSearcher.new(long_needle)
+    far.set_filter(0, 1999)
+    assert far.filter3 == (0, 1999, 1999) and far.position == 1999
+
+
+def test_filter_pairs_too_far_apart_for_any_kernel(ss, O):
+    """A pair more than 16 * 62 + 15 bytes apart (only set_filter can ask: e.g. the reference's pair (0, n-1) of a long needle) has
+    no kernel of its own since the two-stream kernels went: the device filters with the first byte and two partners behind it,
+    and the caller's far byte is the first thing a surviving candidate is tested for in memory.  Answers against the oracle:
+    absent, present at both ends and across tile edges, and near misses that differ from the needle ONLY in the far byte, only
+    in a partner byte, only in the last byte."""
+    rng = np.random.default_rng(11)
+    n = 3000
+    needle = bytes(rng.integers(1, 255, n, dtype=np.uint8))
+    ln = (4 << 20) + 333
+    base = torch.empty(ln + 32, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(base, 0x5EED0BEE)
+    nd = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+    for mis in (0, 5):
+        hay = base[mis:mis + ln]
+        for first, second in ((0, 2999), (0, 1008), (7, 1500), (1900, 2999), (0, 1007)):   # the last one: cross-lane kernel (d = 62)
+            s = ss.DynamicHipSearcher.new(needle)
+            s.set_filter(first, second)
+            assert s.filter3 == (first, second, second)
+            host = hay.cpu().numpy()
+            assert s.search_in(hay) is O.OracleSearcher(needle).search_in(host) is False
+            for at in (0, ln - n, 16384 - first - 1, (2 << 20) + 7):
+                saved = hay[at:at + n].clone()
+                hay[at:at + n] = nd
+                assert s.search_in(hay) is True and s.find(hay) == at, (mis, first, second, at)
+                for k in (second, first + 1, first + 2, n - 1, 0):
+                    if k == first:
+                        continue
+                    hay[at + k] ^= 0x5A
+                    assert s.search_in(hay) is False and s.find(hay) is None, (mis, first, second, at, k)
+                    hay[at + k] = needle[k]
+                hay[at:at + n] = saved
+            assert s.search_in(hay) is False
 
 
 def test_filter_pairs_on_text_and_random_haystacks_vs_oracle(ss, O, corpus):
@@ -355,9 +390,10 @@ def test_epoch_wrap_of_the_flag_slots(ss):
     yes = torch.zeros(ln, dtype=torch.uint8, device="cuda")
     yes[1000:1003] = torch.tensor([7, 7, 9], dtype=torch.uint8)
     no = torch.zeros(ln, dtype=torch.uint8, device="cuda")
-    s = ss.DynamicHipSearcher.new(bytes([7, 7, 9]))
+    with ss.tuning_build():                           # the hooks (ss_debug_*) exist in builds with -DSS_TEST_HOOKS only
+        s = ss.DynamicHipSearcher.new(bytes([7, 7, 9]))
     assert s.search_in(yes) is True and s.search_in(no) is False
-    assert ss.lib().ss_debug_set_epochs(s._h, 2**31 - 3) == 0
+    assert s._L.ss_debug_set_epochs(s._h, 2**31 - 3) == 0
     for it in range(8):                               # slot 0 is reused by every sequential call: crosses the wrap
         assert s.search_in(yes) is True, it
         assert s.search_in(no) is False, it
@@ -368,7 +404,7 @@ def test_epoch_wrap_of_the_flag_slots(ss):
                   (12345, 0xFFFFFFFA, 1000),             # the found count about to wrap
                   (12345, 77, 3),                        # find()'s key about to run out
                   (0x7FFF0000 - 100, 0xFFFFFFFE, 2)):    # all three at once
-        assert ss.lib().ss_debug_set_completion_state(s._h, *state) == 0
+        assert s._L.ss_debug_set_completion_state(s._h, *state) == 0
         for it in range(16):
             assert s.search_in(yes) is True and s.find(yes) == 1000, (state, it)
             assert s.search_in(no) is False and s.find(no) is None, (state, it)

@@ -40,9 +40,13 @@ def _build_native(src, exe, so, extra=()):
 
 
 def test_host_library_stress(tmp_path):
-    """128 threads on one handle (64 flag slots), the epoch wrap, staging-lease contention, communicators."""
+    """128 threads on one handle (64 flag slots), the epoch wrap, staging-lease contention, communicators.  The stress uses the
+    test hooks (fault injection, epoch setters, service counters), so it links against a hooks build: here the tuning library,
+    below the sanitizer builds."""
+    import sys
     import sliceslice_rs_amd as ss
-    so = ss.build()
+    ss.build()
+    so = sys.modules["sliceslice_rs_amd._build"].build_tuning()
     exe = str(tmp_path / "host_stress_test")
     _build_native(os.path.join(ROOT, "tests", "native", "host_stress_test.cpp"), exe, so)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)

@@ -45,11 +45,7 @@ def test_library_is_the_in_tree_hip_build(ss):
 
 
 def test_cross_lane_primitives(ss):
-    import ctypes
-    out = (ctypes.c_uint32 * 320)()
-    rc = ss.lib().ss_selftest_dpp(out)
-    assert rc == 0
-    out = list(out)
+    out = [int(v) for v in ss.selftest_dpp()]
     want = [1000 + l + 1 for l in range(63)] + [0]
     assert out[0:64] == want            # DPP wave_shl:1 = "value of lane l+1"; lane 63 keeps `old` (0)
     assert out[64:128] == want          # the same via __shfl_down
@@ -309,9 +305,9 @@ def test_synthetic_vs_oracle_medium(ss, O):
 
 def test_all_kernel_variants_agree():
     """Every kernel variant ss_searcher_set_variant can name x seven launch shapes against the oracle (tests/_variants_worker.py).
-    The default library holds the 26 scan kernels the constructors and set_filter* can select; the other variants live in the
-    tuning build (-DSS_TUNING_VARIANTS): the full list runs against that one, the launch-shape digits and the automatic
-    choice against the default library - where an unbuilt variant must be REFUSED (SS_ERR_ARGUMENT), not silently replaced."""
+    The product library holds the 18 scan kernels the constructors and set_filter can select and no way to ask for others; the
+    variants live in the tuning build (-DSS_TUNING_VARIANTS -DSS_TEST_HOOKS): the full list runs against that one, the automatic
+    choice against the product library - where asking for a variant must be REFUSED, not silently ignored."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,7 @@
-"""The resident search service (ss_service_*): the same booleans as the launch path and the oracle, the lease that bounds its
-residency, the routing of ss_search_device through it.  Every wait in the service is bounded on both sides; the tests carry
-a timeout all the same."""
+"""The resident search service (ss_service_*): the same booleans as the launch path and the oracle, the lease and the cap that
+bound its residency, stopping it under traffic.  Every wait in the service is bounded on both sides; the tests carry a timeout all
+the same.  Tests that read the service's counters (ss_service_counters: a hooks-build entry point) take the `hooks` fixture and
+run against libsliceslice_hip_tuning.so - the same host code plus the hooks; the others run against the product library."""
 import os
 import random
 import subprocess
@@ -28,7 +29,13 @@ def O():
     return m
 
 
-def test_service_answers_like_the_launch_path_and_the_oracle(ss, O):
+@pytest.fixture
+def hooks(ss):
+    with ss.tuning_build():
+        yield
+
+
+def test_service_answers_like_the_launch_path_and_the_oracle(ss, O, hooks):
     rng = random.Random(7)
     ln = (4 << 20) + 333
     buf = torch.empty(ln + 32, dtype=torch.uint8, device="cuda")
@@ -57,7 +64,7 @@ def test_service_answers_like_the_launch_path_and_the_oracle(ss, O):
                 for nd in (hb[max(0, cut - 16):cut], hb[:min(cut, 3)], b"\xff\x01"):
                     s = ss.DynamicHipSearcher.new(nd)
                     assert sv.search_in(s, sl) == O.OracleSearcher(nd).search_in(host[:cut]), (mis, cut, len(nd))
-        requests, launches = sv.counters()
+        requests, launches, _ = sv.counters()
         # (every searcher construction in the loop above allocates device memory, which waits for the device - i.e. for the
         # service's lease to run out - so here most requests start a residency of their own; bursts are checked below)
         assert requests > 200 and 1 <= launches <= requests
@@ -98,7 +105,7 @@ def test_service_sees_haystack_bytes_written_between_requests(ss):
             assert sv.search_in(s, t) is False, (it, at)
 
 
-def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O):
+def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O, hooks):
     """ss_service_bind: the caller vouches for a range; requests inside it skip the cache acquire - all but the first, and those
     whose needle reached device memory after the latest acquire.  The answers are the launch path's and the oracle's; after
     unbind, bytes written between requests are seen again."""
@@ -113,24 +120,24 @@ def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O):
         s.search_in(t)                                        # (the launch path uploads the needle)
     with ss.SearchService() as sv:
         sv.bind(t)
-        assert sv.settled_requests() == 0
+        assert sv.counters()[2] == 0
         got = [sv.search_in(s, t) for s in searchers]
         assert got == [w in raw for w in sample]
         # the first request acquired the range (the needles were uploaded when the searchers were built); a request that starts a
         # new residency (the lease ran out while Python was busy) acquires by itself
-        n1 = sv.settled_requests()
+        n1 = sv.counters()[2]
         assert len(sample) // 2 < n1 < len(sample)
         got = [sv.search_in(s, t[5:-7]) for s in searchers]   # sub-ranges of the bound range count as bound
         assert got == [w in raw[5:-7] for w in sample]
-        n2 = sv.settled_requests()
+        n2 = sv.counters()[2]
         assert n1 + len(sample) - 3 <= n2 <= n1 + len(sample)
         late = ss.DynamicHipSearcher.new(b"descriptor")       # uploaded AFTER the latest acquire: its first request is not settled
-        assert sv.search_in(late, t) is True and sv.settled_requests() == n2
-        assert sv.search_in(late, t) is True and sv.settled_requests() == n2 + 1
+        assert sv.search_in(late, t) is True and sv.counters()[2] == n2
+        assert sv.search_in(late, t) is True and sv.counters()[2] == n2 + 1
         other = torch.zeros(4096, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
-        before = sv.settled_requests()
-        assert sv.search_in(late, other) is False and sv.settled_requests() == before      # outside the range: acquires
+        before = sv.counters()[2]
+        assert sv.search_in(late, other) is False and sv.counters()[2] == before      # outside the range: acquires
         sv.unbind()
         plant = torch.from_numpy(np.frombuffer(b"descriptor", dtype=np.uint8).copy()).cuda()
         for it in range(50):
@@ -141,7 +148,7 @@ def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O):
             other[at:at + 10] = 0
             torch.cuda.current_stream().synchronize()
             assert sv.search_in(late, other) is False, it
-        assert sv.settled_requests() == before
+        assert sv.counters()[2] == before
         # re-binding after a write: the first request of the new binding acquires
         t2 = t.clone()
         torch.cuda.synchronize()
@@ -155,7 +162,7 @@ def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O):
         assert sv.search_in(late, t2) is False
 
 
-def test_service_lease_bounds_the_residency(ss):
+def test_service_lease_bounds_the_residency(ss, hooks):
     """Without requests the kernel leaves after its lease, so a device-wide wait cannot hang on it; the next request starts a new
     residency (one more launch) and is answered like any other."""
     t = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
@@ -164,7 +171,7 @@ def test_service_lease_bounds_the_residency(ss):
     s = ss.DynamicHipSearcher.new(bytes([7, 8, 9]))
     with ss.SearchService(workgroups=16, lease_ms=2.0) as sv:
         assert sv.search_in(s, t) is True
-        assert sv.counters() == (1, 1)
+        assert sv.counters()[:2] == (1, 1)
         t0 = time.perf_counter()
         torch.cuda.synchronize()                             # waits for the service kernel too: at most the lease
         assert time.perf_counter() - t0 < 1.0
@@ -173,7 +180,7 @@ def test_service_lease_bounds_the_residency(ss):
             assert sv.search_in(s, t) is True
             if it % 5 == 4:
                 time.sleep(0.02)                             # > lease: the kernel has left again
-        requests, launches = sv.counters()
+        requests, launches, _ = sv.counters()
         assert requests == 21 and 4 <= launches <= 21, (requests, launches)
         # a burst shares one residency
         before = sv.counters()[1]
@@ -182,52 +189,43 @@ def test_service_lease_bounds_the_residency(ss):
         assert sv.counters()[1] - before <= 5                # (a scheduler hiccup of 2 ms ends a residency)
 
 
-def test_default_service_routes_ss_search_device(ss, O):
-    ln = 1 << 20
-    t = torch.empty(ln, dtype=torch.uint8, device="cuda")
-    ss.fill_random_device(t, 0xFACADE)
+def test_service_residency_is_capped_under_continuous_traffic(ss, hooks):
+    """Every request renews the lease, so a caller that never pauses would keep the kernel resident for good - and block every
+    device-wide wait in the process with it.  A residency therefore ends after 16 leases (at least 250 ms) whatever the traffic;
+    the request that meets the leaving kernel starts the next one.  Two seconds of back-to-back requests: several residencies,
+    every answer right, and a device-wide wait from another thread returns while the traffic goes on."""
+    import threading
+    t = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    t[-3:] = torch.tensor([7, 8, 9], dtype=torch.uint8)
     torch.cuda.synchronize()
-    host = t.cpu().numpy()
-    present, absent = host[4321:4321 + 16].tobytes(), bytes([255] * 16)
-    with ss.SearchService() as sv:
-        sv.set_default(True)
-        sp, sa = ss.DynamicHipSearcher.new(present), ss.DynamicHipSearcher.new(absent)
-        # the service is used only when the caller's stream is idle (it cannot be ordered behind pending work)
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            for _ in range(50):
-                assert sp.search_in(t) is True and sa.search_in(t) is False
-        assert sv.counters()[0] == 100
-        for _ in range(5):                                   # the default stream: whichever road it takes, the same answers
-            assert sp.search_in(t) is True and sa.search_in(t) is False
-        assert 100 <= sv.counters()[0] <= 110
-        base = sv.counters()[0]
-        # what does not qualify takes the launch path and is still right: a long haystack, a wide pair, a timed search
-        big = torch.zeros(32 << 20, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        assert sa.search_in(big) is False
-        wide = ss.DynamicHipSearcher.new(host[100:200].tobytes())
-        wide.set_filter(0, 99)
-        assert wide.search_in(t) is True
-        sp.set_timing(True)
-        assert sp.search_in(t) is True and sp.last_kernel_ms() > 0
-        assert sv.counters()[0] == base
-        sv.set_default(False)
-        assert sa.search_in(t) is False and sv.counters()[0] == base
+    yes, no = ss.DynamicHipSearcher.new(bytes([7, 8, 9])), ss.DynamicHipSearcher.new(bytes([7, 8, 8]))
+    waits = []
+
+    def waiter():
+        torch.cuda.set_device(0)
+        time.sleep(0.3)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()                         # waits for the service kernel too: at most one capped residency
+            waits.append(time.perf_counter() - t0)
+            time.sleep(0.05)
+
+    with ss.SearchService(workgroups=16, lease_ms=10.0) as sv:
+        th = threading.Thread(target=waiter)
+        th.start()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 2.0:
+            assert sv.search_in(yes, t) is True and sv.search_in(no, t) is False
+            n += 2
+        th.join(timeout=30)
+        assert not th.is_alive()
+        requests, launches, _ = sv.counters()
+        assert requests == n and 4 <= launches <= 40, (requests, launches)      # ~2 s / 250 ms, not one residency and not one per request
+        assert len(waits) == 3 and max(waits) < 1.0, waits
 
 
-def test_parity_suites_in_service_mode():
-    """SLICESLICE_SERVICE=1: the library starts a service by itself and routes every qualifying ss_search_device call through it.
-    The known-answer, boundary and candidate-heavy suites must pass unchanged that way."""
-    env = dict(os.environ, SLICESLICE_SERVICE="1", SLICESLICE_SERVICE_LEASE_MS="5")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
-                          "-k", "kat or boundary or empty or memchr or candidate or beyond or flush or constructor or position"],
-                         capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert " passed" in out.stdout
-
-
-def test_building_searchers_does_not_wait_for_a_resident_service(ss):
+def test_building_searchers_does_not_wait_for_a_resident_service(ss, hooks):
     """Searchers take their device memory from slabs and initialise it through the PCIe BAR: `new` makes no runtime call that
     waits for the device, so a resident service (here with a lease of half a second) does not stall it - with one allocation per
     searcher every `new` below waited out the lease."""
@@ -275,7 +273,7 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-def test_service_restarts_under_a_lease_as_short_as_a_search(ss):
+def test_service_restarts_under_a_lease_as_short_as_a_search(ss, hooks):
     """The lease at its minimum (50 us): the kernel leaves between almost any two requests, and requests keep arriving while the
     stop word spreads - taken by some waves and not by others, never completed, posted again to a new residency.  Every answer
     must still be right."""
@@ -297,11 +295,11 @@ def test_service_restarts_under_a_lease_as_short_as_a_search(ss):
                 t0 = time.perf_counter()
                 while time.perf_counter() - t0 < rng.random() * 1e-4:
                     pass
-        requests, launches = sv.counters()
+        requests, launches, _ = sv.counters()
         assert requests == 4000 and launches > 100, (requests, launches)
 
 
-def test_service_is_shared_by_threads(ss):
+def test_service_is_shared_by_threads(ss, hooks):
     """One request at a time per service: callers from several threads queue on the service's mutex and each gets ITS answer
     (ctypes releases the GIL, so the calls do overlap in the library)."""
     import threading

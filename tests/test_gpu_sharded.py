@@ -10,12 +10,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_sharded_search_both_transports():
+@pytest.mark.parametrize("build", ["product", "hooks"])
+def test_sharded_search_both_transports(build):
+    """Real RCCL, as many ranks as the box has GPUs.  Against the hooks build the worker also injects a failure into the last
+    rank's scan (ss_debug_fail_next_scans): that rank its own error, the others SS_ERR_PEER, nobody left in the collective."""
     import torch
+    import sliceslice_rs_amd  # noqa: F401
     n = max(1, min(torch.cuda.device_count(), 8))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if build == "hooks":
+        env["SLICESLICE_HIP_LIB"] = sys.modules["sliceslice_rs_amd._build"].build_tuning()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "tests", "_sharded_gpu_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", "29533" if build == "product" else "29534", os.path.join(ROOT, "tests", "_sharded_gpu_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "sharded gpu worker ok" in out.stdout
@@ -83,8 +89,12 @@ def test_single_process_multi_gpu_entry():
     assert empty.search_in(shards) is True and empty.find(shards, begins) == 0
     tiny = [s[:5] for s in shards]
     assert node.search_in(tiny) is False and node.find(tiny, begins) is None
-    # epoch wrap of the set's flags
-    assert ss.lib().ss_debug_set_comm_epoch(None, node._set, 2**31 - 3) == 0
+    node.close()
+    empty.close()
+    # epoch wrap of the set's flags (the hook that moves the epoch lives in hooks builds)
+    with ss.tuning_build():
+        node = ss.NodeSearcher(needle, devices=list(range(G)))
+    node.set_epoch(2**31 - 3)
     for mode in (ss.NodeSearcher.COMBINE_RCCL, ss.NodeSearcher.COMBINE_HOST):
         node.set_combine(mode)
         for it in range(4):
@@ -96,7 +106,6 @@ def test_single_process_multi_gpu_entry():
                 ss.fill_random_device(shards[-1], 0x5EED0001, begins[-1])
                 torch.cuda.synchronize()
     node.close()
-    empty.close()
 
 
 def _run_bench(args, env_extra, timeout=900):
@@ -234,97 +243,105 @@ def test_live_bench_line_contract_and_measured_traffic():
     assert abs(r["traffic"] - r["traffic_per_algorithmic_byte"] * r["algorithmic_bytes_per_launch"]) < 1e-3 * r["traffic"]
 
 
-def test_comm_set_bookkeeping_with_three_and_eight_shards_on_one_gpu():
-    """G > 1 in ss_search_sharded_all / ss_find_sharded_all on a one-GPU box: a test set (SLICESLICE_COMM_SET_NO_RCCL=1) lists
-    device 0 several times and creates no communicators, so the per-shard streams, flags, pinned mirrors, epochs and the
-    host-side combine run with G = 3 and G = 8 (the grouped RCCL all-reduce itself needs G distinct devices).  Matches
-    are planted at 0, at the end and across every shard edge."""
-    import numpy as np
-    import torch
-    import sliceslice_rs_amd as ss
-    os.environ["SLICESLICE_COMM_SET_NO_RCCL"] = "1"
-    try:
-        for G in (3, 8):
-            needle = bytes(range(100, 133))                      # 33 bytes: shards overlap by 32
-            n = len(needle)
-            total = (24 << 20) + 4321
-            node = ss.NodeSearcher(needle, devices=[0] * G)
-            with pytest.raises(ss.SlicesliceError):
-                node.set_combine(ss.NodeSearcher.COMBINE_RCCL)   # no communicators in a test set
-            ranges = [node.shard_range(total, g) for g in range(G)]
-            S = -(-total // G)
-            logical = torch.empty(total, dtype=torch.uint8, device="cuda")
-            ss.fill_random_device(logical, 0x5EED0001)
-            pn = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
-            begins = [b for b, _ in ranges]
+# ---- the NATIVE collective code with more than one rank, on one GPU ----------------------------------------------------------
+# Real RCCL refuses two ranks on one device, so on a one-GPU box ss_search_sharded / ss_find_sharded / the RCCL branch of
+# ss_search_sharded_all had only ever executed with nranks == 1 - and the first real multi-rank run is the driver's, unattended.
+# tests/native/fake_rccl.c implements the nine nccl* symbols the library resolves over POSIX shared memory; the library loads it
+# instead of librccl when SLICESLICE_RCCL_LIB names it.  Every worker below is a process of its own (the variable is read once).
 
-            def shards():
-                return [logical[b:e].clone() for b, e in ranges]  # every shard its own allocation, like on G devices
-            assert node.search_in(shards()) is False and node.find(shards(), begins) is None
-            spots = [0, total - n, total // 2] + [r * S - k for r in range(1, G) for k in (1, n // 2, n - 1)] + [r * S for r in range(1, G)]
-            for at in spots:
-                saved = logical[at:at + n].clone()
-                logical[at:at + n] = pn
-                sh = shards()
-                assert node.search_in(sh) is True, (G, at)
-                assert node.find(sh, begins) == at, (G, at)
-                logical[at:at + n] = saved
-            # two occurrences in different shards: the leftmost wins
-            a1, a2 = S + 100, (G - 1) * S + 5000
-            logical[a1:a1 + n] = pn
-            logical[a2:a2 + n] = pn
-            assert node.find(shards(), begins) == a1
-            # epoch wrap of the set
-            assert ss.lib().ss_debug_set_comm_epoch(None, node._set, 2**31 - 3) == 0
-            for it in range(4):
-                assert node.search_in(shards()) is True
-            node.close()
-            absent = ss.NodeSearcher(bytes([255] * 20), devices=[0] * G)
-            assert absent.search_in(shards()) is False and absent.find(shards(), begins) is None
-            absent.close()
-    finally:
-        del os.environ["SLICESLICE_COMM_SET_NO_RCCL"]
+def _fake_env(extra=None):
+    build = sys.modules.get("sliceslice_rs_amd._build")
+    if build is None:
+        import sliceslice_rs_amd  # noqa: F401
+        build = sys.modules["sliceslice_rs_amd._build"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SLICESLICE_RCCL_LIB=build.build_fake_rccl(), FAKE_RCCL_TIMEOUT_S="240")
+    env.update(extra or {})
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    return env, build
+
+
+def _run_ranks(world, loops, env, tmp_path, timeout=1500):
+    worker = os.path.join(ROOT, "tests", "_native_ranks_worker.py")
+    id_file = str(tmp_path / ("uid_%d_%d" % (world, loops)))
+    procs = [subprocess.Popen([sys.executable, worker, "rank", str(r), str(world), id_file, str(loops)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung (rank outputs so far: %r)" % (outs,))
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d of %d ok" % (r, world)) in out, "rank %d: %s %s" % (r, out[-1500:], err[-3000:])
+    return [o for o, _ in outs]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_native_collectives_with_several_ranks_on_one_gpu(world, tmp_path):
+    """ss_comm_init_rank / ss_search_sharded / ss_find_sharded from 2, 3 and 8 PROCESSES sharing cuda:0, the product library on
+    the native transport: absent; a match in every rank's shard, at both ends, straddling every boundary by 1 .. n-1 bytes; two
+    matches (leftmost wins); shards shorter than the needle; 10,000 back-to-back searches (epochs, the every-256th stream wait, the
+    answer word behind the all-reduce) with the needle turning up on one rank now and then."""
+    env, _ = _fake_env()
+    outs = _run_ranks(world, 10000 if world <= 3 else 4000, env, tmp_path)
+    assert "0 injected failures" in outs[0]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_native_collectives_survive_a_failing_rank(world, tmp_path):
+    """The same against the hooks build, plus: ss_debug_fail_next_scans on the last rank -> that rank returns its own error, every
+    other rank SS_ERR_PEER, nobody is left in the all-reduce, the next search finds all ranks in step; and the 2^31 epoch wrap
+    of the communicator's flag pair crossed by all ranks together."""
+    env, build = _fake_env()
+    env["SLICESLICE_HIP_LIB"] = build.build_tuning()
+    outs = _run_ranks(world, 300, env, tmp_path)
+    assert all("3 injected failures" in o for o in outs)
+
+
+@pytest.mark.parametrize("G", [3, 8])
+def test_single_process_set_with_the_grouped_all_reduce_on_one_gpu(G):
+    """ss_comm_init_all / ss_search_sharded_all / ss_find_sharded_all with G = 3 and 8 shards on one GPU: ncclCommInitAll, the G
+    all-reduces inside one ncclGroupStart/End, the read-back from device 0 - against the host combine, with matches at 0, at the
+    end and across every shard edge, 600 back-to-back searches per mode."""
+    env, _ = _fake_env()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_native_ranks_worker.py"), "set", str(G)], capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0 and ("set of %d ok" % G) in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    env, build = _fake_env()
+    env["SLICESLICE_HIP_LIB"] = build.build_tuning()                            # once more with the epoch wrap (a hook)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_native_ranks_worker.py"), "set", str(G)], capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0 and ("set of %d ok" % G) in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
 def test_cross_device_early_exit_of_the_single_process_search():
-    """A match on ONE device ends the other devices' scans too: the host, which waits for the answer words anyway, sees the
-    finding wave's pinned mirror and stores the epoch into the other devices' flags through the BAR.  Three shards of 3 GiB on
-    one GPU (a test set), the needle at the start of shard 0 only: with the relay the call returns long before the other two
-    shards have been read; without it (SLICESLICE_CROSS_EXIT=0) it takes their full scans.  The answers do not change."""
-    import time
-    import numpy as np
-    import torch
-    import sliceslice_rs_amd as ss
-    os.environ["SLICESLICE_COMM_SET_NO_RCCL"] = "1"
-    try:
-        G, each = 3, 3 << 30
-        needle = bytes(range(200, 216))
-        pn = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
-        sh = []
-        for g in range(G):
-            t = torch.empty(each, dtype=torch.uint8, device="cuda")
-            ss.fill_random_device(t, 0x5EED0100 + g)
-            sh.append(t)
-        sh[0][4096:4096 + 16] = pn
-        torch.cuda.synchronize()
-        times = {}
-        for relay in ("1", "0"):
-            os.environ["SLICESLICE_CROSS_EXIT"] = relay
-            node = ss.NodeSearcher(needle, devices=[0] * G)
-            for _ in range(5):
-                assert node.search_in(sh) is True
-            t0 = time.perf_counter()
-            for _ in range(20):
-                assert node.search_in(sh) is True
-            times[relay] = (time.perf_counter() - t0) / 20
-            node.close()
-        # absent: nothing to relay, same answer either way
-        sh[0][4096:4096 + 16] = 0
-        torch.cuda.synchronize()
-        node = ss.NodeSearcher(needle, devices=[0] * G)
-        assert node.search_in(sh) is False
-        node.close()
-        assert times["1"] < 0.6 * times["0"], times
-    finally:
-        del os.environ["SLICESLICE_COMM_SET_NO_RCCL"]
-        os.environ.pop("SLICESLICE_CROSS_EXIT", None)
+    """A match on ONE device ends the other devices' scans too (tests/_native_ranks_worker.py relay_main): three shards of 3 GiB
+    on one GPU, the needle at the start of shard 0 - with the host's relay the call returns in well under 0.6 of the time it
+    takes with SLICESLICE_CROSS_EXIT=0."""
+    env, build = _fake_env()
+    env["SLICESLICE_HIP_LIB"] = build.build_tuning()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_native_ranks_worker.py"), "relay"], capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "relay ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_bench_with_eight_ranks_on_the_native_transport():
+    """`python bench.py --gpus 8` end to end the way the driver launches it - bench.py starts the ranks itself - with all eight on
+    cuda:0: torch.distributed (gloo) for the bootstrap only, the searches through ss_comm_init_rank / ss_search_sharded over the
+    stand-in.  The line must say 8 ranks, the native transport, and that the ranks shared one GPU (its GB/s mean nothing)."""
+    import json
+    env, _ = _fake_env({"SS_BENCH_SHARE_GPU": "1", "SS_BENCH_BACKEND": "gloo"})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+                          "--haystack-gib", "2", "--no-ceiling"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and d["config"]["rccl_ranks"] == 8
+    assert d["config"]["transport"] == "rccl" and d["config"]["transport_note"] is None
+    assert d["config"]["ranks_share_one_gpu"] is True and d["config"]["launcher"] == "self"
+    assert d["config"]["haystack_bytes"] == 2 << 30 and d["config"]["shard_bytes"] == (2 << 30) // 8 + 15
+    assert d["value"] > 0 and d["roofline"]["kernel_launches"] == 20

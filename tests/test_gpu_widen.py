@@ -1,6 +1,6 @@
-"""Rows widened in round 3: ss_find_batched - the leftmost offset per problem, the `Option<usize>` shape of the
-reference's bench competitors (bench/sse4-strstr/src/lib.rs:4-15) for many problems per call - and ss_search_host_all - the literal
-`search_in(&[u8])` (src/x86.rs:523) for a host slice striped over several GPUs' PCIe links."""
+"""ss_find_batched - the leftmost offset per problem, the `Option<usize>` shape of the reference's bench competitors
+(bench/sse4-strstr/src/lib.rs:4-15) for many problems per call - and ss_batch_plan_*: the per-problem set-up done once, searched
+many times (the reference builds its searchers once and times the searches, bench/benches/i386.rs:246-256)."""
 import os
 import random
 
@@ -97,52 +97,118 @@ def test_find_batched_leftmost_across_slices_and_aliased_ranges(ss):
     assert (pos >= 0).all()                               # tests/i386.rs:61-70: every word occurs
 
 
-def test_search_host_all_stripes_a_host_slice_over_devices(ss):
-    """One GPU here: the device list names it three and eight times (each range then has its own staging set and thread), plus every
-    visible device once.  Matches are planted across every range edge; the boolean must be that of a single search."""
-    n_dev = torch.cuda.device_count()
-    total = (40 << 20) + 4321
-    host = ss.fill_random_host(total, 0x5EED0001).copy()
-    needle = bytes(range(200, 233))                        # 33 bytes: ranges overlap by 32
-    n = len(needle)
-    s = ss.DynamicHipSearcher.new(needle)
-    for devices in ([0] * 3, [0] * 8, list(range(n_dev))):
-        G = len(devices)
-        S = -(-total // G)
-        assert ss.search_host_all(s, host, devices) is False
-        spots = [0, total - n, total // 2] + [r * S - k for r in range(1, G) for k in (1, n // 2, n - 1)] + [r * S for r in range(1, G)]
-        for at in spots:
-            saved = host[at:at + n].copy()
-            host[at:at + n] = np.frombuffer(needle, dtype=np.uint8)
-            assert ss.search_host_all(s, host, devices) is True, (G, at)
-            host[at:at + n] = saved
-        assert ss.search_host_all(s, host, devices) is False
-    assert ss.search_host_all(ss.DynamicHipSearcher.new(b""), host[:10], [0, 0]) is True
-    assert ss.search_host_all(s, host[:10], [0, 0]) is False
-    with pytest.raises(ss.SlicesliceError):
-        ss.search_host_all(s, host, [n_dev + 5])
 
 
-def test_search_host_all_stops_the_other_devices_at_the_first_match(ss):
-    """The threads of ss_search_host_all share one word: the device whose range holds the needle says so, and the others stop
-    issuing chunks.  1.5 GiB host slice as three ranges on one GPU, the needle at the start of the first range: far quicker than
-    the absent search, which uploads everything."""
-    import time
-    total = (3 << 29) + 12345
-    host = ss.fill_random_host(total, 0x5EED0200).copy()
-    needle = bytes(range(180, 200))
-    s = ss.DynamicHipSearcher.new(needle)
-    devices = [0, 0, 0]
-    assert ss.search_host_all(s, host, devices) is False          # (also warms the staging buffers)
-    t0 = time.perf_counter()
-    assert ss.search_host_all(s, host, devices) is False
-    absent = time.perf_counter() - t0
-    host[5000:5000 + len(needle)] = np.frombuffer(needle, dtype=np.uint8)
-    t0 = time.perf_counter()
-    assert ss.search_host_all(s, host, devices) is True
-    present = time.perf_counter() - t0
-    assert present < 0.5 * absent, (present, absent)
-    # the needle in the LAST range only: still found
-    host[5000:5000 + len(needle)] = 0
-    host[total - 30:total - 30 + len(needle)] = np.frombuffer(needle, dtype=np.uint8)
-    assert ss.search_host_all(s, host, devices) is True
+def _batch(ss, rng, count, hay_len, needle_len, present_every=3):
+    """`count` problems over one haystack blob (hay_len each) and one needle blob; every `present_every`-th needle is cut out of
+    its haystack.  Returns device tensors + the expected leftmost offsets (-1: absent)."""
+    hay = torch.empty(count * hay_len, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, 0xBA7C4)
+    host = hay.cpu().numpy()
+    needles = bytearray()
+    noff = [0]
+    want = []
+    for i in range(count):
+        h = host[i * hay_len:(i + 1) * hay_len].tobytes()
+        n = needle_len if isinstance(needle_len, int) else rng.choice(needle_len)
+        if i % present_every == 0 and n <= hay_len:
+            at = rng.randrange(hay_len - n + 1)
+            nd = h[at:at + n]
+        else:
+            nd = bytes([255]) * max(n, 1)                 # 0xFF never occurs in the generated haystack
+        needles += nd
+        noff.append(len(needles))
+        want.append(h.find(nd) if len(nd) else 0)
+    hoff = torch.arange(0, (count + 1) * hay_len, hay_len, dtype=torch.int64, device="cuda")
+    nbuf = torch.from_numpy(np.frombuffer(bytes(needles), dtype=np.uint8).copy()).cuda()
+    return hay, hoff, nbuf, torch.tensor(noff, dtype=torch.int64, device="cuda"), want
+
+
+def test_batch_plan_runs_equal_the_unplanned_calls(ss):
+    """A plan's run() must give what search_batched / find_batched give on the same problems - on the first run and on every later
+    one, with haystack CONTENTS changed between runs (plants added and removed), into output buffers full of garbage."""
+    rng = random.Random(41)
+    for count, hay_len, nlen in ((1, 3 << 20, 16), (7, 1 << 20, (1, 2, 5, 16, 17, 40)), (300, 65536, (3, 16, 33)), (4096, 4096, 16),
+                                 (50, 100, (1, 4, 16, 100, 101))):
+        hay, hoff, nbuf, noff, want = _batch(ss, rng, count, hay_len, nlen)
+        plan_s = ss.BatchPlan(hay, hoff, nbuf, noff)
+        plan_f = ss.BatchPlan(hay, hoff, nbuf, noff, find=True)
+        out_s = torch.full((count,), 77, dtype=torch.int32, device="cuda")
+        out_f = torch.full((count,), 77, dtype=torch.int64, device="cuda")
+        for rep in range(4):
+            plan_s.run(out_s)
+            plan_f.run(out_f)
+            assert out_s.tolist() == [1 if w >= 0 else 0 for w in want], (count, hay_len, rep)
+            assert out_f.tolist() == want, (count, hay_len, rep)
+            assert ss.search_batched(hay, hoff, nbuf, noff).tolist() == out_s.tolist()
+            assert ss.find_batched(hay, hoff, nbuf, noff).tolist() == want
+            out_s.fill_(-5)
+            out_f.fill_(-5)
+        # contents change between runs: wipe every planted needle, then put one back further left
+        host = hay.cpu().numpy().copy()
+        nb = nbuf.cpu().numpy().tobytes()
+        no = noff.tolist()
+        first = next((i for i, w in enumerate(want) if w >= 0 and no[i + 1] - no[i] >= 3 and hay_len >= 64), None)
+        if first is not None:
+            nd = nb[no[first]:no[first + 1]]
+            base = first * hay_len
+            hay[base + want[first]] ^= 0x55                                   # gone
+            torch.cuda.synchronize()
+            h = hay[base:base + hay_len].cpu().numpy().tobytes()
+            w2 = h.find(nd)
+            plan_f.run(out_f)
+            plan_s.run(out_s)
+            assert out_f[first].item() == w2 and out_s[first].item() == (1 if w2 >= 0 else 0)
+            hay[base:base + len(nd)] = torch.from_numpy(np.frombuffer(nd, dtype=np.uint8).copy()).cuda()   # back, at offset 0
+            torch.cuda.synchronize()
+            plan_f.run(out_f)
+            plan_s.run(out_s)
+            assert out_f[first].item() == 0 and out_s[first].item() == 1
+        plan_s.close()
+        plan_f.close()
+
+
+def test_batch_plan_trivial_problems_positions_and_graph_replay(ss):
+    """Problems without a scan (empty needle, haystack shorter than the needle, a position that breaks the with_position rules)
+    are answered from the plan on every run; and a run is ONE kernel launch with nothing allocated, so it can be captured into a
+    hipGraph and replayed - which the unplanned call refuses (its per-stream scratch may be reallocated by a later call)."""
+    hay = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    hay[100:103] = torch.tensor([1, 2, 3], dtype=torch.uint8)
+    needles = torch.tensor([1, 2, 3, 9, 9, 9, 9, 9], dtype=torch.uint8, device="cuda")
+    # problems: [1,2,3] in hay (found); [] (empty needle: 1); [9]*5 in a 3-byte haystack (0); [1,2,3] with position 3 (bad); [9,9] absent
+    hb = torch.tensor([0, 0, 100, 0, 0], dtype=torch.int64, device="cuda")
+    he = torch.tensor([4096, 4096, 103, 4096, 4096], dtype=torch.int64, device="cuda")
+    nb = torch.tensor([0, 3, 3, 0, 3], dtype=torch.int64, device="cuda")
+    ne = torch.tensor([3, 3, 8, 3, 5], dtype=torch.int64, device="cuda")
+    pos = torch.tensor([2, 7, 4, 3, 1], dtype=torch.int64, device="cuda")
+    plan = ss.BatchPlan(hay, None, needles, None, position=pos, hay_ranges=(hb, he), needle_ranges=(nb, ne))
+    fplan = ss.BatchPlan(hay, None, needles, None, find=True, hay_ranges=(hb, he), needle_ranges=(nb, ne))
+    out = torch.full((5,), 9, dtype=torch.int32, device="cuda")
+    fout = torch.full((5,), 9, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        plan.run(out)
+        fplan.run(fout)
+        assert out.tolist() == [1, 1, 0, -1, 0] and fout.tolist() == [100, 0, -1, 100, -1]
+        out.fill_(3)
+        fout.fill_(3)
+    assert ss.search_batched(hay, None, needles, None, position=pos, hay_ranges=(hb, he), needle_ranges=(nb, ne)).tolist() == [1, 1, 0, -1, 0]
+    # graph capture: the plan's run is capturable, the unplanned call says why it is not
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        plan.run(out, stream=st.cuda_stream)             # warm-up outside the capture
+    st.synchronize()
+    with torch.cuda.graph(g, stream=st):
+        plan.run(out, stream=torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(ss.SlicesliceError) as e:
+            ss.search_batched(hay, None, needles, None, hay_ranges=(hb, he), needle_ranges=(nb, ne))
+        assert e.value.code == ss.SS_ERR_ARGUMENT and "hipGraph" in str(e.value)
+    for rep in range(5):
+        hay[100] = 1 if rep % 2 == 0 else 0              # present / absent, decided between replays
+        out.fill_(5)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert out.tolist() == [1 if rep % 2 == 0 else 0, 1, 0, -1, 0], rep
+    plan.close()
+    fplan.close()

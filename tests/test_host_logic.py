@@ -20,13 +20,41 @@ def declared_symbols():
 
 
 def test_library_exports_every_declared_symbol():
+    import subprocess
+    import sys
+    build = sys.modules["sliceslice_rs_amd._build"]
     L = ctypes.CDLL(ss.build())
     syms = declared_symbols()
-    assert len(syms) >= 25
+    assert 25 <= len(syms) <= 45
     for name in syms:
         assert hasattr(L, name), name
     # and the Python binding table covers exactly the header
     assert sorted(ss.searcher.ABI) == syms
+    # ... and the product library exports NOTHING else: no test hook, no tuning knob, no internal (-fvisibility=hidden)
+    out = subprocess.run(["nm", "-D", "--defined-only", build.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert exported == syms, sorted(set(exported) ^ set(syms))
+    # the benchmark helpers live in a library of their own, the hooks in the tuning build
+    T = ctypes.CDLL(build.tools_library_path())
+    for name in ss.searcher.TOOLS_ABI:
+        assert hasattr(T, name) and not hasattr(L, name), name
+    H = ctypes.CDLL(build.build_tuning())
+    for name in list(ss.searcher.HOOKS_ABI) + syms:
+        assert hasattr(H, name), name
+    for name in ss.searcher.HOOKS_ABI:
+        assert not hasattr(L, name), name
+
+
+def test_the_rccl_stand_in_exports_what_the_library_resolves():
+    """tests/native/fake_rccl.c (test infrastructure: several ranks on one GPU) must offer every nccl* symbol ss_comm.hip dlsym()s."""
+    import sys
+    build = sys.modules["sliceslice_rs_amd._build"]
+    src = open(os.path.join(ROOT, "sliceslice-rs_amd", "csrc", "ss_comm.hip")).read()
+    wanted = sorted(set(re.findall(r'dlsym\(r\.h, "(nccl[A-Za-z]+)"\)', src)))
+    assert len(wanted) == 9, wanted
+    F = ctypes.CDLL(build.build_fake_rccl())
+    for name in wanted:
+        assert hasattr(F, name), name
 
 
 def test_no_cpu_fallback_constructor_fails_without_gpu():

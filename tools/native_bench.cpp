@@ -6,6 +6,9 @@
 //   native_bench latency  [calls=2000]            per-call microseconds of ss_search_device / ss_find_device /
 //                                                 ss_search_host on 1 KiB, 64 KiB, 1 MiB, 16 MiB haystacks
 //   native_bench sharded  [GiB=8] [steps=50]      the multi-GPU entry points on every visible GPU: per-search overhead
+//   native_bench ranks    <N> [GiB=8] [steps=200] N processes (this binary, re-executed) sharing device 0, one rank each of a native
+//                                                 communicator: per-search overhead outside the kernel (launch skew + barrier + read-back).
+//                                                 Needs an RCCL that allows several ranks per device: SLICESLICE_RCCL_LIB = tests/native/libfake_rccl.so
 //   native_bench soak     [calls=2000000]         small searches through every per-call entry point; RSS / VRAM before and after
 //   native_bench config1  <i386.txt> <words.txt> [iters=5]
 //   native_bench construct [searchers=2000]     what `new` costs (and with a search service resident)
@@ -23,6 +26,7 @@
 #include <vector>
 
 #include "sliceslice_hip.h"
+#include "sliceslice_hip_tuning.h"      // the synthetic haystack generator (libsliceslice_hip_tools.so)
 
 #define CK(x)                                                                  \
     do {                                                                       \
@@ -129,13 +133,8 @@ static int latency(int calls)
     const double floor_us = median_us(calls, [&] { null_kernel<<<1, 64, 0, st>>>(nullptr); (void)hipStreamSynchronize(st); });
     const double launch_only_us = median_us(calls, [&] { null_kernel<<<1, 64, 0, st>>>(nullptr); });
     HK(hipStreamSynchronize(st));
-    // what a resident "search service" would pay per request before touching a haystack byte: host -> pinned mailbox ->
-    // one resident device lane -> pinned answer -> host (ss_mailbox_round_trip_us)
-    double box_med = 0, box_min = 0;
-    CK(ss_mailbox_round_trip_us(2000, &box_med, &box_min));
     std::printf("{\"mode\": \"latency\", \"calls\": %d, \"needle_len\": 16, \"unit\": \"us per call (median)\", "
-                "\"empty_kernel_plus_stream_sync\": %.2f, \"empty_kernel_launch_only\": %.2f, "
-                "\"mailbox_round_trip\": %.2f, \"mailbox_round_trip_min\": %.2f, \"rows\": [", calls, floor_us, launch_only_us, box_med, box_min);
+                "\"empty_kernel_plus_stream_sync\": %.2f, \"empty_kernel_launch_only\": %.2f, \"rows\": [", calls, floor_us, launch_only_us);
     bool first = true;
     ss_service *sv = nullptr;
     CK(ss_service_start(0, 0.0, &sv));
@@ -161,7 +160,7 @@ static int latency(int calls)
         const int f4 = found;
         const double bound_present = median_us(calls, [&] { rc |= ss_service_search(sv, sp, d_hay, len, &found); });
         const int f5 = found;
-        rc |= ss_service_unbind(sv);
+        rc |= ss_service_bind(sv, nullptr, 0);
         for (int w = 0; w < 50; ++w) rc |= ss_search_host(s, h_hay.data(), len, &found);
         const double host_absent = median_us(std::max(200, calls / 4), [&] { rc |= ss_search_host(s, h_hay.data(), len, &found); });
         if (rc != 0 || f0 != 0 || f1 != 1 || f2 != 0 || f3 != 1 || f4 != 0 || f5 != 1 || p0 != SS_NPOS || p1 != 0) {
@@ -226,8 +225,7 @@ static int config1(const char *hay_path, const char *words_path, int iters)
         for (ss_searcher *s : searchers) CK(ss_search_device(s, d_hay, hay.size(), st, &found));
     const double per_call_ms = seconds_since(t0) / iters * 1e3;
 
-    // the same per-needle loop through the resident search service: no launch per search (ss_service_search), and once more
-    // through ss_search_device with the service installed as the device's default (adds the idle check of the caller's stream)
+    // the same per-needle loop through the resident search service: no launch per search (ss_service_search)
     ss_service *sv = nullptr;
     CK(ss_service_start(0, 0.0, &sv));
     size_t svc_hits = 0;
@@ -250,8 +248,6 @@ static int config1(const char *hay_path, const char *words_path, int iters)
     for (int it = 0; it < iters; ++it)
         for (ss_searcher *s : searchers) CK(ss_service_search(sv, s, d_hay, hay.size(), &found));
     const double bound_ms = seconds_since(tb) / iters * 1e3;
-    uint64_t settled = 0;
-    CK(ss_service_settled_requests(sv, &settled));
     if (std::getenv("NATIVE_BENCH_PER_NEEDLE")) {
         // where the bound loop's time goes: the fastest of `iters` timings per needle, against its length and the offset of
         // its first occurrence in the text (stderr; not part of the JSON line)
@@ -299,18 +295,6 @@ static int config1(const char *hay_path, const char *words_path, int iters)
                          (const char *)wordsblob.data() + words[w].first, first_at(w));
         }
     }
-    CK(ss_service_unbind(sv));
-    CK(ss_service_set_default(sv, 1));
-    size_t routed_hits = 0;
-    const auto tr = clk::now();
-    for (int it = 0; it < iters; ++it)
-        for (ss_searcher *s : searchers) {
-            CK(ss_search_device(s, d_hay, hay.size(), st, &found));
-            routed_hits += found != 0;
-        }
-    const double routed_ms = seconds_since(tr) / iters * 1e3;
-    uint64_t svc_requests = 0, svc_launches = 0;
-    CK(ss_service_counters(sv, &svc_requests, &svc_launches));
     ss_service_stop(sv);
 
     // the same loop as ONE launch: every needle range against the one haystack range
@@ -343,26 +327,47 @@ static int config1(const char *hay_path, const char *words_path, int iters)
     const double batched_ms = seconds_since(t1) / (iters * 4) * 1e3;
     size_t bhits = 0;
     for (int f : flags) bhits += f == 1;
+    // ... and with the per-needle set-up done ONCE, like the reference's prebuilt searchers (i386.rs:246-250): a batch plan, then
+    // one scan launch + flag read-back per iteration
+    ss_batch_plan *plan = nullptr;
+    const auto tp0 = clk::now();
+    CK(ss_batch_plan_create(d_hay, d_rng, d_rng + W, d_words, d_rng + 2 * W, d_rng + 3 * W, nullptr, W, 0, st, &plan));
+    const double plan_create_ms = seconds_since(tp0) * 1e3;
+    auto planned = [&]() -> int {
+        CK(ss_batch_plan_run(plan, st, d_found));
+        HK(hipMemcpyAsync(flags.data(), d_found, W * sizeof(int), hipMemcpyDeviceToHost, st));
+        HK(hipStreamSynchronize(st));
+        return 0;
+    };
+    for (int w = 0; w < 3; ++w)
+        if (planned()) return 1;
+    const auto t2 = clk::now();
+    for (int it = 0; it < iters * 4; ++it)
+        if (planned()) return 1;
+    const double planned_ms = seconds_since(t2) / (iters * 4) * 1e3;
+    size_t phits = 0;
+    for (int f : flags) phits += f == 1;
+    ss_batch_plan_free(plan);
     std::printf("{\"mode\": \"config1\", \"haystack_bytes\": %zu, \"needles\": %zu, \"hits\": %zu, \"batched_hits\": %zu, "
                 "\"per_call_ms_per_iteration\": %.3f, \"per_call_us_per_search\": %.3f, "
                 "\"service_ms_per_iteration\": %.3f, \"service_us_per_search\": %.3f, \"service_hits\": %zu, "
                 "\"service_bound_ms_per_iteration\": %.3f, \"service_bound_us_per_search\": %.3f, \"service_bound_hits\": %zu, "
-                "\"service_settled_requests\": %llu, "
-                "\"service_routed_ms_per_iteration\": %.3f, \"service_requests\": %llu, \"service_kernel_launches\": %llu, "
-                "\"batched_ms_per_iteration\": %.4f, \"reference_published_ms\": 35.181, "
+                "\"batched_ms_per_iteration\": %.4f, \"planned_ms_per_iteration\": %.4f, \"plan_create_ms\": %.3f, \"planned_hits\": %zu, "
+                "\"reference_published_ms\": 35.181, "
                 "\"note\": \"per-call = one ss_search_device (launch + completion word) per needle, natively; service = the same loop "
                 "through the resident search service (ss_service_search: no launch per search), bound = the same with the text bound to the service "
-                "(ss_service_bind: no cache acquire per request), routed = ss_search_device with that service "
-                "as the device's default; batched = one ss_search_batched launch + flag read-back for all needles\"}\n",
+                "(ss_service_bind: no cache acquire per request); batched = one ss_search_batched call + flag read-back for all needles; "
+                "planned = ss_batch_plan_create once (the reference builds its searchers once too), then one ss_batch_plan_run + read-back "
+                "per iteration\"}\n",
                 hay.size(), W, hits, bhits, per_call_ms, per_call_ms * 1e3 / (double)W, service_ms, service_ms * 1e3 / (double)W, svc_hits,
-                bound_ms, bound_ms * 1e3 / (double)W, bound_hits, (unsigned long long)settled, routed_ms, (unsigned long long)svc_requests, (unsigned long long)svc_launches, batched_ms);
+                bound_ms, bound_ms * 1e3 / (double)W, bound_hits, batched_ms, planned_ms, plan_create_ms, phits);
     for (ss_searcher *s : searchers) ss_searcher_free(s);
     (void)hipFree(d_found);
     (void)hipFree(d_rng);
     (void)hipFree(d_words);
     (void)hipFree(d_hay);
     (void)hipStreamDestroy(st);
-    if (svc_hits != W || bound_hits != W || routed_hits != W * (size_t)iters) return 1;
+    if (svc_hits != W || bound_hits != W || phits != W) return 1;
     return (hits == W && bhits == W) ? 0 : 1;           // every word of words.txt occurs in i386.txt (tests/i386.rs:61-70)
 }
 
@@ -488,16 +493,13 @@ static int soak(long calls)
         }
     }
     const double secs = seconds_since(t0);
-    uint64_t svc_requests = 0, svc_launches = 0;
-    CK(ss_service_counters(sv, &svc_requests, &svc_launches));
     ss_service_stop(sv);
     HK(hipDeviceSynchronize());
     HK(hipMemGetInfo(&free1, &tot));
     const long rss1 = rss_kib();
     std::printf("{\"mode\": \"soak\", \"calls\": %ld, \"seconds\": %.1f, \"us_per_call\": %.2f, \"rc\": %d, \"wrong_answers\": %ld, "
-                "\"service_requests\": %llu, \"service_kernel_launches\": %llu, "
                 "\"rss_kib_before\": %ld, \"rss_kib_after\": %ld, \"device_free_before\": %zu, \"device_free_after\": %zu}\n",
-                calls, secs, secs / (double)calls * 1e6, rc, wrong, (unsigned long long)svc_requests, (unsigned long long)svc_launches, rss0, rss1,
+                calls, secs, secs / (double)calls * 1e6, rc, wrong, rss0, rss1,
                 free0, free1);
     ss_searcher_free(s);
     ss_searcher_free(sp);
@@ -547,23 +549,145 @@ int construct(int count)
         ss_searcher_free(ss[k]);
     }
     const double resident_us = seconds_since(t0) / n2 * 1e6;
-    uint64_t rq = 0, launches = 0;
-    CK(ss_service_counters(sv, &rq, &launches));
     ss_service_stop(sv);
     ss_searcher_free(warm);
     (void)hipFree(d_hay);
     std::printf("{\"mode\": \"construct\", \"searchers\": %d, \"new_us\": %.2f, \"first_search_us\": %.2f, \"free_us\": %.2f, "
-                "\"hits\": %d, \"with_service_resident_new_search_free_us\": %.2f, \"service_hits\": %d, \"service_kernel_launches\": %llu, "
+                "\"hits\": %d, \"with_service_resident_new_search_free_us\": %.2f, \"service_hits\": %d, "
                 "\"note\": \"new = ss_searcher_new (needle + control block on the device); first_search = the first ss_search_device of "
                 "each; with a service resident: new + ss_service_search + free per needle (a runtime call that waits for the device "
                 "would wait for the 20 ms lease)\"}\n",
-                count, new_us, first_search_us, free_us, hits, resident_us, svc_hits, (unsigned long long)launches);
+                count, new_us, first_search_us, free_us, hits, resident_us, svc_hits);
     const int want2 = n2 > count / 2 ? 1 : 0;
     return hits == 1 && svc_hits == want2 ? 0 : 1;
 }
 
+// ---- N ranks of a native communicator, one process each, all on device 0 -------------------------------------------------------
+// What a sharded search costs OUTSIDE its kernel when more than one rank takes part: every rank scans its shard of one logical
+// haystack (ss_shard_range) and calls ss_search_sharded; a search ends when the slowest rank's all-reduce has completed.  The
+// ranks share ONE GPU here, so their kernels run one after the other and the aggregate GB/s mean nothing - what the mode reports
+// is wall - (sum of the ranks' kernel times): launch skew between the ranks + the all-reduce's barrier + the answer word / stream
+// wait.  Real RCCL refuses several ranks per device; run it with SLICESLICE_RCCL_LIB=tests/native/libfake_rccl.so (the
+// shared-memory stand-in: its all-reduce is a host barrier, a LOWER bound for a collective that crosses xGMI).
+//   parent:  native_bench ranks <N> [GiB] [steps]      forks N children (itself, re-executed) and prints the summary
+//   child:   native_bench rank <r> <N> <idhex> <GiB> <steps> <result-file>
+#include <sys/wait.h>
+#include <unistd.h>
+
+static int rank_child(int rank, int nranks, const char *idhex, double gib, int steps, const char *result_path)
+{
+    uint8_t id[SS_UNIQUE_ID_BYTES];
+    for (int k = 0; k < SS_UNIQUE_ID_BYTES; ++k) {
+        unsigned v = 0;
+        if (std::sscanf(idhex + 2 * k, "%2x", &v) != 1) return 2;
+        id[k] = (uint8_t)v;
+    }
+    HK(hipSetDevice(0));
+    const size_t total = (size_t)(gib * (double)(1ull << 30));
+    uint8_t needle[16];
+    CK(ss_fill_random_host(needle, 0, 16, 0x5EED0002ull));
+    needle[8] = 0xFF;
+    size_t b = 0, e = 0;
+    CK(ss_shard_range(total, 16, nranks, rank, &b, &e));
+    void *d_shard = nullptr;
+    HK(hipMalloc(&d_shard, e - b));
+    CK(ss_fill_random_device(d_shard, b, e - b, 0x5EED0001ull, nullptr));
+    HK(hipDeviceSynchronize());
+    ss_comm *c = nullptr;
+    CK(ss_comm_init_rank(id, nranks, rank, &c));
+    ss_searcher *s = nullptr;
+    CK(ss_searcher_new(needle, 16, &s));
+    CK(ss_searcher_set_timing(s, 1));
+    hipStream_t st = nullptr;
+    HK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int found = 1, rc = 0;
+    for (int w = 0; w < 20; ++w) rc |= ss_search_sharded(s, d_shard, e - b, c, st, &found);
+    double kernel_ms = 0;
+    const auto t0 = clk::now();
+    for (int k = 0; k < steps; ++k) {
+        rc |= ss_search_sharded(s, d_shard, e - b, c, st, &found);
+        float ms = 0;
+        rc |= ss_searcher_last_kernel_ms(s, &ms);
+        kernel_ms += ms;
+    }
+    const double wall_ms = seconds_since(t0) / steps * 1e3;
+    if (rc != 0 || found != 0) {
+        std::fprintf(stderr, "rank %d: rc %d found %d: %s\n", rank, rc, found, ss_last_error());
+        return 1;
+    }
+    FILE *f = std::fopen(result_path, "w");
+    if (!f) return 3;
+    std::fprintf(f, "%.6f %.6f %zu\n", wall_ms, kernel_ms / steps, e - b);
+    std::fclose(f);
+    ss_comm_free(c);
+    ss_searcher_free(s);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(d_shard);
+    return 0;
+}
+
+static int ranks_parent(const char *self, int nranks, double gib, int steps)
+{
+    if (nranks < 1 || nranks > 64) return 2;
+    uint8_t id[SS_UNIQUE_ID_BYTES];
+    CK(ss_comm_unique_id(id));                        // (no HIP call: the children initialise the runtime, not this process)
+    std::string hex;
+    char buf[4];
+    for (int k = 0; k < SS_UNIQUE_ID_BYTES; ++k) { std::snprintf(buf, sizeof buf, "%02x", id[k]); hex += buf; }
+    const std::string base = "/tmp/native_bench_ranks_" + std::to_string((long)getpid()) + "_";
+    std::vector<pid_t> kids;
+    for (int r = 0; r < nranks; ++r) {
+        const pid_t pid = fork();
+        if (pid == 0) {
+            const std::string rs = std::to_string(r), ns = std::to_string(nranks), gs = std::to_string(gib), ss_ = std::to_string(steps),
+                              out = base + rs;
+            execl("/proc/self/exe", self, "rank", rs.c_str(), ns.c_str(), hex.c_str(), gs.c_str(), ss_.c_str(), out.c_str(), (char *)nullptr);
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int bad = 0;
+    for (pid_t pid : kids) {
+        int status = 0;
+        if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) ++bad;
+    }
+    double wall_max = 0, kernel_sum = 0, kernel_max = 0;
+    size_t shard = 0;
+    for (int r = 0; r < nranks && !bad; ++r) {
+        const std::string path = base + std::to_string(r);
+        FILE *f = std::fopen(path.c_str(), "r");
+        double w = 0, k = 0;
+        size_t sb = 0;
+        if (!f || std::fscanf(f, "%lf %lf %zu", &w, &k, &sb) != 3) ++bad;
+        if (f) std::fclose(f);
+        std::remove(path.c_str());
+        wall_max = std::max(wall_max, w);
+        kernel_sum += k;
+        kernel_max = std::max(kernel_max, k);
+        shard = std::max(shard, sb);
+    }
+    if (bad) {
+        std::fprintf(stderr, "ranks: %d rank(s) failed\n", bad);
+        return 1;
+    }
+    const char *lib = std::getenv("SLICESLICE_RCCL_LIB");
+    std::printf("{\"mode\": \"ranks\", \"ranks\": %d, \"ranks_share_one_gpu\": true, \"haystack_bytes\": %zu, \"shard_bytes\": %zu, "
+                "\"steps\": %d, \"wall_ms_per_search\": %.4f, \"kernel_ms_sum_over_ranks\": %.4f, \"kernel_ms_slowest_rank\": %.4f, "
+                "\"overhead_outside_kernels_ms\": %.4f, \"rccl_library\": \"%s\", "
+                "\"note\": \"N processes on ONE device: the ranks' kernels run one after the other, so wall - (sum of kernel times) is what "
+                "a search costs outside its kernels - launch skew between ranks, the all-reduce's barrier, the answer word; a lower bound "
+                "for N devices, where the collective crosses xGMI\"}\n",
+                nranks, (size_t)(gib * (double)(1ull << 30)), shard, steps, wall_max, kernel_sum, kernel_max, wall_max - kernel_sum,
+                lib ? lib : "librccl");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 7 && std::string(argv[1]) == "rank")
+        return rank_child(std::atoi(argv[2]), std::atoi(argv[3]), argv[4], std::atof(argv[5]), std::atoi(argv[6]), argv[7]);
+    if (argc > 2 && std::string(argv[1]) == "ranks")
+        return ranks_parent(argv[0], std::atoi(argv[2]), argc > 3 ? std::atof(argv[3]) : 8.0, argc > 4 ? std::atoi(argv[4]) : 200);
     if (argc > 1 && std::string(argv[1]) == "construct") return construct(argc > 2 ? std::atoi(argv[2]) : 2000);
     const std::string mode = argc > 1 ? argv[1] : "headline";
     if (mode == "latency") return latency(argc > 2 ? std::atoi(argv[2]) : 2000);
