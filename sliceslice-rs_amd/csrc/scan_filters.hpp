@@ -525,12 +525,11 @@ __device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np
 struct VerifyArgs {
     const uint8_t *hay, *needle;
     uint64_t n, end;
-    uint64_t far_off;         // Problem::far_off
 };
 
 template <bool ONE_BYTE>
 __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk, const Problem &pr, const VerifyArgs &va,
-                                             const uint8_t *s_needle, uint64_t &where)
+                                             const uint8_t *s_needle, uint64_t &where, uint64_t far_off = 0)
 {
     bool hit = false;
     // all 16 flags of the lane in one word: flag of byte 4j+t at bit 8t+j (bit 7 of byte t of g[j] >> (7-j))
@@ -547,7 +546,7 @@ __device__ __forceinline__ bool verify_flags(const uint32_t g[4], uint64_t chunk
             const uint64_t i = a - pr.mis;              // wraps for bytes in front of the haystack
             if (i < va.end) {
                 if (ONE_BYTE) hit = va.hay[i] == (uint8_t)pr.n0x4;
-                else if (va.far_off != 0 && va.hay[i + va.far_off] != va.needle[va.far_off]) hit = false;   // the caller's far filter byte
+                else if (far_off != 0 && va.hay[i + far_off] != va.needle[far_off]) hit = false;   // the caller's far filter byte
                 else hit = verify_candidate(va.hay, va.needle, va.n, s_needle, i);
                 where = i;                              // lowest match of this lane when hit
             }

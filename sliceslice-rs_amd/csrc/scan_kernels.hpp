@@ -84,7 +84,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     // needs, the second-level schedule, and the needle's dwords for the exact in-register verification
     // (exact_verify_piece: the single-stream multi-byte kernels, needles that end at most 16 bytes behind the first filter byte).
     RefineOrder ro = {0, {0, 0}, {0, 0}};
-    VerifyArgs va = {nullptr, nullptr, 0, 0, 0};
+    VerifyArgs va = {nullptr, nullptr, 0, 0};
     constexpr bool EXACT_OK = MODE == 0 && !ONE_BYTE;
     uint32_t tail16[4] = {0, 0, 0, 0};
     uint32_t exact_len = 0u;
@@ -282,7 +282,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 va.needle = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(uintptr_t)c->needle));
                 va.n = uniform64(c->n);
                 va.end = uniform64(c->end);
-                va.far_off = MODE == 0 && !ONE_BYTE ? uniform64(c->far_off) : 0;
                 if (!ONE_BYTE && !LAZY_ORDER) {
                     ro.n = c->norder;
                     ro.idx[0] = c->order_idx[0]; ro.idx[1] = c->order_idx[1];
@@ -400,7 +399,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     if (FIND) where = (chunk0 + 64 * u) * 16 - pr.mis + where_off;
                 } else {
                     stage_once();
-                    h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, va, s_needle, where);
+                    // (the caller's far filter byte, if any: read where it is used - carried in registers it cost the kernels
+                    // 17 spilled scalar registers for a field that is zero for every constructor-built searcher)
+                    const uint64_t far_off = MODE == 0 && !ONE_BYTE ? uniform64(cold()->far_off) : 0;
+                    h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, va, s_needle, where, far_off);
                 }
                 hit |= h;
                 // search_in: the first piece with a match settles the wave (a text full of matches holds one in every piece)
