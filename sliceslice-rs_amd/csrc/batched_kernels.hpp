@@ -292,17 +292,11 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         pr.q3 = (d.shifts >> 10) & 3;
         pr.epoch = 1;
         pr.flags = 0;
+        pr.q = (d.shifts >> 6) & 3;
         const ColdInDesc cold = {dp, a.needles};
-        if ((d.bytes >> 24) & 1) {
-            scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink);
-        } else {
-            switch ((d.shifts >> 6) & 3) {          // single stream, non-temporal loads
-            case 0: scan_tiles<0, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
-            case 1: scan_tiles<1, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
-            case 2: scan_tiles<2, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
-            default: scan_tiles<3, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink); break;
-            }
-        }
+        // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
+        if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink);
+        else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink);
     }
     if (COUNTED) {
         // count out (every active slice of the problem gets here, with or without work).  A wave's atomicMin has no return

@@ -50,7 +50,8 @@ struct Problem {
     int epoch;                // the value that means "found" in the flag (1 for caller-owned flags; pool slots
                               // use a fresh value per call, so a slot never has to be cleared)
     uint32_t flags;           // kProblemCounted: a completion word is in use (done_counter / host_done below)
-    uint32_t pad_;
+    uint32_t q;               // (position % 16) / 4: the second byte's dword window - read by kernels instantiated with kQDynamic
+                              // (batched, service); scan_kernel has it as a template argument
     // ---- cold ----
     const uint8_t *hay;       // the caller's pointer
     const uint8_t *needle;    // device copy of the needle
@@ -89,6 +90,7 @@ struct Problem {
     unsigned long long *stats;
 };
 constexpr uint32_t kProblemCounted = 1u;
+constexpr int kQDynamic = -1;                     // scan_tiles<Q = kQDynamic, ...>: the window comes from Problem::q
 constexpr unsigned kStatsSampleShift = 6;           // every 64th workgroup reports
 
 // Where a wave finds the COLD fields of its Problem.

@@ -64,6 +64,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                                            uint64_t tile_step, uint64_t tile_end, void *sink, int *wg_found = nullptr)
 {
     static_assert(!L8 || (MODE == 0 && !FIND), "the 8-byte layout covers the single-stream bool kernels");
+    static_assert(Q != kQDynamic || (MODE == 0 && !L8), "a run-time window is for the single-stream kernels' three-byte phase");
     static_assert(MODE == 0 || MODE == 2, "single-stream kernels only");
     constexpr bool SHIFTED = MODE == 2;
     int *found = static_cast<int *>(sink);
@@ -128,7 +129,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     const u32x2 nx = h + 1 < 2 * U ? Hh[h + 1] : halo8;
                     tn = u32x2{nx.x ^ pr.nlx4, nx.y ^ pr.nlx4};
                 }
-                any8 = filter_half<Q, ONE_BYTE>(Hh[h], tc, tn, pr, lane, any8);
+                any8 = filter_half<(Q < 0 ? 0 : Q), ONE_BYTE>(Hh[h], tc, tn, pr, lane, any8);   // (L8 kernels have a compile-time window)
                 tc = tn;
             }
             if (stop8) {                                      // somebody has already found the needle
@@ -149,9 +150,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         uint32_t G[U][4];
         uint32_t any_tile = 0;
         int stop = 0;
-        auto load_and_filter = [&](auto loaded_c, auto full_c, auto q3_c) {
+        auto load_and_filter = [&](auto loaded_c, auto full_c, auto q3_c, auto q_c) {
             constexpr bool LOADED = decltype(loaded_c)::value, FULL = decltype(full_c)::value;
             constexpr int Q3 = decltype(q3_c)::value;
+            constexpr int QQ = Q == kQDynamic ? decltype(q_c)::value : Q;       // the second byte's dword window
             if constexpr (!LOADED && FULL) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) A[u] = load_chunk<NTA>(pr.base, chunk0 + 64 * u + lane);
@@ -185,7 +187,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 uint32_t *g = G[u];
                 if (THREE) {
                     // lane 63's next lane: lane 0 of the next piece (raw dwords, rotated in), or the halo chunk
-                    constexpr int QM = Q > Q3 ? Q : Q3;
+                    constexpr int QM = QQ > Q3 ? QQ : Q3;
                     uint32_t nx[4] = {0, 0, 0, 0};
                     if (u + 1 < U) {
                         nx[0] = rotate_from_next_lane(A[u + 1].x);
@@ -195,32 +197,47 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     } else {
                         nx[0] = H.x; nx[1] = H.y; nx[2] = H.z; nx[3] = H.w;
                     }
-                    filter_piece3<Q, Q3>(A[u], nx, pr, g);
+                    filter_piece3<QQ, Q3>(A[u], nx, pr, g);
                 } else if (SHIFTED) {
                     // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
                     position_diffs(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
+                    constexpr int QS = Q < 0 ? 0 : Q;        // (a run-time window never comes here: kQDynamic is MODE 0)
                     uint32_t x[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        x[j] = (j >= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d) : 0u;
-                        x[4 + j] = (j <= Q) ? from_lane_ahead(wcur[j], wnext[j], lane, d + 1) : 0u;
+                        x[j] = (j >= QS) ? from_lane_ahead(wcur[j], wnext[j], lane, d) : 0u;
+                        x[4 + j] = (j <= QS) ? from_lane_ahead(wcur[j], wnext[j], lane, d + 1) : 0u;
                     }
-                    g[0] = zero_byte_flags((A[u].x ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 1], x[Q + 0], pr.r));
-                    g[1] = zero_byte_flags((A[u].y ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 2], x[Q + 1], pr.r));
-                    g[2] = zero_byte_flags((A[u].z ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 3], x[Q + 2], pr.r));
-                    g[3] = zero_byte_flags((A[u].w ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[Q + 4], x[Q + 3], pr.r));
+                    // ... and a THIRD byte close behind the first one (within 15 bytes: this lane's chunk and the next lane's, one DPP
+                    // hop like the single-stream kernels' third byte; lane 63 takes lane 0 of the next piece / of the halo chunks).
+                    // A pair this far apart is the caller's (ss_searcher_set_filter3) - on text the reference's own pair (0, n-1)
+                    // passes at percent rates and sent nearly every tile into the second level (0.79 of the roofline); a third
+                    // byte in the first phase makes a candidate tile the exception again.  Whoever builds the Problem provides it.
+                    const u32x4 &NP = u + 1 < U ? A[u + 1] : H;
+                    uint32_t xx[8] = {A[u].x, A[u].y, A[u].z, A[u].w, 0, 0, 0, 0};
+                    xx[4] = from_next_lane_or(rotate_from_next_lane(NP.x), A[u].x);
+                    if (Q3 >= 1) xx[5] = from_next_lane_or(rotate_from_next_lane(NP.y), A[u].y);
+                    if (Q3 >= 2) xx[6] = from_next_lane_or(rotate_from_next_lane(NP.z), A[u].z);
+                    if (Q3 >= 3) xx[7] = from_next_lane_or(rotate_from_next_lane(NP.w), A[u].w);
+                    uint32_t z[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) z[k] = xx[Q3 + k] ^ pr.n3x4;
+                    g[0] = zero_byte_flags((A[u].x ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 1], x[QS + 0], pr.r) | __builtin_amdgcn_alignbyte(z[1], z[0], pr.r3));
+                    g[1] = zero_byte_flags((A[u].y ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 2], x[QS + 1], pr.r) | __builtin_amdgcn_alignbyte(z[2], z[1], pr.r3));
+                    g[2] = zero_byte_flags((A[u].z ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 3], x[QS + 2], pr.r) | __builtin_amdgcn_alignbyte(z[3], z[2], pr.r3));
+                    g[3] = zero_byte_flags((A[u].w ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 4], x[QS + 3], pr.r) | __builtin_amdgcn_alignbyte(z[4], z[3], pr.r3));
                 } else {
                     if (!ONE_BYTE) {
                         // lane 63's "next lane": lane 0 of the next piece, or the halo chunk after the last piece
                         if (u + 1 < U) {
                             position_diffs(A[u + 1], pr.nlx4, wnext);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) wlast[j] = (j <= Q) ? rotate_from_next_lane(wnext[j]) : 0u;
+                            for (int j = 0; j < 4; ++j) wlast[j] = (j <= QQ) ? rotate_from_next_lane(wnext[j]) : 0u;
                         } else {
                             position_diffs(H, pr.nlx4, wlast);
                         }
                     }
-                    filter_piece<Q, ONE_BYTE>(A[u], wcur, wlast, pr, g);
+                    filter_piece<QQ < 0 ? 0 : QQ, ONE_BYTE>(A[u], wcur, wlast, pr, g);
                 }
                 any_tile |= g[0] | g[1] | g[2] | g[3];
                 if (!ONE_BYTE && !THREE && (SHIFTED || u + 1 < U)) {
@@ -232,18 +249,37 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         };
         // the third byte's dword window is wave-uniform run-time data: one copy of the phase per window
         auto run_phase1 = [&](auto loaded_c, auto full_c) {
-            if constexpr (THREE) {
+            using std::integral_constant;
+            if constexpr (THREE && Q == kQDynamic) {
+                // Kernels that serve many problems per grid (batched, service) cannot take the second byte's window from their
+                // template arguments: ONE copy of everything else and one copy of the first phase per (Q, Q3) window pair - ten,
+                // because whoever builds the Problem orders the two further bytes so that q3 <= q - instead of one whole
+                // scan_tiles per Q (five per kernel, each with its own spill slots: 184-245 spilled scalar registers).
+                switch (pr.q * 4 + pr.q3) {
+                case 0: load_and_filter(loaded_c, full_c, integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
+                case 4: load_and_filter(loaded_c, full_c, integral_constant<int, 0>{}, integral_constant<int, 1>{}); break;
+                case 5: load_and_filter(loaded_c, full_c, integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+                case 8: load_and_filter(loaded_c, full_c, integral_constant<int, 0>{}, integral_constant<int, 2>{}); break;
+                case 9: load_and_filter(loaded_c, full_c, integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
+                case 10: load_and_filter(loaded_c, full_c, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+                case 12: load_and_filter(loaded_c, full_c, integral_constant<int, 0>{}, integral_constant<int, 3>{}); break;
+                case 13: load_and_filter(loaded_c, full_c, integral_constant<int, 1>{}, integral_constant<int, 3>{}); break;
+                case 14: load_and_filter(loaded_c, full_c, integral_constant<int, 2>{}, integral_constant<int, 3>{}); break;
+                default: load_and_filter(loaded_c, full_c, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
+                }
+            } else if constexpr (THREE || SHIFTED) {
+                // (SHIFTED: the third byte's window is independent of the far second byte's)
                 // Whoever builds the Problem orders the two further bytes so that q3 <= Q (they are interchangeable): the
                 // copies with Q3 > Q are never taken.  They stay instantiated all the same: with them pruned the register
                 // allocator needed 146 VGPRs instead of 121 for Q < 3 (build() records every kernel's registers in csrc/kernel_resources.json; tests/test_bindings_cpu.py keeps an eye on it).
                 switch (pr.q3) {
-                case 0: load_and_filter(loaded_c, full_c, std::integral_constant<int, 0>{}); break;
-                case 1: load_and_filter(loaded_c, full_c, std::integral_constant<int, 1>{}); break;
-                case 2: load_and_filter(loaded_c, full_c, std::integral_constant<int, 2>{}); break;
-                default: load_and_filter(loaded_c, full_c, std::integral_constant<int, 3>{}); break;
+                case 0: load_and_filter(loaded_c, full_c, integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
+                case 1: load_and_filter(loaded_c, full_c, integral_constant<int, 1>{}, integral_constant<int, 0>{}); break;
+                case 2: load_and_filter(loaded_c, full_c, integral_constant<int, 2>{}, integral_constant<int, 0>{}); break;
+                default: load_and_filter(loaded_c, full_c, integral_constant<int, 3>{}, integral_constant<int, 0>{}); break;
                 }
             } else {
-                load_and_filter(loaded_c, full_c, std::integral_constant<int, 0>{});
+                load_and_filter(loaded_c, full_c, integral_constant<int, 0>{}, integral_constant<int, 0>{});
             }
         };
         if (have16) run_phase1(std::true_type{}, std::true_type{});
@@ -295,7 +331,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 if (!ONE_BYTE && LAZY_ORDER) {
                     // the descriptor came without the schedule (and without the needle's dwords): built here, by the waves
                     // that need them, not on every workgroup's way in
-                    const uint64_t position = pr.d * 16 + 4 * Q + pr.r;
+                    const uint64_t position = pr.d * 16 + 4 * (Q == kQDynamic ? pr.q : (uint32_t)Q) + pr.r;
                     const uint64_t position3 = THREE ? (uint64_t)(4 * pr.q3 + pr.r3) : ~0ull;
                     const uint64_t anchor = (uint64_t)((pr.base + pr.mis) - va.hay);      // index of the first filter byte
                     ro.n = (uint32_t)__builtin_amdgcn_readfirstlane(

@@ -33,7 +33,7 @@ namespace ss {
 // is bounded.
 struct ServiceRequest {
     Problem pr;
-    uint32_t q;            // dword window of the second filter byte (the kernels' template parameter Q)
+    uint32_t q;            // (unused: the window travels in pr.q)
     uint32_t one_byte;
     uint32_t stop;         // != 0: no search - the service ends
     uint32_t settled;      // != 0: every byte this request reads was last written before an earlier request's acquire (or the
@@ -146,16 +146,10 @@ service_kernel(const uint32_t *d_req, uint32_t *h_status, unsigned long long *h_
         __syncthreads();
         const uint64_t ntiles = (rq.pr.npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
         const ColdInRegisters cold = {&rq.pr};
-        if (rq.one_byte) {
+        if (rq.one_byte)
             scan_tiles<0, 0, true, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found);
-        } else {
-            switch (rq.q) {
-            case 0: scan_tiles<0, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
-            case 1: scan_tiles<1, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
-            case 2: scan_tiles<2, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
-            default: scan_tiles<3, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found); break;
-            }
-        }
+        else            // the second byte's window is run-time data (Problem::q)
+            scan_tiles<kQDynamic, 0, false, U, SS_SERVICE_NT, false, false, false>(rq.pr, cold, s_needle, blockIdx.x, rq.active, ntiles, d_found, &s_wg_found);
         // ---- 4. count out; the workgroup that completes the count answers (scan_kernel's completion word) ---------------
         __syncthreads();
         if (threadIdx.x == 0) {

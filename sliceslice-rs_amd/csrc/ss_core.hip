@@ -408,17 +408,26 @@ void filter_for_position(const uint8_t *needle, size_t n, size_t position, size_
 // constructor-built searcher, and the caller's byte needle[fb] is the first thing a surviving candidate is tested for in memory
 // (`far`; scan_filters.hpp verify_flags).  Still tested before any compare, still a necessary condition: results cannot change
 // (/root/reference/src/lib.rs:375-378).
+// A pair WITHOUT a third byte (third == second: what ss_searcher_set_filter3 takes for "a plain two-byte filter", e.g. the
+// reference's own pair (0, n-1)) still gets one on the device - the rarest of the 15 bytes behind the first - because every
+// kernel's first phase tests three bytes anyway (a missing third is the second one tested twice) and on text a two-byte filter of
+// common bytes sends nearly every tile into the second level: the reference's pair ran at 0.79 of the roofline on the i386 text,
+// most of it spent there.  One more necessary condition; ss_searcher_filter3 keeps reporting what the caller set.
 void derive_device_filter(ss_searcher *s)
 {
     s->da = s->fa;
     s->db = s->fb;
     s->dc = s->fc;
     s->far = 0;
-    if (s->n >= 2 && (s->fb - s->fa) / 16 > kShiftMaxD) {
-        const ByteCost cost(nullptr);
+    if (s->n < 3) return;
+    const ByteCost cost(nullptr);
+    if ((s->fb - s->fa) / 16 > kShiftMaxD) {
         s->far = s->fb;
         s->db = choose_third(s->needle.data(), s->n, s->fa, s->fa, cost);              // the rarest of needle[fa+1 .. fa+15]
         s->dc = choose_third(s->needle.data(), s->n, s->fa, s->db, cost);              // ... and the next rarest
+    } else if (s->fc == s->fb || s->fb - s->fa > 15) {
+        const size_t third = choose_third(s->needle.data(), s->n, s->fa, s->fb, cost);
+        s->dc = third > s->fa && third != s->fb ? third : s->fb;
     }
 }
 

@@ -209,14 +209,15 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.npieces = (((uint64_t)pr.mis + pr.end + 15) / 16 + 63) / 64;
     size_t position = fb - fa;                          // distance between the two filter bytes
     pr.d = position / 16;
-    // third first-phase byte (single-stream kernels only, i.e. d == 0); "none" = the second byte once more
-    const bool three = !one_byte && pr.d == 0 && s->dc > fa && s->dc - fa <= 15 && s->dc < n;
+    // third first-phase byte, at most 15 behind the first; "none" (needles of two bytes) = needle[fa + position % 16] once more -
+    // any (byte, offset) of the needle is a valid condition
+    const bool three = !one_byte && s->dc > fa && s->dc - fa <= 15 && s->dc < n && s->dc != fb;
     size_t position3 = three ? s->dc - fa : position % 16;
     // The two further bytes are interchangeable; the kernels are instantiated for "the third byte's dword is not behind
     // the second's" only (10 copies of the first phase instead of 16 - and two of the six others, second byte in dword 0
     // with the third in dword 1 or 3, came out of the compiler waiting for all four loads of a tile before the first
     // xor: 6.3-6.4 instead of 7.4 TB/s, profiles/r02/ab_filter_triples.jsonl).
-    if (three && position3 / 4 > position / 4) std::swap(position, position3);
+    if (three && pr.d == 0 && position3 / 4 > position / 4) std::swap(position, position3);
     const uint32_t sh = (uint32_t)(position % 16);
     pr.r = sh % 4;
     pr.n0x4 = 0x01010101u * s->needle[fa];
@@ -226,7 +227,7 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.n3x4 = 0x01010101u * s->needle[one_byte ? 0 : fa + position3];
     // second-level filter: up to 15 further needle bytes behind the first filter byte
     pr.norder = ss::build_refine_order(s->needle.data() + fa, n - fa, position, pr.order_idx, pr.order_val,
-                                       pr.d == 0 ? (uint64_t)position3 : ~0ull);
+                                       (uint64_t)position3);
     pr.find_base = find_base;
     pr.host_flag = nullptr;
     pr.epoch = 1;
@@ -234,7 +235,7 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.host_done = nullptr;
     pr.done_target = pr.done_hi = 0;
     pr.flags = 0;
-    pr.pad_ = 0;
+    pr.q = (uint32_t)(sh / 4);
     pr.far_off = one_byte ? 0 : (uint64_t)s->far;
     pr.stats = nullptr;
     // exact in-register verification: the needle ends at most 16 bytes behind the first filter byte (lib.rs:222-241)

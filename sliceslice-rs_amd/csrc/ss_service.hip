@@ -155,7 +155,18 @@ int service_post(ss_service *sv, ss::ServiceRequest &rq, uint32_t seq, unsigned 
         st = __atomic_load_n(sv->status(), __ATOMIC_ACQUIRE);
         if (st == ss::kSvcExited) {
             if (rq.stop) return SS_OK;
-            // the lease ran out before (all of) the kernel saw this request: a new residency starts with it
+            // The keeper has left.  It may have left right BEHIND this request (a residency that reached its cap ends between
+            // two requests, not after an idle lease): the workgroup that completes the count may still be about to store the
+            // answer.  Wait for the kernel to be gone - whatever it was going to store has been stored then - and look again
+            // before posting the request a second time: a second residency answering the same request would leave the host's
+            // copy of the counter's found half (taken from the FIRST answer) out of step with the device's.
+            HIP_TRY(hipStreamSynchronize(sv->stream));
+            const unsigned long long late = __atomic_load_n(sv->answer(), __ATOMIC_ACQUIRE);
+            if ((uint32_t)((late >> 1) & 0x7FFFFFFFu) == seq) {
+                *answer = late;
+                return SS_OK;
+            }
+            // the lease ran out (or the cap was reached) before all of the kernel saw this request: a new residency starts with it
             if (int rc = service_restart_with(sv, rq, seq)) return rc;
             launched_now = true;
         }
@@ -277,7 +288,16 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
 #ifdef SS_TEST_HOOKS
     const auto c1 = dbg ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
 #endif
+#ifdef SS_TEST_HOOKS
+    const uint64_t launches_before = sv->launches;
+    const uint32_t hi_before = sv->done_hi, low_before = sv->done_low;
+#endif
     if (int rc = service_post(sv, rq, seq, &a)) return rc;
+#ifdef SS_TEST_HOOKS
+    if (dbg && sv->launches != launches_before)
+        fprintf(stderr, "[service] request %u met %llu relaunch(es): answer %016llx, target %u (active %u), host counter before %u/%u\n", seq,
+                (unsigned long long)(sv->launches - launches_before), a, rq.pr.done_target, rq.active, hi_before, low_before);
+#endif
 #ifdef SS_TEST_HOOKS
     if (dbg) {
         static double prep_us = 0, post_us = 0;

@@ -465,14 +465,14 @@ def test_short_differential_campaign():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # the campaign draws kernel variants at random: it runs against the tuning build (every variant); the default library's
-    # own kernels are the `variant 0` draws of the same campaign and everything else in this suite
+    # the campaign draws kernel variants and launch shapes at random when it runs against the tuning build (every variant); against
+    # the product library it draws haystacks / needles / positions / filter triples and every search takes the automatic choice
     tuning = sys.modules["sliceslice_rs_amd._build"].build_tuning()
     # small-haystack mode; 2 GiB planted-needle mode; both once more with every wait on the stream instead of the pinned
-    # answer words (SLICESLICE_SPIN_WAIT=0: what a service that must not busy-wait runs); and once against the default library
+    # answer words (SLICESLICE_SPIN_WAIT=0: what a service that must not busy-wait runs); and both against the product library
     for extra, env in (([], {"SLICESLICE_HIP_LIB": tuning}), (["2"], {"SLICESLICE_HIP_LIB": tuning}),
                        ([], {"SLICESLICE_SPIN_WAIT": "0", "SLICESLICE_HIP_LIB": tuning}),
-                       (["2"], {"SLICESLICE_SPIN_WAIT": "0", "SLICESLICE_HIP_LIB": tuning}), ([], {"SS_FUZZ_DEFAULT_VARIANTS": "1"})):
+                       (["2"], {"SLICESLICE_SPIN_WAIT": "0", "SLICESLICE_HIP_LIB": tuning}), ([], {}), (["2"], {})):
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "8", "4242"] + extra,
                              capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **env))
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -193,7 +193,9 @@ def test_service_residency_is_capped_under_continuous_traffic(ss, hooks):
     """Every request renews the lease, so a caller that never pauses would keep the kernel resident for good - and block every
     device-wide wait in the process with it.  A residency therefore ends after 16 leases (at least 250 ms) whatever the traffic;
     the request that meets the leaving kernel starts the next one.  Two seconds of back-to-back requests: several residencies,
-    every answer right, and a device-wide wait from another thread returns while the traffic goes on."""
+    every answer right, and a device-wide wait from another thread returns while the traffic goes on.  (A capped residency ends
+    right BEHIND a request, whose answer may still be on its way when the host sees the kernel gone: the host must not post that
+    request a second time - the first cut of this did, and every ~250 ms one answer came back wrong.)"""
     import threading
     t = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
     t[-3:] = torch.tensor([7, 8, 9], dtype=torch.uint8)
@@ -210,7 +212,7 @@ def test_service_residency_is_capped_under_continuous_traffic(ss, hooks):
             waits.append(time.perf_counter() - t0)
             time.sleep(0.05)
 
-    with ss.SearchService(workgroups=16, lease_ms=10.0) as sv:
+    with ss.SearchService(workgroups=16, lease_ms=1.0) as sv:         # cap: max(16 leases, 250 ms) = 250 ms
         th = threading.Thread(target=waiter)
         th.start()
         t0 = time.perf_counter()

@@ -15,14 +15,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sliceslice_rs_amd as ss  # noqa: E402
 
-# Kernel variants drawn at random.  Most of them are tuning-build kernels: run the campaign with
-# SLICESLICE_HIP_LIB=<libsliceslice_hip_tuning.so>, or with SS_FUZZ_DEFAULT_VARIANTS=1 against the default library (the launch
-# shape digits and the automatic choice only - what that library holds).
-DEFAULT_ONLY = os.environ.get("SS_FUZZ_DEFAULT_VARIANTS") == "1"
-VARIANTS = [0, 0, 41, 100041, 300041, 40041] if DEFAULT_ONLY else [0, 40, 41, 80, 81, 141, 241, 281, 1041, 2041, 2081, 100041, 300041, 100241, 40041]
-FIND_VARIANTS = [0, 41] if DEFAULT_ONLY else [0, 40, 41, 141, 241]
-BIG_VARIANTS = [0, 0, 41] if DEFAULT_ONLY else [0, 0, 41, 141, 241, 1041]
-GRIDS = [0, 0, 0, 1, 3, 64, 4096, -1, -2, -3, -7, -64]
+# Kernel variants and launch shapes drawn at random - with the tuning build (SLICESLICE_HIP_LIB=<libsliceslice_hip_tuning.so>: every
+# variant, ss_searcher_set_variant / _set_grid).  The product library has neither the variants nor the overrides: there the campaign
+# draws haystacks, needles, positions and filter triples only, and every search runs the automatic choice.
+TUNING = ss.lib().has_hooks and b"tuning" in ss.lib().ss_version()
+VARIANTS = [0, 40, 41, 80, 81, 241, 281, 1041, 2041, 2081, 100041, 300041, 100241, 40041] if TUNING else [0]
+FIND_VARIANTS = [0, 40, 41, 241] if TUNING else [0]
+BIG_VARIANTS = [0, 0, 41, 241, 1041] if TUNING else [0]
+GRIDS = [0, 0, 0, 1, 3, 64, 4096, -1, -2, -3, -7, -64] if TUNING else [0]
+BIG_GRIDS = [0, 0, 0, -1, -2, -5, 8192] if TUNING else [0]
 
 
 def make_haystack(rng, n_bytes):
@@ -90,7 +91,7 @@ def big(seconds, seed, gib):
         s = ss.DynamicHipSearcher(nd, pos)
         flt = random_filter(rng, s, n)
         s.set_variant(rng.choice(BIG_VARIANTS))
-        s.set_grid(rng.choice([0, 0, 0, -1, -2, -5, 8192]))
+        s.set_grid(rng.choice(BIG_GRIDS))
         got_b, got_p = s.search_in(hay), s.find(hay)
         for o, sv in zip(reversed(offs), reversed(saved)):            # restore (overlapping plants: reverse order)
             hay[o:o + n] = sv
