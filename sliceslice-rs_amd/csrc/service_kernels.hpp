@@ -33,13 +33,11 @@ namespace ss {
 // is bounded.
 struct ServiceRequest {
     Problem pr;
-    uint32_t q;            // (unused: the window travels in pr.q)
     uint32_t one_byte;
     uint32_t stop;         // != 0: no search - the service ends
     uint32_t settled;      // != 0: every byte this request reads was last written before an earlier request's acquire (or the
                            // kernel's start) - a bound haystack (ss_service_bind), a needle uploaded earlier: no acquire
     uint32_t active;       // workgroups 0 .. active-1 scan (tiles b, b + active, ...) and count out; the others only watch
-    uint32_t pad_;
 };
 static_assert(sizeof(ServiceRequest) <= 240 && sizeof(ServiceRequest) % 8 == 0, "four mailbox lines of 60 payload bytes");
 constexpr uint32_t kSvcRunning = 1, kSvcLeaving = 2, kSvcExited = 3;

@@ -95,7 +95,7 @@ struct PerDevice {
     // workgroups of a scan add to (Problem::stats), how far it had got when the latest launch was made, and how many wave-tiles
     // that launch's sampled workgroups cover - what the NEXT launch's workgroups-per-CU choice goes by (ss_scan.hip).  Racy by
     // design when several threads search through one handle (a heuristic: any value is a valid choice).
-    unsigned long long *h_stats = nullptr;
+    unsigned long long *d_stats = nullptr, *h_stats = nullptr;
     unsigned long long stats_seen = 0, stats_sampled = 0;    // (accessed with relaxed __atomic builtins)
     int last_occ = 0, last_rate = -1;                // the latest launch's choice and the rate behind it (ss_debug_last_occupancy)
     uint32_t done_low[64] = {0}, done_hi[64] = {0};

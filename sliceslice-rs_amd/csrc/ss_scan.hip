@@ -92,10 +92,13 @@ struct Launch {
 // only; 2xxx variants force it for tuning.
 
 // Learned occupancy: the previous scan's sampled workgroups must have covered this many wave-tiles (a 64 MiB scan) for its
-// candidate-tile rate to count, and six workgroups per CU are chosen from kLearnDenseRate candidate tiles per 1024 up
-// (profiles/r04/occupancy_learned.jsonl: where four and six per CU cross over).
-constexpr unsigned long long kLearnMinTiles = 256;
-constexpr int kLearnDenseRate = 64;
+// candidate-tile rate to count, and six workgroups per CU are chosen from a rate (candidate wave-tiles per 1024) where six
+// overtake four - measured in one process on one buffer, i386 text tiled to 1 GiB (tools/occ_probe.py,
+// profiles/r04/occupancy_probe.jsonl): single-stream kernels 6.5-6.6 vs 6.9-7.1 TB/s at 30 per 1024, 5.9 vs 7.2 at 118, 5.8 vs 7.1
+// at 208, a tie or four ahead below 10; the cross-lane kernels (more LDS traffic per tile) 7.0 vs 6.4 at 93, a tie at 260,
+// 5.9 vs 6.5 at 598.
+constexpr unsigned long long kLearnMinTiles = 1024;     // = 16,384 one-tile workgroups (256 MiB): at least four refreshes of the host's copy
+constexpr int kLearnDenseRate = 20, kLearnDenseRateCrossLane = 400;
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 
@@ -237,7 +240,7 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.flags = 0;
     pr.q = (uint32_t)(sh / 4);
     pr.far_off = one_byte ? 0 : (uint64_t)s->far;
-    pr.stats = nullptr;
+    pr.stats = pr.host_stats = nullptr;
     // exact in-register verification: the needle ends at most 16 bytes behind the first filter byte (lib.rs:222-241)
     pr.exact_len = 0;
     pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
@@ -277,12 +280,12 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     // candidate-tile rate the haystack actually showed under this filter in the searcher's previous scan on this device.
     const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
                            ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
-    int occ = !one_byte && text_like ? 6 : 4, rate = -1;
+    int occ = !one_byte && text_like && pr.d == 0 ? 6 : 4, rate = -1;
     const unsigned long long stats_now = __atomic_load_n(pd->h_stats, __ATOMIC_RELAXED);
     const unsigned long long sampled_before = __atomic_load_n(&pd->stats_sampled, __ATOMIC_RELAXED);
     if (!one_byte && sampled_before >= kLearnMinTiles) {
         rate = (int)std::min<unsigned long long>((stats_now - __atomic_load_n(&pd->stats_seen, __ATOMIC_RELAXED)) * 1024ull / sampled_before, 1024ull);
-        occ = rate >= kLearnDenseRate ? 6 : 4;
+        occ = rate >= (pr.d == 0 ? kLearnDenseRate : kLearnDenseRateCrossLane) ? 6 : 4;
     }
     const Launch l = pick_variant(s->variant, pr.d, one_byte, occ);
     const uint64_t wpb = l.block / ss::kWave;
@@ -318,10 +321,11 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     }
     if (blocks < 1) blocks = 1;
     // statistics for the next launch's choice: the tiles of every 64th workgroup, per wave
-    pr.stats = nullptr;
+    pr.stats = pr.host_stats = nullptr;
     if (!one_byte && tpb != 0) {
         const unsigned long long sampled = ((blocks + (1u << ss::kStatsSampleShift) - 1) >> ss::kStatsSampleShift) * tpb * wpb;
-        pr.stats = pd->h_stats;
+        pr.stats = pd->d_stats;
+        pr.host_stats = pd->h_stats;
         __atomic_store_n(&pd->stats_seen, stats_now, __ATOMIC_RELAXED);
         __atomic_store_n(&pd->stats_sampled, sampled, __ATOMIC_RELAXED);
     }

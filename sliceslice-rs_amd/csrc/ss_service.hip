@@ -253,7 +253,6 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
     ProblemShape ps;
     fill_problem(s, pd->d_needle, d_haystack, len, 0, &rq.pr, &ps);
     if (rq.pr.d != 0) return fail(SS_ERR_ARGUMENT, "the service runs the single-stream kernels: filter pairs 16 or more apart take the launch path");
-    rq.q = (uint32_t)((ps.position % 16) / 4);
     rq.one_byte = ps.one_byte ? 1u : 0u;
     std::lock_guard<std::mutex> lock(sv->mu);
     if (sv->stopped) return fail(SS_ERR_ARGUMENT, "this search service has been stopped");

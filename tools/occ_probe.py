@@ -32,6 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", default="1,8,32")
     ap.add_argument("--occ", default="0,4,5,6")
+    ap.add_argument("--rounds", type=int, default=1, help="repeat every sweep this many times (A, B, A, B ...: exposes drift)")
     args = ap.parse_args()
     gibs = [float(x) for x in args.gib.split(",")]
     occs = [int(x) for x in args.occ.split(",")]
@@ -44,7 +45,7 @@ def main():
     for gib in gibs:
         n = int(gib * (1 << 30))
         for name, needle, _ in cases:
-            for occ in occs:
+            for occ in occs * args.rounds:
                 s = ss.DynamicHipSearcher.new(needle)
                 s.set_variant(occ * 10000 + 41 if occ else 0)
                 res, med, mn = kernel_ms(s, hay[:n])
@@ -56,17 +57,20 @@ def main():
     raw = np.frombuffer(open(os.path.join(gd, "i386.txt"), "rb").read(), dtype=np.uint8)
     reps = (1 << 30) // raw.size + 1
     text = torch.from_numpy(np.tile(raw, reps)[: 1 << 30].copy()).cuda()
-    phrases = [b"segment descriptor table entries are", b" the quick brown fox ", b"protection exception handler must", b"privilege level zero!"]
+    phrases = [b"segment descriptor table entries are", b" the quick brown fox ", b"protection exception handler must", b"privilege level zero!",
+               b"there is not another one of these", b"instruction", b"the"]
     for ph in phrases:
         for mode in ("new", "refpair"):
-            for occ in occs:
+            for occ in occs * args.rounds:
                 s = ss.DynamicHipSearcher.new(ph)
                 if mode == "refpair":
                     s.set_filter(0, len(ph) - 1)
                 s.set_variant(occ * 10000 + 41 if occ else 0)
                 res, med, mn = kernel_ms(s, text)
+                wg, rate = s.last_occupancy() if ss.lib().has_hooks else (None, None)
                 print(json.dumps({"case": "text:" + ph.decode(), "mode": mode, "occ": occ or "auto", "found": res, "ms": round(med, 4),
-                                  "gbps": round(text.numel() / med / 1e6, 1), "gbps_best": round(text.numel() / mn / 1e6, 1)}), flush=True)
+                                  "gbps": round(text.numel() / med / 1e6, 1), "gbps_best": round(text.numel() / mn / 1e6, 1),
+                                  "filter": list(s.filter3), "chosen": wg, "candidate_tiles_per_1024": rate}), flush=True)
 
 
 if __name__ == "__main__":

@@ -9,11 +9,15 @@ the kernel family expected, the algorithmic bytes per launch and the kernel time
   cases:  headline1g   1 GiB random, 16-byte absent needle, new()              (scan_kernel<3,0,...>)
           onebyte      1 GiB random, 1-byte absent needle (8-byte loads)       (scan_kernel<0,0,true,...,L8>)
           mode2        1 GiB random, 128-byte needle, set_filter(0, 127)       (scan_kernel<.,2,...> cross-lane)
-          mode1        1 GiB random, 2000-byte needle, set_filter(0, 1999)     (scan_kernel<.,1,...> two streams)
+          far_pair     1 GiB random, 2000-byte needle, set_filter(0, 1999)     (rounds 1-3: the two-stream kernels, case "mode1"; now the
+                       single-stream kernels with the caller's far byte checked in memory)
           long_wp      1 GiB random, 2000-byte needle, with_position(1999)     (single stream: partner byte next to 1999)
           long_new     1 GiB random, 2000-byte needle, new()                   (single stream again)
           find         1 GiB random, 16-byte absent needle, find()             (FIND kernel)
-          batched      4096 x 1 MiB, 4096 absent 16-byte needles, one call     (scan_batched_plan_kernel<4, false>)
+          batched      4096 x 1 MiB, 4096 absent 16-byte needles, one call     (scan_batched_plan_kernel<4, false, false>)
+          batched_plan the same problems through an ss_batch_plan: one run() per launch  (scan_batched_plan_kernel<4, false, true>)
+          random_text_needle   'there is not another one of these' through new() on RANDOM bytes: the needle looks like text, the
+                       haystack is not - workgroups per CU from the previous scan's candidate rate, not from the needle
           text_worst   i386.txt tiled to 1 GiB, letters-only absent phrase, new()
           text_refpair the same phrase with the reference's pair (0, n-1), set verbatim
           text_wp      the same phrase through with_position(n-1)
@@ -55,7 +59,7 @@ def main():
     if case.startswith("text"):
         raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
         hay = torch.from_numpy(raw.copy()).cuda().repeat(n_bytes // raw.size)
-    elif case == "batched":
+    elif case.startswith("batched"):
         hay = torch.empty(4096 << 20, dtype=torch.uint8, device="cuda")
         ss.fill_random_device(hay, SEED_HAY)
     else:
@@ -63,7 +67,7 @@ def main():
         ss.fill_random_device(hay, SEED_HAY)
     torch.cuda.synchronize()
     out["algorithmic_bytes_per_launch"] = hay.numel()
-    if case == "batched":
+    if case.startswith("batched"):
         count, each = 4096, 1 << 20
         nd = bytearray(ss.fill_random_host(16 * count, SEED_NEEDLE + 1).tobytes())
         for i in range(count):
@@ -72,11 +76,14 @@ def main():
         hay_off = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
         nd_off = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        spin(lambda: ss.search_batched(hay, hay_off, nblob, nd_off))
+        plan = ss.BatchPlan(hay, hay_off, nblob, nd_off) if case == "batched_plan" else None
+        flags = torch.empty(count, dtype=torch.int32, device="cuda")
+        call = (lambda: plan.run(flags)) if plan is not None else (lambda: ss.search_batched(hay, hay_off, nblob, nd_off))
+        spin(call)
         ms = []
         for _ in range(launches):
             e0.record()
-            found = ss.search_batched(hay, hay_off, nblob, nd_off)
+            found = call()
             e1.record()
             e1.synchronize()
             ms.append(e0.elapsed_time(e1))
@@ -94,6 +101,8 @@ def main():
             "onebyte": lambda: ss.DynamicHipSearcher.new(absent(1)),
             "mode2": lambda: exact(absent(128)),
             "mode1": lambda: exact(absent(2000)),
+            "far_pair": lambda: exact(absent(2000)),
+            "random_text_needle": lambda: ss.DynamicHipSearcher.new(b"there is not another one of these"),
             "long_wp": lambda: ss.DynamicHipSearcher.with_position(absent(2000), 1999),
             "text_wp": lambda: ss.DynamicHipSearcher.with_position(phrase, len(phrase) - 1),
             "long_new": lambda: ss.DynamicHipSearcher.new(absent(2000)),
@@ -105,6 +114,9 @@ def main():
             "text_common_new": lambda: ss.DynamicHipSearcher.new(b"there is not another one of these"),
         }[case]()
         s.set_timing(True)
+        if len(sys.argv) > 3:
+            s.set_variant(int(sys.argv[3]))              # tuning build: e.g. 40041 / 60041 = at most 4 / 6 workgroups per CU
+            out["variant"] = int(sys.argv[3])
         spin(lambda: s.find(hay) if case == "find" else s.search_in(hay))
         ms = []
         for _ in range(launches):
@@ -112,6 +124,8 @@ def main():
             ms.append(s.last_kernel_ms())
         assert r in (False, None), r
         out.update(kernel="scan_kernel", filter_bytes=list(s.filter3), ms=round(float(np.median(ms)), 4), ms_min=round(float(np.min(ms)), 4))
+        if ss.lib().has_hooks:
+            out["workgroups_per_cu"], out["candidate_tiles_per_1024"] = s.last_occupancy()
     out["gbps"] = round(hay.numel() / out["ms"] / 1e6, 1)
     print(json.dumps(out), flush=True)
 

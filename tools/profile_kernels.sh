@@ -9,7 +9,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-kp}
 shift || true
-CASES=${@:-headline1g onebyte mode2 mode1 long_new long_wp find batched text_worst text_wp text_refpair text_spaces text_spaces_new text_common_new}
+CASES=${@:-headline1g onebyte mode2 far_pair long_new long_wp find batched batched_plan text_worst text_wp text_refpair text_spaces text_spaces_new text_common_new random_text_needle}
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in $CASES; do
