@@ -79,15 +79,20 @@ def cpu_baseline(needle, sample_bytes):
     s = O.OracleSearcher(needle)
     assert s.search_in(hay[: 1 << 20]) is False
 
-    def best(threads, reps):
-        b = float("inf")
-        for _ in range(reps):
+    def rates(threads, reps, discard):
+        """GB/s of `reps` timed scans after `discard` untimed ones (the first call with a new thread count builds the pool and
+        pins its threads; the second finds the pages where the first left them): (min, median, max)."""
+        got = []
+        for k in range(discard + reps):
             t = time.perf_counter()
             r = s.search_in(hay, threads=threads)
-            b = min(b, time.perf_counter() - t)
+            dt = time.perf_counter() - t
             assert r is False
-        return sample_bytes / b / 1e9
-    one = best(1, 3)
+            if k >= discard:
+                got.append(sample_bytes / dt / 1e9)
+        got.sort()
+        return got[0], got[len(got) // 2], got[-1]
+    one = rates(1, 3, 1)[1]
     # The reference is single-threaded; the multi-thread figure uses the same range-shard rule as the GPUs, on a
     # LARGER sample (4x, so that creating the threads does not dominate a few-millisecond scan) that the same
     # number of NUMA-confined threads first touched.  More threads is not always faster (memory-bound): report
@@ -101,8 +106,11 @@ def cpu_baseline(needle, sample_bytes):
         hay = O.fill_random(mt_bytes, SEED_HAY, threads=cores)
         gen_mt_s = time.perf_counter() - t0
         sample_bytes_1t, sample_bytes = sample_bytes, mt_bytes
+        spread = {}
         for th in counts:
-            sweep[th] = best(th, 5)
+            lo, med, hi = rates(th, 7, 2)
+            sweep[th] = med
+            spread[str(th)] = {"min": round(lo, 1), "median": round(med, 1), "max": round(hi, 1)}
         sample_bytes = sample_bytes_1t
     best_th = max(sweep, key=sweep.get) if sweep else 1
     out = {
@@ -111,13 +119,26 @@ def cpu_baseline(needle, sample_bytes):
         "single_thread_value": round(one, 2), "hardware_threads": cores,
         "by_threads": {str(k): round(v, 2) for k, v in sweep.items()}, "avx2": bool(O.have_avx2()),
         "sample": "the same synthetic haystack in host RAM, same 16-byte absent needle; C/AVX2 restatement of "
-                  "DynamicAvx2Searcher (oracle/sliceslice_oracle.c): %d MiB, best of 3 runs on 1 thread; %d MiB "
-                  "(first touched by %d NUMA-confined threads), best of 5 per thread count in by_threads (range "
-                  "shards, n-1 overlap, threads confined to the NUMA node of their share); value = the fastest "
-                  "thread count" % (sample_bytes >> 20, mt_bytes >> 20, cores),
+                  "DynamicAvx2Searcher (oracle/sliceslice_oracle.c): %d MiB, median of 3 runs (1 discarded) on 1 thread; %d MiB "
+                  "(first touched by %d NUMA-confined threads), per thread count in by_threads the MEDIAN of 7 runs after 2 "
+                  "discarded ones (range shards, n-1 overlap, a persistent pool of threads confined to the NUMA node of their "
+                  "share; by_threads_spread has min / median / max); value = the fastest thread count's median"
+                  % (sample_bytes >> 20, mt_bytes >> 20, cores),
     }
     if counts:
         out["host_generate_mt_s"] = round(gen_mt_s, 2)
+        out["by_threads_spread"] = spread
+        ks = sorted(sweep)
+        dips = [k for a, k in zip(ks, ks[1:]) if sweep[k] < 0.97 * sweep[a]]
+        try:
+            nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+        except OSError:
+            nodes = None
+        out["numa_nodes"] = nodes
+        if dips:
+            out["by_threads_note"] = ("medians are not monotone at %s threads: the pages were first touched by %d threads (one share each, "
+                                      "%s NUMA node(s)), so a count that does not divide that partition evenly reads part of its range "
+                                      "from the other node(s); the figure to compare with is `value`" % (dips, cores, nodes))
     # BASELINE.json configs[0]: data/i386.txt x data/words.txt, shape of bench/benches/i386.rs:246-256
     try:
         gd = os.path.join(ROOT, "tests", "golden", "data")
@@ -370,15 +391,25 @@ def other_configs(ss, shard, reps=20):
         assert int(found.sum().item()) == 0
         med, steady = _events_ms(lambda: ss.search_batched(blob, hay_off, nblob, nd_off), 15)
         nb = count * each
+        # plan once / search many (ss_batch_plan_*): the reference builds its searchers once and times only the searches
+        plan = ss.BatchPlan(blob, hay_off, nblob, nd_off)
+        flags = torch.empty(count, dtype=torch.int32, device="cuda")
+        plan.run(flags)
+        assert int(flags.sum().item()) == 0
+        pmed, psteady = _events_ms(lambda: plan.run(flags), 15)
+        plan.close()
         return {"problems": count, "haystack_each": each, "call_ms": round(med, 4), "gbps": round(nb / med / 1e6, 1),
                 "frac": round(nb / med / 1e6 / HBM_PEAK_GBPS, 4), "steady_call_ms": round(steady, 4),
-                "gbps_steady": round(nb / steady / 1e6, 1), "frac_steady": round(nb / steady / 1e6 / HBM_PEAK_GBPS, 4)}
+                "gbps_steady": round(nb / steady / 1e6, 1), "frac_steady": round(nb / steady / 1e6 / HBM_PEAK_GBPS, 4),
+                "plan_run_ms": round(pmed, 4), "plan_gbps": round(nb / pmed / 1e6, 1), "plan_frac": round(nb / pmed / 1e6 / HBM_PEAK_GBPS, 4),
+                "plan_steady_ms": round(psteady, 4), "plan_frac_steady": round(nb / psteady / 1e6 / HBM_PEAK_GBPS, 4)}
     if shard.numel() >= 4 * gib:
         r = batched(4096, 1 << 20, shard)
         out["5"] = {"workload": "4096 x 1 MiB haystacks, 4096 distinct absent 16-byte needles, ONE ss_search_batched call (plan kernel + "
                                 "scan grid; events on the launch stream)", "launch_ms": r["call_ms"], **r,
-                    "note": "call_ms: one call on an idle stream, host launch path included; steady_call_ms: per call when 10 are "
-                            "issued back to back"}
+                    "note": "call_ms: one ss_search_batched call on an idle stream, host launch path included; steady_call_ms: per call "
+                            "when 10 are issued back to back; plan_*: the same problems through an ss_batch_plan made once "
+                            "(ss_batch_plan_run: one scan launch, no plan kernel, no scratch)"}
         out["5_shapes"] = {"workload": "the same call on other cuts of 1 GiB (and one of 4 GiB): the lengths live on the device, the "
                                        "grid is sized from the problem count alone",
                            "rows": [batched(c, e, shard) for c, e in ((1024, 1 << 20), (256, 4 << 20), (64, 16 << 20), (16384, 64 << 10),
