@@ -72,9 +72,9 @@ SS_API int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
 /* ... and make the next `count` scans launched through `s` fail before they reach the device (SS_ERR_HIP): how the tests
  * check that a rank-local failure leaves no other rank waiting in the collective of ss_search_sharded / ss_find_sharded. */
 SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
-/* The workgroups-per-CU choice of `s`'s latest scan on the current device (4 or 6) and the candidate-tile rate it was made
- * from (sampled candidate tiles per 1024 sampled tiles of the scan before it; -1: none yet, the needle's bytes decided). */
-SS_API int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *candidate_tiles_per_1024);
+/* The workgroups-per-CU setting of `s`'s latest scan on the current device (4 or 6) and what the searcher has learned so far from
+ * the time of its full scans there: the running GB/s at four and at six workgroups per CU (0: not tried yet). */
+SS_API int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *gbps_at_four, int *gbps_at_six);
 
 /* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */
 SS_API int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches, uint64_t *settled);

@@ -83,19 +83,9 @@ struct Problem {
     // with the first byte and two partners close behind it, and the caller's far byte needle[far_off] is what a surviving
     // candidate at index i is tested for FIRST when it reaches memory (hay[i + far_off]).  0: none.
     uint64_t far_off;
-    // Candidate-tile statistics (scan_kernel launches of ss_scan.hip only; null otherwise): a counter in DEVICE memory that the
-    // waves of every 64th workgroup add 1 to for each of their tiles that enters the second phase (relaxed, no return value:
-    // nothing waits for it), and its pinned-host copy, which every 4096th workgroup refreshes on its way out (a posted store).
-    // The host knows how many tiles the sampled workgroups scan, so the copy's growth over a launch is the haystack's
-    // candidate-tile rate under this filter - what the NEXT launch through the same searcher picks its workgroups per CU by
-    // (ss_scan.hip, learned occupancy).  (First cut: the sampled waves added to the pinned word directly - a thousand atomics
-    // over PCIe on one address turned a 0.15 ms scan of text into 0.9 ms.)
-    unsigned long long *stats, *host_stats;
 };
 constexpr uint32_t kProblemCounted = 1u;
 constexpr int kQDynamic = -1;                     // scan_tiles<Q = kQDynamic, ...>: the window comes from Problem::q
-constexpr unsigned kStatsSampleShift = 6;           // every 64th workgroup counts its candidate tiles ...
-constexpr unsigned kStatsPublishShift = 12;         // ... every 4096th copies the running total to the host
 
 // Where a wave finds the COLD fields of its Problem.
 struct ColdInKernarg {        // scan_kernel: the Problem is the kernel's FIRST argument, i.e. offset 0 of the kernarg segment

@@ -301,13 +301,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
             return;
         }
         if (cand_tile) {
-            if constexpr (std::is_same<ColdT, ColdInKernarg>::value) {
-                // sampled workgroups report the tile (one relaxed system-scope add by one lane, nothing waits for it)
-                if ((blockIdx.x & ((1u << kStatsSampleShift) - 1)) == 0) {
-                    unsigned long long *stats = cold()->stats;
-                    if (stats != nullptr && lane == 0) __hip_atomic_fetch_add(stats, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
             // Kernels whose Problem sits in the kernarg segment re-read the cold fields for EVERY tile with candidates (scalar
             // cache hits, the lines were touched at entry) instead of carrying ~25 scalar registers from tile to tile: carried,
             // they pushed as many loop invariants out to vector lanes in front of every workgroup's first load.  Kernels that
@@ -557,14 +550,6 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         }
         scan_tiles<Q, MODE, ONE_BYTE, U, NTMODE, FIND, L8, false, ColdInKernarg>(pr, ColdInKernarg{}, s_needle, t0, step, t1, found,
                                                                                  counted ? &s_wg_found : nullptr);
-    }
-    if (!ONE_BYTE && (blockIdx.x & ((1u << kStatsPublishShift) - 1)) == (1u << kStatsPublishShift) - 1 && threadIdx.x == 0) {
-        // candidate-tile statistics: the running total, to its pinned-host copy (see Problem::stats)
-        const auto c = ColdInKernarg{}();
-        unsigned long long *stats = c->stats;
-        if (stats != nullptr)
-            __hip_atomic_store(c->host_stats, __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (counted) {
         // Completion word of the bool kernels.  Every workgroup counts itself out with ONE relaxed 64-bit atomic add that

@@ -74,8 +74,8 @@ namespace {
 // a kernel's start drops the caches' copy of the block; a resident service kernel acquires what was uploaded after its last
 // look (upload tickets).  Without a large BAR (or with SLICESLICE_NO_BAR_WRITES=1) the image goes by one hipMemcpy.
 constexpr size_t kBlockDevBytes = 4096, kBlockHostBytes = 2048, kBlockNeedleOff = 2048, kBlockNeedleMax = 2048;
-constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kOffStats = 1792, kCtlBytes = 1808;
-constexpr size_t kHostOffFlags = 0, kHostOffBest = 256, kHostOffDone = 768, kHostOffStats = 1280;
+constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kCtlBytes = 1792;
+constexpr size_t kHostOffFlags = 0, kHostOffBest = 256, kHostOffDone = 768;
 constexpr uint32_t kBlocksPerSlab = 512;        // 2 MiB of device memory per slab: one page-table fragment
 
 struct BlockPool {
@@ -179,19 +179,17 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
     p.d_best = reinterpret_cast<uint64_t *>(db + kOffBest);
     p.d_done = reinterpret_cast<unsigned long long *>(db + kOffDone);
     p.d_best_done = reinterpret_cast<uint64_t *>(db + kOffBestDone);
-    p.d_stats = reinterpret_cast<unsigned long long *>(db + kOffStats);
     p.h_flags = reinterpret_cast<int *>(hb + kHostOffFlags);
     p.h_best = reinterpret_cast<uint64_t *>(hb + kHostOffBest);
     p.h_done = reinterpret_cast<long long *>(hb + kHostOffDone);
-    p.h_stats = reinterpret_cast<unsigned long long *>(hb + kHostOffStats);
     memset(hb, 0, kBlockHostBytes);                    // blocks are recycled: a stale value must not equal an epoch
     for (int k = 0; k < kSlots; ++k) p.find_tag[k] = kFindTagMax;
-    // the block's image: flags 0 | minima all ones | completion counters 0 | keyed minima all ones | statistics 0 | the needle
+    // the block's image: flags 0 | minima all ones | completion counters 0 | keyed minima all ones | the needle
     const bool inside = s->n <= kBlockNeedleMax;
     alignas(16) uint8_t img[kBlockDevBytes];
     memset(img, 0, sizeof img);
     memset(img + kOffBest, 0xFF, kOffDone - kOffBest);
-    memset(img + kOffBestDone, 0xFF, kOffStats - kOffBestDone);
+    memset(img + kOffBestDone, 0xFF, kCtlBytes - kOffBestDone);
     if (inside && s->n) memcpy(img + kBlockNeedleOff, s->needle.data(), s->n);
     const size_t img_bytes = inside ? kBlockNeedleOff + ((s->n + 15) & ~(size_t)15) : kCtlBytes;
     hipError_t e = hipSuccess;

@@ -91,13 +91,11 @@ struct PerDevice {
     unsigned long long *d_done = nullptr;   // kSlots counters: found-workgroups << 32 | workgroups
     long long *h_done = nullptr;            // pinned: the answer word, stored by the workgroup that completes the count
     uint64_t *d_best_done = nullptr;        // kSlots keyed minima of find()
-    // Candidate-tile statistics of the scans launched through this searcher on this device: a pinned counter the sampled
-    // workgroups of a scan add to (Problem::stats), how far it had got when the latest launch was made, and how many wave-tiles
-    // that launch's sampled workgroups cover - what the NEXT launch's workgroups-per-CU choice goes by (ss_scan.hip).  Racy by
-    // design when several threads search through one handle (a heuristic: any value is a valid choice).
-    unsigned long long *d_stats = nullptr, *h_stats = nullptr;
-    unsigned long long stats_seen = 0, stats_sampled = 0;    // (accessed with relaxed __atomic builtins)
-    int last_occ = 0, last_rate = -1;                // the latest launch's choice and the rate behind it (ss_debug_last_occupancy)
+    // Workgroups per CU, learned from the time of this searcher's full scans on this device (ss_scan.hip): running MB/s and sample
+    // count at four [0] and at six [1] workgroups per CU, the number of choices made, the latest launch's setting.  Racy by
+    // design when several threads search through one handle (relaxed __atomic accesses; any value is a valid choice).
+    uint32_t learn_mbps[2] = {0, 0}, learn_n[2] = {0, 0}, learn_calls = 0, learn_warm = 0;
+    int last_occ = 0;
     uint32_t done_low[64] = {0}, done_hi[64] = {0};
     uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax
     uint64_t free_mask = 0;
@@ -207,7 +205,8 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
 // sees (the leftmost one survives).  Preconditions: 1 <= n <= len.  done_slot >= 0: the call owns flag slot `done_slot` and would
 // like to wait on the slot's completion word instead of the stream; granted (*used_done = true) for small grids.
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find = false,
-                 uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1, int done_slot = -1, bool *used_done = nullptr);
+                 uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1, int done_slot = -1, bool *used_done = nullptr,
+                 int *occ_used = nullptr);
 void timer_forget(const ss_searcher *s);                         // ss_searcher_free: the calling thread's timing record
 
 // Scans too large for the workgroup count of the completion word still answer through a pinned word when the scan is short enough

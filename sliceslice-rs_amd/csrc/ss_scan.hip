@@ -91,14 +91,19 @@ struct Launch {
 // transposition into the 16-byte layout on top of the regular filter.  Automatic choice: one-byte needles
 // only; 2xxx variants force it for tuning.
 
-// Learned occupancy: the previous scan's sampled workgroups must have covered this many wave-tiles (a 64 MiB scan) for its
-// candidate-tile rate to count, and six workgroups per CU are chosen from a rate (candidate wave-tiles per 1024) where six
-// overtake four - measured in one process on one buffer, i386 text tiled to 1 GiB (tools/occ_probe.py,
-// profiles/r04/occupancy_probe.jsonl): single-stream kernels 6.5-6.6 vs 6.9-7.1 TB/s at 30 per 1024, 5.9 vs 7.2 at 118, 5.8 vs 7.1
-// at 208, a tie or four ahead below 10; the cross-lane kernels (more LDS traffic per tile) 7.0 vs 6.4 at 93, a tie at 260,
-// 5.9 vs 6.5 at 598.
-constexpr unsigned long long kLearnMinTiles = 1024;     // = 16,384 one-tile workgroups (256 MiB): at least four refreshes of the host's copy
-constexpr int kLearnDenseRate = 20, kLearnDenseRateCrossLane = 400;
+// Workgroups per CU, learned.  Four suit a scan that rarely meets a candidate, six one that keeps meeting them (pick_variant has
+// the measurements), and which of the two a haystack is cannot be told from the needle: a text-like needle on binary data gave
+// up 3-5 % under the needle-byte guess, a stock phrase of the manual with rare-looking bytes 15-20 % the other way.  So the
+// searcher LEARNS it, per device, from what its own full scans cost: ss_search_device times every call that scanned the whole
+// haystack (answer "absent") of at least kLearnMinBytes, keeps a rate estimate for each of the two settings, alternates between
+// them over its first few such calls and looks at the other one every kLearnExploreEvery calls, and otherwise launches with the
+// faster one.  Nothing in
+// the kernels: a first cut counted candidate tiles in the scan kernel (a relaxed atomic in the candidate path of every 64th
+// workgroup - never executed on random bytes) and cost the headline 3-8 % through what the compiler did to the hot loop around
+// it (profiles/r04/ab_stats_counter.jsonl).  Entry points that do not see their scan's duration (the _async forms, the sharded
+// searches) launch with what has been learned so far, or with the needle-byte guess.
+constexpr size_t kLearnMinBytes = (size_t)256 << 20;
+constexpr uint32_t kLearnExploreEvery = 64;
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 
@@ -240,7 +245,6 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.flags = 0;
     pr.q = (uint32_t)(sh / 4);
     pr.far_off = one_byte ? 0 : (uint64_t)s->far;
-    pr.stats = pr.host_stats = nullptr;
     // exact in-register verification: the needle ends at most 16 bytes behind the first filter byte (lib.rs:222-241)
     pr.exact_len = 0;
     pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
@@ -258,8 +262,36 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     shape->one_byte = one_byte;
 }
 
+// The setting to launch with (racy by design when several threads search through one handle: any value read is a valid choice).
+// The first kLearnTrials recorded scans alternate between the two settings; after that the better estimate wins, and every
+// kLearnExploreEvery-th choice looks at the other one again (haystacks change).
+constexpr uint32_t kLearnTrials = 6;
+int learned_occupancy(PerDevice *pd, int guess)
+{
+    const uint32_t n4 = __atomic_load_n(&pd->learn_n[0], __ATOMIC_RELAXED), n6 = __atomic_load_n(&pd->learn_n[1], __ATOMIC_RELAXED);
+    if (n4 + n6 < kLearnTrials) return n4 == n6 ? guess : n4 < n6 ? 4 : 6;
+    const uint32_t g4 = __atomic_load_n(&pd->learn_mbps[0], __ATOMIC_RELAXED), g6 = __atomic_load_n(&pd->learn_mbps[1], __ATOMIC_RELAXED);
+    const int best = g6 > g4 ? 6 : 4;
+    const uint32_t calls = __atomic_fetch_add(&pd->learn_calls, 1u, __ATOMIC_RELAXED) + 1;
+    return calls % kLearnExploreEvery == 0 ? (best == 4 ? 6 : 4) : best;
+}
+
+// One full scan's lesson.  Whatever disturbs a timing makes it LONGER (a cold first launch, clocks still ramping up after an idle
+// gap, a preempted host thread), so the estimate per setting is the best rate seen, fading by 1/32 per further sample of the same
+// setting so that a haystack that has become slower under it is noticed; the searcher's very first scan is not recorded at all.
+void learn_from_scan(PerDevice *pd, int occ, size_t len, double seconds)
+{
+    if (len < kLearnMinBytes || seconds <= 0 || (occ != 4 && occ != 6)) return;
+    if (__atomic_exchange_n(&pd->learn_warm, 1u, __ATOMIC_RELAXED) == 0) return;
+    const int k = occ == 6 ? 1 : 0;
+    const uint32_t rate = (uint32_t)std::min((double)len / seconds / 1e6, 4.0e9);                    // MB/s
+    const uint32_t old = __atomic_load_n(&pd->learn_mbps[k], __ATOMIC_RELAXED);
+    __atomic_store_n(&pd->learn_mbps[k], std::max(rate, old - old / 32), __ATOMIC_RELAXED);
+    __atomic_fetch_add(&pd->learn_n[k], 1u, __ATOMIC_RELAXED);
+}
+
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find,
-                 uint64_t find_base, int *host_flag, int epoch, int done_slot, bool *used_done)
+                 uint64_t find_base, int *host_flag, int epoch, int done_slot, bool *used_done, int *occ_used)
 {
 #ifdef SS_TEST_HOOKS
     if (s->debug_fail_scans.load(std::memory_order_relaxed) > 0 && s->debug_fail_scans.fetch_sub(1) > 0)
@@ -275,18 +307,13 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     const size_t fa = ps.fa, position = ps.position, position3 = ps.position3;
     const uint32_t sh = (uint32_t)(position % 16);
 
-    // Workgroups per CU: four for a scan that rarely meets a candidate, six for one that keeps meeting them (see pick_variant).
-    // First use: a guess from the NEEDLE (every filter byte text-like -> the haystack is presumably text).  After that: the
-    // candidate-tile rate the haystack actually showed under this filter in the searcher's previous scan on this device.
+    // Workgroups per CU (see "learned" above).  First use: a guess from the NEEDLE (every filter byte text-like -> the haystack
+    // is presumably text; single-stream kernels only - the cross-lane ones gain from six only at very high candidate rates).
     const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
                            ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
-    int occ = !one_byte && text_like && pr.d == 0 ? 6 : 4, rate = -1;
-    const unsigned long long stats_now = __atomic_load_n(pd->h_stats, __ATOMIC_RELAXED);
-    const unsigned long long sampled_before = __atomic_load_n(&pd->stats_sampled, __ATOMIC_RELAXED);
-    if (!one_byte && sampled_before >= kLearnMinTiles) {
-        rate = (int)std::min<unsigned long long>((stats_now - __atomic_load_n(&pd->stats_seen, __ATOMIC_RELAXED)) * 1024ull / sampled_before, 1024ull);
-        occ = rate >= (pr.d == 0 ? kLearnDenseRate : kLearnDenseRateCrossLane) ? 6 : 4;
-    }
+    int occ = !one_byte && text_like && pr.d == 0 ? 6 : 4;
+    if (!one_byte && len >= kLearnMinBytes) occ = learned_occupancy(pd, occ);
+    if (occ_used) *occ_used = occ;
     const Launch l = pick_variant(s->variant, pr.d, one_byte, occ);
     const uint64_t wpb = l.block / ss::kWave;
     const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
@@ -320,17 +347,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         }
     }
     if (blocks < 1) blocks = 1;
-    // statistics for the next launch's choice: the tiles of every 64th workgroup, per wave
-    pr.stats = pr.host_stats = nullptr;
-    if (!one_byte && tpb != 0) {
-        const unsigned long long sampled = ((blocks + (1u << ss::kStatsSampleShift) - 1) >> ss::kStatsSampleShift) * tpb * wpb;
-        pr.stats = pd->d_stats;
-        pr.host_stats = pd->h_stats;
-        __atomic_store_n(&pd->stats_seen, stats_now, __ATOMIC_RELAXED);
-        __atomic_store_n(&pd->stats_sampled, sampled, __ATOMIC_RELAXED);
-    }
     __atomic_store_n(&pd->last_occ, s->variant == 0 ? occ : 0, __ATOMIC_RELAXED);
-    __atomic_store_n(&pd->last_rate, rate, __ATOMIC_RELAXED);
     const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
     if (used_done) *used_done = false;
     if (done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks && (!find || len < (1ull << ss::kFindOffsetBits))) {
@@ -437,13 +454,14 @@ using namespace ssh;
 extern "C" {
 
 #ifdef SS_TEST_HOOKS
-int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *candidate_tiles_per_1024)
+int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *gbps_at_four, int *gbps_at_six)
 {
-    if (!s || !workgroups_per_cu || !candidate_tiles_per_1024) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (!s || !workgroups_per_cu || !gbps_at_four || !gbps_at_six) return fail(SS_ERR_ARGUMENT, "NULL argument");
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     *workgroups_per_cu = __atomic_load_n(&pd->last_occ, __ATOMIC_RELAXED);
-    *candidate_tiles_per_1024 = __atomic_load_n(&pd->last_rate, __ATOMIC_RELAXED);
+    *gbps_at_four = (int)(__atomic_load_n(&pd->learn_mbps[0], __ATOMIC_RELAXED) / 1000);
+    *gbps_at_six = (int)(__atomic_load_n(&pd->learn_mbps[1], __ATOMIC_RELAXED) / 1000);
     return SS_OK;
 }
 #endif
@@ -496,8 +514,11 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     // the slot's completion word may hold a find()'s answer (offset + 1), which could pass for 2 * epoch + found
     __atomic_store_n(pd->h_done + k, 0ll, __ATOMIC_RELAXED);
     bool used_done = false;
+    int occ_used = 0;
+    const bool learning = len >= kLearnMinBytes && s->n > 1 && s->variant == 0;
+    const auto t_launch = learning ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch, spin_ok ? k : -1,
-                          &used_done);
+                          &used_done, &occ_used);
     bool answered = false;
     // the answer word of a small grid: found-half of the slot's counter << 32 | epoch << 1 | found
     auto take = [&](long long v) {
@@ -537,6 +558,9 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
         else *found = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
     }
     if (rc != SS_OK) start_over(pd, k);             // a failed launch may have left a partial workgroup count behind
+    // a full scan (the needle is absent: every byte was read) teaches the searcher what this setting is worth on this haystack
+    if (rc == SS_OK && learning && *found == 0)
+        learn_from_scan(pd, occ_used, len, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count());
     release_slot(s, pd, k);
     return rc;
 }

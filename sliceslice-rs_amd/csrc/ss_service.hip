@@ -87,7 +87,11 @@ void service_write_mailbox(ss_service *sv, const ss::ServiceRequest &rq, uint32_
         static double total_us = 0;
         static unsigned long n = 0;
         total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
-        if ((++n & 0x3FFF) == 0) fprintf(stderr, "[service] mailbox write: %.3f us average over %lu requests\n", total_us / n, n);
+        if (++n == 0x4000) {            // the average of the last 16,384 requests, then start over
+            fprintf(stderr, "[service] mailbox write: %.3f us average over %lu requests\n", total_us / n, n);
+            total_us = 0;
+            n = 0;
+        }
     }
 #endif
 }
@@ -304,7 +308,11 @@ int ss_service_search(ss_service *sv, const ss_searcher *s, const void *d_haysta
         const auto c2 = std::chrono::steady_clock::now();
         prep_us += std::chrono::duration<double, std::micro>(c1 - c0).count();
         post_us += std::chrono::duration<double, std::micro>(c2 - c1).count();
-        if ((++n & 0x3FFF) == 0) fprintf(stderr, "[service] per request: %.3f us before the post, %.3f us post + wait (%lu requests)\n", prep_us / n, post_us / n, n);
+        if (++n == 0x4000) {
+            fprintf(stderr, "[service] per request: %.3f us before the post, %.3f us post + wait (%lu requests)\n", prep_us / n, post_us / n, n);
+            prep_us = post_us = 0;
+            n = 0;
+        }
     }
 #endif
     if (!rq.settled) {

@@ -102,7 +102,7 @@ HOOKS_ABI = {
     "ss_debug_set_completion_state": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
-    "ss_debug_last_occupancy": (_int, [_vp, _pint, _pint]),
+    "ss_debug_last_occupancy": (_int, [_vp, _pint, _pint, _pint]),
     "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
 
@@ -380,10 +380,10 @@ class DynamicHipSearcher:
             self._ck(_hooks(self._L).ss_searcher_set_grid(self._h, int(blocks)))
 
     def last_occupancy(self):
-        """(workgroups per CU of the latest scan, candidate tiles per 1024 it went by or -1) - hooks builds."""
-        w, r = ctypes.c_int(0), ctypes.c_int(0)
-        self._ck(_hooks(self._L).ss_debug_last_occupancy(self._h, ctypes.byref(w), ctypes.byref(r)))
-        return w.value, r.value
+        """(workgroups per CU of the latest scan, learned GB/s at four, learned GB/s at six; 0 = not tried) - hooks builds."""
+        w, a, b = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._ck(_hooks(self._L).ss_debug_last_occupancy(self._h, ctypes.byref(w), ctypes.byref(a), ctypes.byref(b)))
+        return w.value, a.value, b.value
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -17,8 +17,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-from settle import wait_for_vram_reclaim  # noqa: E402
+import sliceslice_rs_amd as ss  # noqa: E402  (the synthetic haystack generator: libsliceslice_hip_tools.so)
 
 vp, sz = ctypes.c_void_p, ctypes.c_size_t
 
@@ -30,8 +29,6 @@ def load(path):
     L.ss_searcher_set_timing.argtypes = [vp, ctypes.c_int]
     L.ss_searcher_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.ss_searcher_free.argtypes = [vp]
-    L.ss_fill_random_device.argtypes = [vp, ctypes.c_uint64, sz, ctypes.c_uint64, vp]
-    L.ss_fill_random_host.argtypes = [vp, ctypes.c_uint64, sz, ctypes.c_uint64]
     L.ss_last_error.restype = ctypes.c_char_p
     return L
 
@@ -44,7 +41,6 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--cases", default="n16,n1,n2000,tworst,tspaces")
     args = ap.parse_args()
-    wait_for_vram_reclaim()
     # name=path[@variant[:grid]]: the same build can appear several times with different kernel-variant / grid overrides
     # ...#a-b-c: the filter triple (ss_searcher_set_filter3; a-b: a pair) instead of the constructor's choice
     libs, variants, grids, filters = [], {}, {}, {}
@@ -59,13 +55,12 @@ def main():
         grids[name] = int(grid) if grid else 0
     n_bytes = int(args.gib * (1 << 30))
     hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
-    assert libs[0][1].ss_fill_random_device(hay.data_ptr(), 0, n_bytes, 0x5EED0001, None) == 0
+    ss.fill_random_device(hay, 0x5EED0001)
     torch.cuda.synchronize()
     text = None
 
     def absent(n):
-        a = np.empty(n, dtype=np.uint8)
-        libs[0][1].ss_fill_random_host(a.ctypes.data, 0, n, 0x5EED0002)
+        a = ss.fill_random_host(n, 0x5EED0002)
         a[0 if n == 1 else (1 if n == 2 else n // 2)] = 0xFF
         return a.tobytes()
     table = {}
@@ -86,8 +81,8 @@ def main():
             s = vp()
             if c.startswith("tref") or c.startswith("nref"):    # the reference's pair (0, n-1), verbatim
                 assert L.ss_searcher_new(nd, len(nd), ctypes.byref(s)) == 0, L.ss_last_error()
-                L.ss_searcher_set_filter.argtypes = [vp, sz, sz]
-                assert L.ss_searcher_set_filter(s, 0, len(nd) - 1) == 0, L.ss_last_error()
+                L.ss_searcher_set_filter3.argtypes = [vp, sz, sz, sz]
+                assert L.ss_searcher_set_filter3(s, 0, len(nd) - 1, len(nd) - 1) == 0, L.ss_last_error()
             elif c.startswith("twp") or c.startswith("nwp"):    # with_position(n-1)
                 L.ss_searcher_with_position.argtypes = [vp, sz, sz, ctypes.POINTER(vp)]
                 assert L.ss_searcher_with_position(nd, len(nd), len(nd) - 1, ctypes.byref(s)) == 0, L.ss_last_error()
@@ -96,9 +91,8 @@ def main():
             L.ss_searcher_set_timing(s, 1)
             if filters[name]:
                 f = filters[name]
-                L.ss_searcher_set_filter.argtypes = [vp, sz, sz]
                 L.ss_searcher_set_filter3.argtypes = [vp, sz, sz, sz]
-                rc = L.ss_searcher_set_filter(s, f[0], f[1]) if len(f) == 2 else L.ss_searcher_set_filter3(s, f[0], f[1], f[2])
+                rc = L.ss_searcher_set_filter3(s, f[0], f[1], f[1] if len(f) == 2 else f[2])
                 assert rc == 0, L.ss_last_error()
             if variants[name]:
                 L.ss_searcher_set_variant.argtypes = [vp, ctypes.c_int]
@@ -121,7 +115,13 @@ def main():
                     acc[name].append(ms.value)
         row = {name: round(h.numel() / statistics.median(v) / 1e6, 1) for name, v in acc.items()}
         table[c] = row
-        print(json.dumps({"case": c, "found": found.value, "gbps": row}), flush=True)
+        occ = {}
+        for name, L, s in hs:                             # hooks builds: what the searcher settled on
+            if hasattr(L, "ss_debug_last_occupancy"):
+                w, a, b = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+                L.ss_debug_last_occupancy(s, ctypes.byref(w), ctypes.byref(a), ctypes.byref(b))
+                occ[name] = [w.value, a.value, b.value]
+        print(json.dumps({"case": c, "found": found.value, "gbps": row, "workgroups_per_cu,gbps_at_4,gbps_at_6": occ}), flush=True)
         for name, L, s in hs:
             L.ss_searcher_free(s)
     print(json.dumps({"median_gbps": table}), flush=True)
