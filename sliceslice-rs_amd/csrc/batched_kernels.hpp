@@ -65,37 +65,19 @@ constexpr ClassPlanes make_class_planes()
     return p;
 }
 
-// One LANE per problem.  `nslices` = slices per problem of the scan launch that follows, `min_tiles` = the shortest slice worth a
-// workgroup.  Same rules as scan_batched_kernel: needle[position] is always a first-phase byte; its partner is needle[0]
-// when position < 16, else the rarest (class) byte of the 15 in front of it, closest to `position` among equals; the third
-// byte is the rarest of the 15 behind the anchor, the later one among equals; the two are ordered by dword (q3 <= Q).
-// Written for LATENCY - the scan cannot start before this kernel has ended: the rarity classes come from a 256-entry table
-// in LDS (byte_rarity_rank is a dozen branches), and the needle bytes of a step are fetched by unconditional loads
-// (out-of-range slots re-read byte 0 of the window) that are all in flight together; a first cut with a predicated
-// load-rank loop ran 8-12 us, one memory round trip per byte.
-__global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
-                                                             uint32_t nslices, uint32_t min_tiles, int tile_pieces)
+// What the plan kernel tells the host about a plan's problems (ss_batch_plan_create sizes the grid of the runs from it).
+struct PlanStats {
+    uint32_t max_slices;       // the most active slices any problem got
+    uint32_t max_tiles;        // the longest scan, in tiles (saturating)
+    uint64_t total_tiles;
+};
+
+// One problem's descriptor (and, for the unplanned calls, its initial output); returns its number of active slices.
+__device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, uint64_t h0, uint64_t h1, uint64_t n0, uint64_t n1, uint64_t given,
+                                             BatchDesc *descs, uint32_t nslices, uint32_t min_tiles, int tile_pieces, const uint8_t *s_class,
+                                             uint64_t *tiles_out)
 {
-    __shared__ uint8_t s_class[256];
-    {
-        constexpr ClassPlanes P = make_class_planes();                         // compile-time constants, selected by wave
-        const uint32_t t = threadIdx.x, w = t >> 5;                            // kBlock == 256: one table entry per thread
-        uint32_t lo = P.lo[0], hi = P.hi[0];
-#pragma unroll
-        for (uint32_t k = 1; k < 8; ++k) {
-            lo = w == k ? P.lo[k] : lo;
-            hi = w == k ? P.hi[k] : hi;
-        }
-        s_class[t] = (uint8_t)(((lo >> (t & 31)) & 1u) | (((hi >> (t & 31)) & 1u) << 1));
-    }
-    const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool live = prob < count;
-    const uint64_t pi = live ? prob : 0;                                       // (every lane reaches the barrier)
-    const uint64_t h0 = a.hay_begin[pi], h1 = a.hay_end[pi];
-    const uint64_t n0 = a.needle_begin[pi], n1 = a.needle_end[pi];
-    const uint64_t given = a.position ? a.position[pi] : 0;
-    __syncthreads();
-    if (!live) return;
+    *tiles_out = 0;
     const uint64_t len = h1 - h0, n = n1 - n0;
     const uint64_t position = (a.position && n) ? given : n - 1;
     BatchDesc d;
@@ -166,11 +148,70 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         uint64_t eff = (ntiles + min_tiles - 1) / min_tiles;
         eff = eff < nslices ? (eff ? eff : 1) : nslices;
         d.per = (eff << 32) | ((ntiles + eff - 1) / eff);
+        *tiles_out = ntiles;
     }
     if (d.per == 0) d.shifts = (uint32_t)flag;             // no scan: the answer travels in the descriptor too (plan runs)
     if (a.best) a.best[prob] = n == 0 ? 0ull : ~0ull;      // the empty needle matches at offset 0 of every haystack
     else if (a.found) a.found[prob] = flag;
     descs[prob] = d;
+    return (uint32_t)(d.per >> 32);
+}
+
+// One LANE per problem.  `nslices` = slices per problem of the scan launch that follows, `min_tiles` = the shortest slice worth a
+// workgroup.  Same rules as scan_batched_kernel: needle[position] is always a first-phase byte; its partner is needle[0]
+// when position < 16, else the rarest (class) byte of the 15 in front of it, closest to `position` among equals; the third
+// byte is the rarest of the 15 behind the anchor, the later one among equals; the two are ordered by dword (q3 <= Q).
+// Written for LATENCY - the scan cannot start before this kernel has ended: the rarity classes come from a 256-entry table
+// in LDS (byte_rarity_rank is a dozen branches), and the needle bytes of a step are fetched by unconditional loads
+// (out-of-range slots re-read byte 0 of the window) that are all in flight together; a first cut with a predicated
+// load-rank loop ran 8-12 us, one memory round trip per byte.
+// `stats` (plans only, else null): see PlanStats.
+__global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
+                                                             uint32_t nslices, uint32_t min_tiles, int tile_pieces, PlanStats *stats)
+{
+    __shared__ uint8_t s_class[256];
+    __shared__ uint32_t s_max, s_maxt;
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) {
+        s_max = s_maxt = 0;
+        s_sum = 0;
+    }
+    {
+        constexpr ClassPlanes P = make_class_planes();                         // compile-time constants, selected by wave
+        const uint32_t t = threadIdx.x, w = t >> 5;                            // kBlock == 256: one table entry per thread
+        uint32_t lo = P.lo[0], hi = P.hi[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; ++k) {
+            lo = w == k ? P.lo[k] : lo;
+            hi = w == k ? P.hi[k] : hi;
+        }
+        s_class[t] = (uint8_t)(((lo >> (t & 31)) & 1u) | (((hi >> (t & 31)) & 1u) << 1));
+    }
+    const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = prob < count;
+    const uint64_t pi = live ? prob : 0;                                       // (every lane reaches the barrier)
+    const uint64_t h0 = a.hay_begin[pi], h1 = a.hay_end[pi];
+    const uint64_t n0 = a.needle_begin[pi], n1 = a.needle_end[pi];
+    const uint64_t given = a.position ? a.position[pi] : 0;
+    __syncthreads();
+    uint64_t tiles = 0;
+    if (stats) {                                                               // (uniform: a kernel argument)
+        uint32_t eff = 0;
+        if (live) eff = plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles);
+        if (eff != 0) {
+            atomicMax(&s_max, eff);
+            atomicMax(&s_maxt, tiles > 0xffffffffull ? 0xffffffffu : (uint32_t)tiles);
+            atomicAdd(&s_sum, (unsigned long long)tiles);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_max != 0) {
+            atomicMax(&stats->max_slices, s_max);
+            atomicMax(&stats->max_tiles, s_maxt);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&stats->total_tiles), s_sum);
+        }
+        return;
+    }
+    if (live) (void)plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles);
 }
 
 // The cold fields of a planned problem, re-read from its descriptor by the waves that need them (scan_tiles' ColdT).
@@ -218,21 +259,34 @@ struct ColdInDesc {
 //     (1,024 x 1 MiB: 150 us instead of 162, kernel time) - and when one of them finds the needle the others are at the same
 //     depth and stop at their next poll.
 constexpr uint32_t kPlanSliceMajorMax = 8;
+constexpr uint32_t kPlanCounterHitShift = 16;   // a counter: workgroups counted out | workgroups that found the needle << 16
+constexpr uint32_t kPlanFanIn = 32;            // plans of more than this many slices per problem: first-level counters per problem
+constexpr uint32_t kPlanCounterStride = 32;     // uint32 words between the counters of two problems: one 128-byte line each
 // FIND: the sink is the problem's uint64 (leftmost offset, atomicMin); a workgroup skips only what lies right of the best so far
 // (scan_tiles does that tile by tile, so the slice-major entry poll is not needed).
 // COUNTED (ss_batch_plan_run: descriptors built once, searched many times - the reference builds its searchers once and times
 // the searches, bench/benches/i386.rs:246-256): ONE launch does everything, outputs included, and can be replayed from a
-// hipGraph.  The workgroups of a problem work on the plan's own state word (flag / minimum, `state`), count themselves out on
-// the problem's counter, and the workgroup that completes the count writes the caller's output, then puts state and counter back
-// to their idle values for the next run - nothing is initialised by the host or by another kernel, so nothing races with a
-// workgroup that is already scanning.  Problems without a scan (eff == 0: the empty needle, a bad position, a haystack shorter
-// than the needle) are answered by their slice-0 workgroup from the descriptor.
+// hipGraph; nothing is initialised by the host or by another kernel, so nothing races with a workgroup that is already
+// scanning.  What shapes it: a workgroup of a batch lives for a few tiles, and ANY memory round trip at its end - a returning
+// atomic, a load of the problem's flag - is time its slot on the CU stands idle (a load + two stores at the end of every
+// workgroup: 65,536 x 64 KiB at 0.72 ms instead of 0.60; counters of 32 problems in one 128-byte line, where device-scope
+// atomics queue one at a time: 1,024 x 1 MiB at 0.31 ms instead of 0.15).  So:
+//   * a match goes to a word in the workgroup's LDS (scan_tiles' wg_sink), and the epilogue reads the answer there;
+//   * a problem scanned by ONE workgroup (eff == 1) is published by that workgroup with one store: no counter, no global flag;
+//   * otherwise the workgroups of a problem also raise the plan's own state word (flag / minimum: the others stop early) and
+//     count themselves out with ONE returning atomic each on the problem's counter - a 128-byte line of its own - that
+//     carries "found here" in its high half: the workgroup that completes the count knows a bool answer from the sum, stores
+//     it, and puts counter and state word back to idle with plain stores (a find plan reads the minimum back, and only when
+//     somebody found something).
+// Problems without a scan (eff == 0: the empty needle, a bad position, a haystack shorter than the needle) are answered by
+// their slice-0 workgroup from the descriptor.
 template <int U, bool FIND = false, bool COUNTED = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock)
 scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state,
                          uint32_t *counters)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
+    __shared__ unsigned long long s_wg;             // COUNTED: this workgroup's match (bool: the low int, 0 -> 1; FIND: minimum)
     const uint32_t w = blockIdx.x;
     const bool slice_major = nslices <= kPlanSliceMajorMax;
     uint32_t prob, slice;
@@ -249,7 +303,18 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     // slice-major, later slices: the problem's flag (one coherent load) is requested together with the descriptor (one scalar
     // load, s_load_dwordx16) - one round trip decides whether and what to scan
     const int seen = !FIND && slice_major && slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    const BatchDesc d = *dp;
+    BatchDesc d = *dp;
+    if (COUNTED) {
+        // The hot fields are pinned in scalar registers HERE, in front of the first store of the kernel (the LDS word's
+        // initial value, the trivial problem's answer below): a load the compiler sinks behind a store cannot go through the scalar cache any more, so it became a
+        // per-lane load and everything computed from it - tile bounds, loop control, addresses - per-lane arithmetic under exec
+        // masks (101 VGPRs, and 311 us where the uncounted kernel takes 154 on 1,024 x 1 MiB).
+        uint64_t base = reinterpret_cast<uint64_t>(d.base);
+        __asm__ volatile("" : "+s"(base), "+s"(d.end), "+s"(d.nchunks_all), "+s"(d.per), "+s"(d.bytes), "+s"(d.shifts));
+        d.base = reinterpret_cast<const uint8_t *>(base);
+        if (threadIdx.x == 0) __hip_atomic_store(&s_wg, FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+    }
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
     const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
@@ -291,32 +356,59 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         pr.r3 = (d.shifts >> 8) & 3;
         pr.q3 = (d.shifts >> 10) & 3;
         pr.epoch = 1;
-        pr.flags = 0;
+        pr.flags = COUNTED && eff > 1 ? kProblemWgMirror : 0u;
         pr.q = (d.shifts >> 6) & 3;
         const ColdInDesc cold = {dp, a.needles};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
-        if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink);
-        else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink);
+        void *wg_sink = COUNTED ? static_cast<void *>(&s_wg) : nullptr;
+        if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
+        else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
     }
     if (COUNTED) {
-        // count out (every active slice of the problem gets here, with or without work).  A wave's atomicMin has no return
-        // value and the barrier does not wait for vector memory: every wave drains its own queue first (see scan_kernel).
-        if (FIND) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every active slice of the problem gets here, with or without work.  A find plan's atomicMin on the state word has no
+        // return value and the barrier does not wait for vector memory: every wave drains its own queue first (see scan_kernel).
+        if (FIND && eff > 1) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t c = __hip_atomic_fetch_add(counters + prob, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            if (c == eff) {                         // the last workgroup of this problem: publish, and back to idle
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (FIND) {
-                    uint64_t *st = static_cast<uint64_t *>(state) + prob;
-                    a.best[prob] = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(st, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    int *st = static_cast<int *>(state) + prob;
-                    a.found[prob] = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                    __hip_atomic_store(st, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long mine = __hip_atomic_load(&s_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool hit = FIND ? mine != ~0ull : mine != 0;
+            if (eff == 1) {
+                if (FIND) a.best[prob] = mine;
+                else a.found[prob] = hit;
+            } else {
+                // A problem of many slices counts in two levels: its workgroups on kPlanFanIn counters of their own lines (slice
+                // mod kPlanFanIn), the workgroup that completes one of those on the problem's counter - thousands of workgroups
+                // on ONE line queued there again (one haystack of 1 GiB: 0.18 ms a run instead of 0.16).
+                constexpr uint32_t kMask = (1u << kPlanCounterHitShift) - 1;
+                const bool fan = nslices > kPlanFanIn;                           // (uniform over the grid: the plan's layout)
+                uint32_t *ctr = counters + (size_t)prob * (fan ? 1 + kPlanFanIn : 1) * kPlanCounterStride;
+                uint32_t add = 1u + (hit ? 1u << kPlanCounterHitShift : 0u), expect = eff;
+                bool top = true;
+                if (fan && eff > kPlanFanIn) {
+                    const uint32_t j = slice % kPlanFanIn;
+                    uint32_t *sub = ctr + (1 + j) * kPlanCounterStride;
+                    const uint32_t t = __hip_atomic_fetch_add(sub, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+                    top = (t & kMask) == (eff - j + kPlanFanIn - 1) / kPlanFanIn;
+                    if (top) {
+                        __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        add = 1u + ((t >> kPlanCounterHitShift) != 0 ? 1u << kPlanCounterHitShift : 0u);
+                        expect = kPlanFanIn;
+                    }
                 }
-                __hip_atomic_store(counters + prob, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t total = top ? __hip_atomic_fetch_add(ctr, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add : 0u;
+                if (top && (total & kMask) == expect) {                          // the last workgroup of this problem
+                    const bool any = (total >> kPlanCounterHitShift) != 0;
+                    __asm__ volatile("" ::: "memory");
+                    if (FIND) {
+                        uint64_t *st = static_cast<uint64_t *>(state) + prob;
+                        a.best[prob] = any ? __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                        if (any) __hip_atomic_store(st, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        a.found[prob] = any;
+                        if (any) __hip_atomic_store(static_cast<int *>(state) + prob, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }

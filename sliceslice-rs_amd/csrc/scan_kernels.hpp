@@ -61,7 +61,7 @@ namespace ss {
 template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false,
           typename ColdT = ColdInRegisters>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_t *s_needle_block, uint64_t tile0,
-                                           uint64_t tile_step, uint64_t tile_end, void *sink, int *wg_found = nullptr)
+                                           uint64_t tile_step, uint64_t tile_end, void *sink, void *wg_sink = nullptr)
 {
     static_assert(!L8 || (MODE == 0 && !FIND), "the 8-byte layout covers the single-stream bool kernels");
     static_assert(Q != kQDynamic || (MODE == 0 && !L8), "a run-time window is for the single-stream kernels' three-byte phase");
@@ -69,6 +69,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     constexpr bool SHIFTED = MODE == 2;
     int *found = static_cast<int *>(sink);
     uint64_t *best = static_cast<uint64_t *>(sink);
+    // `wg_sink`, when given: a word in the workgroup's LDS that takes the match INSTEAD of the global sink (bool: int 0 -> 1;
+    // FIND: uint64 minimum) - for launches whose epilogue carries the answer on, so that no wave queues a device-scope atomic in
+    // front of it - or, with kProblemWgMirror in pr.flags, as well as the global sink (other workgroups still stop early).
+    int *wg_found = static_cast<int *>(wg_sink);
     constexpr bool NTA = NTMODE >= 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
@@ -445,7 +449,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         const uint64_t mine = pr.find_base + (((uint64_t)hi << 32) | lo);
                         // only a wave that can actually lower the minimum touches it (matches everywhere
                         // would otherwise serialise one atomic per wave on a single address)
-                        if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        if (wg_sink != nullptr && lane == 0)
+                            __hip_atomic_fetch_min(static_cast<uint64_t *>(wg_sink), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if ((wg_sink == nullptr || (pr.flags & kProblemWgMirror) != 0) && lane == 0 &&
+                            mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                             __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         forget_scalar_cache_unless(small_grid);
                         return;                         // the wave's later pieces and tiles are further right
@@ -459,13 +466,13 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // pinned-host mirror: a needle that occurs everywhere would otherwise have every wave of
                     // the grid queue a system-scope store to the same host address (measured: 14 ms for a
                     // one-byte needle over 1 GiB instead of 0.02 ms).
-                    if (wg_found != nullptr) {
+                    if (wg_found != nullptr && lane == __ffsll((unsigned long long)hits) - 1)
+                        __hip_atomic_store(wg_found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (wg_found != nullptr && (pr.flags & kProblemWgMirror) == 0) {
                         // Completion-word launches (grids of at most 256 workgroups, all of them resident from the start):
                         // the answer travels in the workgroup count (scan_kernel's epilogue) and there is nobody left to
                         // stop early, so the device flag is not even written - a global store in front of the count-out
                         // atomic of the same wave is a memory round trip on the path a match's latency is made of.
-                        if (lane == __ffsll((unsigned long long)hits) - 1)
-                            __hip_atomic_store(wg_found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else if (lane == __ffsll((unsigned long long)hits) - 1 &&
                                __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.epoch) {
                         const int old = __hip_atomic_exchange(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

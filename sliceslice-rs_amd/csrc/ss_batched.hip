@@ -19,6 +19,13 @@ namespace {
 // at 4 GiB in 4,096 problems 256 per CU is 2 % faster (583 vs 597 us), which is not worth the rest.
 constexpr unsigned kPlanWgsPerCu = 96;
 constexpr uint32_t kPlanMinTiles = 2;       // shortest slice worth a workgroup, in 16 KiB tiles
+// ... and in a plan, where a problem scanned by several workgroups costs each of them a returning device-scope atomic (the count
+// that tells the last one to publish) and a problem scanned by one costs none; and where the lengths are known when the grid is
+// sized (ss_batch_plan_create reads them back from the plan kernel): about kPlanTilesPerWg tiles per workgroup - 6,500 workgroups
+// for 1 GiB, 26,000 for 4 GiB - was best or within 1 % of the best on every cut (tools/batch_probe.py under SLICESLICE_BATCH_WGS x
+// SLICESLICE_BATCH_MIN_TILES, profiles/r04/batch_plan_sweep.jsonl).
+constexpr uint32_t kPlanMinTilesCounted = 8;
+constexpr uint32_t kPlanTilesPerWg = 10;
 
 // Descriptor scratch of the unplanned calls: one grow-only device buffer per (device, stream), kept for the life of the process.
 // Launches on one stream execute in order, so a buffer that belongs to the stream can be reused by the next call on that
@@ -128,13 +135,13 @@ int fill_batch_args(ss::BatchArgs *a, const void *d_haystacks, const uint64_t *d
 struct BatchShape {
     uint32_t slices, min_tiles;
 };
-int batch_shape(int dev, size_t count, BatchShape *out)
+int batch_shape(int dev, size_t count, BatchShape *out, bool counted = false)
 {
     DeviceInfo di;
     if (int rc = device_info(dev, &di)) return rc;
     if (count > 0x3fffffffull) return fail(SS_ERR_ARGUMENT, "too many problems");
     uint64_t wg_target = (uint64_t)di.cus * kPlanWgsPerCu;
-    uint32_t min_tiles = kPlanMinTiles;
+    uint32_t min_tiles = counted ? kPlanMinTilesCounted : kPlanMinTiles;
 #ifdef SS_TEST_HOOKS
     if (const char *e = getenv("SLICESLICE_BATCH_WGS")) { const long v = atol(e); if (v > 0) wg_target = (uint64_t)v; }
     if (const char *e = getenv("SLICESLICE_BATCH_MIN_TILES")) { const long v = atol(e); if (v > 0) min_tiles = (uint32_t)v; }
@@ -142,16 +149,18 @@ int batch_shape(int dev, size_t count, BatchShape *out)
     uint64_t slices = (wg_target + count - 1) / count;
     if (slices < 1) slices = 1;
     while (slices > 1 && (uint64_t)count * slices > 0x7fffffffull) --slices;   // gridDim.x
+    if (slices > 0x7fffu) slices = 0x7fffu;                                  // a plan's counter holds the count in 16 bits
     out->slices = (uint32_t)slices;
     out->min_tiles = min_tiles;
     return SS_OK;
 }
 
-hipError_t launch_plan_kernel(const ss::BatchArgs &a, size_t count, ss::BatchDesc *descs, const BatchShape &sh, hipStream_t st)
+hipError_t launch_plan_kernel(const ss::BatchArgs &a, size_t count, ss::BatchDesc *descs, const BatchShape &sh, hipStream_t st,
+                              ss::PlanStats *stats = nullptr)
 {
     const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
     ss::batch_plan_kernel<<<dim3((unsigned)pblocks), dim3(ss::kBlock), 0, st>>>(a, (uint64_t)count, descs, sh.slices, sh.min_tiles,
-                                                                               ss::kWavesPerBlock * 4);
+                                                                               ss::kWavesPerBlock * 4, stats);
     return hipGetLastError();
 }
 
@@ -190,7 +199,10 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
 
 using namespace ssh;
 
-// One buffer of the plan's own: descriptors | state words (uint64 each; the bool plans use the low int) | counters.
+// The plan's own memory: descriptors | state words (uint64 each; the bool plans use the low int) | the plan kernel's PlanStats;
+// and - only when some problem is scanned by more than one workgroup - one counter per problem, a
+// 128-byte line each, or 33 of them in plans of more than 32 slices per problem (batched_kernels.hpp, kPlanCounterStride,
+// kPlanFanIn; either way well under 1 % of the haystack bytes such a plan covers).
 struct ss_batch_plan {
     int dev = 0;
     size_t count = 0;
@@ -198,9 +210,10 @@ struct ss_batch_plan {
     ss::BatchArgs args;
     BatchShape shape = {1, 1};
     uint8_t *mem = nullptr;
+    uint32_t *ctr = nullptr;
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
     void *state() const { return mem + count * sizeof(ss::BatchDesc); }
-    uint32_t *counters() const { return reinterpret_cast<uint32_t *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t))); }
+    ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t))); }
 };
 
 extern "C" {
@@ -249,22 +262,52 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     int rc = fill_batch_args(&p->args, d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end, find ? nullptr : d_position);
     hipError_t e = hipSuccess;
     if (rc == SS_OK && (e = hipGetDevice(&p->dev)) != hipSuccess) rc = fail(SS_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
-    if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape);
+    if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape, true);
     if (rc == SS_OK) {
-        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t) + sizeof(uint32_t));
+        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64;
         if ((e = hipMalloc((void **)&p->mem, bytes)) != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     if (rc == SS_OK) {
-        // idle values: flags 0 / minima all ones, counters 0; then the descriptors (the plan kernel writes no outputs here:
-        // args.found and args.best are both null)
+        // idle values: flags 0 / minima all ones; then the descriptors (the plan kernel writes no outputs here: args.found and
+        // args.best are both null).  The lengths live on the device, so the first pass runs with the grid guessed from the problem
+        // count and reports what it saw; the host then sizes the slices for about kPlanTilesPerWg tiles per workgroup (bounded:
+        // one huge haystack among many short ones must not multiply everybody's surplus slices) and, if that changes anything,
+        // has the descriptors rebuilt.  The runs launch as many slices per problem as the busiest problem uses.
+        ss::PlanStats seen = {0, 0, 0};
         e = hipMemsetAsync(p->state(), p->find ? 0xFF : 0, count * sizeof(uint64_t), st);
-        if (e == hipSuccess) e = hipMemsetAsync(p->counters(), 0, count * sizeof(uint32_t), st);
-        if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs(), p->shape, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = fail(SS_ERR_HIP, "plan set-up: %s", hipGetErrorString(e));
+        for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+            e = hipMemsetAsync(p->stats(), 0, 64, st);
+            if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs(), p->shape, st, p->stats());
+            if (e == hipSuccess) e = hipMemcpyAsync(&seen, p->stats(), sizeof(seen), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess || pass == 1 || seen.max_slices == 0) break;
+#ifdef SS_TEST_HOOKS
+            if (getenv("SLICESLICE_BATCH_WGS")) break;                         // tuning: the grid is what the variable says
+#endif
+            const uint64_t want = ((uint64_t)seen.max_tiles + kPlanTilesPerWg - 1) / kPlanTilesPerWg;
+            const uint64_t fair = ((seen.total_tiles + kPlanTilesPerWg - 1) / kPlanTilesPerWg + count - 1) / count;
+            uint64_t slices = std::min<uint64_t>(want, 4 * fair);
+            slices = std::max<uint64_t>(1, std::min<uint64_t>(slices, 0x7fffu));
+            while (slices > 1 && (uint64_t)count * slices > 0x7fffffffull) --slices;
+            if (slices == p->shape.slices) break;
+            p->shape.slices = (uint32_t)slices;
+        }
+        if (e == hipSuccess) {
+            const uint32_t most = seen.max_slices;
+            p->shape.slices = most < 1 ? 1 : (most < p->shape.slices ? most : p->shape.slices);
+            if (p->shape.slices > 1) {
+                const size_t cbytes = count * (p->shape.slices > ss::kPlanFanIn ? 1 + ss::kPlanFanIn : 1) * ss::kPlanCounterStride * sizeof(uint32_t);
+                if ((e = hipMalloc((void **)&p->ctr, cbytes)) == hipSuccess) e = hipMemsetAsync(p->ctr, 0, cbytes, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+            }
+        }
+        if (e != hipSuccess)
+            rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan set-up: %s", hipGetErrorString(e));
     }
     if (rc != SS_OK) {
+        (void)hipGetLastError();
+        (void)hipFree(p->ctr);
         (void)hipFree(p->mem);
         delete p;
         return rc;
@@ -285,11 +328,11 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     if (p->find) {
         a.best = static_cast<uint64_t *>(d_out);
         ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices,
-                                                                                                   p->state(), p->counters());
+                                                                                                   p->state(), p->ctr);
     } else {
         a.found = static_cast<int *>(d_out);
         ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices,
-                                                                                                    p->state(), p->counters());
+                                                                                                    p->state(), p->ctr);
     }
     HIP_TRY(hipGetLastError());
     return SS_OK;
@@ -298,7 +341,8 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
 void ss_batch_plan_free(ss_batch_plan *p)
 {
     if (!p) return;
-    (void)hipFree(p->mem);          // (waits for the device: a run the caller forgot about cannot read freed memory)
+    (void)hipFree(p->ctr);          // (waits for the device: a run the caller forgot about cannot read freed memory)
+    (void)hipFree(p->mem);
     delete p;
 }
 

@@ -280,10 +280,10 @@ def test_rccl_enum_values_the_library_hard_codes():
 SGPR_SPILL_CEILINGS = {
     "scan_kernel, single stream (MODE 0), search": 55,
     "scan_kernel, single stream (MODE 0), find": 51,
-    "scan_kernel, cross-lane (MODE 2)": 17,
+    "scan_kernel, cross-lane (MODE 2)": 19,
     "scan_kernel, one-byte needles": 0,
-    "scan_batched_plan_kernel": 60,
-    "service_kernel": 88,
+    "scan_batched_plan_kernel": 81,
+    "service_kernel": 90,
 }
 
 

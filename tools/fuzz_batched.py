@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential run of the two many-problem kernels (ss_search_batched, ss_search_pairs) against Python's `in`:
+"""Randomised differential run of the many-problem kernels (ss_search_batched, ss_search_pairs, and ss_batch_plan_run for bool and
+find plans: two runs each into garbage-filled outputs, so the self-resetting state is exercised) against Python's `in` / find:
 ragged problems over small alphabets and random bytes, planted and near-miss needles, every kind of `position` (none, near,
 16 or more behind needle[0]), haystacks from empty to a few MiB so that slices, the tile floor and surplus workgroups all
 occur.    python tools/fuzz_batched.py SECONDS SEED      (SLICESLICE_BATCH_WGS=N varies the grid)"""
@@ -17,14 +18,14 @@ import sliceslice_rs_amd as ss  # noqa: E402
 
 
 def one_round(rng, count):
-    hays, needles, positions, want = [], [], [], []
+    hays, needles, positions, want, where = [], [], [], [], []
     big_budget = 3
     for _ in range(count):
         alpha = rng.choice([b"ab", b"abc", b"\x00\x01", b"the quick brown fox ", bytes(range(256))])
         n = rng.choice([0, 1, 2, 3, 5, 8, 15, 16, 17, 18, 24, 31, 32, 33, 64, 100, 300, 1100, 2100])
         ln = rng.choice([0, 1, max(n - 1, 0), n, n + 1, n + 7, 2 * n + 100, 1500, 20000, 70000])
         if big_budget and rng.random() < 0.01:
-            ln = rng.choice([(1 << 20) + 5, (3 << 20) - 7, 200000])
+            ln = rng.choice([(1 << 20) + 5, (3 << 20) - 7, 200000, (9 << 20) + 3])   # 9 MiB: a plan counts those out in two levels
             big_budget -= 1
         if ln > 4096:
             base = bytes(rng.choice(alpha) for _ in range(4096))
@@ -43,6 +44,7 @@ def one_round(rng, count):
         needles.append(nd)
         positions.append(rng.choice([0, n - 1, n // 2, rng.randrange(n)]) if n else 0)
         want.append(nd in hay)
+        where.append(hay.find(nd))
     hay_off = np.zeros(count + 1, dtype=np.int64)
     hay_off[1:] = np.cumsum([len(h) for h in hays])
     nd_off = np.zeros(count + 1, dtype=np.int64)
@@ -60,7 +62,23 @@ def one_round(rng, count):
                 print(json.dumps({"MISMATCH": True, "pairs": pairs, "with_positions": p is not None, "problem": k, "needle_len": len(needles[k]),
                                   "haystack_len": len(hays[k]), "position": positions[k], "want": want[k], "needle": needles[k][:40].hex()}))
                 sys.exit(1)
-    return 4 * count
+    # plans: the same problems, set up once, run twice; outputs start as garbage
+    for find in (False, True):
+        plan = ss.BatchPlan(blob, ho, nblob, no, find=find)
+        out = torch.full((count,), 0x5a5a5a5a, dtype=torch.int64 if find else torch.int32, device="cuda")
+        for run in range(2):
+            plan.run(out)
+            got = out.cpu().tolist()
+            exp = where if find else [1 if w else 0 for w in want]
+            bad = [k for k in range(count) if got[k] != exp[k]]
+            if bad:
+                k = bad[0]
+                print(json.dumps({"MISMATCH": True, "plan": True, "find": find, "run": run, "problem": k, "needle_len": len(needles[k]),
+                                  "haystack_len": len(hays[k]), "want": exp[k], "got": got[k], "needle": needles[k][:40].hex()}))
+                sys.exit(1)
+            out.fill_(-7)
+        plan.close()
+    return 8 * count
 
 
 def main():
