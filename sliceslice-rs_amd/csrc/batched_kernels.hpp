@@ -280,8 +280,11 @@ constexpr uint32_t kPlanCounterStride = 32;     // uint32 words between the coun
 //     somebody found something).
 // Problems without a scan (eff == 0: the empty needle, a bad position, a haystack shorter than the needle) are answered by
 // their slice-0 workgroup from the descriptor.
+#ifndef SS_BATCH_WAVES_MAX
+#define SS_BATCH_WAVES_MAX 4
+#endif
 template <int U, bool FIND = false, bool COUNTED = false>
-__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(kBlock)
+__global__ void __attribute__((amdgpu_waves_per_eu(4, SS_BATCH_WAVES_MAX))) __launch_bounds__(kBlock)
 scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state,
                          uint32_t *counters)
 {

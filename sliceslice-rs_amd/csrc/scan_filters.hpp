@@ -120,14 +120,14 @@ __device__ __forceinline__ uint32_t rotate_from_next_lane(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
 }
 
-// A haystack is global memory by contract, and the load says so: where the pointer arrives through memory (the batched
-// kernels' descriptors, the service's mailbox) the compiler cannot tell and would emit FLAT loads, which count on vmcnt AND
-// lgkmcnt - every wait for an LDS or scalar result would then also wait for the haystack loads in flight.
-#define SS_GLOBAL __attribute__((address_space(1)))
+// (Round 4 typed these loads as address_space(1) for a while, because the batched and service kernels - whose base pointer arrives
+// through memory - get FLAT loads from the generic pointer.  It bought those kernels nothing measurable and cost the one-byte
+// kernel 16 % (6.1 instead of 7.3 TB/s at 1 GiB: one of its eight loads lost its immediate offset and the schedule around it
+// changed) and the 16-byte kernels 1-2 % at 1 GiB - profiles/r04/ab_global_cast.jsonl.  Generic pointers it is.)
 template <bool NT>
 __device__ __forceinline__ u32x4 load_chunk(const uint8_t *base, uint64_t chunk)
 {
-    const SS_GLOBAL u32x4 *p = (const SS_GLOBAL u32x4 *)(reinterpret_cast<const u32x4 *>(base) + chunk);
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(base) + chunk;
     if (NT) return __builtin_nontemporal_load(p);
     return *p;
 }
@@ -715,7 +715,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <bool NT>
 __device__ __forceinline__ u32x2 load_half(const uint8_t *base, uint64_t half_chunk)
 {
-    const SS_GLOBAL u32x2 *p = (const SS_GLOBAL u32x2 *)(reinterpret_cast<const u32x2 *>(base) + half_chunk);
+    const u32x2 *p = reinterpret_cast<const u32x2 *>(base) + half_chunk;
     if (NT) return __builtin_nontemporal_load(p);
     return *p;
 }

@@ -278,12 +278,12 @@ def test_rccl_enum_values_the_library_hard_codes():
 # (26 -> 53 on the headline kernel, 91 -> 184/245 on the batched ones, which inlined one whole scan_tiles per filter window) because
 # nothing looked; a build that goes 25 % over what is recorded here fails.  Lower the numbers when a kernel improves.
 SGPR_SPILL_CEILINGS = {
-    "scan_kernel, single stream (MODE 0), search": 55,
+    "scan_kernel, single stream (MODE 0), search": 53,
     "scan_kernel, single stream (MODE 0), find": 51,
-    "scan_kernel, cross-lane (MODE 2)": 19,
+    "scan_kernel, cross-lane (MODE 2)": 17,
     "scan_kernel, one-byte needles": 0,
     "scan_batched_plan_kernel": 81,
-    "service_kernel": 90,
+    "service_kernel": 88,
 }
 
 

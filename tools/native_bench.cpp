@@ -565,9 +565,11 @@ int construct(int count)
 // ---- N ranks of a native communicator, one process each, all on device 0 -------------------------------------------------------
 // What a sharded search costs OUTSIDE its kernel when more than one rank takes part: every rank scans its shard of one logical
 // haystack (ss_shard_range) and calls ss_search_sharded; a search ends when the slowest rank's all-reduce has completed.  The
-// ranks share ONE GPU here, so their kernels run one after the other and the aggregate GB/s mean nothing - what the mode reports
-// is wall - (sum of the ranks' kernel times): launch skew between the ranks + the all-reduce's barrier + the answer word / stream
-// wait.  Real RCCL refuses several ranks per device; run it with SLICESLICE_RCCL_LIB=tests/native/libfake_rccl.so (the
+// ranks share ONE GPU here, so the aggregate GB/s mean nothing (their kernels share the device's bandwidth, overlapping as the
+// hardware sees fit) - what the mode reports is the difference between two loops of the same ranks on the same shards at the same
+// time: `steps` sharded searches, then - started together by the last of those - `steps` plain ss_search_device calls, the same
+// scans without the collective.  The difference is what taking part in a collective search costs a rank per search: the
+// all-reduce's barrier (launch skew between the ranks included) and the communicator's stream wait.  Real RCCL refuses several ranks per device; run it with SLICESLICE_RCCL_LIB=tests/native/libfake_rccl.so (the
 // shared-memory stand-in: its all-reduce is a host barrier, a LOWER bound for a collective that crosses xGMI).
 //   parent:  native_bench ranks <N> [GiB] [steps]      forks N children (itself, re-executed) and prints the summary
 //   child:   native_bench rank <r> <N> <idhex> <GiB> <steps> <result-file>
@@ -611,13 +613,17 @@ static int rank_child(int rank, int nranks, const char *idhex, double gib, int s
         kernel_ms += ms;
     }
     const double wall_ms = seconds_since(t0) / steps * 1e3;
+    // the same scans without the collective (every rank left the last all-reduce at the same moment)
+    const auto t1 = clk::now();
+    for (int k = 0; k < steps; ++k) rc |= ss_search_device(s, d_shard, e - b, st, &found);
+    const double local_ms = seconds_since(t1) / steps * 1e3;
     if (rc != 0 || found != 0) {
         std::fprintf(stderr, "rank %d: rc %d found %d: %s\n", rank, rc, found, ss_last_error());
         return 1;
     }
     FILE *f = std::fopen(result_path, "w");
     if (!f) return 3;
-    std::fprintf(f, "%.6f %.6f %zu\n", wall_ms, kernel_ms / steps, e - b);
+    std::fprintf(f, "%.6f %.6f %zu %.6f\n", wall_ms, kernel_ms / steps, e - b, local_ms);
     std::fclose(f);
     ss_comm_free(c);
     ss_searcher_free(s);
@@ -651,19 +657,20 @@ static int ranks_parent(const char *self, int nranks, double gib, int steps)
         int status = 0;
         if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) ++bad;
     }
-    double wall_max = 0, kernel_sum = 0, kernel_max = 0;
+    double wall_max = 0, kernel_sum = 0, kernel_max = 0, local_max = 0;
     size_t shard = 0;
     for (int r = 0; r < nranks && !bad; ++r) {
         const std::string path = base + std::to_string(r);
         FILE *f = std::fopen(path.c_str(), "r");
-        double w = 0, k = 0;
+        double w = 0, k = 0, l = 0;
         size_t sb = 0;
-        if (!f || std::fscanf(f, "%lf %lf %zu", &w, &k, &sb) != 3) ++bad;
+        if (!f || std::fscanf(f, "%lf %lf %zu %lf", &w, &k, &sb, &l) != 4) ++bad;
         if (f) std::fclose(f);
         std::remove(path.c_str());
         wall_max = std::max(wall_max, w);
         kernel_sum += k;
         kernel_max = std::max(kernel_max, k);
+        local_max = std::max(local_max, l);
         shard = std::max(shard, sb);
     }
     if (bad) {
@@ -672,12 +679,15 @@ static int ranks_parent(const char *self, int nranks, double gib, int steps)
     }
     const char *lib = std::getenv("SLICESLICE_RCCL_LIB");
     std::printf("{\"mode\": \"ranks\", \"ranks\": %d, \"ranks_share_one_gpu\": true, \"haystack_bytes\": %zu, \"shard_bytes\": %zu, "
-                "\"steps\": %d, \"wall_ms_per_search\": %.4f, \"kernel_ms_sum_over_ranks\": %.4f, \"kernel_ms_slowest_rank\": %.4f, "
-                "\"overhead_outside_kernels_ms\": %.4f, \"rccl_library\": \"%s\", "
-                "\"note\": \"N processes on ONE device: the ranks' kernels run one after the other, so wall - (sum of kernel times) is what "
-                "a search costs outside its kernels - launch skew between ranks, the all-reduce's barrier, the answer word; a lower bound "
-                "for N devices, where the collective crosses xGMI\"}\n",
-                nranks, (size_t)(gib * (double)(1ull << 30)), shard, steps, wall_max, kernel_sum, kernel_max, wall_max - kernel_sum,
+                "\"steps\": %d, \"wall_ms_per_sharded_search\": %.4f, \"wall_ms_per_local_search\": %.4f, "
+                "\"collective_overhead_ms\": %.4f, \"kernel_ms_sum_over_ranks\": %.4f, \"kernel_ms_slowest_rank\": %.4f, "
+                "\"rccl_library\": \"%s\", "
+                "\"note\": \"N processes on ONE device.  wall_ms_*: the slowest rank's time per search in a loop of ss_search_sharded calls, and "
+                "in a loop of plain ss_search_device calls on the same shards run by all ranks at the same time; their difference is what "
+                "the collective costs a rank per search (the all-reduce's barrier with the launch skew between ranks, the communicator's "
+                "stream wait) - a lower bound for N devices, where the collective crosses xGMI.  kernel_ms_*: by events, while the other "
+                "ranks' kernels share the device\"}\n",
+                nranks, (size_t)(gib * (double)(1ull << 30)), shard, steps, wall_max, local_max, wall_max - local_max, kernel_sum, kernel_max,
                 lib ? lib : "librccl");
     return 0;
 }
