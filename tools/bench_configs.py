@@ -182,7 +182,7 @@ def main():
             s.set_filter(*ss.choose_filter_triple(nd, hist))
             res, ms = timed(s, text, args.reps)
             emit(config="text", needle=nd.decode("latin1"), label=label + "; filter bytes chosen from a byte histogram of the haystack "
-                 "(ss_byte_histogram_device + ss_choose_filter_triple_hist)", filter_bytes=list(s.filter3),
+                 "(ss_byte_histogram_device + ss_choose_filter_triple with the histogram)", filter_bytes=list(s.filter3),
                  filter_chars=[chr(nd[k]) for k in s.filter3], haystack_bytes=text.numel(), found=res, kernel_ms=round(ms, 3),
                  gbps=round(text.numel() / ms / 1e6, 1))
         del text
