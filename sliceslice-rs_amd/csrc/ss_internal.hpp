@@ -95,7 +95,7 @@ struct PerDevice {
     // count at four [0] and at six [1] workgroups per CU, the number of choices made, the latest launch's setting.  Racy by
     // design when several threads search through one handle (relaxed __atomic accesses; any value is a valid choice).
     uint32_t learn_mbps[2] = {0, 0}, learn_n[2] = {0, 0}, learn_calls = 0, learn_warm = 0;
-    int last_occ = 0;
+    int last_occ = 0, learn_choice = 0;
     uint32_t done_low[64] = {0}, done_hi[64] = {0};
     uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax
     uint64_t free_mask = 0;

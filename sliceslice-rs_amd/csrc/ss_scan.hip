@@ -271,7 +271,13 @@ int learned_occupancy(PerDevice *pd, int guess)
     const uint32_t n4 = __atomic_load_n(&pd->learn_n[0], __ATOMIC_RELAXED), n6 = __atomic_load_n(&pd->learn_n[1], __ATOMIC_RELAXED);
     if (n4 + n6 < kLearnTrials) return n4 == n6 ? guess : n4 < n6 ? 4 : 6;
     const uint32_t g4 = __atomic_load_n(&pd->learn_mbps[0], __ATOMIC_RELAXED), g6 = __atomic_load_n(&pd->learn_mbps[1], __ATOMIC_RELAXED);
-    const int best = g6 > g4 ? 6 : 4;
+    // with hysteresis: on random bytes the two settings are 2 % apart and a timing's noise is 1 %, and a searcher that keeps
+    // changing its mind spends half its scans on the slower one
+    int best = __atomic_load_n(&pd->learn_choice, __ATOMIC_RELAXED);
+    if (best == 0) best = g6 > g4 ? 6 : 4;
+    else if (best == 4 && g6 > g4 + g4 / 64) best = 6;
+    else if (best == 6 && g4 > g6 + g6 / 64) best = 4;
+    __atomic_store_n(&pd->learn_choice, best, __ATOMIC_RELAXED);
     const uint32_t calls = __atomic_fetch_add(&pd->learn_calls, 1u, __ATOMIC_RELAXED) + 1;
     return calls % kLearnExploreEvery == 0 ? (best == 4 ? 6 : 4) : best;
 }

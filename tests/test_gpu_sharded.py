@@ -183,7 +183,8 @@ def test_bench_short_timed_region_runs_on_settled_clocks():
     short = _line(_run_bench(["--haystack-gib", "8", "--steps", "20", "--warmup", "5"] + QUICK, {}))
     long_ = _line(_run_bench(["--haystack-gib", "8", "--steps", "200", "--warmup", "5"] + QUICK, {}))
     assert short["config"]["prewarm_ms"] >= 100 and short["config"]["prewarm_steps"] >= 8
-    assert abs(short["value"] / long_["value"] - 1) < 0.015, (short["value"], long_["value"])
+    # (two processes: their placement alone moves a rate by 1-2 % on one box - profiles/r04/README.md)
+    assert abs(short["value"] / long_["value"] - 1) < 0.025, (short["value"], long_["value"])
     assert short["roofline"]["kernel_ms"] <= short["roofline"]["kernel_ms_avg"] * 1.02        # the median is the reported statistic
     assert short["roofline"]["kernel_launches"] == 20
 
