@@ -293,5 +293,30 @@ private:
     ss_service *sv_ = nullptr;
 };
 
+// Plan once, search many (ss_batch_plan_*): the reference's bench shape - build the searchers once (bench/benches/i386.rs:246-250),
+// time the searches (:252-256) - for a whole batch of (needle, haystack) problems given as ranges of one haystack blob and one
+// needle blob in device memory.  run() is ONE kernel launch that also produces the outputs (capturable into a hipGraph); the
+// problems' CONTENTS may change between runs, their ranges may not.  One run at a time per plan.
+class BatchPlan {
+public:
+    // bool plan: run() writes `count` int flags (1 found, 0 absent, SS_BATCH_BAD_POSITION); find plan: `count` uint64 leftmost
+    // offsets (SS_NPOS: absent).  `d_position` (bool plans): the with_position argument per problem, or nullptr for n - 1.
+    BatchPlan(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end, const void *d_needles,
+              const uint64_t *d_needle_begin, const uint64_t *d_needle_end, const uint64_t *d_position, size_t count, bool find,
+              void *hip_stream = nullptr)
+    {
+        check(ss_batch_plan_create(d_haystacks, d_hay_begin, d_hay_end, d_needles, d_needle_begin, d_needle_end, d_position, count,
+                                   find ? 1 : 0, hip_stream, &plan_));
+    }
+    BatchPlan(const BatchPlan &) = delete;
+    BatchPlan &operator=(const BatchPlan &) = delete;
+    ~BatchPlan() { ss_batch_plan_free(plan_); }
+
+    void run(void *d_out, void *hip_stream = nullptr) const { check(ss_batch_plan_run(plan_, hip_stream, d_out)); }
+
+private:
+    ss_batch_plan *plan_ = nullptr;
+};
+
 }  // namespace hip
 }  // namespace sliceslice

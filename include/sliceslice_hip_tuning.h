@@ -73,7 +73,8 @@ SS_API int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
  * check that a rank-local failure leaves no other rank waiting in the collective of ss_search_sharded / ss_find_sharded. */
 SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
 /* The workgroups-per-CU setting of `s`'s latest scan on the current device (4 or 6) and what the searcher has learned so far from
- * the time of its full scans there: the running GB/s at four and at six workgroups per CU (0: not tried yet). */
+ * the time of its full scans there: GB/s at four and at six workgroups per CU - the recent best for the setting it has chosen,
+ * the best of the latest exploration for the other (0: not tried yet). */
 SS_API int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *gbps_at_four, int *gbps_at_six);
 
 /* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */

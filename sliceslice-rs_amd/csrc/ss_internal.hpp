@@ -91,10 +91,11 @@ struct PerDevice {
     unsigned long long *d_done = nullptr;   // kSlots counters: found-workgroups << 32 | workgroups
     long long *h_done = nullptr;            // pinned: the answer word, stored by the workgroup that completes the count
     uint64_t *d_best_done = nullptr;        // kSlots keyed minima of find()
-    // Workgroups per CU, learned from the time of this searcher's full scans on this device (ss_scan.hip): running MB/s and sample
-    // count at four [0] and at six [1] workgroups per CU, the number of choices made, the latest launch's setting.  Racy by
-    // design when several threads search through one handle (relaxed __atomic accesses; any value is a valid choice).
-    uint32_t learn_mbps[2] = {0, 0}, learn_n[2] = {0, 0}, learn_calls = 0, learn_warm = 0;
+    // Workgroups per CU, learned from the time of this searcher's full scans on this device (ss_scan.hip): the current choice, a
+    // best-of rate (MB/s) and a sample count at four [0] and at six [1] workgroups per CU - recent calls for the current choice,
+    // the latest exploration for the other - the number of choices made, what is left of an exploration, the latest launch's
+    // setting.  Racy by design when several threads search through one handle (relaxed __atomic accesses; any value is valid).
+    uint32_t learn_mbps[2] = {0, 0}, learn_n[2] = {0, 0}, learn_calls = 0, learn_warm = 0, learn_explore_left = 0;
     int last_occ = 0, learn_choice = 0;
     uint32_t done_low[64] = {0}, done_hi[64] = {0};
     uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax

@@ -95,15 +95,21 @@ struct Launch {
 // the measurements), and which of the two a haystack is cannot be told from the needle: a text-like needle on binary data gave
 // up 3-5 % under the needle-byte guess, a stock phrase of the manual with rare-looking bytes 15-20 % the other way.  So the
 // searcher LEARNS it, per device, from what its own full scans cost: ss_search_device times every call that scanned the whole
-// haystack (answer "absent") of at least kLearnMinBytes, keeps a rate estimate for each of the two settings, alternates between
-// them over its first few such calls and looks at the other one every kLearnExploreEvery calls, and otherwise launches with the
-// faster one.  Nothing in
+// haystack (answer "absent") of at least kLearnMinBytes.  What makes this harder than it sounds is that a device's speed drifts -
+// its clocks ramp up over the first tens of milliseconds after an idle gap, power management moves them later - so a rate
+// measured now says nothing against a rate measured fifty calls ago (a first cut kept a best-rate estimate per setting and
+// locked onto whichever setting it happened to try last during the ramp).  Hence PAIRED comparisons: the searcher runs on its
+// current choice and keeps a short-memory best rate for it; at the 2nd, 8th, 16th and 32nd such call and every
+// kLearnExploreEvery-th after that it gives the other setting two calls in a row, and changes its mind when the better of those
+// two beats the current setting's recent best by more than 1.5 % (on random bytes the two settings are 2 % apart and a timing's
+// noise is 1 %).  Nothing in
 // the kernels: a first cut counted candidate tiles in the scan kernel (a relaxed atomic in the candidate path of every 64th
 // workgroup - never executed on random bytes) and cost the headline 3-8 % through what the compiler did to the hot loop around
 // it (profiles/r04/ab_stats_counter.jsonl).  Entry points that do not see their scan's duration (the _async forms, the sharded
 // searches) launch with what has been learned so far, or with the needle-byte guess.
 constexpr size_t kLearnMinBytes = (size_t)256 << 20;
 constexpr uint32_t kLearnExploreEvery = 64;
+constexpr uint32_t kLearnExploreCalls = 2;      // calls in a row the other setting gets when it is looked at
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 
@@ -263,28 +269,31 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
 }
 
 // The setting to launch with (racy by design when several threads search through one handle: any value read is a valid choice).
-// The first kLearnTrials recorded scans alternate between the two settings; after that the better estimate wins, and every
-// kLearnExploreEvery-th choice looks at the other one again (haystacks change).
-constexpr uint32_t kLearnTrials = 6;
 int learned_occupancy(PerDevice *pd, int guess)
 {
-    const uint32_t n4 = __atomic_load_n(&pd->learn_n[0], __ATOMIC_RELAXED), n6 = __atomic_load_n(&pd->learn_n[1], __ATOMIC_RELAXED);
-    if (n4 + n6 < kLearnTrials) return n4 == n6 ? guess : n4 < n6 ? 4 : 6;
-    const uint32_t g4 = __atomic_load_n(&pd->learn_mbps[0], __ATOMIC_RELAXED), g6 = __atomic_load_n(&pd->learn_mbps[1], __ATOMIC_RELAXED);
-    // with hysteresis: on random bytes the two settings are 2 % apart and a timing's noise is 1 %, and a searcher that keeps
-    // changing its mind spends half its scans on the slower one
-    int best = __atomic_load_n(&pd->learn_choice, __ATOMIC_RELAXED);
-    if (best == 0) best = g6 > g4 ? 6 : 4;
-    else if (best == 4 && g6 > g4 + g4 / 64) best = 6;
-    else if (best == 6 && g4 > g6 + g6 / 64) best = 4;
-    __atomic_store_n(&pd->learn_choice, best, __ATOMIC_RELAXED);
+    int choice = __atomic_load_n(&pd->learn_choice, __ATOMIC_RELAXED);
+    if (choice == 0) {
+        choice = guess;
+        __atomic_store_n(&pd->learn_choice, choice, __ATOMIC_RELAXED);
+    }
+    const int other = choice == 4 ? 6 : 4;
+    uint32_t left = __atomic_load_n(&pd->learn_explore_left, __ATOMIC_RELAXED);
+    if (left != 0) {                                        // the second call of an exploration
+        __atomic_store_n(&pd->learn_explore_left, left - 1, __ATOMIC_RELAXED);
+        return other;
+    }
     const uint32_t calls = __atomic_fetch_add(&pd->learn_calls, 1u, __ATOMIC_RELAXED) + 1;
-    return calls % kLearnExploreEvery == 0 ? (best == 4 ? 6 : 4) : best;
+    const bool explore = calls % kLearnExploreEvery == 0 || calls == 2 || (calls < kLearnExploreEvery && calls >= 8 && (calls & (calls - 1)) == 0);
+    if (!explore) return choice;
+    __atomic_store_n(&pd->learn_explore_left, kLearnExploreCalls - 1, __ATOMIC_RELAXED);
+    __atomic_store_n(&pd->learn_mbps[other == 6], 0u, __ATOMIC_RELAXED);      // this exploration's samples only
+    __atomic_store_n(&pd->learn_n[other == 6], 0u, __ATOMIC_RELAXED);
+    return other;
 }
 
-// One full scan's lesson.  Whatever disturbs a timing makes it LONGER (a cold first launch, clocks still ramping up after an idle
-// gap, a preempted host thread), so the estimate per setting is the best rate seen, fading by 1/32 per further sample of the same
-// setting so that a haystack that has become slower under it is noticed; the searcher's very first scan is not recorded at all.
+// One full scan's lesson.  Whatever disturbs a single timing makes it LONGER (a preempted host thread, a busy PCIe link), so the
+// rate kept per setting is a best-of: of the exploration's calls for the other setting, of the recent calls (fading by 1/16 per
+// sample) for the current one.  The searcher's very first scan (a cold launch path) is not recorded at all.
 void learn_from_scan(PerDevice *pd, int occ, size_t len, double seconds)
 {
     if (len < kLearnMinBytes || seconds <= 0 || (occ != 4 && occ != 6)) return;
@@ -292,8 +301,18 @@ void learn_from_scan(PerDevice *pd, int occ, size_t len, double seconds)
     const int k = occ == 6 ? 1 : 0;
     const uint32_t rate = (uint32_t)std::min((double)len / seconds / 1e6, 4.0e9);                    // MB/s
     const uint32_t old = __atomic_load_n(&pd->learn_mbps[k], __ATOMIC_RELAXED);
-    __atomic_store_n(&pd->learn_mbps[k], std::max(rate, old - old / 32), __ATOMIC_RELAXED);
-    __atomic_fetch_add(&pd->learn_n[k], 1u, __ATOMIC_RELAXED);
+    const int choice = __atomic_load_n(&pd->learn_choice, __ATOMIC_RELAXED);
+    if (occ == choice) {
+        __atomic_store_n(&pd->learn_mbps[k], std::max(rate, old - old / 16), __ATOMIC_RELAXED);
+        __atomic_fetch_add(&pd->learn_n[k], 1u, __ATOMIC_RELAXED);
+        return;
+    }
+    const uint32_t best = std::max(rate, old);
+    __atomic_store_n(&pd->learn_mbps[k], best, __ATOMIC_RELAXED);
+    const uint32_t n = __atomic_fetch_add(&pd->learn_n[k], 1u, __ATOMIC_RELAXED) + 1;
+    if (n < kLearnExploreCalls) return;
+    const uint32_t cur = __atomic_load_n(&pd->learn_mbps[1 - k], __ATOMIC_RELAXED);
+    if (cur == 0 || best > cur + cur / 64) __atomic_store_n(&pd->learn_choice, occ, __ATOMIC_RELAXED);   // a change of mind
 }
 
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find,

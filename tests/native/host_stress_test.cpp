@@ -362,6 +362,67 @@ int main(int argc, char **argv)
         (void)hipFree(d_big);
     }
 
+    // Batched calls and batch plans from several threads: the unplanned calls share per-stream scratch (same stream here: the
+    // entry's mutex keeps each call's two launches adjacent), every thread owns a bool plan and a find plan and runs them on its
+    // own stream (one run at a time per plan is the caller's side of the contract), plans are created and freed while other
+    // threads' runs are in flight, and a plan made for another device's number is refused.  Two problems per call: the needle in
+    // d_yes (present at len - 7) and in d_no (absent), addressed as ranges of ONE base pointer.
+    {
+        const uint8_t *lo = d_yes < d_no ? d_yes : d_no;
+        const uint64_t off_yes = (uint64_t)(d_yes - lo), off_no = (uint64_t)(d_no - lo);
+        const uint64_t h_hb[2] = {off_yes, off_no}, h_he[2] = {off_yes + len, off_no + len}, h_nb[2] = {0, 0}, h_ne[2] = {7, 7};
+        uint64_t *d_rng = nullptr;
+        uint8_t *d_nd = nullptr;
+        CHECK(hipMalloc((void **)&d_rng, 8 * sizeof(uint64_t)) == hipSuccess && hipMalloc((void **)&d_nd, 16) == hipSuccess);
+        CHECK(hipMemcpy(d_rng, h_hb, 16, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_rng + 2, h_he, 16, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(d_rng + 4, h_nb, 16, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_rng + 6, h_ne, 16, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(d_nd, needle, 7, hipMemcpyHostToDevice) == hipSuccess);
+        std::vector<std::thread> callers;
+        for (int t = 0; t < 4; ++t)
+            callers.emplace_back([&, t]() {
+                (void)hipSetDevice(0);
+                hipStream_t st = nullptr;
+                TCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+                int *d_found = nullptr;
+                uint64_t *d_pos = nullptr;
+                TCHECK(hipMalloc((void **)&d_found, 8) == hipSuccess && hipMalloc((void **)&d_pos, 16) == hipSuccess);
+                for (int round = 0; round < 6; ++round) {
+                    ss_batch_plan *pb = nullptr, *pf = nullptr;
+                    TCHECK(ss_batch_plan_create(lo, d_rng, d_rng + 2, d_nd, d_rng + 4, d_rng + 6, nullptr, 2, 0, st, &pb) == SS_OK);
+                    TCHECK(ss_batch_plan_create(lo, d_rng, d_rng + 2, d_nd, d_rng + 4, d_rng + 6, nullptr, 2, 1, st, &pf) == SS_OK);
+                    for (int it = 0; it < 25; ++it) {
+                        int h_found[2] = {-1, -1};
+                        uint64_t h_pos[2] = {1, 1};
+                        TCHECK(hipMemsetAsync(d_found, 0x5a, 8, st) == hipSuccess && hipMemsetAsync(d_pos, 0x5a, 16, st) == hipSuccess);
+                        TCHECK(ss_batch_plan_run(pb, st, d_found) == SS_OK && ss_batch_plan_run(pf, st, d_pos) == SS_OK);
+                        TCHECK(hipMemcpyAsync(h_found, d_found, 8, hipMemcpyDeviceToHost, st) == hipSuccess);
+                        TCHECK(hipMemcpyAsync(h_pos, d_pos, 16, hipMemcpyDeviceToHost, st) == hipSuccess);
+                        TCHECK(hipStreamSynchronize(st) == hipSuccess);
+                        TCHECK(h_found[0] == 1 && h_found[1] == 0 && h_pos[0] == len - 7 && h_pos[1] == SS_NPOS);
+                        // the unplanned forms on the SHARED null stream (per-stream scratch, one entry for all four threads)
+                        if ((it & 3) == t) {
+                            TCHECK(ss_search_batched(lo, d_rng, d_rng + 2, d_nd, d_rng + 4, d_rng + 6, nullptr, 2, nullptr, d_found) == SS_OK);
+                            TCHECK(hipMemcpy(h_found, d_found, 8, hipMemcpyDeviceToHost) == hipSuccess && h_found[0] == 1 && h_found[1] == 0);
+                        }
+                    }
+                    ss_batch_plan_free(pf);
+                    ss_batch_plan_free(pb);
+                }
+                (void)hipFree(d_pos);
+                (void)hipFree(d_found);
+                (void)hipStreamDestroy(st);
+            });
+        for (auto &t : callers) t.join();
+        CHECK(g_failures == 0);
+        ss_batch_plan *none = nullptr;
+        CHECK(ss_batch_plan_create(lo, d_rng, d_rng + 2, d_nd, d_rng + 4, d_rng + 6, nullptr, 0, 0, nullptr, &none) == SS_ERR_ARGUMENT && none == nullptr);
+        CHECK(ss_batch_plan_run(nullptr, nullptr, d_rng) == SS_ERR_ARGUMENT);
+        ss_batch_plan_free(nullptr);
+        std::puts("batch plans from 4 threads ok");
+        (void)hipFree(d_nd);
+        (void)hipFree(d_rng);
+    }
+
     ss_searcher_free(s);
     (void)hipFree(d_no);
     (void)hipFree(d_yes);

@@ -143,6 +143,47 @@ int main()
             for (size_t k = 0; k < ss.size(); ++k) CHECK(service.search_in(ss[k], DeviceSlice{dt, text.size()}) == expect[k]);
         service.unbind();
         CHECK(service.search_in(ss[0], DeviceSlice{dt + 4, text.size() - 4}));
+
+        // BatchPlan: the same loop as ONE launch per iteration - the needles as ranges of a blob, every problem the whole text
+        std::string blob;
+        std::vector<uint64_t> nb, ne, hb, he;
+        for (const char *w : words) {
+            nb.push_back(blob.size());
+            blob += w;
+            ne.push_back(blob.size());
+            hb.push_back(0);
+            he.push_back(text.size());
+        }
+        const size_t count = nb.size();
+        uint8_t *dn = nullptr;
+        uint64_t *dr = nullptr, *dpos = nullptr;
+        int *dflags = nullptr;
+        CHECK(hipMalloc((void **)&dn, blob.size()) == hipSuccess && hipMalloc((void **)&dr, 4 * count * 8) == hipSuccess);
+        CHECK(hipMalloc((void **)&dpos, count * 8) == hipSuccess && hipMalloc((void **)&dflags, count * 4) == hipSuccess);
+        CHECK(hipMemcpy(dn, blob.data(), blob.size(), hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(dr, hb.data(), count * 8, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(dr + count, he.data(), count * 8, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(dr + 2 * count, nb.data(), count * 8, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(dr + 3 * count, ne.data(), count * 8, hipMemcpyHostToDevice) == hipSuccess);
+        sliceslice::hip::BatchPlan plan(dt, dr, dr + count, dn, dr + 2 * count, dr + 3 * count, nullptr, count, false);
+        sliceslice::hip::BatchPlan fplan(dt, dr, dr + count, dn, dr + 2 * count, dr + 3 * count, nullptr, count, true);
+        for (int round = 0; round < 3; ++round) {
+            std::vector<int> flags(count, -7);
+            std::vector<uint64_t> pos(count, 7);
+            plan.run(dflags);
+            fplan.run(dpos);
+            CHECK(hipMemcpy(flags.data(), dflags, count * 4, hipMemcpyDeviceToHost) == hipSuccess);
+            CHECK(hipMemcpy(pos.data(), dpos, count * 8, hipMemcpyDeviceToHost) == hipSuccess);
+            for (size_t k = 0; k < count; ++k) {
+                const size_t at = text.find(words[k]);
+                CHECK(flags[k] == (expect[k] ? 1 : 0));
+                CHECK(pos[k] == (at == std::string::npos ? DynamicHipSearcher::npos : at));
+            }
+        }
+        (void)hipFree(dflags);
+        (void)hipFree(dpos);
+        (void)hipFree(dr);
+        (void)hipFree(dn);
         (void)hipFree(dt);
     }
     std::puts("veneer_test ok");

@@ -520,3 +520,50 @@ def test_second_level_far_bytes_at_lane_piece_and_tile_edges(ss):
                                 hay[at + k] = needle[k]
                             hay[at:at + 40] = 0x2E
         assert s.search_in(hay) is False
+
+
+@pytest.mark.gpu
+def test_workgroups_per_cu_are_learned_from_the_searchers_own_scans():
+    """four or six workgroups per CU is learned per searcher and device from the time of its own full scans
+    (ss_scan.hip: learned_occupancy / learn_from_scan), not guessed from the needle.  Hooks build (ss_debug_last_occupancy):
+    after a few dozen scans of 1 GiB both settings have been tried, an estimate exists for each, the searcher launches with the
+    one it measured faster (explorations aside): six for a stock phrase on text, and for a text-like needle on RANDOM bytes - the
+    case the needle-byte guess got wrong - whichever it measures faster there.  Answers are never affected; small haystacks are
+    not timed."""
+    import sliceslice_rs_amd as ss
+    with ss.tuning_build():
+        hay = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        ss.fill_random_device(hay, 0x5EED0001)
+        raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
+        text = torch.from_numpy(raw.copy()).cuda().repeat((1 << 30) // raw.size)
+        torch.cuda.synchronize()
+        for needle, h in ((b"there is not another one of these", hay), (b"segment descriptor table entries are", text)):
+            s = ss.DynamicHipSearcher.new(needle)
+            assert s.search_in(h[: 1 << 20]) is False
+            assert s.last_occupancy()[1:] == (0, 0), "a 1 MiB scan is not a lesson"
+            seen = set()
+            for _ in range(40):
+                assert s.search_in(h) is False
+                seen.add(s.last_occupancy()[0])
+            wg, at4, at6 = s.last_occupancy()
+            assert seen == {4, 6} and at4 > 0 and at6 > 0, (seen, at4, at6)
+            picks = []
+            for _ in range(20):
+                assert s.search_in(h) is False
+                picks.append(s.last_occupancy()[0])
+            wg, at4, at6 = s.last_occupancy()
+            mode = max(set(picks), key=picks.count)
+            assert picks.count(mode) >= 16, (needle, picks)                     # it has settled (an exploration aside)
+            # ... and not on a setting it has just measured clearly slower (the rates are paired in time: the chosen setting's
+            # recent best, the other's best of its latest two-call exploration)
+            chosen, other = (at4, at6) if mode == 4 else (at6, at4)
+            assert chosen >= other * 0.97, (needle, mode, at4, at6)
+            if h is text:
+                assert mode == 6, (picks, at4, at6)                              # stock phrases want six: 10-15 % apart
+            # a found needle teaches nothing and answers as ever
+            h2 = h[: 300 << 20].clone()
+            h2[12345:12345 + len(needle)] = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+            before = s.last_occupancy()[1:]
+            assert s.search_in(h2) is True and s.find(h2) == 12345
+            assert s.last_occupancy()[1:] == before
+            del h2
