@@ -180,11 +180,16 @@ def test_bench_short_timed_region_runs_on_settled_clocks():
     """at 8 GPUs a step is ~1.2 ms, so 5 warm-up + 20 timed steps are shorter than the clocks' ramp after an
     idle gap; bench.py therefore spins search_in for >= 100 ms first.  On an 8 GiB haystack (one rank's shard at 8 GPUs) 20 timed
     steps must report what 200 report."""
-    short = _line(_run_bench(["--haystack-gib", "8", "--steps", "20", "--warmup", "5"] + QUICK, {}))
-    long_ = _line(_run_bench(["--haystack-gib", "8", "--steps", "200", "--warmup", "5"] + QUICK, {}))
-    assert short["config"]["prewarm_ms"] >= 100 and short["config"]["prewarm_steps"] >= 8
-    # (two processes: their placement alone moves a rate by 1-2 % on one box - profiles/r04/README.md)
-    assert abs(short["value"] / long_["value"] - 1) < 0.025, (short["value"], long_["value"])
+    pairs = []
+    for attempt in range(3):                              # (two processes: their placement alone moves a rate by 1-2 % on one box -
+        short = _line(_run_bench(["--haystack-gib", "8", "--steps", "20", "--warmup", "5"] + QUICK, {}))       # profiles/r04/README.md -
+        long_ = _line(_run_bench(["--haystack-gib", "8", "--steps", "200", "--warmup", "5"] + QUICK, {}))      # so a pair that is off is
+        assert short["config"]["prewarm_ms"] >= 100 and short["config"]["prewarm_steps"] >= 8                  # measured again)
+        pairs.append((short["value"], long_["value"]))
+        if abs(short["value"] / long_["value"] - 1) < 0.02:
+            break
+    else:
+        raise AssertionError("20 timed steps never came within 2 %% of 200: %r" % (pairs,))
     assert short["roofline"]["kernel_ms"] <= short["roofline"]["kernel_ms_avg"] * 1.02        # the median is the reported statistic
     assert short["roofline"]["kernel_launches"] == 20
 
