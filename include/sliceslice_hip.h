@@ -192,12 +192,13 @@ SS_API int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin,
 /* Plan once, search many: the reference builds its 4,585 searchers ONCE and times only the searches
  * (bench/benches/i386.rs:246-256).  ss_batch_plan_create does for a batch what the constructors do for one needle: it reads
  * the range arrays and the NEEDLE bytes (on `hip_stream`, and waits for it) and keeps one descriptor per problem in memory of
- * its own; ss_batch_plan_run is then a single scan launch that also re-arms the outputs - no plan kernel, no scratch
- * acquire, nothing allocated, capturable into a hipGraph.  `find` != 0: the plan answers leftmost offsets (d_out = `count`
+ * its own; ss_batch_plan_run is then the scan launch alone, which writes the outputs itself (a plan in which some problem is
+ * scanned by several workgroups adds one small kernel behind it that copies those problems' answers out) - no plan kernel, no
+ * scratch acquire, nothing allocated, capturable into a hipGraph.  `find` != 0: the plan answers leftmost offsets (d_out = `count`
  * uint64, as ss_find_batched), else flags (d_out = `count` int32, as ss_search_batched).  The caller vouches that ranges,
  * needle bytes and the haystacks' ADDRESSES are unchanged between create and the last run; haystack CONTENTS may change
- * freely.  ONE run at a time per plan (the plan's state words are the run's scratch; the last workgroup of every problem
- * puts them back to idle): runs must be ordered one behind the other - the same stream, or events.  d_out needs no
+ * freely.  ONE run at a time per plan (the plan's state words are the run's scratch; every run leaves them at their idle
+ * values): runs must be ordered one behind the other - the same stream, or events.  d_out needs no
  * initialisation.  No run may be in flight when the plan is freed. */
 typedef struct ss_batch_plan ss_batch_plan;
 SS_API int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,

@@ -295,7 +295,8 @@ private:
 
 // Plan once, search many (ss_batch_plan_*): the reference's bench shape - build the searchers once (bench/benches/i386.rs:246-250),
 // time the searches (:252-256) - for a whole batch of (needle, haystack) problems given as ranges of one haystack blob and one
-// needle blob in device memory.  run() is ONE kernel launch that also produces the outputs (capturable into a hipGraph); the
+// needle blob in device memory.  run() is the scan launch alone (plus one small kernel in plans with long haystacks) and produces
+// the outputs itself - nothing allocated, capturable into a hipGraph; the
 // problems' CONTENTS may change between runs, their ranges may not.  One run at a time per plan.
 class BatchPlan {
 public:

@@ -259,37 +259,37 @@ struct ColdInDesc {
 //     (1,024 x 1 MiB: 150 us instead of 162, kernel time) - and when one of them finds the needle the others are at the same
 //     depth and stop at their next poll.
 constexpr uint32_t kPlanSliceMajorMax = 8;
-constexpr uint32_t kPlanCounterHitShift = 16;   // a counter: workgroups counted out | workgroups that found the needle << 16
-constexpr uint32_t kPlanFanIn = 32;            // plans of more than this many slices per problem: first-level counters per problem
-constexpr uint32_t kPlanCounterStride = 32;     // uint32 words between the counters of two problems: one 128-byte line each
 // FIND: the sink is the problem's uint64 (leftmost offset, atomicMin); a workgroup skips only what lies right of the best so far
 // (scan_tiles does that tile by tile, so the slice-major entry poll is not needed).
-// COUNTED (ss_batch_plan_run: descriptors built once, searched many times - the reference builds its searchers once and times
-// the searches, bench/benches/i386.rs:246-256): ONE launch does everything, outputs included, and can be replayed from a
-// hipGraph; nothing is initialised by the host or by another kernel, so nothing races with a workgroup that is already
-// scanning.  What shapes it: a workgroup of a batch lives for a few tiles, and ANY memory round trip at its end - a returning
-// atomic, a load of the problem's flag - is time its slot on the CU stands idle (a load + two stores at the end of every
-// workgroup: 65,536 x 64 KiB at 0.72 ms instead of 0.60; counters of 32 problems in one 128-byte line, where device-scope
-// atomics queue one at a time: 1,024 x 1 MiB at 0.31 ms instead of 0.15).  So:
-//   * a match goes to a word in the workgroup's LDS (scan_tiles' wg_sink), and the epilogue reads the answer there;
-//   * a problem scanned by ONE workgroup (eff == 1) is published by that workgroup with one store: no counter, no global flag;
-//   * otherwise the workgroups of a problem also raise the plan's own state word (flag / minimum: the others stop early) and
-//     count themselves out with ONE returning atomic each on the problem's counter - a 128-byte line of its own - that
-//     carries "found here" in its high half: the workgroup that completes the count knows a bool answer from the sum, stores
-//     it, and puts counter and state word back to idle with plain stores (a find plan reads the minimum back, and only when
-//     somebody found something).
+// PLAN (ss_batch_plan_run: descriptors built once, searched many times - the reference builds its searchers once and times the
+// searches, bench/benches/i386.rs:246-256): a run produces the caller's outputs itself - nothing is initialised by the host or by
+// a kernel in front of the scan, so a run can be replayed from a hipGraph.  What shapes it: a workgroup of a batch lives for a
+// few tiles, and ANY memory round trip at its end - a returning atomic, a load of the problem's flag - is time its slot on the CU
+// stands idle.  Counting the workgroups of a problem out (so that the last one publishes) was built first and is gone again: with
+// the counters of 32 problems in one 128-byte line the device-scope atomics queued line by line (1,024 x 1 MiB: 0.31 ms a run
+// instead of 0.15); with a line per problem and a second level for problems of many workgroups the wait for ONE returning atomic
+// per workgroup still cost a plan of few long problems 5-8 % (one haystack of 1 GiB: 164 us of kernel time instead of 152), and the
+// workgroups that leave early because the needle has been found still had to count (the reference's 4,585-needle loop: 0.190 ms
+// instead of 0.178).  So:
+//   * a problem scanned by ONE workgroup (eff == 1): a match goes to a word in the workgroup's LDS (scan_tiles' wg_sink) and the
+//     workgroup publishes the answer with one store - no state word, no atomic, no second kernel;
+//   * a problem scanned by several: they work on the plan's own state word (flag / minimum, the others stop early) exactly as the
+//     unplanned kernel works on the caller's output, and batch_publish_kernel - one lane per problem, launched behind the scan
+//     only by plans that have such problems - copies the state word to the output and puts it back to idle.
 // Problems without a scan (eff == 0: the empty needle, a bad position, a haystack shorter than the needle) are answered by
 // their slice-0 workgroup from the descriptor.
 #ifndef SS_BATCH_WAVES_MAX
 #define SS_BATCH_WAVES_MAX 4
 #endif
-template <int U, bool FIND = false, bool COUNTED = false>
+template <int U, bool FIND = false, bool PLAN = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, SS_BATCH_WAVES_MAX))) __launch_bounds__(kBlock)
-scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state,
-                         uint32_t *counters)
+scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state)
 {
+    constexpr bool COUNTED = PLAN;                  // (the name the code below grew up with)
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
-    __shared__ unsigned long long s_wg;             // COUNTED: this workgroup's match (bool: the low int, 0 -> 1; FIND: minimum)
+    // PLAN, eff == 1: a match word per WAVE (bool: the low int, 0 -> 1; FIND: minimum) - each wave sets its own word to idle before
+    // it scans, so no barrier is needed in front of the scan; the one behind it settles all four for thread 0
+    __shared__ unsigned long long s_wg[kWavesPerBlock];
     const uint32_t w = blockIdx.x;
     const bool slice_major = nslices <= kPlanSliceMajorMax;
     uint32_t prob, slice;
@@ -308,15 +308,15 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     const int seen = !FIND && slice_major && slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     BatchDesc d = *dp;
     if (COUNTED) {
-        // The hot fields are pinned in scalar registers HERE, in front of the first store of the kernel (the LDS word's
-        // initial value, the trivial problem's answer below): a load the compiler sinks behind a store cannot go through the scalar cache any more, so it became a
+        // The hot fields are pinned in scalar registers HERE, in front of the first store of the kernel (the LDS words'
+        // initial values, the trivial problem's answer below): a load the compiler sinks behind a store cannot go through the scalar cache any more, so it became a
         // per-lane load and everything computed from it - tile bounds, loop control, addresses - per-lane arithmetic under exec
         // masks (101 VGPRs, and 311 us where the uncounted kernel takes 154 on 1,024 x 1 MiB).
         uint64_t base = reinterpret_cast<uint64_t>(d.base);
         __asm__ volatile("" : "+s"(base), "+s"(d.end), "+s"(d.nchunks_all), "+s"(d.per), "+s"(d.bytes), "+s"(d.shifts));
         d.base = reinterpret_cast<const uint8_t *>(base);
-        if (threadIdx.x == 0) __hip_atomic_store(&s_wg, FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __syncthreads();
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            __hip_atomic_store(&s_wg[threadIdx.x / kWave], FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
@@ -342,7 +342,7 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         step = eff;
     }
     work = work && t0 < te;
-    if (!COUNTED && !work) return;
+    if (!work) return;                              // (a plan's single-workgroup problem always has work: t0 = 0 < te)
 
     if (work) {
         Problem pr;                                 // hot fields only; the cold ones are re-read from the descriptor
@@ -359,61 +359,48 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         pr.r3 = (d.shifts >> 8) & 3;
         pr.q3 = (d.shifts >> 10) & 3;
         pr.epoch = 1;
-        pr.flags = COUNTED && eff > 1 ? kProblemWgMirror : 0u;
+        pr.flags = 0;
         pr.q = (d.shifts >> 6) & 3;
         const ColdInDesc cold = {dp, a.needles};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
-        void *wg_sink = COUNTED ? static_cast<void *>(&s_wg) : nullptr;
+        void *wg_sink = COUNTED && eff == 1 ? static_cast<void *>(&s_wg[threadIdx.x / kWave]) : nullptr;
         if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
         else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
     }
-    if (COUNTED) {
-        // every active slice of the problem gets here, with or without work.  A find plan's atomicMin on the state word has no
-        // return value and the barrier does not wait for vector memory: every wave drains its own queue first (see scan_kernel).
-        if (FIND && eff > 1) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (COUNTED && eff == 1) {
+        // the only workgroup of its problem: the answer is in the LDS word (a bare barrier settles it), one store publishes it
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned long long mine = __hip_atomic_load(&s_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool hit = FIND ? mine != ~0ull : mine != 0;
-            if (eff == 1) {
-                if (FIND) a.best[prob] = mine;
-                else a.found[prob] = hit;
-            } else {
-                // A problem of many slices counts in two levels: its workgroups on kPlanFanIn counters of their own lines (slice
-                // mod kPlanFanIn), the workgroup that completes one of those on the problem's counter - thousands of workgroups
-                // on ONE line queued there again (one haystack of 1 GiB: 0.18 ms a run instead of 0.16).
-                constexpr uint32_t kMask = (1u << kPlanCounterHitShift) - 1;
-                const bool fan = nslices > kPlanFanIn;                           // (uniform over the grid: the plan's layout)
-                uint32_t *ctr = counters + (size_t)prob * (fan ? 1 + kPlanFanIn : 1) * kPlanCounterStride;
-                uint32_t add = 1u + (hit ? 1u << kPlanCounterHitShift : 0u), expect = eff;
-                bool top = true;
-                if (fan && eff > kPlanFanIn) {
-                    const uint32_t j = slice % kPlanFanIn;
-                    uint32_t *sub = ctr + (1 + j) * kPlanCounterStride;
-                    const uint32_t t = __hip_atomic_fetch_add(sub, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-                    top = (t & kMask) == (eff - j + kPlanFanIn - 1) / kPlanFanIn;
-                    if (top) {
-                        __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        add = 1u + ((t >> kPlanCounterHitShift) != 0 ? 1u << kPlanCounterHitShift : 0u);
-                        expect = kPlanFanIn;
-                    }
-                }
-                const uint32_t total = top ? __hip_atomic_fetch_add(ctr, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add : 0u;
-                if (top && (total & kMask) == expect) {                          // the last workgroup of this problem
-                    const bool any = (total >> kPlanCounterHitShift) != 0;
-                    __asm__ volatile("" ::: "memory");
-                    if (FIND) {
-                        uint64_t *st = static_cast<uint64_t *>(state) + prob;
-                        a.best[prob] = any ? __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-                        if (any) __hip_atomic_store(st, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        a.found[prob] = any;
-                        if (any) __hip_atomic_store(static_cast<int *>(state) + prob, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            unsigned long long mine = FIND ? ~0ull : 0ull;
+#pragma unroll
+            for (int k = 0; k < kWavesPerBlock; ++k) {
+                const unsigned long long v = __hip_atomic_load(&s_wg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                mine = FIND ? (v < mine ? v : mine) : (mine | v);
             }
+            if (FIND) a.best[prob] = mine;
+            else a.found[prob] = mine != 0;
         }
+    }
+}
+
+// Behind the scan of a plan that has problems of several workgroups: one LANE per problem copies the state word of such a
+// problem to the caller's output and puts it back to its idle value (the kernel boundary is the ordering; ~3 us).
+__global__ void __launch_bounds__(kBlock) batch_publish_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count,
+                                                                void *state)
+{
+    const uint32_t prob = blockIdx.x * kBlock + threadIdx.x;
+    if (prob >= count) return;
+    if ((uint32_t)(descs[prob].per >> 32) <= 1) return;              // published by the scan itself
+    if (a.best) {
+        uint64_t *st = static_cast<uint64_t *>(state) + prob;
+        const uint64_t v = *st;
+        a.best[prob] = v;
+        if (v != ~0ull) *st = ~0ull;
+    } else {
+        int *st = static_cast<int *>(state) + prob;
+        const int v = *st;
+        a.found[prob] = v != 0;
+        if (v != 0) *st = 0;
     }
 }
 

@@ -85,7 +85,6 @@ struct Problem {
     uint64_t far_off;
 };
 constexpr uint32_t kProblemCounted = 1u;
-constexpr uint32_t kProblemWgMirror = 2u;    // a match goes to the workgroup's LDS word (scan_tiles' wg_sink) AND to the global sink
 constexpr int kQDynamic = -1;                     // scan_tiles<Q = kQDynamic, ...>: the window comes from Problem::q
 
 // Where a wave finds the COLD fields of its Problem.

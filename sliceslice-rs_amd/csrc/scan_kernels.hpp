@@ -70,12 +70,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     int *found = static_cast<int *>(sink);
     uint64_t *best = static_cast<uint64_t *>(sink);
     // `wg_sink`, when given: a word in the workgroup's LDS that takes the match INSTEAD of the global sink (bool: int 0 -> 1;
-    // FIND: uint64 minimum) - for launches whose epilogue carries the answer on, so that no wave queues a device-scope atomic in
-    // front of it - or, with kProblemWgMirror in pr.flags, as well as the global sink (other workgroups still stop early).
-    // The mirrored form exists in the batched kernels only (LAZY_ORDER): compiled into scan_kernel it moved the 16-byte kernels'
-    // 1 GiB rates by 1-3 % although it sits in the candidate path.
+    // FIND, batched kernels only: uint64 minimum) - for launches whose epilogue carries the answer on, so that no wave queues a
+    // device-scope atomic in front of it.
     int *wg_found = static_cast<int *>(wg_sink);
-    constexpr bool MIRROR_OK = LAZY_ORDER;
+    constexpr bool WG_FIND = LAZY_ORDER;            // (compiled into scan_kernel's FIND path it would be dead code that still moves registers)
     constexpr bool NTA = NTMODE >= 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
@@ -452,11 +450,12 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         const uint64_t mine = pr.find_base + (((uint64_t)hi << 32) | lo);
                         // only a wave that can actually lower the minimum touches it (matches everywhere
                         // would otherwise serialise one atomic per wave on a single address)
-                        if (MIRROR_OK && wg_sink != nullptr && lane == 0)
-                            __hip_atomic_fetch_min(static_cast<uint64_t *>(wg_sink), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if ((!MIRROR_OK || wg_sink == nullptr || (pr.flags & kProblemWgMirror) != 0) && lane == 0 &&
-                            mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        if (WG_FIND && wg_sink != nullptr) {
+                            if (lane == 0)
+                                __hip_atomic_fetch_min(static_cast<uint64_t *>(wg_sink), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         forget_scalar_cache_unless(small_grid);
                         return;                         // the wave's later pieces and tiles are further right
                     }
@@ -469,10 +468,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // pinned-host mirror: a needle that occurs everywhere would otherwise have every wave of
                     // the grid queue a system-scope store to the same host address (measured: 14 ms for a
                     // one-byte needle over 1 GiB instead of 0.02 ms).
-                    const bool mirror = MIRROR_OK && wg_found != nullptr && (pr.flags & kProblemWgMirror) != 0;
-                    if (mirror && lane == __ffsll((unsigned long long)hits) - 1)
-                        __hip_atomic_store(wg_found, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (wg_found != nullptr && !mirror) {
+                    if (wg_found != nullptr) {
                         // Completion-word launches (grids of at most 256 workgroups, all of them resident from the start):
                         // the answer travels in the workgroup count (scan_kernel's epilogue) and there is nobody left to
                         // stop early, so the device flag is not even written - a global store in front of the count-out

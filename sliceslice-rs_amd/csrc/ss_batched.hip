@@ -19,13 +19,13 @@ namespace {
 // at 4 GiB in 4,096 problems 256 per CU is 2 % faster (583 vs 597 us), which is not worth the rest.
 constexpr unsigned kPlanWgsPerCu = 96;
 constexpr uint32_t kPlanMinTiles = 2;       // shortest slice worth a workgroup, in 16 KiB tiles
-// ... and in a plan, where a problem scanned by several workgroups costs each of them a returning device-scope atomic (the count
-// that tells the last one to publish) and a problem scanned by one costs none; and where the lengths are known when the grid is
-// sized (ss_batch_plan_create reads them back from the plan kernel): about kPlanTilesPerWg tiles per workgroup - 6,500 workgroups
+// ... and in a plan, where a problem scanned by ONE workgroup is published by that workgroup (no state word, no second kernel), and
+// where the lengths are known when the grid is sized (ss_batch_plan_create reads them back from the plan kernel): about kPlanTilesPerWg tiles per workgroup - 6,500 workgroups
 // for 1 GiB, 26,000 for 4 GiB - was best or within 1 % of the best on every cut (tools/batch_probe.py under SLICESLICE_BATCH_WGS x
 // SLICESLICE_BATCH_MIN_TILES, profiles/r04/batch_plan_sweep.jsonl).
 constexpr uint32_t kPlanMinTilesCounted = 8;
 constexpr uint32_t kPlanTilesPerWg = 10;
+constexpr uint32_t kPlanTilesPerWgLong = 4, kPlanMinTilesLong = 4;   // problems of more than 80 tiles (1.25 MiB): see ss_batch_plan_create
 
 // Descriptor scratch of the unplanned calls: one grow-only device buffer per (device, stream), kept for the life of the process.
 // Launches on one stream execute in order, so a buffer that belongs to the stream can be reused by the next call on that
@@ -149,7 +149,6 @@ int batch_shape(int dev, size_t count, BatchShape *out, bool counted = false)
     uint64_t slices = (wg_target + count - 1) / count;
     if (slices < 1) slices = 1;
     while (slices > 1 && (uint64_t)count * slices > 0x7fffffffull) --slices;   // gridDim.x
-    if (slices > 0x7fffu) slices = 0x7fffu;                                  // a plan's counter holds the count in 16 bits
     out->slices = (uint32_t)slices;
     out->min_tiles = min_tiles;
     return SS_OK;
@@ -184,9 +183,9 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
     if (e == hipSuccess) {
         const dim3 grid((unsigned)((uint64_t)count * sh.slices));
         if (a.best)
-            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
+            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr);
         else
-            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
+            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr);
         e = hipGetLastError();
     }
     ps->mu.unlock();
@@ -199,10 +198,7 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
 
 using namespace ssh;
 
-// The plan's own memory: descriptors | state words (uint64 each; the bool plans use the low int) | the plan kernel's PlanStats;
-// and - only when some problem is scanned by more than one workgroup - one counter per problem, a
-// 128-byte line each, or 33 of them in plans of more than 32 slices per problem (batched_kernels.hpp, kPlanCounterStride,
-// kPlanFanIn; either way well under 1 % of the haystack bytes such a plan covers).
+// The plan's own memory: descriptors | state words (uint64 each; the bool plans use the low int) | the plan kernel's PlanStats.
 struct ss_batch_plan {
     int dev = 0;
     size_t count = 0;
@@ -210,7 +206,6 @@ struct ss_batch_plan {
     ss::BatchArgs args;
     BatchShape shape = {1, 1};
     uint8_t *mem = nullptr;
-    uint32_t *ctr = nullptr;
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
     void *state() const { return mem + count * sizeof(ss::BatchDesc); }
     ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t))); }
@@ -285,29 +280,29 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
 #ifdef SS_TEST_HOOKS
             if (getenv("SLICESLICE_BATCH_WGS")) break;                         // tuning: the grid is what the variable says
 #endif
-            const uint64_t want = ((uint64_t)seen.max_tiles + kPlanTilesPerWg - 1) / kPlanTilesPerWg;
-            const uint64_t fair = ((seen.total_tiles + kPlanTilesPerWg - 1) / kPlanTilesPerWg + count - 1) / count;
+            // problems short enough for the slice-major layout (contiguous runs): about kPlanTilesPerWg tiles per workgroup; longer
+            // ones are scanned round robin by workgroups side by side, like ONE haystack by the single-problem kernel, and like
+            // there short workgroups win: kPlanTilesPerWgLong
+            const bool longp = seen.max_tiles > ss::kPlanSliceMajorMax * kPlanTilesPerWg;
+            const uint32_t per = longp ? kPlanTilesPerWgLong : kPlanTilesPerWg, min_tiles = longp ? kPlanMinTilesLong : kPlanMinTilesCounted;
+            const uint64_t want = ((uint64_t)seen.max_tiles + per - 1) / per;
+            const uint64_t fair = ((seen.total_tiles + per - 1) / per + count - 1) / count;
             uint64_t slices = std::min<uint64_t>(want, 4 * fair);
-            slices = std::max<uint64_t>(1, std::min<uint64_t>(slices, 0x7fffu));
+            slices = std::max<uint64_t>(1, slices);
             while (slices > 1 && (uint64_t)count * slices > 0x7fffffffull) --slices;
-            if (slices == p->shape.slices) break;
+            if (slices == p->shape.slices && min_tiles == p->shape.min_tiles) break;
             p->shape.slices = (uint32_t)slices;
+            p->shape.min_tiles = min_tiles;
         }
         if (e == hipSuccess) {
             const uint32_t most = seen.max_slices;
             p->shape.slices = most < 1 ? 1 : (most < p->shape.slices ? most : p->shape.slices);
-            if (p->shape.slices > 1) {
-                const size_t cbytes = count * (p->shape.slices > ss::kPlanFanIn ? 1 + ss::kPlanFanIn : 1) * ss::kPlanCounterStride * sizeof(uint32_t);
-                if ((e = hipMalloc((void **)&p->ctr, cbytes)) == hipSuccess) e = hipMemsetAsync(p->ctr, 0, cbytes, st);
-                if (e == hipSuccess) e = hipStreamSynchronize(st);
-            }
         }
         if (e != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan set-up: %s", hipGetErrorString(e));
     }
     if (rc != SS_OK) {
         (void)hipGetLastError();
-        (void)hipFree(p->ctr);
         (void)hipFree(p->mem);
         delete p;
         return rc;
@@ -327,22 +322,24 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     const dim3 grid((unsigned)((uint64_t)p->count * p->shape.slices));
     if (p->find) {
         a.best = static_cast<uint64_t *>(d_out);
-        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices,
-                                                                                                   p->state(), p->ctr);
+        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state());
     } else {
         a.found = static_cast<int *>(d_out);
-        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices,
-                                                                                                    p->state(), p->ctr);
+        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state());
     }
     HIP_TRY(hipGetLastError());
+    // problems scanned by several workgroups leave their answer in the plan's state words: one lane per problem publishes
+    if (p->shape.slices > 1) {
+        ss::batch_publish_kernel<<<dim3((unsigned)((p->count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(a, p->descs(), (uint32_t)p->count, p->state());
+        HIP_TRY(hipGetLastError());
+    }
     return SS_OK;
 }
 
 void ss_batch_plan_free(ss_batch_plan *p)
 {
     if (!p) return;
-    (void)hipFree(p->ctr);          // (waits for the device: a run the caller forgot about cannot read freed memory)
-    (void)hipFree(p->mem);
+    (void)hipFree(p->mem);          // (waits for the device: a run the caller forgot about cannot read freed memory)
     delete p;
 }
 

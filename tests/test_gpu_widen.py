@@ -171,7 +171,7 @@ def test_batch_plan_runs_equal_the_unplanned_calls(ss):
 
 def test_batch_plan_trivial_problems_positions_and_graph_replay(ss):
     """Problems without a scan (empty needle, haystack shorter than the needle, a position that breaks the with_position rules)
-    are answered from the plan on every run; and a run is ONE kernel launch with nothing allocated, so it can be captured into a
+    are answered from the plan on every run; and a run is one or two kernel launches with nothing allocated, so it can be captured into a
     hipGraph and replayed - which the unplanned call refuses (its per-stream scratch may be reallocated by a later call)."""
     hay = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     hay[100:103] = torch.tensor([1, 2, 3], dtype=torch.uint8)
