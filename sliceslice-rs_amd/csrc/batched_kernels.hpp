@@ -278,6 +278,8 @@ constexpr uint32_t kPlanSliceMajorMax = 8;
 //     only by plans that have such problems - copies the state word to the output and puts it back to idle.
 // Problems without a scan (eff == 0: the empty needle, a bad position, a haystack shorter than the needle) are answered by
 // their slice-0 workgroup from the descriptor.
+// (-DSS_BATCH_WAVES_MAX=6 lets the register allocator aim at six waves per SIMD - tried with SLICESLICE_BATCH_OCC = 5 and 6 on
+// every batch shape: no difference, so four it stays)
 #ifndef SS_BATCH_WAVES_MAX
 #define SS_BATCH_WAVES_MAX 4
 #endif

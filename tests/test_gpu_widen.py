@@ -128,7 +128,7 @@ def test_batch_plan_runs_equal_the_unplanned_calls(ss):
     """A plan's run() must give what search_batched / find_batched give on the same problems - on the first run and on every later
     one, with haystack CONTENTS changed between runs (plants added and removed), into output buffers full of garbage."""
     rng = random.Random(41)
-    # (1 x 24 MiB and 3 x 9 MiB: more than 32 workgroups per problem - those count out in two levels)
+    # (1 x 24 MiB and 3 x 9 MiB: long problems - four tiles per workgroup, round robin, hundreds of workgroups per problem)
     for count, hay_len, nlen in ((1, 3 << 20, 16), (7, 1 << 20, (1, 2, 5, 16, 17, 40)), (300, 65536, (3, 16, 33)), (4096, 4096, 16),
                                  (50, 100, (1, 4, 16, 100, 101)), (1, 24 << 20, 16), (3, 9 << 20, (5, 16))):
         hay, hoff, nbuf, noff, want = _batch(ss, rng, count, hay_len, nlen)

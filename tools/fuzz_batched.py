@@ -25,7 +25,7 @@ def one_round(rng, count):
         n = rng.choice([0, 1, 2, 3, 5, 8, 15, 16, 17, 18, 24, 31, 32, 33, 64, 100, 300, 1100, 2100])
         ln = rng.choice([0, 1, max(n - 1, 0), n, n + 1, n + 7, 2 * n + 100, 1500, 20000, 70000])
         if big_budget and rng.random() < 0.01:
-            ln = rng.choice([(1 << 20) + 5, (3 << 20) - 7, 200000, (9 << 20) + 3])   # 9 MiB: a plan counts those out in two levels
+            ln = rng.choice([(1 << 20) + 5, (3 << 20) - 7, 200000, (9 << 20) + 3])   # 9 MiB: a plan scans those round robin, four tiles per workgroup
             big_budget -= 1
         if ln > 4096:
             base = bytes(rng.choice(alpha) for _ in range(4096))
