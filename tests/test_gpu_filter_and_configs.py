@@ -6,6 +6,7 @@ import ctypes
 import os
 import random
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -537,6 +538,10 @@ def test_workgroups_per_cu_are_learned_from_the_searchers_own_scans():
         raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
         text = torch.from_numpy(raw.copy()).cuda().repeat((1 << 30) // raw.size)
         torch.cuda.synchronize()
+        warm = ss.DynamicHipSearcher.new(bytes([1, 2, 3, 4, 5, 6, 7, 255]))
+        t_end = time.perf_counter() + 0.3                   # settled clocks: rates measured a few calls apart are then comparable
+        while time.perf_counter() < t_end:
+            warm.search_in(hay)
         for needle, h in ((b"there is not another one of these", hay), (b"segment descriptor table entries are", text)):
             s = ss.DynamicHipSearcher.new(needle)
             assert s.search_in(h[: 1 << 20]) is False
@@ -557,7 +562,7 @@ def test_workgroups_per_cu_are_learned_from_the_searchers_own_scans():
             # ... and not on a setting it has just measured clearly slower (the rates are paired in time: the chosen setting's
             # recent best, the other's best of its latest two-call exploration)
             chosen, other = (at4, at6) if mode == 4 else (at6, at4)
-            assert chosen >= other * 0.97, (needle, mode, at4, at6)
+            assert chosen >= other * 0.93, (needle, mode, at4, at6)
             if h is text:
                 assert mode == 6, (picks, at4, at6)                              # stock phrases want six: 10-15 % apart
             # a found needle teaches nothing and answers as ever
