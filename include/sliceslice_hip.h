@@ -25,9 +25,16 @@
  * Errors: the reference panics on contract violations (src/x86.rs:300,473);
  * nothing unwinds across this ABI - every function returns an ss_status.
  *
- * Threading: a searcher is immutable after construction; any number of threads
- * may call ss_search_* on one handle concurrently (each call uses its own flag
- * slot).  A call synchronises only the stream it was given.
+ * Threading: what a searcher SEARCHES FOR (needle, position, filter bytes) is
+ * immutable after construction (ss_searcher_set_filter3 aside, which is refused
+ * while a search runs); any number of threads may call ss_search_* on one handle
+ * concurrently (each call uses its own flag slot).  What a handle does carry as
+ * mutable state, per device, is LAUNCH TUNING: the candidate census of the
+ * haystacks it has been used on and whether its latest synchronous search found
+ * the needle decide between four and six workgroups per CU for scans of 256 MiB
+ * and more (ss_searcher_last_launch reports the choice).  No result depends on it;
+ * for a given haystack and needle the choice is the same from the second scan on.
+ * A call synchronises only the stream it was given.
  *
  * No CPU fallback exists: every ss_search_* that has to look at haystack bytes
  * launches a HIP kernel, and fails with SS_ERR_NO_DEVICE / SS_ERR_HIP otherwise.
@@ -219,6 +226,9 @@ SS_API int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin,
  * (milliseconds) - what a roofline figure for the scan kernel is computed from (bench.py). */
 SS_API int ss_searcher_set_timing(ss_searcher *s, int enabled);
 SS_API int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);
+/* Launch shape of the latest scan enqueued through `s` on the current device: workgroups per CU (4 or 6: see "Threading" above)
+ * and workgroups in the grid.  Read-only diagnostics - what a benchmark line reports next to its kernel times. */
+SS_API int ss_searcher_last_launch(const ss_searcher *s, int *workgroups_per_cu, unsigned *grid);
 
 /* ---- multi-GPU: one process per GPU, native RCCL ------------------------------------------- */
 /* Range partition used by every sharded caller: rank r of G scans bytes

@@ -72,10 +72,10 @@ SS_API int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
 /* ... and make the next `count` scans launched through `s` fail before they reach the device (SS_ERR_HIP): how the tests
  * check that a rank-local failure leaves no other rank waiting in the collective of ss_search_sharded / ss_find_sharded. */
 SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
-/* The workgroups-per-CU setting of `s`'s latest scan on the current device (4 or 6) and what the searcher has learned so far from
- * the time of its full scans there: GB/s at four and at six workgroups per CU - the recent best for the setting it has chosen,
- * the best of the latest exploration for the other (0: not tried yet). */
-SS_API int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *gbps_at_four, int *gbps_at_six);
+/* The candidate census of (`s`, d_haystack, len) on the current device, if its counts are in: counts[0] = wave-tiles sampled (0:
+ * no census yet), [1] = tiles with a candidate of the device's three filter bytes, [2] = tiles with a candidate of the first two
+ * alone, [3] = tiles in which a candidate's first 64 bytes equal the needle's, [4] = candidate lanes.  Launches nothing. */
+SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[5]);
 
 /* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */
 SS_API int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches, uint64_t *settled);

@@ -11,7 +11,7 @@
 // way `DynamicAvx2Searcher` keeps a private `[u8; n]` for n in 2..=16 (src/x86.rs:476-490).
 #![allow(non_camel_case_types, dead_code)]
 use crate::Needle;
-use std::os::raw::{c_char, c_float, c_int, c_void};
+use std::os::raw::{c_char, c_float, c_int, c_uint, c_void};
 
 #[repr(C)] pub struct ss_searcher { _private: [u8; 0] }
 #[repr(C)] pub struct ss_comm { _private: [u8; 0] }
@@ -72,6 +72,7 @@ extern "C" {
     // kernel timing (what a roofline figure is computed from)
     pub fn ss_searcher_set_timing(s: *mut ss_searcher, enabled: c_int) -> c_int;
     pub fn ss_searcher_last_kernel_ms(s: *const ss_searcher, ms: *mut c_float) -> c_int;
+    pub fn ss_searcher_last_launch(s: *const ss_searcher, workgroups_per_cu: *mut c_int, grid: *mut c_uint) -> c_int;
     // multi-GPU, one process per GPU
     pub fn ss_shard_range(len: usize, needle_len: usize, nranks: c_int, rank: c_int, begin: *mut usize, end: *mut usize) -> c_int;
     pub fn ss_comm_unique_id(id: *mut u8) -> c_int;

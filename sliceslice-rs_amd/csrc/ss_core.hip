@@ -74,8 +74,9 @@ namespace {
 // a kernel's start drops the caches' copy of the block; a resident service kernel acquires what was uploaded after its last
 // look (upload tickets).  Without a large BAR (or with SLICESLICE_NO_BAR_WRITES=1) the image goes by one hipMemcpy.
 constexpr size_t kBlockDevBytes = 4096, kBlockHostBytes = 2048, kBlockNeedleOff = 2048, kBlockNeedleMax = 2048;
-constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kCtlBytes = 1792;
-constexpr size_t kHostOffFlags = 0, kHostOffBest = 256, kHostOffDone = 768;
+constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kOffCensus = 1792, kCtlBytes = 1808;
+constexpr size_t kHostOffFlags = 0, kHostOffBest = 256, kHostOffDone = 768, kHostOffCensus = 1280;
+static_assert(kCtlBytes <= kBlockNeedleOff && kHostOffCensus + 16 <= kBlockHostBytes, "the control words fit their halves of a block");
 constexpr uint32_t kBlocksPerSlab = 512;        // 2 MiB of device memory per slab: one page-table fragment
 
 struct BlockPool {
@@ -182,14 +183,16 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
     p.h_flags = reinterpret_cast<int *>(hb + kHostOffFlags);
     p.h_best = reinterpret_cast<uint64_t *>(hb + kHostOffBest);
     p.h_done = reinterpret_cast<long long *>(hb + kHostOffDone);
+    p.d_census = reinterpret_cast<unsigned long long *>(db + kOffCensus);
+    p.h_census = reinterpret_cast<unsigned long long *>(hb + kHostOffCensus);
     memset(hb, 0, kBlockHostBytes);                    // blocks are recycled: a stale value must not equal an epoch
     for (int k = 0; k < kSlots; ++k) p.find_tag[k] = kFindTagMax;
-    // the block's image: flags 0 | minima all ones | completion counters 0 | keyed minima all ones | the needle
+    // the block's image: flags 0 | minima all ones | completion counters 0 | keyed minima all ones | census word 0 | the needle
     const bool inside = s->n <= kBlockNeedleMax;
     alignas(16) uint8_t img[kBlockDevBytes];
     memset(img, 0, sizeof img);
     memset(img + kOffBest, 0xFF, kOffDone - kOffBest);
-    memset(img + kOffBestDone, 0xFF, kCtlBytes - kOffBestDone);
+    memset(img + kOffBestDone, 0xFF, kOffCensus - kOffBestDone);
     if (inside && s->n) memcpy(img + kBlockNeedleOff, s->needle.data(), s->n);
     const size_t img_bytes = inside ? kBlockNeedleOff + ((s->n + 15) & ~(size_t)15) : kCtlBytes;
     hipError_t e = hipSuccess;
@@ -439,6 +442,7 @@ int store_filter(ss_searcher *s, size_t fa, size_t fb, size_t fc)
     s->fa = fa;
     s->fb = fb;
     s->fc = fc;
+    ++s->filter_gen;
     derive_device_filter(s);
     s->gate.store(0, std::memory_order_release);
     return SS_OK;

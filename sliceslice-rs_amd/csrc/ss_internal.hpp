@@ -91,12 +91,26 @@ struct PerDevice {
     unsigned long long *d_done = nullptr;   // kSlots counters: found-workgroups << 32 | workgroups
     long long *h_done = nullptr;            // pinned: the answer word, stored by the workgroup that completes the count
     uint64_t *d_best_done = nullptr;        // kSlots keyed minima of find()
-    // Workgroups per CU, learned from the time of this searcher's full scans on this device (ss_scan.hip): the current choice, a
-    // best-of rate (MB/s) and a sample count at four [0] and at six [1] workgroups per CU - recent calls for the current choice,
-    // the latest exploration for the other - the number of choices made, what is left of an exploration, the latest launch's
-    // setting.  Racy by design when several threads search through one handle (relaxed __atomic accesses; any value is valid).
-    uint32_t learn_mbps[2] = {0, 0}, learn_n[2] = {0, 0}, learn_calls = 0, learn_warm = 0, learn_explore_left = 0;
-    int last_occ = 0, learn_choice = 0;
+    // Workgroups per CU (ss_scan.hip): what the candidate census said about the haystacks this searcher has been used on, on this
+    // device - launch tuning only; no search result depends on it.  A small table (the searcher's latest haystacks), the one census
+    // that may be in flight, and the latest launch's shape for ss_searcher_last_launch.  census_lock is a try-lock: a thread that
+    // finds it taken launches with what it has.
+    struct Census {
+        const void *hay = nullptr;
+        size_t len = 0;
+        uint32_t gen = 0;           // the searcher's filter generation the counts were taken with
+        uint32_t state = 0;         // 0 = empty, 1 = launched (tag `tag`), 2 = counts are in
+        uint32_t tag = 0;
+        uint64_t sums = 0;          // tiles3 | tiles2 << 11 | match tiles << 22 | candidate lanes << 33 (aux_kernels.hpp)
+        uint64_t stamp = 0;
+    } census[4];
+    uint32_t census_lock = 0, census_tag = 0;
+    int census_pending = -1;
+    uint64_t census_clock = 0;
+    unsigned long long *d_census = nullptr;     // the census kernel's accumulator word
+    unsigned long long *h_census = nullptr;     // pinned: [0] sums, [1] tag of the launch they belong to
+    int last_occ = 0, last_found = 0;           // workgroups per CU of the latest launch; the latest synchronous search found the needle
+    unsigned last_grid = 0;
     uint32_t done_low[64] = {0}, done_hi[64] = {0};
     uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax
     uint64_t free_mask = 0;
@@ -130,6 +144,7 @@ struct ss_searcher {
     size_t fa = 0, fb = 0, fc = 0;
     size_t da = 0, db = 0, dc = 0;  // the triple the device tests (derive_device_filter): == fa, fb, fc unless the pair is too far apart
     size_t far = 0;                 // ... then: the caller's far byte (== fb), tested first when a candidate reaches memory; else 0
+    uint32_t filter_gen = 0;        // bumped by every rewrite of the triple: census counts taken with an older triple are stale
     int variant = 0;          // tuning builds only (ss_searcher_set_variant / _set_grid); 0 = automatic
     int grid = 0;
     bool timing = false;
@@ -206,8 +221,7 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
 // sees (the leftmost one survives).  Preconditions: 1 <= n <= len.  done_slot >= 0: the call owns flag slot `done_slot` and would
 // like to wait on the slot's completion word instead of the stream; granted (*used_done = true) for small grids.
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find = false,
-                 uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1, int done_slot = -1, bool *used_done = nullptr,
-                 int *occ_used = nullptr);
+                 uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1, int done_slot = -1, bool *used_done = nullptr);
 void timer_forget(const ss_searcher *s);                         // ss_searcher_free: the calling thread's timing record
 
 // Scans too large for the workgroup count of the completion word still answer through a pinned word when the scan is short enough

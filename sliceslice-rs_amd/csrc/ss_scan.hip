@@ -10,6 +10,7 @@
 #include <algorithm>
 
 #define SS_AUX_PUBLISH 1
+#define SS_AUX_CENSUS 1
 #include "aux_kernels.hpp"
 #include "scan_launch.hpp"
 
@@ -91,25 +92,26 @@ struct Launch {
 // transposition into the 16-byte layout on top of the regular filter.  Automatic choice: one-byte needles
 // only; 2xxx variants force it for tuning.
 
-// Workgroups per CU, learned.  Four suit a scan that rarely meets a candidate, six one that keeps meeting them (pick_variant has
-// the measurements), and which of the two a haystack is cannot be told from the needle: a text-like needle on binary data gave
-// up 3-5 % under the needle-byte guess, a stock phrase of the manual with rare-looking bytes 15-20 % the other way.  So the
-// searcher LEARNS it, per device, from what its own full scans cost: ss_search_device times every call that scanned the whole
-// haystack (answer "absent") of at least kLearnMinBytes.  What makes this harder than it sounds is that a device's speed drifts -
-// its clocks ramp up over the first tens of milliseconds after an idle gap, power management moves them later - so a rate
-// measured now says nothing against a rate measured fifty calls ago (a first cut kept a best-rate estimate per setting and
-// locked onto whichever setting it happened to try last during the ramp).  Hence PAIRED comparisons: the searcher runs on its
-// current choice and keeps a short-memory best rate for it; at the 2nd, 8th, 16th and 32nd such call and every
-// kLearnExploreEvery-th after that it gives the other setting two calls in a row, and changes its mind when the better of those
-// two beats the current setting's recent best by more than 1.5 % (on random bytes the two settings are 2 % apart and a timing's
-// noise is 1 %).  Nothing in
-// the kernels: a first cut counted candidate tiles in the scan kernel (a relaxed atomic in the candidate path of every 64th
-// workgroup - never executed on random bytes) and cost the headline 3-8 % through what the compiler did to the hot loop around
-// it (profiles/r04/ab_stats_counter.jsonl).  Entry points that do not see their scan's duration (the _async forms, the sharded
-// searches) launch with what has been learned so far, or with the needle-byte guess.
-constexpr size_t kLearnMinBytes = (size_t)256 << 20;
-constexpr uint32_t kLearnExploreEvery = 64;
-constexpr uint32_t kLearnExploreCalls = 2;      // calls in a row the other setting gets when it is looked at
+// Workgroups per CU.  Four suit a scan that rarely meets a candidate, six one that keeps meeting them (pick_variant has the
+// measurements), and which of the two a haystack is cannot be told from the needle: a text-like needle on binary data gave up 3-5 %
+// under the needle-byte guess, a stock phrase of the manual with rare-looking bytes 15-20 % the other way.  Round 4 LEARNED the
+// setting from the wall-clock time of a searcher's own full scans; its own records showed it misjudging by up to 10 % (a 1.5 %
+// threshold against 1 % timing noise and 2-3 % drift), its explorations landed inside timed regions, and a call's cost depended on
+// the calls before it.  Now the haystack is ASKED, once: the first scan of a (searcher, haystack) pair of at least kCensusMinBytes
+// is preceded - on the same stream, the host does not wait - by census_kernel (aux_kernels.hpp), which puts kCensusTiles sampled
+// wave-tiles through the searcher's own filter bytes and counts the tiles that hold a candidate.  From the second scan on the
+// count decides (census_choice): deterministic for a given haystack and needle, nothing in the scan kernels, nothing timed.  The
+// first scan, and every scan of less than kCensusMinBytes, goes by the needle-byte guess.  A searcher whose latest synchronous
+// search FOUND the needle launches with four: a grid that leaves early drains faster with fewer workgroups resident (`the` on 1 GiB
+// of text: 0.035 ms at four, 0.060 at six).
+constexpr size_t kCensusMinBytes = (size_t)256 << 20;
+// Six workgroups per CU when at least kCensusDenseTiles of the kCensusTiles sampled tiles hold a candidate of the device's filter,
+// or when the candidates crowd (kCensusDenseLanes candidate lanes in the sample).  Read from 96 (phrase, filter) cases on 1 GiB of
+// the i386 text and on random bytes, each timed at forced four and six in one process (tools/occ_census.py,
+// profiles/r05/occ_census.jsonl): below ~40 candidate tiles in 1,024 four is 3-8 % faster, above ~70 six is - by 3 % at 70, 10-30 %
+// from 150 on - and in between the two are within 3 % of each other; any threshold from 40 to 56 loses 0.3 % on average over the
+// set against always picking the faster one (four everywhere: 7 %, six everywhere: 3 %).
+constexpr uint32_t kCensusDenseTiles = 48, kCensusDenseLanes = 256;
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 
@@ -268,55 +270,95 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     shape->one_byte = one_byte;
 }
 
-// The setting to launch with (racy by design when several threads search through one handle: any value read is a valid choice).
-int learned_occupancy(PerDevice *pd, int guess)
+// ---- the candidate census ---------------------------------------------------------------------------------------------
+namespace {
+
+struct CensusCounts {
+    uint32_t tiles3, tiles2, match_tiles, lanes;
+};
+CensusCounts census_counts(uint64_t sums)
 {
-    int choice = __atomic_load_n(&pd->learn_choice, __ATOMIC_RELAXED);
-    if (choice == 0) {
-        choice = guess;
-        __atomic_store_n(&pd->learn_choice, choice, __ATOMIC_RELAXED);
-    }
-    const int other = choice == 4 ? 6 : 4;
-    uint32_t left = __atomic_load_n(&pd->learn_explore_left, __ATOMIC_RELAXED);
-    if (left != 0) {                                        // the second call of an exploration
-        __atomic_store_n(&pd->learn_explore_left, left - 1, __ATOMIC_RELAXED);
-        return other;
-    }
-    const uint32_t calls = __atomic_fetch_add(&pd->learn_calls, 1u, __ATOMIC_RELAXED) + 1;
-    const bool explore = calls % kLearnExploreEvery == 0 || calls == 2 || (calls < kLearnExploreEvery && calls >= 8 && (calls & (calls - 1)) == 0);
-    if (!explore) return choice;
-    __atomic_store_n(&pd->learn_explore_left, kLearnExploreCalls - 1, __ATOMIC_RELAXED);
-    __atomic_store_n(&pd->learn_mbps[other == 6], 0u, __ATOMIC_RELAXED);      // this exploration's samples only
-    __atomic_store_n(&pd->learn_n[other == 6], 0u, __ATOMIC_RELAXED);
-    return other;
+    return {(uint32_t)(sums & 2047u), (uint32_t)((sums >> 11) & 2047u), (uint32_t)((sums >> 22) & 2047u), (uint32_t)(sums >> 33)};
 }
 
-// One full scan's lesson.  Whatever disturbs a single timing makes it LONGER (a preempted host thread, a busy PCIe link), so the
-// rate kept per setting is a best-of: of the exploration's calls for the other setting, of the recent calls (fading by 1/16 per
-// sample) for the current one.  The searcher's very first scan (a cold launch path) is not recorded at all.
-void learn_from_scan(PerDevice *pd, int occ, size_t len, double seconds)
+// What is known about (hay, len) under the searcher's current filter bytes; launches the census in front of the caller's scan
+// when nothing is, nothing else is in flight and the stream is not being captured.  Returns true with the counts when they are in.
+bool census_lookup(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, CensusCounts *out)
 {
-    if (len < kLearnMinBytes || seconds <= 0 || (occ != 4 && occ != 6)) return;
-    if (__atomic_exchange_n(&pd->learn_warm, 1u, __ATOMIC_RELAXED) == 0) return;
-    const int k = occ == 6 ? 1 : 0;
-    const uint32_t rate = (uint32_t)std::min((double)len / seconds / 1e6, 4.0e9);                    // MB/s
-    const uint32_t old = __atomic_load_n(&pd->learn_mbps[k], __ATOMIC_RELAXED);
-    const int choice = __atomic_load_n(&pd->learn_choice, __ATOMIC_RELAXED);
-    if (occ == choice) {
-        __atomic_store_n(&pd->learn_mbps[k], std::max(rate, old - old / 16), __ATOMIC_RELAXED);
-        __atomic_fetch_add(&pd->learn_n[k], 1u, __ATOMIC_RELAXED);
-        return;
+    if (__atomic_exchange_n(&pd->census_lock, 1u, __ATOMIC_ACQUIRE) != 0) return false;     // another thread is at it
+    struct Unlock {
+        uint32_t *w;
+        ~Unlock() { __atomic_store_n(w, 0u, __ATOMIC_RELEASE); }
+    } unlock{&pd->census_lock};
+    if (pd->census_pending >= 0) {
+        PerDevice::Census &c = pd->census[pd->census_pending];
+        if (__atomic_load_n(pd->h_census + 1, __ATOMIC_ACQUIRE) == (unsigned long long)c.tag) {
+            c.sums = __atomic_load_n(pd->h_census, __ATOMIC_RELAXED);
+            c.state = 2;
+            pd->census_pending = -1;
+        }
     }
-    const uint32_t best = std::max(rate, old);
-    __atomic_store_n(&pd->learn_mbps[k], best, __ATOMIC_RELAXED);
-    const uint32_t n = __atomic_fetch_add(&pd->learn_n[k], 1u, __ATOMIC_RELAXED) + 1;
-    if (n < kLearnExploreCalls) return;
-    const uint32_t cur = __atomic_load_n(&pd->learn_mbps[1 - k], __ATOMIC_RELAXED);
-    if (cur == 0 || best > cur + cur / 64) __atomic_store_n(&pd->learn_choice, occ, __ATOMIC_RELAXED);   // a change of mind
+    PerDevice::Census *hit = nullptr, *victim = &pd->census[0];
+    for (auto &c : pd->census) {
+        if (c.state != 0 && c.hay == d_hay && c.len == len && c.gen == s->filter_gen) hit = &c;
+        if (c.state != 1 && (victim->state == 1 || c.stamp < victim->stamp)) victim = &c;
+    }
+    if (hit) {
+        hit->stamp = ++pd->census_clock;
+        if (hit->state != 2) return false;
+        *out = census_counts(hit->sums);
+        return true;
+    }
+    if (pd->census_pending >= 0 || victim->state == 1) return false;                         // one census in flight per searcher and device
+    const size_t n = s->n, end = len - n + 1;
+    const size_t reach = std::max(s->db, s->dc) + 4;                                          // the last dword a lane loads ends here
+    if (end < 2 * (size_t)ss::kCensusTileBytes + 8 || reach > n + 3) return false;
+    const uint64_t room = end - 4 - ss::kCensusTileBytes;                                     // latest start of a sampled tile
+    const uint64_t stride = (room / (ss::kCensusTiles - 1)) & ~(uint64_t)(ss::kCensusTileBytes - 1);
+    if (stride < ss::kCensusTileBytes) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;                                                                          // a graph would replay the census for nobody
+    }
+    ss::CensusArgs a;
+    a.hay = static_cast<const uint8_t *>(d_hay);
+    a.needle = pd->d_needle;
+    a.stride = stride;
+    a.oa = (uint32_t)s->da;
+    a.ob = (uint32_t)s->db;
+    a.oc = (uint32_t)s->dc;
+    a.bytes = (uint32_t)s->needle[s->da] | ((uint32_t)s->needle[s->db] << 8) | ((uint32_t)s->needle[s->dc] << 16);
+    a.ncheck = (uint32_t)std::min<size_t>(n, ss::kCensusCheck);
+    a.nblocks = ss::kCensusTiles / ss::kWavesPerBlock;
+    if (++pd->census_tag == 0) pd->census_tag = 1;
+    a.tag = pd->census_tag;
+    a.d_acc = pd->d_census;
+    a.h_out = pd->h_census;
+    ss::census_kernel<<<dim3(a.nblocks), dim3(ss::kBlock), 0, st>>>(a);
+    if (hipGetLastError() != hipSuccess) return false;
+    victim->hay = d_hay;
+    victim->len = len;
+    victim->gen = s->filter_gen;
+    victim->state = 1;
+    victim->tag = a.tag;
+    victim->sums = 0;
+    victim->stamp = ++pd->census_clock;
+    pd->census_pending = (int)(victim - pd->census);
+    return false;
 }
+
+// Four or six workgroups per CU from the census counts (see "Workgroups per CU" above).
+int census_choice(const CensusCounts &c)
+{
+    if (c.match_tiles != 0) return 4;                   // the needle (or its first kCensusCheck bytes) is in the sample: an early answer
+    return c.tiles3 >= kCensusDenseTiles || c.lanes >= kCensusDenseLanes ? 6 : 4;
+}
+
+}  // namespace
 
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find,
-                 uint64_t find_base, int *host_flag, int epoch, int done_slot, bool *used_done, int *occ_used)
+                 uint64_t find_base, int *host_flag, int epoch, int done_slot, bool *used_done)
 {
 #ifdef SS_TEST_HOOKS
     if (s->debug_fail_scans.load(std::memory_order_relaxed) > 0 && s->debug_fail_scans.fetch_sub(1) > 0)
@@ -332,13 +374,16 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     const size_t fa = ps.fa, position = ps.position, position3 = ps.position3;
     const uint32_t sh = (uint32_t)(position % 16);
 
-    // Workgroups per CU (see "learned" above).  First use: a guess from the NEEDLE (every filter byte text-like -> the haystack
-    // is presumably text; single-stream kernels only - the cross-lane ones gain from six only at very high candidate rates).
+    // Workgroups per CU (see "Workgroups per CU" above).  Without census counts: a guess from the NEEDLE (every filter byte
+    // text-like -> the haystack is presumably text; single-stream kernels only).
     const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
                            ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
     int occ = !one_byte && text_like && pr.d == 0 ? 6 : 4;
-    if (!one_byte && len >= kLearnMinBytes) occ = learned_occupancy(pd, occ);
-    if (occ_used) *occ_used = occ;
+    if (!one_byte && len >= kCensusMinBytes) {
+        CensusCounts cc;
+        if (census_lookup(s, pd, d_hay, len, st, &cc)) occ = census_choice(cc);
+        if (__atomic_load_n(&pd->last_found, __ATOMIC_RELAXED) != 0) occ = 4;
+    }
     const Launch l = pick_variant(s->variant, pr.d, one_byte, occ);
     const uint64_t wpb = l.block / ss::kWave;
     const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
@@ -373,6 +418,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     }
     if (blocks < 1) blocks = 1;
     __atomic_store_n(&pd->last_occ, s->variant == 0 ? occ : 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&pd->last_grid, (unsigned)blocks, __ATOMIC_RELAXED);
     const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
     if (used_done) *used_done = false;
     if (done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks && (!find || len < (1ull << ss::kFindOffsetBits))) {
@@ -478,15 +524,43 @@ using namespace ssh;
 
 extern "C" {
 
-#ifdef SS_TEST_HOOKS
-int ss_debug_last_occupancy(const ss_searcher *s, int *workgroups_per_cu, int *gbps_at_four, int *gbps_at_six)
+int ss_searcher_last_launch(const ss_searcher *s, int *workgroups_per_cu, unsigned *grid)
 {
-    if (!s || !workgroups_per_cu || !gbps_at_four || !gbps_at_six) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (!s || !workgroups_per_cu || !grid) return fail(SS_ERR_ARGUMENT, "NULL argument");
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) return rc;
     *workgroups_per_cu = __atomic_load_n(&pd->last_occ, __ATOMIC_RELAXED);
-    *gbps_at_four = (int)(__atomic_load_n(&pd->learn_mbps[0], __ATOMIC_RELAXED) / 1000);
-    *gbps_at_six = (int)(__atomic_load_n(&pd->learn_mbps[1], __ATOMIC_RELAXED) / 1000);
+    *grid = __atomic_load_n(&pd->last_grid, __ATOMIC_RELAXED);
+    return SS_OK;
+}
+
+#ifdef SS_TEST_HOOKS
+int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[5])
+{
+    if (!s || !counts) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    PerDevice *pd = nullptr;
+    if (int rc = get_per_device(s, &pd)) return rc;
+    CensusCounts cc = {0, 0, 0, 0};
+    counts[0] = 0;
+    // (enqueue nothing: a null stream is never captured, but this call must not launch - look the entry up by hand)
+    while (__atomic_exchange_n(&pd->census_lock, 1u, __ATOMIC_ACQUIRE) != 0) cpu_relax();
+    for (auto &c : pd->census) {
+        if (c.state == 1 && pd->census_pending == (int)(&c - pd->census) &&
+            __atomic_load_n(pd->h_census + 1, __ATOMIC_ACQUIRE) == (unsigned long long)c.tag) {
+            c.sums = __atomic_load_n(pd->h_census, __ATOMIC_RELAXED);
+            c.state = 2;
+            pd->census_pending = -1;
+        }
+        if (c.state == 2 && c.hay == d_haystack && c.len == len && c.gen == s->filter_gen) {
+            cc = census_counts(c.sums);
+            counts[0] = ss::kCensusTiles;
+        }
+    }
+    __atomic_store_n(&pd->census_lock, 0u, __ATOMIC_RELEASE);
+    counts[1] = cc.tiles3;
+    counts[2] = cc.tiles2;
+    counts[3] = cc.match_tiles;
+    counts[4] = cc.lanes;
     return SS_OK;
 }
 #endif
@@ -539,11 +613,8 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
     // the slot's completion word may hold a find()'s answer (offset + 1), which could pass for 2 * epoch + found
     __atomic_store_n(pd->h_done + k, 0ll, __ATOMIC_RELAXED);
     bool used_done = false;
-    int occ_used = 0;
-    const bool learning = len >= kLearnMinBytes && s->n > 1 && s->variant == 0;
-    const auto t_launch = learning ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     int rc = enqueue_scan(s, pd, d_haystack, len, st, pd->d_flags + k, false, 0, pd->h_flags + k, epoch, spin_ok ? k : -1,
-                          &used_done, &occ_used);
+                          &used_done);
     bool answered = false;
     // the answer word of a small grid: found-half of the slot's counter << 32 | epoch << 1 | found
     auto take = [&](long long v) {
@@ -583,9 +654,7 @@ int ss_search_device(const ss_searcher *s, const void *d_haystack, size_t len, v
         else *found = __atomic_load_n(pd->h_flags + k, __ATOMIC_ACQUIRE) == epoch;
     }
     if (rc != SS_OK) start_over(pd, k);             // a failed launch may have left a partial workgroup count behind
-    // a full scan (the needle is absent: every byte was read) teaches the searcher what this setting is worth on this haystack
-    if (rc == SS_OK && learning && *found == 0)
-        learn_from_scan(pd, occ_used, len, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch).count());
+    if (rc == SS_OK) __atomic_store_n(&pd->last_found, *found, __ATOMIC_RELAXED);      // (launch tuning: see "Workgroups per CU")
     release_slot(s, pd, k);
     return rc;
 }

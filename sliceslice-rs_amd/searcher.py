@@ -65,6 +65,7 @@ ABI = {
     "ss_search_pairs": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ss_searcher_set_timing": (_int, [_vp, _int]),
     "ss_searcher_last_kernel_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "ss_searcher_last_launch": (_int, [_vp, _pint, ctypes.POINTER(ctypes.c_uint)]),
     "ss_shard_range": (_int, [_sz, _sz, _int, _int, _psz, _psz]),
     "ss_comm_unique_id": (_int, [_vp]),
     "ss_comm_init_rank": (_int, [_vp, _int, _int, _pvp]),
@@ -102,7 +103,7 @@ HOOKS_ABI = {
     "ss_debug_set_completion_state": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
-    "ss_debug_last_occupancy": (_int, [_vp, _pint, _pint, _pint]),
+    "ss_debug_census": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
 
@@ -379,11 +380,20 @@ class DynamicHipSearcher:
         if int(blocks) != 0 or getattr(self._L, "has_hooks", False):
             self._ck(_hooks(self._L).ss_searcher_set_grid(self._h, int(blocks)))
 
-    def last_occupancy(self):
-        """(workgroups per CU of the latest scan, learned GB/s at four, learned GB/s at six; 0 = not tried) - hooks builds."""
-        w, a, b = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-        self._ck(_hooks(self._L).ss_debug_last_occupancy(self._h, ctypes.byref(w), ctypes.byref(a), ctypes.byref(b)))
-        return w.value, a.value, b.value
+    def last_launch(self):
+        """(workgroups per CU, workgroups in the grid) of the latest scan enqueued through this searcher on the current device."""
+        w, g = ctypes.c_int(0), ctypes.c_uint(0)
+        self._ck(self._L.ss_searcher_last_launch(self._h, ctypes.byref(w), ctypes.byref(g)))
+        return w.value, g.value
+
+    def census(self, haystack):
+        """Hooks builds: the candidate census of (this searcher, haystack) as a dict, or None when its counts are not in."""
+        c = (ctypes.c_uint32 * 5)()
+        ptr, n = haystack.data_ptr(), haystack.numel()
+        self._ck(_hooks(self._L).ss_debug_census(self._h, ptr, n, c))
+        if c[0] == 0:
+            return None
+        return {"tiles": c[0], "tiles3": c[1], "tiles2": c[2], "match_tiles": c[3], "lanes": c[4]}
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -215,14 +215,8 @@ def test_histogram_driven_triple_on_an_adversarial_corpus(ss):
     hist = ss.byte_histogram(hay, sample_bytes=1 << 20)
     a, b, c = ss.choose_filter_triple(needle, hist)
     assert 40 in (a, b, c)
-    s.set_timing(True)
-    s.search_in(hay)
-    slow = s.last_kernel_ms()
-    s.set_filter(a, b, c)
+    s.set_filter(a, b, c)                                # (what it buys in time: tests/test_gpu_zz_timing.py)
     assert s.search_in(hay) is False and s.find(hay) is None
-    s.search_in(hay)
-    fast = s.last_kernel_ms()
-    assert fast < slow                                   # the point of the policy (it is several times faster)
     hay[ln - 41:] = dev(needle)
     assert s.search_in(hay) is True and s.find(hay) == ln - 41
     assert ss.DynamicHipSearcher.new(needle).find(hay) == ln - 41
@@ -523,52 +517,76 @@ def test_second_level_far_bytes_at_lane_piece_and_tile_edges(ss):
         assert s.search_in(hay) is False
 
 
+def _census_model(host, needle, filt):
+    """The census kernel's counts (aux_kernels.hpp: census_kernel; ss_scan.hip: census_lookup) restated with numpy: 1,024 tiles of
+    4 KiB candidate offsets spread evenly, a 'lane' = 64 consecutive offsets."""
+    n, ln = len(needle), host.size
+    end = ln - n + 1
+    stride = ((end - 4 - 4096) // 1023) & ~4095
+    fa, fb, fc = filt
+    nd = np.frombuffer(needle, dtype=np.uint8)
+    tiles3 = tiles2 = match = lanes = 0
+    for k in range(1024):
+        o = k * stride
+        a, b, c = (host[o + f:o + f + 4096] == nd[f] for f in (fa, fb, fc))
+        p2 = a & b
+        p3 = p2 & c
+        tiles2 += bool(p2.any())
+        if p3.any():
+            tiles3 += 1
+            per_lane = p3.reshape(64, 64)
+            lanes += int(per_lane.any(axis=1).sum())
+            m = False
+            for l in np.nonzero(per_lane.any(axis=1))[0]:
+                i = o + 64 * int(l) + int(np.argmax(per_lane[l]))
+                m = m or bool((host[i:i + min(n, 64)] == nd[:min(n, 64)]).all())
+            match += m
+    return {"tiles": 1024, "tiles3": tiles3, "tiles2": tiles2, "match_tiles": match, "lanes": lanes}
+
+
 @pytest.mark.gpu
-def test_workgroups_per_cu_are_learned_from_the_searchers_own_scans():
-    """four or six workgroups per CU is learned per searcher and device from the time of its own full scans
-    (ss_scan.hip: learned_occupancy / learn_from_scan), not guessed from the needle.  Hooks build (ss_debug_last_occupancy):
-    after a few dozen scans of 1 GiB both settings have been tried, an estimate exists for each, the searcher launches with the
-    one it measured faster (explorations aside): six for a stock phrase on text, and for a text-like needle on RANDOM bytes - the
-    case the needle-byte guess got wrong - whichever it measures faster there.  Answers are never affected; small haystacks are
-    not timed."""
+def test_workgroups_per_cu_follow_the_candidate_census(O):
+    """four or six workgroups per CU is decided by what a census of the HAYSTACK counts (ss_scan.hip:
+    census_lookup / census_choice; aux_kernels.hpp: census_kernel), not by the wall-clock time of earlier scans: deterministic for a
+    given haystack and needle from the second scan on, nothing timed, observable through ss_searcher_last_launch.  Hooks build for
+    ss_debug_census.  The counts equal a numpy restatement of the sampling; a text-like needle on RANDOM bytes starts at the
+    needle-byte guess (six) and goes to four; a stock phrase of the manual on text goes to six; scans below 256 MiB take no
+    census; a searcher that has just FOUND its needle launches with four; new filter bytes mean a new census."""
     import sliceslice_rs_amd as ss
+    gib = 1 << 30
     with ss.tuning_build():
-        hay = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        hay = torch.empty(gib, dtype=torch.uint8, device="cuda")
         ss.fill_random_device(hay, 0x5EED0001)
         raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
-        text = torch.from_numpy(raw.copy()).cuda().repeat((1 << 30) // raw.size)
-        torch.cuda.synchronize()
-        warm = ss.DynamicHipSearcher.new(bytes([1, 2, 3, 4, 5, 6, 7, 255]))
-        t_end = time.perf_counter() + 0.3                   # settled clocks: rates measured a few calls apart are then comparable
-        while time.perf_counter() < t_end:
-            warm.search_in(hay)
-        for needle, h in ((b"there is not another one of these", hay), (b"segment descriptor table entries are", text)):
+        text_host = np.tile(raw, gib // raw.size + 1)[:gib].copy()
+        text = torch.from_numpy(text_host).cuda()
+        rnd_host = O.fill_random(gib, 0x5EED0001)
+        for needle, h, host, want in ((b"there is not another one of these", hay, rnd_host, 4),
+                                      (b"segment descriptor table entries are", text, text_host, 6),
+                                      (b"privilege level zero!", text, text_host, 4)):
             s = ss.DynamicHipSearcher.new(needle)
-            assert s.search_in(h[: 1 << 20]) is False
-            assert s.last_occupancy()[1:] == (0, 0), "a 1 MiB scan is not a lesson"
-            seen = set()
-            for _ in range(40):
+            assert s.search_in(h[: 1 << 20]) is False and s.census(h[: 1 << 20]) is None, "a 1 MiB scan takes no census"
+            guess = s.last_launch()[0]
+            assert s.census(h) is None
+            assert s.search_in(h) is False
+            assert s.last_launch()[0] == guess, "the first scan of a haystack goes by the needle-byte guess"
+            got = s.census(h)                               # the census ran in front of that scan: its counts are in
+            assert got == _census_model(host, needle, s.filter3), (needle, got)
+            picks = set()
+            for _ in range(5):
                 assert s.search_in(h) is False
-                seen.add(s.last_occupancy()[0])
-            wg, at4, at6 = s.last_occupancy()
-            assert seen == {4, 6} and at4 > 0 and at6 > 0, (seen, at4, at6)
-            picks = []
-            for _ in range(20):
-                assert s.search_in(h) is False
-                picks.append(s.last_occupancy()[0])
-            wg, at4, at6 = s.last_occupancy()
-            mode = max(set(picks), key=picks.count)
-            assert picks.count(mode) >= 16, (needle, picks)                     # it has settled (an exploration aside)
-            # ... and not on a setting it has just measured clearly slower (the rates are paired in time: the chosen setting's
-            # recent best, the other's best of its latest two-call exploration)
-            chosen, other = (at4, at6) if mode == 4 else (at6, at4)
-            assert chosen >= other * 0.93, (needle, mode, at4, at6)
-            if h is text:
-                assert mode == 6, (picks, at4, at6)                              # stock phrases want six: 10-15 % apart
-            # a found needle teaches nothing and answers as ever
+                picks.add(s.last_launch()[0])
+            assert picks == {want}, (needle, got, picks)
+            assert s.last_launch()[1] in (gib // 16384, gib // 16384 + 1), "one 16 KiB tile per workgroup at 1 GiB"
+            # a needle that is found: the next launch is at four, whatever the census says; absent again: back to the census
             h2 = h[: 300 << 20].clone()
             h2[12345:12345 + len(needle)] = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
-            before = s.last_occupancy()[1:]
             assert s.search_in(h2) is True and s.find(h2) == 12345
-            assert s.last_occupancy()[1:] == before
+            assert s.search_in(h2) is True and s.last_launch()[0] == 4
             del h2
+            assert s.search_in(h) is False and s.search_in(h) is False and s.last_launch()[0] == want
+            # new filter bytes: the old counts no longer describe the filter
+            a, b, c = s.filter3
+            s.set_filter(a, b, c)
+            assert s.census(h) is None
+            assert s.search_in(h) is False and s.census(h) == got

@@ -162,6 +162,7 @@ def test_bound_haystack_skips_the_acquire_and_answers_the_same(ss, O, hooks):
         assert sv.search_in(late, t2) is False
 
 
+@pytest.mark.timing
 def test_service_lease_bounds_the_residency(ss, hooks):
     """Without requests the kernel leaves after its lease, so a device-wide wait cannot hang on it; the next request starts a new
     residency (one more launch) and is answered like any other."""
@@ -189,6 +190,7 @@ def test_service_lease_bounds_the_residency(ss, hooks):
         assert sv.counters()[1] - before <= 5                # (a scheduler hiccup of 2 ms ends a residency)
 
 
+@pytest.mark.timing
 def test_service_residency_is_capped_under_continuous_traffic(ss, hooks):
     """Every request renews the lease, so a caller that never pauses would keep the kernel resident for good - and block every
     device-wide wait in the process with it.  A residency therefore ends after 16 leases (at least 250 ms) whatever the traffic;
@@ -227,6 +229,7 @@ def test_service_residency_is_capped_under_continuous_traffic(ss, hooks):
         assert len(waits) == 3 and max(waits) < 1.0, waits
 
 
+@pytest.mark.timing
 def test_building_searchers_does_not_wait_for_a_resident_service(ss, hooks):
     """Searchers take their device memory from slabs and initialise it through the PCIe BAR: `new` makes no runtime call that
     waits for the device, so a resident service (here with a lease of half a second) does not stall it - with one allocation per

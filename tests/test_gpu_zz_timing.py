@@ -1,0 +1,66 @@
+"""Wall-clock assertions, collected LAST (tests/conftest.py sorts every @pytest.mark.timing test behind everything else): under the
+driver's `pytest -x` a noisy box can only ever hide tests of this kind, never a comparison with the oracle.  Each test states its
+noise model - the spread observed over repeated runs, recorded in profiles/r05/timing_test_spread.jsonl by
+tools/timing_spread.py - and keeps its threshold at three or more of those spreads from the typical value.  The service's and the
+relay's timing tests live next to their functional siblings (tests/test_gpu_service.py, tests/test_gpu_sharded.py) and carry the
+same marker."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timing, pytest.mark.timeout(900)]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import sliceslice_rs_amd as m
+    m.lib()
+    return m
+
+
+def test_histogram_driven_triple_is_faster_on_an_adversarial_corpus(ss):
+    """An all-'a' haystack against a...ae: `new` filters on three 'a's and every offset reaches the second level; the
+    histogram-driven triple contains the 'e' and nothing passes (the functional half: test_gpu_filter_and_configs.py).
+    Noise model: the ratio slow / fast was 5.1-6.3 over 12 runs; the bar is 1.5."""
+    ln = 64 << 20
+    hay = torch.full((ln,), 0x61, dtype=torch.uint8, device="cuda")
+    needle = b"a" * 40 + b"e"
+    s = ss.DynamicHipSearcher.new(needle)
+    s.set_timing(True)
+
+    def median_ms():
+        got = []
+        for _ in range(7):
+            assert s.search_in(hay) is False
+            got.append(s.last_kernel_ms())
+        return sorted(got)[3]
+    slow = median_ms()
+    s.set_filter(*ss.choose_filter_triple(needle, ss.byte_histogram(hay, sample_bytes=1 << 20)))
+    fast = median_ms()
+    assert slow > 1.5 * fast, (slow, fast)
+
+
+def test_sharded_search_costs_what_the_plain_search_costs():
+    """The N = 1 search through the sharded code path (native RCCL, ONE rank: scan + ncclAllReduce + answer word on one stream)
+    against the plain ss_search_device, in ONE process on ONE 8 GiB buffer (tools/native_bench sharded): the collective and the
+    answer word behind it may not cost a measurable share of a 1.2 ms scan - the shard of an 8-GPU run.  (Rounds 2-4 compared two
+    bench.py PROCESSES at 64 GiB, whose placement alone differs by 2-3 %, and had to retry.)
+    Noise model: sharded / plain was 0.997-1.012 over 12 runs (a ~10 us collective on a 1.17 ms call); the bar is 1.04."""
+    import sliceslice_rs_amd  # noqa: F401
+    exe = sys.modules["sliceslice_rs_amd._build"].build_native_bench()
+    ratios = []
+    for _ in range(2):
+        out = subprocess.run([exe, "sharded", "8", "60"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                             env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert out.returncode == 0, out.stdout[-800:] + out.stderr[-1500:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["devices"] == 1 and d["search_sharded_one_rank_ms"] > 0
+        ratios.append(d["search_sharded_one_rank_ms"] / d["search_device_ms"])
+        if ratios[-1] < 1.04:
+            return
+    raise AssertionError("the one-rank sharded search cost %.3f / %.3f of the plain one" % tuple(ratios))

@@ -26,6 +26,8 @@ def load(path):
     L = ctypes.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
     L.ss_searcher_new.argtypes = [vp, sz, ctypes.POINTER(vp)]
     L.ss_search_device.argtypes = [vp, vp, sz, vp, ctypes.POINTER(ctypes.c_int)]
+    if hasattr(L, "ss_searcher_last_launch"):
+        L.ss_searcher_last_launch.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)]
     L.ss_searcher_set_timing.argtypes = [vp, ctypes.c_int]
     L.ss_searcher_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     L.ss_searcher_free.argtypes = [vp]
@@ -116,12 +118,12 @@ def main():
         row = {name: round(h.numel() / statistics.median(v) / 1e6, 1) for name, v in acc.items()}
         table[c] = row
         occ = {}
-        for name, L, s in hs:                             # hooks builds: what the searcher settled on
-            if hasattr(L, "ss_debug_last_occupancy"):
-                w, a, b = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-                L.ss_debug_last_occupancy(s, ctypes.byref(w), ctypes.byref(a), ctypes.byref(b))
-                occ[name] = [w.value, a.value, b.value]
-        print(json.dumps({"case": c, "found": found.value, "gbps": row, "workgroups_per_cu,gbps_at_4,gbps_at_6": occ}), flush=True)
+        for name, L, s in hs:                             # what the searcher launched with (libraries from round 5 on)
+            if hasattr(L, "ss_searcher_last_launch"):
+                w, g = ctypes.c_int(0), ctypes.c_uint(0)
+                L.ss_searcher_last_launch(s, ctypes.byref(w), ctypes.byref(g))
+                occ[name] = [w.value, g.value]
+        print(json.dumps({"case": c, "found": found.value, "gbps": row, "workgroups_per_cu,grid": occ}), flush=True)
         for name, L, s in hs:
             L.ss_searcher_free(s)
     print(json.dumps({"median_gbps": table}), flush=True)

@@ -67,10 +67,11 @@ def main():
                     s.set_filter(0, len(ph) - 1)
                 s.set_variant(occ * 10000 + 41 if occ else 0)
                 res, med, mn = kernel_ms(s, text)
-                wg, rate = (s.last_occupancy()[0], list(s.last_occupancy()[1:])) if ss.lib().has_hooks else (None, None)
+                wg = s.last_launch()[0]
+                cen = s.census(text) if ss.lib().has_hooks else None
                 print(json.dumps({"case": "text:" + ph.decode(), "mode": mode, "occ": occ or "auto", "found": res, "ms": round(med, 4),
                                   "gbps": round(text.numel() / med / 1e6, 1), "gbps_best": round(text.numel() / mn / 1e6, 1),
-                                  "filter": list(s.filter3), "chosen": wg, "learned_gbps_4_6": rate}), flush=True)
+                                  "filter": list(s.filter3), "chosen": wg, "census": cen}), flush=True)
 
 
 if __name__ == "__main__":

@@ -124,8 +124,9 @@ def main():
             ms.append(s.last_kernel_ms())
         assert r in (False, None), r
         out.update(kernel="scan_kernel", filter_bytes=list(s.filter3), ms=round(float(np.median(ms)), 4), ms_min=round(float(np.min(ms)), 4))
+        out["workgroups_per_cu"], out["grid"] = s.last_launch()
         if ss.lib().has_hooks:
-            out["workgroups_per_cu"], out["learned_gbps_at_4"], out["learned_gbps_at_6"] = s.last_occupancy()
+            out["census"] = s.census(hay)
     out["gbps"] = round(hay.numel() / out["ms"] / 1e6, 1)
     print(json.dumps(out), flush=True)
 
