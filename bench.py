@@ -15,10 +15,16 @@ host.  The haystack is synthetic (SURVEY.md 8d generator), generated on the devi
 before the timed region starts.  The logical haystack has a FIXED total size (default 64 GiB, the size
 BASELINE.json's target is quoted on; it fits one 288 GB MI355X), so scaling is "strong".
 
-`--single-process` drives all N GPUs from ONE process instead (`ss_comm_init_all` = ncclCommInitAll, one stream per device, the
-N all-reduces in one group: the form a drop-in `search_in` over a node calls, and the one without a rendezvous to fail); it
-is also what bench.py falls back to - and says so in `config.launcher` / `config.transport_note` - when the ranks of the
-multi-process form cannot be brought up.
+N > 1 runs BOTH forms of the sharded search in one invocation (`--forms both`, the default): first one rank per GPU
+(`ss_search_sharded`: scan + ncclAllReduce + answer word on each rank's stream), then - the other ranks idle on a CPU barrier, their
+shards freed - all N GPUs from rank 0's process (`ss_comm_init_all` = ncclCommInitAll, one issue thread and one stream per device:
+the form a drop-in `search_in` over a node calls, and the one without a rendezvous to fail).  The better one is the line's `value`,
+the other one's figures sit under `config.other_form`; `--forms multi` / `--forms single` (= `--single-process`) run one.  The
+single-process form is also what bench.py falls back to - and says so in `config.launcher` / `config.transport_note` - when the
+ranks of the multi-process form cannot be brought up.  An N > 1 line explains itself: `roofline.per_rank` (min / median / max of
+every rank's kernel times), `step_breakdown` (slowest rank's kernel vs the rest of a step; the cost of a sharded search of a
+4 MiB shard - launch + collective + answer word - beside a plain one; the host's issue times in the single-process form) and
+`config.workgroups_per_cu_timed` (what the timed launches ran with).
 
 Before the `--warmup` steps every rank spins `search_in` for >= 100 ms of wall time (untimed; `config.prewarm_ms`): at 8 GPUs
 a step is ~1.2 ms, so warm-up + timed region together are shorter than the clocks' ramp after an idle gap.
@@ -560,6 +566,21 @@ def headline_config(args, total, n, shard_bytes, world, filt, info, **kw):
     return cfg
 
 
+def rank_stats(per_rank_ms):
+    """[{rank, kernel_ms_min / median / max}] from every rank's (device's) list of timed kernel durations."""
+    return [{"rank": r, "kernel_ms_min": round(float(np.min(v)), 4), "kernel_ms_median": round(float(np.median(v)), 4),
+             "kernel_ms_max": round(float(np.max(v)), 4), "launches": len(v)} for r, v in enumerate(per_rank_ms)]
+
+
+def step_breakdown(ms_per_step, per_rank_ms, **kw):
+    """Where a step's time went: the slowest rank's kernel (median over the timed steps) and everything else - launch, skew between
+    the ranks, the collective, the answer word's way to the host."""
+    slowest = max(float(np.median(v)) for v in per_rank_ms)
+    out = {"kernel_ms_slowest_rank": round(slowest, 4), "outside_kernel_ms": round(ms_per_step - slowest, 4)}
+    out.update(kw)
+    return out
+
+
 def roofline_block(shard_bytes, kernel_ms, value, world, traffic_ratio, traffic_source):
     k_med, k_mean = float(np.median(kernel_ms)), float(np.mean(kernel_ms))
     achieved = shard_bytes / (k_med * 1e-3) / 1e9
@@ -591,38 +612,44 @@ def write_line(real_stdout, out):
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
-def run_single_process(args, real_stdout, why=None):
-    """All `--gpus` devices from THIS process: ss_comm_init_all (ncclCommInitAll), one shard and one stream per device, the G
-    all-reduces of a search in one ncclGroupStart/End (ss_search_sharded_all).  Same line, `config.launcher` = "single-process"."""
+def wg_histogram(seen):
+    from collections import Counter
+    return {str(k): v for k, v in sorted(Counter(seen).items())}
+
+
+def run_single_process(args, why=None, share=False):
+    """All `--gpus` devices from THIS process: ss_comm_init_all (ncclCommInitAll), one shard, one stream and one issue thread per
+    device (ss_search_sharded_all).  Returns the line (a dict), `config.launcher` = "single-process"."""
     import sliceslice_rs_amd as ss
     ss.lib()
     G = args.gpus
-    if torch.cuda.device_count() < G:
+    if torch.cuda.device_count() < G and not share:
         fail("--gpus %d but only %d HIP device(s) visible" % (G, torch.cuda.device_count()))
+    devices = [0] * G if share else list(range(G))
     torch.cuda.set_device(0)
     info = ss.device_info()
     n = args.needle_len
     total = int(args.haystack_gib * (1 << 30))
-    waited_s, used_at_start = vram_settle(0, False, args.settle_seconds)
-    free_b = min(torch.cuda.mem_get_info(g)[0] for g in range(G))
+    waited_s, used_at_start = vram_settle(0, share, args.settle_seconds)
+    free_b = min(torch.cuda.mem_get_info(g)[0] for g in set(devices))
+    if share:
+        free_b //= G
     while (total + G - 1) // G + n > 0.92 * free_b and total > (1 << 28):
         total //= 2
     needle = absent_needle(ss, n)
     note = why
-    try:
-        node = ss.NodeSearcher(needle, devices=list(range(G)))
-        transport = "rccl (ncclCommInitAll; the G all-reduces of a search in one group)"
-    except ss.SlicesliceError as e:
-        # no communicators: the host ORs the G pinned flag mirrors instead (possible only because all ranks live here)
-        os.environ["SLICESLICE_COMM_SET_NO_RCCL"] = "1"
-        node = ss.NodeSearcher(needle, devices=list(range(G)))
-        transport = "host OR of the G pinned flag mirrors (no collective)"
-        note = ((why + "; ") if why else "") + "ncclCommInitAll failed (%s)" % e
+    node = ss.NodeSearcher(needle, devices=devices)            # (ncclCommInitAll; raises when RCCL refuses the set)
+    transport = "rccl (ncclCommInitAll; one issue thread per device, each with its own ncclAllReduce)"
+    rccl_ranks = node.rccl_ranks() if transport.startswith("rccl") else None      # ncclCommCount of every communicator of the set
+    if transport.startswith("rccl") and rccl_ranks != G:
+        fail("RCCL reports %r ranks for the set, expected %d" % (rccl_ranks, G))
+    if os.environ.get("SLICESLICE_SET_THREADS") == "0":
+        transport = transport.replace("one issue thread per device, each with its own ncclAllReduce", "issued from one thread, the all-reduces as one group")
     shards = []
     for g in range(G):
         b, e = node.shard_range(total, g)
-        with torch.cuda.device(g):
-            t = torch.empty(e - b, dtype=torch.uint8, device="cuda:%d" % g)
+        with torch.cuda.device(devices[g]):
+            t = torch.empty(e - b, dtype=torch.uint8, device="cuda:%d" % devices[g])
             ss.fill_random_device(t, SEED_HAY, b)
             torch.cuda.synchronize()
         shards.append(t)
@@ -632,142 +659,85 @@ def run_single_process(args, real_stdout, why=None):
     inner.set_timing(True)
 
     def sync_all():
-        for g in range(G):
+        for g in set(devices):
             torch.cuda.synchronize(g)
     prewarm_ms, prewarm_steps = prewarm(lambda: node.search_in(shards))
     for _ in range(args.warmup):
         assert node.search_in(shards) is False
-    kernel_ms = []
+    per_dev = [[] for _ in range(G)]
+    issue, wgs = [], []
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        found = node.search_in(shards)                         # G launches -> grouped all-reduce -> bool on the host
-        kernel_ms.append(inner.last_kernel_ms())               # the last device's scan (hipEvents on its stream)
+        found = node.search_in(shards)                         # G chains (scan -> all-reduce -> answer word) -> bool on the host
+        for g, ms in enumerate(node.last_kernel_ms()):         # every device's scan (hipEvents on its stream)
+            per_dev[g].append(ms)
+        issue.append(node.last_issue_us())
+        wgs.append(inner.last_launch()[0])
     sync_all()
     elapsed = time.perf_counter() - t0
     assert found is False
     value = total * args.steps / elapsed / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+    # what a search costs besides its scan: the same call on 4 MiB shards (launches + collective + answer words)
+    small = [t[: 4 << 20] for t in shards]
+    for _ in range(20):
+        node.search_in(small)
+    t1 = time.perf_counter()
+    for _ in range(100):
+        node.search_in(small)
+    small_us = (time.perf_counter() - t1) / 100 * 1e6
+    iss = np.median(np.array(issue), axis=0)
     ratio, src = stored_traffic()
-    shard_bytes = shards[-1].numel()
+    shard_bytes = max(t.numel() for t in shards)
+    slowest = int(np.argmax([np.median(v) for v in per_dev]))
     out = {
         "metric": "haystack GB/s scanned (and % HBM roofline), 16-byte needle, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": headline_config(args, total, n, shard_bytes, G, inner.filter3, info, ranks=G, rccl_ranks=G if "rccl" in transport else None,
+        "config": headline_config(args, total, n, shard_bytes, G, inner.filter3, info, ranks=G, rccl_ranks=rccl_ranks,
                                   transport=transport, transport_note=note, launcher="single-process",
-                                  ranks_share_one_gpu=False, prewarm_ms=round(prewarm_ms, 1), prewarm_steps=prewarm_steps,
-                                  waited_for_free_vram_s=round(waited_s, 2), vram_used_at_start=used_at_start),
-        "roofline": roofline_block(shard_bytes, kernel_ms, value, G, ratio, src),
+                                  ranks_share_one_gpu=bool(share and G > 1), prewarm_ms=round(prewarm_ms, 1), prewarm_steps=prewarm_steps,
+                                  waited_for_free_vram_s=round(waited_s, 2), vram_used_at_start=used_at_start,
+                                  workgroups_per_cu_timed=wg_histogram(wgs)),
+        "roofline": roofline_block(shard_bytes, per_dev[slowest], value, G, ratio, src),
+        "step_breakdown": step_breakdown(ms_per_step, per_dev, small_shard_call_us=round(small_us, 1),
+                                         issue_us={"scans": round(float(iss[0]), 1), "collective": round(float(iss[1]), 1),
+                                                   "answer_words": round(float(iss[2]), 1), "all": round(float(iss[3]), 1),
+                                                   "note": "host time of ss_search_sharded_all's issue phase, median over the timed steps: per-device "
+                                                           "maxima when every device has its own issue thread, sums when one thread issues everything"},
+                                         note="small_shard_call_us: the same call on 4 MiB shards (launches + collective + answer words; ~1 us of scan)"),
     }
-    write_line(real_stdout, out)
+    out["roofline"]["per_rank"] = rank_stats(per_dev)
+    out["roofline"]["kernel_ms_of"] = "device %d of the set, the slowest by median" % slowest
     node.close()
+    del shards, small
+    torch.cuda.empty_cache()
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--haystack-gib", type=float, default=64.0, help="TOTAL logical haystack size")
-    ap.add_argument("--needle-len", type=int, default=16)
-    ap.add_argument("--transport", choices=["torch", "rccl"], default="rccl",
-                    help="N > 1, flag all-reduce: native RCCL via the C ABI (ss_search_sharded: scan + ncclAllReduce + "
-                         "read-back on one HIP stream; the default) or torch.distributed (RCCL backend)")
-    ap.add_argument("--single-process", action="store_true",
-                    help="drive all --gpus devices from ONE process (ss_comm_init_all / ss_search_sharded_all) instead of one rank per GPU")
-    ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--grid", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mib", type=int, default=1024)
-    ap.add_argument("--no-ceiling", action="store_true",
-                    help="skip the plain streaming-read ceiling (roofline.read_ceiling_gbps; a few launches, untimed)")
-    ap.add_argument("--ceiling", action="store_true", help="(default now) kept for compatibility")
-    ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/5 + latency block (N = 1 only, untimed)")
-    ap.add_argument("--no-traffic", action="store_true",
-                    help="skip the live `rocprofv3 --pmc FETCH_SIZE` pass (N = 1 only, untimed); roofline.traffic then uses the stored ratio")
-    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--settle-seconds", type=float, default=20.0,
-                    help="upper bound on the wait for a previous process' VRAM to be reclaimed before allocating")
-    ap.add_argument("--cpu-report", action="store_true",
-                    help="print the extended CPU-side report (JSON lines; no GPU needed) and exit")
-    args = ap.parse_args()
-    if args.gpus < 1:
-        fail("--gpus must be >= 1")
-    if args.cpu_report:
-        with os.fdopen(os.dup(1), "wb") as out:
-            cpu_report(out)
-        return
-    if args.traffic_child:
-        traffic_child(args)
-        return
-    fallback_why = None
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.single_process:
-        fallback_why = self_launch(args)                       # returns only when the ranks could not be brought up
+def other_form_summary(o):
+    """What the line keeps of the form that was NOT chosen."""
+    keep = {k: o[k] for k in ("value", "ms_per_step") if k in o}
+    keep.update(launcher=o["config"].get("launcher"), transport=o["config"].get("transport"), rccl_ranks=o["config"].get("rccl_ranks"),
+                transport_note=o["config"].get("transport_note"), step_breakdown=o.get("step_breakdown"),
+                per_rank=o["roofline"].get("per_rank"), roofline_frac=o["roofline"].get("frac"),
+                workgroups_per_cu_timed=o["config"].get("workgroups_per_cu_timed"))
+    return keep
 
-    # Exactly ONE line may reach stdout.  Libraries (the RCCL banner, for one) print to fd 1, so fd 1 is
-    # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
 
-    if args.single_process or fallback_why:
-        if int(os.environ.get("RANK", "0")) != 0:
-            return                                             # under a launcher: rank 0 drives every device, the others have nothing to do
-        if not torch.cuda.is_available():
-            fail("needs a GPU: the scan has no CPU path")
-        run_single_process(args, real_stdout, fallback_why)
-        return
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        fail("WORLD_SIZE=%d but --gpus %d: refusing to label a %d-rank run as %d GPUs" % (world, args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
-        fail("needs a GPU: the scan has no CPU path")
-    # SS_BENCH_SHARE_GPU=1 + SS_BENCH_BACKEND=gloo: run the N > 1 code path with every rank on cuda:0 (a
-    # functional check on a one-GPU box; the numbers of such a run mean nothing and the line says so)
-    share = os.environ.get("SS_BENCH_SHARE_GPU") == "1"
-    if share:
-        local_rank = 0
-    elif torch.cuda.device_count() < world:
-        fail("%d ranks but only %d HIP device(s) visible" % (world, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    force_dist = os.environ.get("SS_BENCH_FORCE_DIST") == "1"     # exercise the N > 1 code path on one GPU
-    backend = "none"
-    if world > 1 or force_dist:
-        import datetime
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
-        try:
-            if os.environ.get("SS_BENCH_FAIL_DIST_INIT") == "1":     # test hook: the bootstrap "fails" on every rank
-                raise RuntimeError("SS_BENCH_FAIL_DIST_INIT=1")
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                        timeout=datetime.timedelta(seconds=300))
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-            probe = torch.zeros(1, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(probe)                             # the first collective is where a broken fabric shows
-        except Exception as e:
-            # The ranks cannot talk to each other.  Rank 0 still has every device of the node in reach: it runs the
-            # single-process form (no rendezvous at all) and says so; the other ranks have nothing left to do.
-            log("bench.py: rank %d: torch.distributed bootstrap failed (%r)" % (rank, e))
-            if rank != 0 or share:
-                raise SystemExit(0 if not share else 1)
-            run_single_process(args, real_stdout, "torch.distributed bootstrap failed on rank 0 (%s); every device driven from rank 0's "
-                                                  "process instead" % (repr(e)[:200],))
-            return
+def run_multi_process(args, ctx):
+    """One rank per GPU (or the plain N = 1 run): every rank scans its shard and - N > 1 - joins ONE all-reduce per search
+    (ss_search_sharded, native RCCL).  Rank 0 returns the line (a dict), the other ranks None."""
+    import sliceslice_rs_amd as ss
+    dist, backend, world, rank, local_rank, share = ctx["dist"], ctx["backend"], ctx["world"], ctx["rank"], ctx["local_rank"], ctx["share"]
     transport = args.transport
     if share and world > 1 and transport == "rccl" and not os.environ.get("SLICESLICE_RCCL_LIB"):
         transport = "torch"                                    # RCCL refuses two ranks on one device (a stand-in named by SLICESLICE_RCCL_LIB does not)
-
-    import sliceslice_rs_amd as ss
     ss.lib()
     info = ss.device_info()
+    dev = "cuda" if backend == "nccl" else "cpu"
 
     n = args.needle_len
     total = int(args.haystack_gib * (1 << 30))
@@ -777,7 +747,7 @@ def main():
         free_b //= world
     if dist is not None:
         # every rank must partition the SAME logical haystack: agree on the smallest free VRAM first
-        fb = torch.tensor([free_b], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        fb = torch.tensor([free_b], dtype=torch.int64, device=dev)
         dist.all_reduce(fb, op=dist.ReduceOp.MIN)
         free_b = int(fb.item())
     while (total + world - 1) // world + n > 0.92 * free_b and total > (1 << 28):
@@ -831,7 +801,7 @@ def main():
         pw_steps += 8
         go_on = 1 if time.perf_counter() - t_pw < 0.1 else 0
         if dist is not None:
-            g = torch.tensor([go_on], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            g = torch.tensor([go_on], dtype=torch.int32, device=dev)
             dist.broadcast(g, src=0)
             go_on = int(g.item())
         if not go_on:
@@ -839,24 +809,54 @@ def main():
     prewarm_ms = (time.perf_counter() - t_pw) * 1e3
     for _ in range(args.warmup):
         one()
-    kernel_ms = []
+    kernel_ms, wgs = [], []
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         found = searcher.search_in(shard)                      # launch -> (all-reduce) -> bool on the host
         kernel_ms.append(inner.last_kernel_ms())               # hipEvents on the launch stream
+        wgs.append(inner.last_launch()[0])
     sync_all()
     elapsed = time.perf_counter() - t0
     assert found is False
+    per_rank = [kernel_ms]
+    breakdown_extra = {}
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's kernel times, and what a sharded search costs besides its scan: the same collective call on a 4 MiB shard
+        # (launch + ~1 us of scan + all-reduce + answer word) next to the plain, rank-local call on the same bytes
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, [float(x) for x in kernel_ms])
+        small = shard[: 4 << 20]
+        for _ in range(20):
+            searcher.search_in(small)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            searcher.search_in(small)
+        sharded_us = (time.perf_counter() - t1) / 100 * 1e6
+        for _ in range(20):
+            inner.search_in(small)
+        t1 = time.perf_counter()
+        for _ in range(100):
+            inner.search_in(small)
+        plain_us = (time.perf_counter() - t1) / 100 * 1e6
+        tt = torch.tensor([sharded_us, plain_us], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sharded_us, plain_us = float(tt[0].item()), float(tt[1].item())
+        breakdown_extra = dict(small_shard_sharded_call_us=round(sharded_us, 1), small_shard_plain_call_us=round(plain_us, 1),
+                               collective_only_us=round(sharded_us - plain_us, 1),
+                               note="small_shard_*: a search of a 4 MiB shard (about 1 us of scan), slowest rank, mean of 100 calls - through "
+                                    "ss_search_sharded (launch + all-reduce + answer word) and through the rank-local ss_search_device; "
+                                    "collective_only_us is their difference")
 
     ceiling = None
     if not args.no_ceiling and rank == 0:
         ceiling = ss.read_ceiling_gbps(shard[: (shard.numel() // 16) * 16], reps=5)
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed / 1e9
@@ -873,9 +873,14 @@ def main():
                 transport_note=transport_note,
                 launcher=os.environ.get("SS_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
                 ranks_share_one_gpu=bool(share and world > 1), prewarm_ms=round(prewarm_ms, 1), prewarm_steps=pw_steps,
-                waited_for_free_vram_s=round(waited_s, 2), vram_used_at_start=used_at_start),
+                waited_for_free_vram_s=round(waited_s, 2), vram_used_at_start=used_at_start,
+                workgroups_per_cu_timed=wg_histogram(wgs)),
             "roofline": roofline_block(shard.numel(), kernel_ms, value, world, ratio, src),
         }
+        if dist is not None:
+            out["roofline"]["per_rank"] = rank_stats(per_rank)
+            out["roofline"]["kernel_ms_of"] = "rank 0"
+            out["step_breakdown"] = step_breakdown(ms_per_step, per_rank, **breakdown_extra)
         if ceiling is not None:
             out["roofline"]["read_ceiling_gbps"] = round(ceiling, 2)
             # a diagnosis, not a correction: the scan normally runs at 0.975-0.992 of what a plain streaming read of the same
@@ -908,11 +913,143 @@ def main():
                     out["roofline"]["traffic_note"] = "live pass not available (%s)" % why
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(needle, args.cpu_sample_mib << 20)
+    if dist is not None and hasattr(searcher, "close"):
+        dist.barrier()
+        searcher.close()                                       # the native communicator goes before the other form starts
+    shard = None
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--haystack-gib", type=float, default=64.0, help="TOTAL logical haystack size")
+    ap.add_argument("--needle-len", type=int, default=16)
+    ap.add_argument("--transport", choices=["torch", "rccl"], default="rccl",
+                    help="N > 1, flag all-reduce: native RCCL via the C ABI (ss_search_sharded: scan + ncclAllReduce + "
+                         "read-back on one HIP stream; the default) or torch.distributed (RCCL backend)")
+    ap.add_argument("--forms", choices=["both", "multi", "single"], default="both",
+                    help="N > 1: one rank per GPU (multi), all GPUs from one process (single), or both - the better one is the "
+                         "line's value, the other sits under config.other_form (the default)")
+    ap.add_argument("--single-process", action="store_true", help="the same as --forms single")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--no-ceiling", action="store_true",
+                    help="skip the plain streaming-read ceiling (roofline.read_ceiling_gbps; a few launches, untimed)")
+    ap.add_argument("--ceiling", action="store_true", help="(default now) kept for compatibility")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs 1/3/5 + latency block (N = 1 only, untimed)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the live `rocprofv3 --pmc FETCH_SIZE` pass (N = 1 only, untimed); roofline.traffic then uses the stored ratio")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--settle-seconds", type=float, default=20.0,
+                    help="upper bound on the wait for a previous process' VRAM to be reclaimed before allocating")
+    ap.add_argument("--cpu-report", action="store_true",
+                    help="print the extended CPU-side report (JSON lines; no GPU needed) and exit")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        fail("--gpus must be >= 1")
+    if args.single_process:
+        args.forms = "single"
+    if args.cpu_report:
+        with os.fdopen(os.dup(1), "wb") as out:
+            cpu_report(out)
+        return
+    if args.traffic_child:
+        traffic_child(args)
+        return
+    fallback_why = None
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.forms != "single":
+        fallback_why = self_launch(args)                       # returns only when the ranks could not be brought up
+
+    # Exactly ONE line may reach stdout.  Libraries (the RCCL banner, for one) print to fd 1, so fd 1 is
+    # pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    share = os.environ.get("SS_BENCH_SHARE_GPU") == "1"
+
+    if args.forms == "single" or fallback_why:
+        if int(os.environ.get("RANK", "0")) != 0:
+            return                                             # under a launcher: rank 0 drives every device, the others have nothing to do
+        if not torch.cuda.is_available():
+            fail("needs a GPU: the scan has no CPU path")
+        write_line(real_stdout, run_single_process(args, fallback_why, share))
+        return
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        fail("WORLD_SIZE=%d but --gpus %d: refusing to label a %d-rank run as %d GPUs" % (world, args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        fail("needs a GPU: the scan has no CPU path")
+    # SS_BENCH_SHARE_GPU=1 + SS_BENCH_BACKEND=gloo: run the N > 1 code path with every rank on cuda:0 (a
+    # functional check on a one-GPU box; the numbers of such a run mean nothing and the line says so)
+    if share:
+        local_rank = 0
+    elif torch.cuda.device_count() < world:
+        fail("%d ranks but only %d HIP device(s) visible" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    cpu_group = None
+    force_dist = os.environ.get("SS_BENCH_FORCE_DIST") == "1"     # exercise the N > 1 code path on one GPU
+    backend = "none"
+    if world > 1 or force_dist:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
+        try:
+            if os.environ.get("SS_BENCH_FAIL_DIST_INIT") == "1":     # test hook: the bootstrap "fails" on every rank
+                raise RuntimeError("SS_BENCH_FAIL_DIST_INIT=1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            probe = torch.zeros(1, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)                             # the first collective is where a broken fabric shows
+            if world > 1 and args.forms == "both":
+                # the ranks that idle while rank 0 runs the single-process form wait on the CPU: a barrier of the RCCL backend
+                # would keep a kernel spinning on every device that is being measured
+                cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=1800)) if backend == "nccl" else dist.group.WORLD
+        except Exception as e:
+            # The ranks cannot talk to each other.  Rank 0 still has every device of the node in reach: it runs the
+            # single-process form (no rendezvous at all) and says so; the other ranks have nothing left to do.
+            log("bench.py: rank %d: torch.distributed bootstrap failed (%r)" % (rank, e))
+            if rank != 0 or share:
+                raise SystemExit(0 if not share else 1)
+            write_line(real_stdout, run_single_process(args, "torch.distributed bootstrap failed on rank 0 (%s); every device driven from rank 0's "
+                                                             "process instead" % (repr(e)[:200],)))
+            return
+
+    ctx = dict(dist=dist, backend=backend, world=world, rank=rank, local_rank=local_rank, share=share)
+    out = run_multi_process(args, ctx)
+
+    if cpu_group is not None:
+        # the other form: every device from rank 0's process, the other ranks parked on a CPU barrier with their shards freed
+        single = None
+        if rank == 0:
+            try:
+                single = run_single_process(args, None, share)
+            except BaseException as e:                          # (SystemExit from fail() included: the multi-process line still stands)
+                log("bench.py: the single-process form failed: %r" % (e,))
+                out["config"]["other_form"] = {"launcher": "single-process", "error": repr(e)[:300]}
+        dist.barrier(group=cpu_group)
+        if rank == 0 and single is not None:
+            best, other = (single, out) if single["value"] > out["value"] else (out, single)
+            best["config"]["other_form"] = other_form_summary(other)
+            best["config"]["forms_run"] = "one rank per GPU, then all GPUs from one process; this line is the better of the two"
+            out = best
+    if rank == 0:
         write_line(real_stdout, out)
     if dist is not None:
-        dist.barrier()
-        if hasattr(searcher, "close"):
-            searcher.close()
+        dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -43,6 +43,7 @@
  *     SLICESLICE_SPIN_WAIT=0      wait for the stream instead of spinning on the pinned answer word
  *     SLICESLICE_NO_BAR_WRITES=1  never write device memory from the CPU (control blocks go by hipMemcpy; no service, no relay)
  *     SLICESLICE_RCCL_LIB=<path>  the RCCL library to dlopen instead of librccl.so.1 / librccl.so
+ *     SLICESLICE_SET_THREADS=0    communicator sets issue their per-device work from the calling thread (SS_ISSUE_SERIAL)
  */
 #ifndef SLICESLICE_HIP_H
 #define SLICESLICE_HIP_H
@@ -269,13 +270,27 @@ SS_API int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t sha
  * ss_search_sharded_all ends every device's scan at the first match on ANY device: the host relays the finding device's flag
  * into the others' through their PCIe BARs while it waits (needs CPU-visible device memory, else each device runs its scan
  * to the end).  One search at a time per set (the set's streams and flags are its scratch): a second concurrent call is
- * refused with SS_ERR_ARGUMENT. */
+ * refused with SS_ERR_ARGUMENT.
+ * Who issues the per-device work: SS_ISSUE_THREADS (the default for sets of two or more devices) - the set keeps one thread per
+ * device, parked on that device; each enqueues its device's scan, its ncclAllReduce (RCCL's one-thread-per-communicator form, no
+ * group) and the answer word, so the G chains start side by side.  SS_ISSUE_SERIAL - everything from the calling thread, the
+ * all-reduces as one group (SLICESLICE_SET_THREADS=0 makes it the default).  ss_find_sharded_all is always issued serially.
+ * Diagnostics (read-only; what a benchmark line reports): ss_comm_set_count = ncclCommCount of EVERY communicator of the set
+ * (SS_ERR_RCCL if they disagree); ss_comm_set_last_kernel_ms = every device's scan-kernel time of the latest search (needs
+ * ss_searcher_set_timing on its searcher; ms[count >= devices]); ss_comm_set_last_issue_us = host time the latest search spent
+ * issuing {scans, collective, answer words / read-back, all of it} - per device maxima under SS_ISSUE_THREADS, sums otherwise. */
 typedef struct ss_comm_set ss_comm_set;
 #define SS_COMBINE_RCCL 0
 #define SS_COMBINE_HOST 1
+#define SS_ISSUE_THREADS 0
+#define SS_ISSUE_SERIAL 1
 SS_API int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out);
 SS_API void ss_comm_set_free(ss_comm_set *set);
 SS_API int ss_comm_set_combine(ss_comm_set *set, int combine);
+SS_API int ss_comm_set_issue(ss_comm_set *set, int issue);
+SS_API int ss_comm_set_count(const ss_comm_set *set, int *nranks);
+SS_API int ss_comm_set_last_kernel_ms(ss_comm_set *set, float *ms, int count);
+SS_API int ss_comm_set_last_issue_us(const ss_comm_set *set, float us[4]);
 SS_API int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,
                                  ss_comm_set *set, int *found);
 SS_API int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens,

@@ -86,6 +86,10 @@ extern "C" {
     pub fn ss_comm_init_all(ndev: c_int, devs: *const c_int, out: *mut *mut ss_comm_set) -> c_int;
     pub fn ss_comm_set_free(set: *mut ss_comm_set);
     pub fn ss_comm_set_combine(set: *mut ss_comm_set, combine: c_int) -> c_int;
+    pub fn ss_comm_set_issue(set: *mut ss_comm_set, issue: c_int) -> c_int;
+    pub fn ss_comm_set_count(set: *const ss_comm_set, nranks: *mut c_int) -> c_int;
+    pub fn ss_comm_set_last_kernel_ms(set: *mut ss_comm_set, ms: *mut c_float, count: c_int) -> c_int;
+    pub fn ss_comm_set_last_issue_us(set: *const ss_comm_set, us: *mut c_float) -> c_int;
     pub fn ss_search_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, set: *mut ss_comm_set, found: *mut c_int) -> c_int;
     pub fn ss_find_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, shard_begins: *const u64,
                                set: *mut ss_comm_set, position: *mut u64) -> c_int;

@@ -745,6 +745,19 @@ __device__ __forceinline__ uint32_t filter_half(const u32x2 &a, const u32x2 &t, 
     return acc | zero_byte_flags(c0) | zero_byte_flags(c1);
 }
 
+// THREE-byte filter of one half-piece when both further bytes lie within three bytes of the first (Q == 0 and q3 == 0: the window
+// is this lane's two dwords and the FIRST dword of the next lane - one DPP hop, where a farther byte would need the lane after
+// next as well: two hops per value, which costs more than the 8-byte loads bring).  a = this lane's 8 bytes, nx = dword 0 of the
+// next lane (lane 63: of lane 0 of the next half-piece / the halo).  Returns acc | flags.
+__device__ __forceinline__ uint32_t filter_half3_near(const u32x2 &a, uint32_t nx, const Problem &pr, uint32_t acc)
+{
+    const uint32_t y0 = a.x ^ pr.nlx4, y1 = a.y ^ pr.nlx4, y2 = nx ^ pr.nlx4;
+    const uint32_t z0 = a.x ^ pr.n3x4, z1 = a.y ^ pr.n3x4, z2 = nx ^ pr.n3x4;
+    const uint32_t c0 = (a.x ^ pr.n0x4) | __builtin_amdgcn_alignbyte(y1, y0, pr.r) | __builtin_amdgcn_alignbyte(z1, z0, pr.r3);
+    const uint32_t c1 = (a.y ^ pr.n0x4) | __builtin_amdgcn_alignbyte(y2, y1, pr.r) | __builtin_amdgcn_alignbyte(z2, z1, pr.r3);
+    return acc | zero_byte_flags(c0) | zero_byte_flags(c1);
+}
+
 // two half-pieces (lo = bytes 0..511, hi = bytes 512..1023 of a piece, 8 bytes per lane) -> the piece in
 // the 16-bytes-per-lane layout: lane l takes the two half-chunks 2*(l%32), 2*(l%32)+1 of half l/32.
 __device__ __forceinline__ u32x4 transpose_halves(const u32x2 &lo, const u32x2 &hi, int lane)

@@ -65,8 +65,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
 {
     static_assert(!L8 || (MODE == 0 && !FIND), "the 8-byte layout covers the single-stream bool kernels");
     static_assert(Q != kQDynamic || (MODE == 0 && !L8), "a run-time window is for the single-stream kernels' three-byte phase");
-    static_assert(MODE == 0 || MODE == 2, "single-stream kernels only");
-    constexpr bool SHIFTED = MODE == 2;
+    static_assert(MODE == 0 || MODE == 2 || MODE == 3, "single-stream kernels only");
+    constexpr bool SHIFTED = MODE >= 2;
+    constexpr bool SHIFTED3 = MODE == 2;            // ... with a third byte close behind the first (MODE 3: the pair alone)
     int *found = static_cast<int *>(sink);
     uint64_t *best = static_cast<uint64_t *>(sink);
     // `wg_sink`, when given: a word in the workgroup's LDS that takes the match INSTEAD of the global sink (bool: int 0 -> 1;
@@ -127,15 +128,24 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
             }
             const int stop8 = poll_found(found, pr.epoch);
             uint32_t any8 = 0;
-            u32x2 tc = {Hh[0].x ^ pr.nlx4, Hh[0].y ^ pr.nlx4}, tn = {0, 0};
+            // all three filter bytes within four bytes (Q == 0 and q3 == 0): the three-byte filter on the 8-byte layout
+            if (THREE && Q == 0 && pr.q3 == 0) {                  // (wave-uniform)
 #pragma unroll
-            for (int h = 0; h < 2 * U; ++h) {
-                if (!ONE_BYTE) {
-                    const u32x2 nx = h + 1 < 2 * U ? Hh[h + 1] : halo8;
-                    tn = u32x2{nx.x ^ pr.nlx4, nx.y ^ pr.nlx4};
+                for (int h = 0; h < 2 * U; ++h) {
+                    const uint32_t nx0 = h + 1 < 2 * U ? Hh[h + 1].x : halo8.x;
+                    any8 = filter_half3_near(Hh[h], from_next_lane_or(rotate_from_next_lane(nx0), Hh[h].x), pr, any8);
                 }
-                any8 = filter_half<(Q < 0 ? 0 : Q), ONE_BYTE>(Hh[h], tc, tn, pr, lane, any8);   // (L8 kernels have a compile-time window)
-                tc = tn;
+            } else {
+                u32x2 tc = {Hh[0].x ^ pr.nlx4, Hh[0].y ^ pr.nlx4}, tn = {0, 0};
+#pragma unroll
+                for (int h = 0; h < 2 * U; ++h) {
+                    if (!ONE_BYTE) {
+                        const u32x2 nx = h + 1 < 2 * U ? Hh[h + 1] : halo8;
+                        tn = u32x2{nx.x ^ pr.nlx4, nx.y ^ pr.nlx4};
+                    }
+                    any8 = filter_half<(Q < 0 ? 0 : Q), ONE_BYTE>(Hh[h], tc, tn, pr, lane, any8);   // (L8 kernels have a compile-time window)
+                    tc = tn;
+                }
             }
             if (stop8) {                                      // somebody has already found the needle
                 forget_scalar_cache_unless(small_grid);
@@ -218,19 +228,28 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // A pair this far apart is the caller's (ss_searcher_set_filter3) - on text the reference's own pair (0, n-1)
                     // passes at percent rates and sent nearly every tile into the second level (0.79 of the roofline); a third
                     // byte in the first phase makes a candidate tile the exception again.  Whoever builds the Problem provides it.
-                    const u32x4 &NP = u + 1 < U ? A[u + 1] : H;
-                    uint32_t xx[8] = {A[u].x, A[u].y, A[u].z, A[u].w, 0, 0, 0, 0};
-                    xx[4] = from_next_lane_or(rotate_from_next_lane(NP.x), A[u].x);
-                    if (Q3 >= 1) xx[5] = from_next_lane_or(rotate_from_next_lane(NP.y), A[u].y);
-                    if (Q3 >= 2) xx[6] = from_next_lane_or(rotate_from_next_lane(NP.z), A[u].z);
-                    if (Q3 >= 3) xx[7] = from_next_lane_or(rotate_from_next_lane(NP.w), A[u].w);
-                    uint32_t z[5];
+                    if constexpr (SHIFTED3) {
+                        const u32x4 &NP = u + 1 < U ? A[u + 1] : H;
+                        uint32_t xx[8] = {A[u].x, A[u].y, A[u].z, A[u].w, 0, 0, 0, 0};
+                        xx[4] = from_next_lane_or(rotate_from_next_lane(NP.x), A[u].x);
+                        if (Q3 >= 1) xx[5] = from_next_lane_or(rotate_from_next_lane(NP.y), A[u].y);
+                        if (Q3 >= 2) xx[6] = from_next_lane_or(rotate_from_next_lane(NP.z), A[u].z);
+                        if (Q3 >= 3) xx[7] = from_next_lane_or(rotate_from_next_lane(NP.w), A[u].w);
+                        uint32_t z[5];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) z[k] = xx[Q3 + k] ^ pr.n3x4;
-                    g[0] = zero_byte_flags((A[u].x ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 1], x[QS + 0], pr.r) | __builtin_amdgcn_alignbyte(z[1], z[0], pr.r3));
-                    g[1] = zero_byte_flags((A[u].y ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 2], x[QS + 1], pr.r) | __builtin_amdgcn_alignbyte(z[2], z[1], pr.r3));
-                    g[2] = zero_byte_flags((A[u].z ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 3], x[QS + 2], pr.r) | __builtin_amdgcn_alignbyte(z[3], z[2], pr.r3));
-                    g[3] = zero_byte_flags((A[u].w ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 4], x[QS + 3], pr.r) | __builtin_amdgcn_alignbyte(z[4], z[3], pr.r3));
+                        for (int k = 0; k < 5; ++k) z[k] = xx[Q3 + k] ^ pr.n3x4;
+                        g[0] = zero_byte_flags((A[u].x ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 1], x[QS + 0], pr.r) | __builtin_amdgcn_alignbyte(z[1], z[0], pr.r3));
+                        g[1] = zero_byte_flags((A[u].y ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 2], x[QS + 1], pr.r) | __builtin_amdgcn_alignbyte(z[2], z[1], pr.r3));
+                        g[2] = zero_byte_flags((A[u].z ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 3], x[QS + 2], pr.r) | __builtin_amdgcn_alignbyte(z[3], z[2], pr.r3));
+                        g[3] = zero_byte_flags((A[u].w ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 4], x[QS + 3], pr.r) | __builtin_amdgcn_alignbyte(z[4], z[3], pr.r3));
+                    } else {
+                        // MODE 3: the pair alone - for haystacks on which it rarely matches (the census says so: ss_scan.hip), where
+                        // the third byte's 6.25 LDS operations and dozen VALU per KiB thin out nothing
+                        g[0] = zero_byte_flags((A[u].x ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 1], x[QS + 0], pr.r));
+                        g[1] = zero_byte_flags((A[u].y ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 2], x[QS + 1], pr.r));
+                        g[2] = zero_byte_flags((A[u].z ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 3], x[QS + 2], pr.r));
+                        g[3] = zero_byte_flags((A[u].w ^ pr.n0x4) | __builtin_amdgcn_alignbyte(x[QS + 4], x[QS + 3], pr.r));
+                    }
                 } else {
                     if (!ONE_BYTE) {
                         // lane 63's "next lane": lane 0 of the next piece, or the halo chunk after the last piece
@@ -272,7 +291,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 case 14: load_and_filter(loaded_c, full_c, integral_constant<int, 2>{}, integral_constant<int, 3>{}); break;
                 default: load_and_filter(loaded_c, full_c, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
                 }
-            } else if constexpr (THREE || SHIFTED) {
+            } else if constexpr (THREE || SHIFTED3) {
                 // (SHIFTED: the third byte's window is independent of the far second byte's)
                 // Whoever builds the Problem orders the two further bytes so that q3 <= Q (they are interchangeable): the
                 // copies with Q3 > Q are never taken.  They stay instantiated all the same: with them pruned the register
@@ -369,7 +388,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
 #ifndef SS_MODE2_TILE_WIDE
 #define SS_MODE2_TILE_WIDE 1
 #endif
-            constexpr bool TILE_WIDE = MODE != 2 || SS_MODE2_TILE_WIDE != 0;
+            constexpr bool TILE_WIDE = MODE < 2 || SS_MODE2_TILE_WIDE != 0;
             // Which pieces of the tile hold candidates?  With the three-byte first phase a tile that gets here
             // usually holds ONE (text: a frequent phrase that shares the filter bytes); the second-level filter
             // then runs on that piece alone instead of on all U - a quarter of the work.  Tiles dense with

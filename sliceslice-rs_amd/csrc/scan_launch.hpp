@@ -16,19 +16,20 @@ struct Shape {
     uint32_t lds_pad;
 };
 // Which kernels a build holds.  The PRODUCT library has what the constructors and ss_searcher_set_filter3 can reach - U = 4,
-// non-temporal loads, the single-stream (MODE 0) and cross-lane (MODE 2) kernels, the 8-byte first phase for one-byte needles
-// only: 18 scan kernels (4 Q x 2 modes + one-byte, search and find).  -DSS_TUNING_VARIANTS adds every other combination
+// non-temporal loads, the single-stream (MODE 0) and cross-lane (MODE 2; MODE 3 = without the third byte, search only) kernels, the
+// 8-byte first phase for one-byte needles only: 22 scan kernels (4 Q x 2 modes + one-byte, search and find; 4 Q of MODE 3).  -DSS_TUNING_VARIANTS adds every other combination
 // ss_searcher_set_variant can name (U = 8, plain loads, the 8-byte phase for two-byte filters, the 16-byte layout for one-byte
 // needles) - tuning residue: libsliceslice_hip_tuning.so (sliceslice_rs_amd._build.build_tuning), used by tools/ and by the
 // variant tests.
 constexpr bool kernel_built(int mode, bool one_byte, int U, int NT, bool FIND, bool L8)
 {
 #ifdef SS_TUNING_VARIANTS
-    return (void)mode, (void)one_byte, (void)U, (void)NT, (void)FIND, (void)L8, true;
+    return (void)one_byte, (void)U, (void)NT, (void)L8, !(mode == 3 && FIND);
 #else
+    if (mode == 3 && FIND) return false;          // find() keeps the third byte (one kernel family less; the leftmost match is rarely far)
     if (U != 4 || NT != 1) return false;
     if (one_byte) return FIND ? !L8 : L8;
-    return (void)mode, !L8;
+    return !L8;
 #endif
 }
 
@@ -67,11 +68,12 @@ bool launch_scan_un(const Problem &pr, int q, int mode, bool one_byte, const Sha
     }
     if (one_byte) return launch_one<0, 0, true, U, NT, FIND, false>(pr, sh, st, flag);
 #define SS_CASE(QQ, MM)                                                                            \
-    case (QQ) * 3 + (MM):                                                                          \
+    case (QQ) * 4 + (MM):                                                                          \
         return launch_one<QQ, MM, false, U, NT, FIND, false>(pr, sh, st, flag);
-    switch (q * 3 + mode) {
+    switch (q * 4 + mode) {
         SS_CASE(0, 0) SS_CASE(0, 2) SS_CASE(1, 0) SS_CASE(1, 2)
         SS_CASE(2, 0) SS_CASE(2, 2) SS_CASE(3, 0) SS_CASE(3, 2)
+        SS_CASE(0, 3) SS_CASE(1, 3) SS_CASE(2, 3) SS_CASE(3, 3)
     }
 #undef SS_CASE
     return false;

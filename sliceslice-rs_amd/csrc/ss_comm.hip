@@ -100,17 +100,21 @@ struct ss_comm {
 };
 
 // All ranks of a communicator inside ONE process (ncclCommInitAll): one stream, flag and read-back per device.
+struct SetWorker;
 struct ss_comm_set {
     int ndev = 0;
     int combine = 0;            // SS_COMBINE_RCCL / SS_COMBINE_HOST
+    int issue = 0;              // SS_ISSUE_THREADS / SS_ISSUE_SERIAL
     int epoch = 0;
     std::vector<int> devs;
     std::vector<void *> comms;
     std::vector<hipStream_t> streams;
-    std::vector<int *> d_flag, d_recv, h_flag;          // h_flag[g]: pinned mirror written by device g's finding wave
+    // per device: the flag PAIR {found, a device failed its local part} (both epoch-valued, never cleared), the all-reduce(MAX)
+    // result, the pinned mirror the finding wave writes, the pinned source of the copy that raises the pair's second word
+    std::vector<int *> d_flag, d_recv, h_flag, h_err;
     std::vector<uint64_t *> d_best, d_best_recv;
     bool no_rccl = false;                               // librccl could not be loaded: no communicators, host combine only
-    int *h_recv = nullptr;                              // pinned: device 0's all-reduce result
+    int *h_recv = nullptr;                              // pinned int[2]: device 0's all-reduce result
     long long *h_words = nullptr;                       // pinned: ndev answer words of signal_flag_kernel (spinning read-back)
     uint64_t *h_best = nullptr;                         // pinned: ndev offsets (host combine) / [0] = all-reduce result
     std::atomic<bool> busy{false};                      // one search at a time per set: a second concurrent call is refused
@@ -119,7 +123,43 @@ struct ss_comm_set {
     // their workgroups see it at their next poll and leave.  Possible when every device's memory is CPU-visible.
     bool relay_ok = false;
     std::vector<volatile uint32_t *> hdp_flush;         // per device: HDP flush register (pushes the store out of the host data path)
+    // One issue thread per device (SS_ISSUE_THREADS): see SetWorker below.  Created with the set, joined by ss_comm_set_free.
+    std::vector<SetWorker *> workers;
+    const ss_searcher *timed = nullptr;                 // the searcher of the latest search (ss_comm_set_last_kernel_ms)
+    float issue_us[4] = {0, 0, 0, 0};                   // the latest search's host time: scans, collective, answer words, all of it
 };
+
+// ---- per-device issue threads -----------------------------------------------------------------------------------------
+// From ONE thread a search over G devices is 3 G runtime calls in a row - G scan launches, G all-reduces (one group), G
+// answer-word kernels, a hipSetDevice in front of each - and device G-1 starts its scan G-1 launches after device 0: at eight
+// devices and a 1.2 ms shard scan that skew is a few per cent of the step (profiles/r05/native_set8.json has the host times).
+// So a set keeps one thread per device, parked on the device for good: ss_search_sharded_all hands every thread its shard
+// (one store per thread), each enqueues scan -> all-reduce -> answer word on its device's stream - the G chains are issued side by
+// side, and RCCL's "one thread per communicator" form needs no group - and reports back.  A thread spins for kWorkerSpinUs after
+// its latest job (back-to-back searches find it awake), then sleeps on a condition variable.
+struct SetJob {
+    int kind = 0;                       // 1 = one shard of a search, 2 = read the thread's kernel time
+    const ss_searcher *s = nullptr;
+    const void *shard = nullptr;
+    size_t len = 0;
+    int epoch = 0;
+    bool rccl = false, signal = false;
+};
+struct SetWorker {
+    ss_comm_set *set = nullptr;
+    int g = 0;
+    std::thread th;
+    std::atomic<uint32_t> posted{0}, done{0};
+    std::atomic<bool> asleep{false}, quit{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    SetJob job;
+    int rc = SS_OK;
+    char msg[256] = "";
+    float kernel_ms = 0;
+    float issue_us[3] = {0, 0, 0};
+};
+constexpr long long kWorkerSpinUs = 500;
 
 namespace {
 
@@ -152,8 +192,23 @@ void free_comm(ss_comm *c)
     delete c;
 }
 
+void stop_workers(ss_comm_set *set)
+{
+    for (SetWorker *w : set->workers) {
+        w->quit.store(true, std::memory_order_seq_cst);
+        {
+            std::lock_guard<std::mutex> lock(w->mu);
+            w->cv.notify_one();
+        }
+        if (w->th.joinable()) w->th.join();
+        delete w;
+    }
+    set->workers.clear();
+}
+
 void free_comm_set(ss_comm_set *set)
 {
+    stop_workers(set);
     Rccl *r = rccl();
     DeviceGuard guard;
     for (int g = 0; g < set->ndev; ++g) {
@@ -166,6 +221,7 @@ void free_comm_set(ss_comm_set *set)
         if (g < (int)set->d_flag.size()) (void)hipFree(set->d_flag[g]);
         if (g < (int)set->d_recv.size()) (void)hipFree(set->d_recv[g]);
         if (g < (int)set->h_flag.size()) (void)hipHostFree(set->h_flag[g]);
+        if (g < (int)set->h_err.size()) (void)hipHostFree(set->h_err[g]);
         if (g < (int)set->d_best.size()) (void)hipFree(set->d_best[g]);
         if (g < (int)set->d_best_recv.size()) (void)hipFree(set->d_best_recv[g]);
     }
@@ -173,6 +229,125 @@ void free_comm_set(ss_comm_set *set)
     (void)hipHostFree(set->h_words);
     (void)hipHostFree(set->h_best);
     delete set;
+}
+
+double us_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// One device's chain of a search: scan -> all-reduce -> answer word (or the stream wait), enqueued on the device's stream by
+// whoever runs this - the device's issue thread, or the caller's thread for every device in turn (SS_ISSUE_SERIAL; then the
+// all-reduces are issued separately, as one group).  The current device is the chain's.  A chain whose scan cannot be enqueued
+// still goes on: it raises the pair's second word and ENTERS THE COLLECTIVE, so that no other device's all-reduce waits for it.
+int issue_chain(ss_comm_set *set, int g, const SetJob &job, bool collective_here, float issue_us[3])
+{
+    const ss_searcher *s = job.s;
+    hipStream_t st = set->streams[g];
+    int rc = SS_OK;
+    auto t0 = std::chrono::steady_clock::now();
+    if (job.len >= s->n) {                                   // a shard shorter than the needle holds no candidate: the flag stays old
+        PerDevice *pd = nullptr;
+        rc = get_per_device(s, &pd);
+        if (rc == SS_OK) rc = enqueue_scan(s, pd, job.shard, job.len, st, set->d_flag[g], false, 0, set->h_flag[g], job.epoch);
+        if (rc != SS_OK) {
+            *set->h_err[g] = job.epoch;
+            (void)hipMemcpyAsync(set->d_flag[g] + 1, set->h_err[g], sizeof(int), hipMemcpyHostToDevice, st);
+        }
+    }
+    issue_us[0] = (float)us_since(t0);
+    t0 = std::chrono::steady_clock::now();
+    if (job.rccl && collective_here) {
+        Rccl *r = rccl();
+        const int nrc = r->AllReduce(set->d_flag[g], set->d_recv[g], 2, kNcclInt32, kNcclMax, set->comms[g], st);
+        if (nrc != 0 && rc == SS_OK) rc = rccl_fail(r, nrc, "ncclAllReduce");
+    }
+    issue_us[1] = (float)us_since(t0);
+    return rc;
+}
+
+// ... and what follows the all-reduce on the device's stream: the answer word for a host that spins, or the read-back + stream wait.
+int issue_tail(ss_comm_set *set, int g, const SetJob &job, bool wait_here, float issue_us[3])
+{
+    hipStream_t st = set->streams[g];
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipSuccess;
+    if (job.signal) {
+        e = launch_signal_flag(st, job.rccl ? set->d_recv[g] : set->d_flag[g], job.epoch, set->h_words + g, 1);
+    } else {
+        if (job.rccl && g == 0) e = hipMemcpyAsync(set->h_recv, set->d_recv[0], 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && wait_here) e = hipStreamSynchronize(st);
+    }
+    issue_us[2] = (float)us_since(t0);
+    if (e != hipSuccess) return fail(SS_ERR_HIP, "device %d: %s", set->devs[g], hipGetErrorString(e));
+    return SS_OK;
+}
+
+void run_job(SetWorker *w)
+{
+    ss_comm_set *set = w->set;
+    w->rc = SS_OK;
+    w->msg[0] = 0;
+    if (w->job.kind == 2) {
+        w->rc = thread_last_kernel_ms(w->job.s, set->devs[w->g], &w->kernel_ms);
+    } else {
+        w->rc = issue_chain(set, w->g, w->job, true, w->issue_us);
+        if (w->rc != SS_OK) snprintf(w->msg, sizeof w->msg, "%s", last_error());
+        const int trc = issue_tail(set, w->g, w->job, true, w->issue_us);
+        if (trc != SS_OK && w->rc == SS_OK) {
+            w->rc = trc;
+            snprintf(w->msg, sizeof w->msg, "%s", last_error());
+        }
+    }
+    if (w->rc != SS_OK && !w->msg[0]) snprintf(w->msg, sizeof w->msg, "%s", last_error());
+}
+
+void worker_main(SetWorker *w)
+{
+    (void)hipSetDevice(w->set->devs[w->g]);
+    uint32_t seen = 0;
+    auto idle_since = std::chrono::steady_clock::now();
+    for (;;) {
+        uint32_t p = seen;
+        for (unsigned spins = 0;; ++spins) {
+            p = w->posted.load(std::memory_order_acquire);
+            if (p != seen || w->quit.load(std::memory_order_acquire)) break;
+            cpu_relax();
+            if ((spins & 1023) == 1023 && us_since(idle_since) > (double)kWorkerSpinUs) {
+                std::unique_lock<std::mutex> lock(w->mu);
+                w->asleep.store(true, std::memory_order_seq_cst);
+                w->cv.wait(lock, [&]() { return w->posted.load(std::memory_order_seq_cst) != seen || w->quit.load(std::memory_order_seq_cst); });
+                w->asleep.store(false, std::memory_order_seq_cst);
+            }
+        }
+        if (p == seen) return;                                // quit
+        run_job(w);
+        seen = p;
+        w->done.store(p, std::memory_order_release);
+        idle_since = std::chrono::steady_clock::now();
+    }
+}
+
+uint32_t post_job(SetWorker *w)
+{
+    const uint32_t p = w->posted.load(std::memory_order_relaxed) + 1;
+    w->posted.store(p, std::memory_order_seq_cst);
+    if (w->asleep.load(std::memory_order_seq_cst)) {
+        std::lock_guard<std::mutex> lock(w->mu);
+        w->cv.notify_one();
+    }
+    return p;
+}
+
+void wait_job(SetWorker *w, uint32_t p)
+{
+    while (w->done.load(std::memory_order_acquire) != p) cpu_relax();
+}
+
+bool threads_wanted()
+{
+    static const bool on = []() { const char *v = getenv("SLICESLICE_SET_THREADS"); return !(v && v[0] == '0'); }();
+    return on;
 }
 
 }  // namespace
@@ -397,6 +572,7 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
     set->d_flag.assign(ndev, nullptr);
     set->d_recv.assign(ndev, nullptr);
     set->h_flag.assign(ndev, nullptr);
+    set->h_err.assign(ndev, nullptr);
     set->d_best.assign(ndev, nullptr);
     set->d_best_recv.assign(ndev, nullptr);
     DeviceGuard guard;
@@ -411,13 +587,16 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&set->streams[g], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&set->d_flag[g], 2 * sizeof(int));
         if (e == hipSuccess) e = hipMemset(set->d_flag[g], 0, 2 * sizeof(int));
-        if (e == hipSuccess) e = hipMalloc((void **)&set->d_recv[g], sizeof(int));
+        if (e == hipSuccess) e = hipMalloc((void **)&set->d_recv[g], 2 * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(set->d_recv[g], 0, 2 * sizeof(int));
         if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_flag[g], sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
         if (e == hipSuccess) *set->h_flag[g] = 0;
+        if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_err[g], sizeof(int), hipHostMallocPortable);
         if (e == hipSuccess) e = hipMalloc((void **)&set->d_best[g], sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void **)&set->d_best_recv[g], sizeof(uint64_t));
     }
-    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_recv, sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_recv, 2 * sizeof(int), hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) set->h_recv[0] = set->h_recv[1] = 0;
     if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_words, (size_t)ndev * sizeof(long long), hipHostMallocPortable | hipHostMallocMapped);
     if (e == hipSuccess) memset(set->h_words, 0, (size_t)ndev * sizeof(long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&set->h_best, (size_t)ndev * sizeof(uint64_t), hipHostMallocPortable | hipHostMallocMapped);
@@ -434,6 +613,21 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
             else set->hdp_flush[g] = di.hdp_flush;
             (void)hipSetDevice(set->devs[g]);
             (void)hipDeviceSynchronize();               // the memsets above are asynchronous to the host: done before anyone stores there
+        }
+    }
+    // one issue thread per device (a set of one device has nothing to issue side by side)
+    set->issue = ndev >= 2 && threads_wanted() ? SS_ISSUE_THREADS : SS_ISSUE_SERIAL;
+    if (set->issue == SS_ISSUE_THREADS) {
+        for (int g = 0; g < ndev; ++g) {
+            SetWorker *w = new (std::nothrow) SetWorker;
+            if (!w) {
+                free_comm_set(set);
+                return fail(SS_ERR_NOMEM, "out of memory");
+            }
+            w->set = set;
+            w->g = g;
+            set->workers.push_back(w);
+            w->th = std::thread(worker_main, w);
         }
     }
     *out = set;
@@ -453,6 +647,76 @@ int ss_comm_set_combine(ss_comm_set *set, int combine)
     return SS_OK;
 }
 
+int ss_comm_set_issue(ss_comm_set *set, int issue)
+{
+    if (!set || (issue != SS_ISSUE_THREADS && issue != SS_ISSUE_SERIAL)) return fail(SS_ERR_ARGUMENT, "bad issue mode");
+    BusyGuard busy(&set->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator set is in use by a search");
+    if (issue == SS_ISSUE_THREADS && set->workers.empty()) {
+        if (set->ndev < 2) return SS_OK;                      // one device: the caller's thread is the issue thread
+        for (int g = 0; g < set->ndev; ++g) {
+            SetWorker *w = new (std::nothrow) SetWorker;
+            if (!w) return fail(SS_ERR_NOMEM, "out of memory");
+            w->set = set;
+            w->g = g;
+            set->workers.push_back(w);
+            w->th = std::thread(worker_main, w);
+        }
+    }
+    set->issue = issue;
+    return SS_OK;
+}
+
+int ss_comm_set_count(const ss_comm_set *set, int *nranks)
+{
+    if (!set || !nranks) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    if (set->no_rccl) return fail(SS_ERR_RCCL, "this set was created without communicators (librccl could not be loaded)");
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl not loaded");
+    int agreed = -1;
+    for (int g = 0; g < set->ndev; ++g) {                    // what RCCL itself says, of EVERY communicator of the set
+        int n = 0;
+        if (int rc = r->CommCount(set->comms[g], &n)) return rccl_fail(r, rc, "ncclCommCount");
+        if (agreed >= 0 && n != agreed) return fail(SS_ERR_RCCL, "communicator %d of the set reports %d ranks, communicator 0 %d", g, n, agreed);
+        agreed = n;
+    }
+    *nranks = agreed;
+    return SS_OK;
+}
+
+int ss_comm_set_last_kernel_ms(ss_comm_set *set, float *ms, int count)
+{
+    if (!set || !ms || count < set->ndev) return fail(SS_ERR_ARGUMENT, "bad argument");
+    BusyGuard busy(&set->busy);
+    if (!busy.mine) return fail(SS_ERR_ARGUMENT, "this communicator set is in use by a search");
+    if (!set->timed) return fail(SS_ERR_ARGUMENT, "no search has been made through this set yet");
+    if (set->issue == SS_ISSUE_THREADS && !set->workers.empty()) {
+        std::vector<uint32_t> posted(set->ndev);
+        for (int g = 0; g < set->ndev; ++g) {
+            set->workers[g]->job.kind = 2;
+            set->workers[g]->job.s = set->timed;
+            posted[g] = post_job(set->workers[g]);
+        }
+        int rc = SS_OK;
+        for (int g = 0; g < set->ndev; ++g) {
+            wait_job(set->workers[g], posted[g]);
+            if (set->workers[g]->rc != SS_OK && rc == SS_OK) rc = fail(set->workers[g]->rc, "%s", set->workers[g]->msg);
+            ms[g] = set->workers[g]->kernel_ms;
+        }
+        return rc;
+    }
+    for (int g = 0; g < set->ndev; ++g)
+        if (int rc = thread_last_kernel_ms(set->timed, set->devs[g], ms + g)) return rc;
+    return SS_OK;
+}
+
+int ss_comm_set_last_issue_us(const ss_comm_set *set, float us[4])
+{
+    if (!set || !us) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    for (int k = 0; k < 4; ++k) us[k] = set->issue_us[k];
+    return SS_OK;
+}
+
 int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, const size_t *shard_lens, ss_comm_set *set,
                           int *found)
 {
@@ -469,116 +733,170 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
     SearchGate gate(s);
     DeviceGuard guard;
     const int epoch = next_comm_epoch(&set->epoch, set->d_flag.data(), set->devs.data(), G, set->h_flag.data());
-    int rc = SS_OK;
-    // 1. one scan per device, each on its device's stream; the finding wave also writes the epoch to that device's
-    //    pinned-host mirror
-    for (int g = 0; g < G && rc == SS_OK; ++g) {
-        if (shard_lens[g] < s->n) continue;                 // shorter than the needle: no candidate, flag stays old
-        if (hipSetDevice(set->devs[g]) != hipSuccess) { rc = fail(SS_ERR_HIP, "hipSetDevice(%d) failed", set->devs[g]); break; }
-        PerDevice *pd = nullptr;
-        rc = get_per_device(s, &pd);
-        if (rc == SS_OK) rc = enqueue_scan(s, pd, d_shards[g], shard_lens[g], set->streams[g], set->d_flag[g], false, 0, set->h_flag[g], epoch);
-    }
-    // 2. combine: G all-reduce(MAX) calls as ONE group (the default), or no collective at all - the host ORs the
-    //    G pinned mirrors (possible only because all ranks live in this process)
-    if (rc == SS_OK && set->combine == SS_COMBINE_RCCL) {
-        int nrc = r->GroupStart();
-        for (int g = 0; g < G && nrc == 0; ++g)
-            nrc = r->AllReduce(set->d_flag[g], set->d_recv[g], 1, kNcclInt32, kNcclMax, set->comms[g], set->streams[g]);
-        const int erc = r->GroupEnd();
-        if (nrc == 0) nrc = erc;
-        if (nrc != 0) rc = rccl_fail(r, nrc, "grouped ncclAllReduce");
-        if (rc == SS_OK) {
-            hipError_t e = hipSetDevice(set->devs[0]);
-            if (e == hipSuccess) e = hipMemcpyAsync(set->h_recv, set->d_recv[0], sizeof(int), hipMemcpyDeviceToHost, set->streams[0]);
-            if (e != hipSuccess) rc = fail(SS_ERR_HIP, "flag read-back: %s", hipGetErrorString(e));
-        }
-    }
-    // 3. every stream is drained before the call returns: the haystacks are only borrowed for the call.  Scans short
-    //    enough to be waited for by spinning (spin_for_word) end with a one-lane kernel per device that stores the device's
-    //    answer word - behind the scan and the all-reduce, so a word that has arrived says its stream is done - and the
-    //    host collects the G words; whatever is missing when the spin budget runs out is waited for on the stream.
+    set->timed = s;
+    // Scans short enough to be waited for by spinning (spin_for_word) end with a one-lane kernel per device that stores the
+    // device's answer word - behind the scan and the all-reduce, so a word that has arrived says its stream is done - and the
+    // host collects the G words; longer ones are waited for on their streams.
     const bool spin_ok = spin_wait_enabled();
     size_t longest = 0;
     for (int g = 0; g < G; ++g) longest = shard_lens[g] > longest ? shard_lens[g] : longest;
     const double estimate = scan_estimate_us(longest) + 100.0;
-    bool spun = false;
-    int any_word = 0;
-    if (rc == SS_OK && spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(longest) >= kSpinMinEstimateUs) {
-        bool launched = true;
-        for (int g = 0; g < G && launched; ++g) {
-            __atomic_store_n(set->h_words + g, 0ll, __ATOMIC_RELAXED);
-            launched = hipSetDevice(set->devs[g]) == hipSuccess;
-            if (launched) {
-                launched = launch_signal_flag(set->streams[g], set->combine == SS_COMBINE_RCCL ? set->d_recv[g] : set->d_flag[g], epoch,
-                                              set->h_words + g, 0) == hipSuccess;
-            }
+    const bool signal = spin_ok && estimate <= kSpinMaxEstimateUs && scan_estimate_us(longest) >= kSpinMinEstimateUs;
+    const bool rccl_on = set->combine == SS_COMBINE_RCCL;
+    const bool threads = set->issue == SS_ISSUE_THREADS && (int)set->workers.size() == G;
+    if (signal)
+        for (int g = 0; g < G; ++g) __atomic_store_n(set->h_words + g, 0ll, __ATOMIC_RELAXED);
+    int rc = SS_OK;
+    char msg[256] = "";
+    bool tails_waited = false;                              // every stream has been waited for already
+    const auto t_issue = std::chrono::steady_clock::now();
+    float us[3] = {0, 0, 0};
+    if (threads) {
+        // 1t. every device's chain - scan, all-reduce(MAX) of the flag pair, answer word - from that device's own thread
+        std::vector<uint32_t> posted(G);
+        for (int g = 0; g < G; ++g) {
+            SetJob &j = set->workers[g]->job;
+            j.kind = 1;
+            j.s = s;
+            j.shard = d_shards[g];
+            j.len = shard_lens[g];
+            j.epoch = epoch;
+            j.rccl = rccl_on;
+            j.signal = signal;
+            posted[g] = post_job(set->workers[g]);
         }
-        if (launched) {
-            // Collect the G answer words; meanwhile - cross-device early exit - watch the pinned mirrors: the first device that
-            // reports a match has its epoch stored into every other device's flag through the BAR, so that THEIR grids stop
-            // scanning too (a match in shard 0 of a 64 GiB haystack over eight devices otherwise costs the full 1.2 ms scan of
-            // the seven others).  The flag only ever means "found somewhere": the OR of the answers is unchanged.
+        for (int g = 0; g < G; ++g) {
+            SetWorker *w = set->workers[g];
+            wait_job(w, posted[g]);
+            if (w->rc != SS_OK && rc == SS_OK) {
+                rc = w->rc;
+                snprintf(msg, sizeof msg, "%s", w->msg);
+            }
+            for (int k = 0; k < 3; ++k) us[k] = std::max(us[k], w->issue_us[k]);
+        }
+        tails_waited = !signal;
+    } else {
+        // 1s. one scan per device, each on its device's stream, from this thread; the finding wave also writes the epoch to
+        //     that device's pinned-host mirror
+        SetJob j;
+        j.kind = 1;
+        j.s = s;
+        j.epoch = epoch;
+        j.rccl = rccl_on;
+        j.signal = signal;
+        float one[3];
+        for (int g = 0; g < G && rc == SS_OK; ++g) {
+            if (hipSetDevice(set->devs[g]) != hipSuccess) { rc = fail(SS_ERR_HIP, "hipSetDevice(%d) failed", set->devs[g]); break; }
+            j.shard = d_shards[g];
+            j.len = shard_lens[g];
+            rc = issue_chain(set, g, j, false, one);
+            us[0] += one[0];
+        }
+        if (rc != SS_OK) snprintf(msg, sizeof msg, "%s", last_error());
+        // 2s. combine: G all-reduce(MAX) calls as ONE group, or no collective at all - the host ORs the G pinned mirrors
+        //     (possible only because all ranks live in this process).  Nothing has entered a collective yet, so a failed enqueue
+        //     simply ends the call.
+        if (rc == SS_OK && rccl_on) {
             const auto t0 = std::chrono::steady_clock::now();
-            const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
-            uint64_t got = 0;
-            bool relayed = !set->relay_ok || G < 2 || !cross_exit_enabled();
-            spun = true;
-            for (unsigned spins = 0; got != (G >= 64 ? ~0ull : (1ull << G) - 1); ++spins) {
-                for (int g = 0; g < G; ++g) {
-                    if ((got >> g) & 1) continue;
-                    const long long v = __atomic_load_n(set->h_words + g, __ATOMIC_ACQUIRE);
-                    if (((uint32_t)v >> 1) == (uint32_t)epoch) {
-                        any_word |= (int)(v & 1);
-                        got |= 1ull << g;
-                    }
-                }
-                if (!relayed) {
-                    for (int g = 0; g < G; ++g) {
-                        if (__atomic_load_n(set->h_flag[g], __ATOMIC_ACQUIRE) != epoch) continue;
-                        for (int o = 0; o < G; ++o) {
-                            if (o == g || ((got >> o) & 1) || shard_lens[o] < s->n) continue;
-                            *reinterpret_cast<volatile int *>(set->d_flag[o]) = epoch;
-                        }
-                        _mm_sfence();
-                        // push the stores out of each device's host data path and WAIT for them (read the register back, as
-                        // bar_write does): a posted write still in flight when this call returns could land after the NEXT
-                        // search on the set has moved that flag on to its own epoch, and put it back
-                        for (int o = 0; o < G; ++o) {
-                            if (o == g || ((got >> o) & 1) || shard_lens[o] < s->n) continue;
-                            if (set->hdp_flush[o]) {
-                                __atomic_store_n(set->hdp_flush[o], 1u, __ATOMIC_RELAXED);
-                                (void)__atomic_load_n(set->hdp_flush[o], __ATOMIC_RELAXED);
-                            } else {
-                                (void)*reinterpret_cast<volatile int *>(set->d_flag[o]);
-                            }
-                        }
-                        relayed = true;
-                        break;
-                    }
-                }
-                cpu_relax();
-                if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) { spun = false; break; }
+            int nrc = r->GroupStart();
+            for (int g = 0; g < G && nrc == 0; ++g)
+                nrc = r->AllReduce(set->d_flag[g], set->d_recv[g], 2, kNcclInt32, kNcclMax, set->comms[g], set->streams[g]);
+            const int erc = r->GroupEnd();
+            if (nrc == 0) nrc = erc;
+            if (nrc != 0) {
+                rc = rccl_fail(r, nrc, "grouped ncclAllReduce");
+                snprintf(msg, sizeof msg, "%s", last_error());
             }
-            if (spun && (epoch & 255) != 0) {
-                *found = any_word;
-                return SS_OK;
+            us[1] = (float)us_since(t0);
+        }
+        // 3s. the answer words / the read-back
+        for (int g = 0; g < G && rc == SS_OK; ++g) {
+            if (hipSetDevice(set->devs[g]) != hipSuccess) { rc = fail(SS_ERR_HIP, "hipSetDevice(%d) failed", set->devs[g]); break; }
+            rc = issue_tail(set, g, j, false, one);
+            us[2] += one[2];
+            if (rc != SS_OK) snprintf(msg, sizeof msg, "%s", last_error());
+        }
+    }
+    set->issue_us[0] = us[0];
+    set->issue_us[1] = us[1];
+    set->issue_us[2] = us[2];
+    set->issue_us[3] = (float)us_since(t_issue);
+    bool spun = false;
+    int any_word = 0, any_failed = 0;
+    if (rc == SS_OK && signal) {
+        // Collect the G answer words (epoch << 2 | a device failed << 1 | found); meanwhile - cross-device early exit - watch the
+        // pinned mirrors: the first device that reports a match has its epoch stored into every other device's flag through the
+        // BAR, so that THEIR grids stop scanning too (a match in shard 0 of a 64 GiB haystack over eight devices otherwise costs
+        // the full 1.2 ms scan of the seven others).  The flag only ever means "found somewhere": the OR of the answers is unchanged.
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto budget = std::chrono::microseconds((long long)(2.0 * estimate) + 300);
+        uint64_t got = 0;
+        bool relayed = !set->relay_ok || G < 2 || !cross_exit_enabled();
+        spun = true;
+        for (unsigned spins = 0; got != (G >= 64 ? ~0ull : (1ull << G) - 1); ++spins) {
+            for (int g = 0; g < G; ++g) {
+                if ((got >> g) & 1) continue;
+                const unsigned long long v = (unsigned long long)__atomic_load_n(set->h_words + g, __ATOMIC_ACQUIRE);
+                if ((v >> 2) == (unsigned long long)(uint32_t)epoch) {
+                    any_word |= (int)(v & 1);
+                    any_failed |= (int)((v >> 1) & 1);
+                    got |= 1ull << g;
+                }
+            }
+            if (!relayed) {
+                for (int g = 0; g < G; ++g) {
+                    if (__atomic_load_n(set->h_flag[g], __ATOMIC_ACQUIRE) != epoch) continue;
+                    for (int o = 0; o < G; ++o) {
+                        if (o == g || ((got >> o) & 1) || shard_lens[o] < s->n) continue;
+                        *reinterpret_cast<volatile int *>(set->d_flag[o]) = epoch;
+                    }
+                    _mm_sfence();
+                    // push the stores out of each device's host data path and WAIT for them (read the register back, as
+                    // bar_write does): a posted write still in flight when this call returns could land after the NEXT
+                    // search on the set has moved that flag on to its own epoch, and put it back
+                    for (int o = 0; o < G; ++o) {
+                        if (o == g || ((got >> o) & 1) || shard_lens[o] < s->n) continue;
+                        if (set->hdp_flush[o]) {
+                            __atomic_store_n(set->hdp_flush[o], 1u, __ATOMIC_RELAXED);
+                            (void)__atomic_load_n(set->hdp_flush[o], __ATOMIC_RELAXED);
+                        } else {
+                            (void)*reinterpret_cast<volatile int *>(set->d_flag[o]);
+                        }
+                    }
+                    relayed = true;
+                    break;
+                }
+            }
+            cpu_relax();
+            if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > budget) { spun = false; break; }
+        }
+        if (spun && (epoch & 255) != 0) {
+            if (any_failed) return fail(SS_ERR_HIP, "a device of the set failed its part of this search; no answer");
+            *found = any_word;
+            return SS_OK;
+        }
+    }
+    // every stream is drained before the call returns: the haystacks are only borrowed for the call
+    if (!tails_waited || rc != SS_OK) {
+        for (int g = 0; g < G; ++g) {
+            hipError_t e = hipSetDevice(set->devs[g]);
+            if (e == hipSuccess) e = hipStreamSynchronize(set->streams[g]);
+            if (e != hipSuccess && rc == SS_OK) {
+                rc = fail(SS_ERR_HIP, "stream wait on device %d: %s", set->devs[g], hipGetErrorString(e));
+                snprintf(msg, sizeof msg, "%s", last_error());
             }
         }
     }
-    for (int g = 0; g < G; ++g) {
-        hipError_t e = hipSetDevice(set->devs[g]);
-        if (e == hipSuccess) e = hipStreamSynchronize(set->streams[g]);
-        if (e != hipSuccess && rc == SS_OK) rc = fail(SS_ERR_HIP, "stream wait on device %d: %s", set->devs[g], hipGetErrorString(e));
-    }
-    if (rc != SS_OK) return rc;
+    if (rc != SS_OK) return fail(rc, "%s", msg);
     if (spun) {
+        if (any_failed) return fail(SS_ERR_HIP, "a device of the set failed its part of this search; no answer");
         *found = any_word;
         return SS_OK;
     }
     int any = 0;
-    if (set->combine == SS_COMBINE_RCCL) {
-        any = *set->h_recv == epoch;
+    if (rccl_on) {
+        any = set->h_recv[0] == epoch;
+        if (set->h_recv[1] == epoch) return fail(SS_ERR_HIP, "a device of the set failed its part of this search; no answer");
     } else {
         for (int g = 0; g < G; ++g) any |= __atomic_load_n(set->h_flag[g], __ATOMIC_ACQUIRE) == epoch;
     }

@@ -223,6 +223,7 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find = false,
                  uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1, int done_slot = -1, bool *used_done = nullptr);
 void timer_forget(const ss_searcher *s);                         // ss_searcher_free: the calling thread's timing record
+int thread_last_kernel_ms(const ss_searcher *s, int dev, float *ms);   // the calling thread's latest timed scan on `dev` (< 0: its latest)
 
 // Scans too large for the workgroup count of the completion word still answer through a pinned word when the scan is short enough
 // to be waited for by spinning: a one-lane kernel behind the scan (behind the all-reduce, for a sharded search) stores the word.

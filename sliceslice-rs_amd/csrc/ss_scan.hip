@@ -22,8 +22,8 @@ namespace ssh {
 namespace {
 struct ThreadTimer {
     hipEvent_t ev0[kMaxDevices] = {nullptr}, ev1[kMaxDevices] = {nullptr};
-    const void *owner = nullptr;      // the searcher of the most recent timed scan
-    int dev = -1;
+    const void *owner[kMaxDevices] = {nullptr};     // per device: the searcher of the most recent timed scan there
+    int dev = -1;                                   // the device of the most recent timed scan
     ~ThreadTimer()
     {
         if (process_exiting()) return;                  // leak: see ExitMark (ss_core.hip)
@@ -38,7 +38,20 @@ thread_local ThreadTimer g_timer;
 
 void timer_forget(const ss_searcher *s)
 {
-    if (g_timer.owner == s) g_timer.owner = nullptr;
+    for (auto &o : g_timer.owner)
+        if (o == s) o = nullptr;
+}
+
+// The calling thread's most recent timed scan through `s` on device `dev` (dev < 0: on the device it last launched on).
+int thread_last_kernel_ms(const ss_searcher *s, int dev, float *ms)
+{
+    ThreadTimer &tm = g_timer;
+    if (dev < 0) dev = tm.dev;
+    if (dev < 0 || dev >= kMaxDevices || tm.owner[dev] != s)
+        return fail(SS_ERR_ARGUMENT, "no timed scan has been launched through this searcher by the calling thread");
+    HIP_TRY(hipEventSynchronize(tm.ev1[dev]));
+    HIP_TRY(hipEventElapsedTime(ms, tm.ev0[dev], tm.ev1[dev]));
+    return SS_OK;
 }
 
 bool spin_wait_enabled()
@@ -80,7 +93,7 @@ namespace {
 struct Launch {
     int U;
     int nt;
-    int mode;   // 0: d == 0, 2: shifted flags
+    int mode;   // 0: d == 0, 2: shifted flags + a third byte, 3: shifted flags alone
     bool l8;    // 8-bytes-per-lane first phase (mode 0 / one-byte needles)
     uint32_t dyn_lds;   // unused dynamic LDS per workgroup (caps workgroups per CU; tuning: variant 10000*OCC)
     unsigned block;     // threads per workgroup: 128 / 256 / 512 (tuning: variant 100000*B, B = 1 / 2 / 3)
@@ -112,6 +125,10 @@ constexpr size_t kCensusMinBytes = (size_t)256 << 20;
 // from 150 on - and in between the two are within 3 % of each other; any threshold from 40 to 56 loses 0.3 % on average over the
 // set against always picking the faster one (four everywhere: 7 %, six everywhere: 3 %).
 constexpr uint32_t kCensusDenseTiles = 48, kCensusDenseLanes = 256;
+// Filter pairs 16 or more apart (ss_searcher_set_filter3 only; the cross-lane kernels): the third first-phase byte pays on text,
+// where the reference's own pair (0, n-1) passes at percent rates, and costs 2-3 % where the pair alone rarely matches.  The pair
+// runs alone (MODE 3) when at most this many of the sampled tiles hold a candidate of the PAIR (random bytes: ~63 of 1,024).
+constexpr uint32_t kCensusSparsePairTiles = 128;
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 
@@ -138,11 +155,11 @@ uint32_t occupancy_pad(int occ, unsigned block)
 // text-like (byte_rarity_rank >= 64: letters, digits, blanks, common punctuation, NUL) the haystack is presumably text and
 // candidates are to be expected - six per CU; otherwise (a random or binary needle: its rarest bytes are in the filter) four.
 // One-byte needles (8-byte loads, 36-68 VGPRs) stay at four: 7.28-7.44 TB/s either way.
-Launch pick_variant(int variant, uint64_t d, bool one_byte, int workgroups_per_cu)
+Launch pick_variant(int variant, uint64_t d, bool one_byte, int workgroups_per_cu, bool pair_alone)
 {
     Launch l;
     l.U = kAutoU;
-    l.mode = d == 0 ? 0 : 2;
+    l.mode = d == 0 ? 0 : (pair_alone ? 3 : 2);
     l.nt = 1;
     l.l8 = one_byte;
     l.block = ss::kBlock;
@@ -163,7 +180,7 @@ Launch pick_variant(int variant, uint64_t d, bool one_byte, int workgroups_per_c
         variant %= 1000;
         const int m = variant / 100, u = (variant / 10) % 10;
         if (u == 4 || u == 8) l.U = u;
-        (void)m;
+        if (d != 0 && (m == 2 || m == 3)) l.mode = m;         // x2xx / x3xx: the cross-lane kernels with / without the third byte
         l.nt = (variant % 10) ? 1 : 0;
 #ifndef SS_TUNING_VARIANTS
         // a hooks build without the variant kernels holds ONE load flavour (scan_launch.hpp::kernel_built): the launch-shape
@@ -379,12 +396,20 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
                            ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
     int occ = !one_byte && text_like && pr.d == 0 ? 6 : 4;
+    bool pair_alone = false;
     if (!one_byte && len >= kCensusMinBytes) {
         CensusCounts cc;
-        if (census_lookup(s, pd, d_hay, len, st, &cc)) occ = census_choice(cc);
+        if (census_lookup(s, pd, d_hay, len, st, &cc)) {
+            occ = census_choice(cc);
+            // a pair 16 or more apart that rarely matches on this haystack needs no third byte in the first phase (MODE 3)
+            pair_alone = pr.d != 0 && !find && cc.tiles2 <= kCensusSparsePairTiles;
+        }
         if (__atomic_load_n(&pd->last_found, __ATOMIC_RELAXED) != 0) occ = 4;
     }
-    const Launch l = pick_variant(s->variant, pr.d, one_byte, occ);
+    Launch l = pick_variant(s->variant, pr.d, one_byte, occ, pair_alone);
+    if (find && l.mode == 3) l.mode = 2;                     // find() has no pair-alone kernels
+    if (l.mode == 3)                                        // the third byte goes back into the second level's schedule
+        pr.norder = ss::build_refine_order(s->needle.data() + fa, s->n - fa, position, pr.order_idx, pr.order_val);
     const uint64_t wpb = l.block / ss::kWave;
     const uint64_t ntiles = (pr.npieces + wpb * l.U - 1) / (wpb * l.U);
     uint64_t blocks, tpb;
@@ -470,7 +495,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(tm.ev1[pd->dev], st));
-        tm.owner = s;
+        tm.owner[pd->dev] = s;
         tm.dev = pd->dev;
     }
     return SS_OK;
@@ -568,11 +593,7 @@ int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, ui
 int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms)
 {
     if (!s || !ms) return fail(SS_ERR_ARGUMENT, "NULL argument");
-    ThreadTimer &tm = g_timer;
-    if (tm.owner != s || tm.dev < 0) return fail(SS_ERR_ARGUMENT, "no timed scan has been launched through this searcher by the calling thread");
-    HIP_TRY(hipEventSynchronize(tm.ev1[tm.dev]));
-    HIP_TRY(hipEventElapsedTime(ms, tm.ev0[tm.dev], tm.ev1[tm.dev]));
-    return SS_OK;
+    return thread_last_kernel_ms(s, -1, ms);
 }
 
 int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,

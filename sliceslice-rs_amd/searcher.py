@@ -76,6 +76,10 @@ ABI = {
     "ss_comm_init_all": (_int, [_int, _pint, _pvp]),
     "ss_comm_set_free": (None, [_vp]),
     "ss_comm_set_combine": (_int, [_vp, _int]),
+    "ss_comm_set_issue": (_int, [_vp, _int]),
+    "ss_comm_set_count": (_int, [_vp, _pint]),
+    "ss_comm_set_last_kernel_ms": (_int, [_vp, ctypes.POINTER(ctypes.c_float), _int]),
+    "ss_comm_set_last_issue_us": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "ss_search_sharded_all": (_int, [_vp, _pvp, _psz, _vp, _pint]),
     "ss_find_sharded_all": (_int, [_vp, _pvp, _psz, _pu64, _vp, _pu64]),
     "ss_service_start": (_int, [_int, ctypes.c_double, _pvp]),
@@ -663,6 +667,7 @@ class NodeSearcher:
     (ranges from ``shard_range``)."""
 
     COMBINE_RCCL, COMBINE_HOST = 0, 1
+    ISSUE_THREADS, ISSUE_SERIAL = 0, 1
 
     def __init__(self, needle, position=None, devices=None, ndev=None):
         import torch
@@ -678,6 +683,29 @@ class NodeSearcher:
 
     def set_combine(self, mode):
         self._ck(self._L.ss_comm_set_combine(self._set, mode))
+
+    def set_issue(self, mode):
+        """ISSUE_THREADS: one issue thread per device (the default from two devices up); ISSUE_SERIAL: the calling thread."""
+        self._ck(self._L.ss_comm_set_issue(self._set, mode))
+
+    def rccl_ranks(self):
+        """ncclCommCount of every communicator of the set (they must agree), or None for a set without communicators."""
+        n = ctypes.c_int(0)
+        if self._L.ss_comm_set_count(self._set, ctypes.byref(n)) != 0:
+            return None
+        return n.value
+
+    def last_kernel_ms(self):
+        """Every device's scan-kernel time of the latest search (the searcher's timing must be on)."""
+        ms = (ctypes.c_float * len(self.devices))()
+        self._ck(self._L.ss_comm_set_last_kernel_ms(self._set, ms, len(self.devices)))
+        return [float(x) for x in ms]
+
+    def last_issue_us(self):
+        """Host microseconds the latest search spent issuing (scans, collective, answer words, all of it)."""
+        us = (ctypes.c_float * 4)()
+        self._ck(self._L.ss_comm_set_last_issue_us(self._set, us))
+        return [float(x) for x in us]
 
     def _ck(self, rc):
         _check(rc, self._L)

@@ -33,10 +33,11 @@ def main():
     cases += [host[12345:12345 + n].tobytes() for n in (33, 100, 257, 1000)]
     # variant = 100000*B + 10000*OCC + 1000*LAYOUT + 100*MODE + 10*U + NT (include/sliceslice_hip_tuning.h), tuning build only:
     # launch-shape digits (1xxxxx / 3xxxxx = 128- / 512-thread workgroups, x4xxxx = occupancy cap), plain loads, U = 8, the 8-byte
-    # phase for two-byte filters (2xxx) and the 16-byte layout for one-byte needles (1xxx).  The product library launches the
+    # phase for two-byte filters (2xxx) and the 16-byte layout for one-byte needles (1xxx), the cross-lane kernels without the third
+    # byte (x3xx: what the census selects for pairs that rarely match).  The product library launches the
     # automatic choice only (variant 0, grid 0) and has no entry point to ask for anything else.
-    variants = (41, 100041, 300041, 40041, 40, 80, 81, 240, 241, 280, 281, 1040, 1041, 1081, 2040, 2041, 2080, 2081, 100241, 302041,
-                130081) if tuning else (0,)
+    variants = (41, 100041, 300041, 40041, 40, 80, 81, 240, 241, 280, 281, 340, 341, 381, 1040, 1041, 1081, 2040, 2041, 2080, 2081, 100241,
+                100341, 302041, 130081) if tuning else (0,)
     checked = refused = 0
     for nd in cases:
         want = O.OracleSearcher(nd).search_in(host)

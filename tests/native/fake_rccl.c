@@ -13,8 +13,10 @@
  *     barrier, reduce all slots element-wise (MAX / MIN of int32 / uint64), barrier, copy the result to the receive
  *     buffer.  The call returns with the result in place - real RCCL returns after ENQUEUEING; everything the library
  *     orders behind the all-reduce on the same stream sees the same values either way.
- *   * in-process communicators (ncclCommInitAll) are N peers of one heap segment; their all-reduces must be issued
- *     inside ncclGroupStart/End (as with real RCCL from one thread) and are carried out in ncclGroupEnd.
+ *   * in-process communicators (ncclCommInitAll) are N peers of one heap segment; all-reduces issued inside
+ *     ncclGroupStart/End (real RCCL's rule for ONE thread driving several peers) are carried out in ncclGroupEnd; issued
+ *     outside a group - one THREAD per peer, real RCCL's other form - the peers meet at the segment's barrier like the
+ *     ranks of separate processes.
  *   * every wait is bounded (FAKE_RCCL_TIMEOUT_S, default 120 s): a rank that never arrives gives the others
  *     ncclSystemError instead of a hang.
  * Built by sliceslice_rs_amd._build.build_fake_rccl() into tests/native/libfake_rccl.so and handed to the library
@@ -330,7 +332,8 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
             const int rc = fetch(&p, c->dev, one);
             return rc != kOk ? rc : deliver(&p, c->dev, one);
         }
-        if (g_group_depth == 0 || c->has_pending) return kInvalidUsage;   /* one thread, several peers: group them */
+        if (c->has_pending) return kInvalidUsage;
+        if (g_group_depth == 0) goto meet;                                /* one thread per peer: the barrier below */
         c->pending = p;
         c->has_pending = 1;
         c->next_in_group = NULL;
@@ -343,6 +346,7 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
         }
         return kOk;
     }
+meet:;
     Segment *s = c->seg;
     int rc = fetch(&p, c->dev, s->slot[c->rank]);
     if (rc != kOk) {

@@ -9,6 +9,10 @@
 //   native_bench ranks    <N> [GiB=8] [steps=200] N processes (this binary, re-executed) sharing device 0, one rank each of a native
 //                                                 communicator: per-search overhead outside the kernel (launch skew + barrier + read-back).
 //                                                 Needs an RCCL that allows several ranks per device: SLICESLICE_RCCL_LIB = tests/native/libfake_rccl.so
+//   native_bench set      <G> [GiB=8] [steps=200] ONE process, a communicator set of G members (devices 0 .. G-1, or all on device 0 when fewer
+//                                                 are visible - then under SLICESLICE_RCCL_LIB = the stand-in): what ss_search_sharded_all
+//                                                 costs the host - issuing G scans + all-reduces + answer words - from per-device
+//                                                 threads and from the calling thread, RCCL and host combine
 //   native_bench soak     [calls=2000000]         small searches through every per-call entry point; RSS / VRAM before and after
 //   native_bench config1  <i386.txt> <words.txt> [iters=5]
 //   native_bench construct [searchers=2000]     what `new` costs (and with a search service resident)
@@ -443,6 +447,87 @@ static int sharded(double gib, int steps)
     return 0;
 }
 
+// The single-process multi-GPU search: host time spent ISSUING the G chains (ss_comm_set_last_issue_us), the call's wall time and
+// every member's kernel time, with the per-device issue threads and without, RCCL and host combine.  G members on G devices, or
+// - fewer devices visible - all on device 0 (the collective then needs the stand-in: real RCCL refuses two ranks on one device).
+static int set_mode(int G, double gib, int steps)
+{
+    int ndev = 0;
+    HK(hipGetDeviceCount(&ndev));
+    const bool shared = ndev < G;
+    std::vector<int> devs(G);
+    for (int g = 0; g < G; ++g) devs[g] = shared ? 0 : g;
+    const size_t total = (size_t)(gib * (double)(1ull << 30));
+    uint8_t needle[16];
+    CK(ss_fill_random_host(needle, 0, 16, 0x5EED0002ull));
+    needle[8] = 0xFF;
+    ss_searcher *s = nullptr;
+    CK(ss_searcher_new(needle, 16, &s));
+    CK(ss_searcher_set_timing(s, 1));
+    std::vector<void *> bufs(G);
+    std::vector<const void *> shards(G);
+    std::vector<size_t> lens(G);
+    for (int g = 0; g < G; ++g) {
+        size_t b = 0, e = 0;
+        CK(ss_shard_range(total, 16, G, g, &b, &e));
+        HK(hipSetDevice(devs[g]));
+        HK(hipMalloc(&bufs[g], e - b));
+        CK(ss_fill_random_device(bufs[g], b, e - b, 0x5EED0001ull, nullptr));
+        HK(hipDeviceSynchronize());
+        shards[g] = bufs[g];
+        lens[g] = e - b;
+    }
+    HK(hipSetDevice(0));
+    ss_comm_set *set = nullptr;
+    CK(ss_comm_init_all(G, devs.data(), &set));
+    int counted = -1;
+    if (ss_comm_set_count(set, &counted) != 0) counted = -1;
+    std::printf("{\"mode\": \"set\", \"members\": %d, \"devices_visible\": %d, \"members_share_device_0\": %s, \"haystack_bytes\": %zu, "
+                "\"shard_bytes\": %zu, \"steps\": %d, \"comm_count\": %d, \"rccl\": \"%s\", \"rows\": [",
+                G, ndev, shared ? "true" : "false", total, lens[0], steps, counted, getenv("SLICESLICE_RCCL_LIB") ? getenv("SLICESLICE_RCCL_LIB") : "librccl");
+    int found = 1, rc = 0;
+    bool first = true;
+    for (int combine : {SS_COMBINE_RCCL, SS_COMBINE_HOST}) {
+        if (ss_comm_set_combine(set, combine) != 0) continue;          // no RCCL at all: host combine only
+        for (int issue : {SS_ISSUE_THREADS, SS_ISSUE_SERIAL}) {
+            CK(ss_comm_set_issue(set, issue));
+            for (int w = 0; w < 10; ++w) rc |= ss_search_sharded_all(s, shards.data(), lens.data(), set, &found);
+            std::vector<double> wall(steps), iss[4];
+            std::vector<float> kms(G), kmax(steps);
+            for (int k = 0; k < steps; ++k) {
+                const auto t0 = clk::now();
+                rc |= ss_search_sharded_all(s, shards.data(), lens.data(), set, &found);
+                wall[k] = seconds_since(t0) * 1e6;
+                float us[4];
+                CK(ss_comm_set_last_issue_us(set, us));
+                for (int j = 0; j < 4; ++j) iss[j].push_back(us[j]);
+                CK(ss_comm_set_last_kernel_ms(set, kms.data(), G));
+                kmax[k] = *std::max_element(kms.begin(), kms.end());
+            }
+            auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            std::vector<float> km = kmax;
+            std::sort(km.begin(), km.end());
+            std::printf("%s{\"combine\": \"%s\", \"issue\": \"%s\", \"call_us\": %.1f, \"issue_scans_us\": %.1f, \"issue_collective_us\": %.1f, "
+                        "\"issue_answer_words_us\": %.1f, \"issue_all_us\": %.1f, \"slowest_kernel_us\": %.1f, \"outside_kernel_us\": %.1f}",
+                        first ? "" : ", ", combine == SS_COMBINE_RCCL ? "rccl" : "host", issue == SS_ISSUE_THREADS ? "threads" : "serial", med(wall),
+                        med(iss[0]), med(iss[1]), med(iss[2]), med(iss[3]), km[km.size() / 2] * 1e3, med(wall) - km[km.size() / 2] * 1e3);
+            first = false;
+        }
+    }
+    std::printf("]}\n");
+    if (rc != 0 || found != 0) {
+        std::fprintf(stderr, "set: rc %d found %d: %s\n", rc, found, ss_last_error());
+        return 1;
+    }
+    ss_comm_set_free(set);
+    ss_searcher_free(s);
+    for (int g = 0; g < G; ++g) {
+        (void)hipSetDevice(devs[g]);
+        (void)hipFree(bufs[g]);
+    }
+    return 0;
+}
+
 // Soak: millions of small searches through every per-call entry point, resident set size and free device memory before
 // and after - the completion-word path returns without a stream wait, so this is where an unbounded backlog of
 // un-retired commands or a leaked slot would show.
@@ -698,6 +783,8 @@ int main(int argc, char **argv)
         return rank_child(std::atoi(argv[2]), std::atoi(argv[3]), argv[4], std::atof(argv[5]), std::atoi(argv[6]), argv[7]);
     if (argc > 2 && std::string(argv[1]) == "ranks")
         return ranks_parent(argv[0], std::atoi(argv[2]), argc > 3 ? std::atof(argv[3]) : 8.0, argc > 4 ? std::atoi(argv[4]) : 200);
+    if (argc > 2 && std::string(argv[1]) == "set")
+        return set_mode(std::atoi(argv[2]), argc > 3 ? std::atof(argv[3]) : 8.0, argc > 4 ? std::atoi(argv[4]) : 200);
     if (argc > 1 && std::string(argv[1]) == "construct") return construct(argc > 2 ? std::atoi(argv[2]) : 2000);
     const std::string mode = argc > 1 ? argv[1] : "headline";
     if (mode == "latency") return latency(argc > 2 ? std::atoi(argv[2]) : 2000);
