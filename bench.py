@@ -1032,19 +1032,33 @@ def main():
     out = run_multi_process(args, ctx)
 
     if cpu_group is not None:
-        # the other form: every device from rank 0's process, the other ranks parked on a CPU barrier with their shards freed
+        # The other form: every device from ONE process, the ranks parked on a CPU barrier with their shards freed.  It runs in a
+        # CHILD of rank 0 with a time limit, so that whatever happens to it - a refusal, a crash inside the collective library, a
+        # hang - the multi-process line above still gets printed.
         single = None
         if rank == 0:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--forms", "single", "--gpus", str(args.gpus), "--steps", str(args.steps),
+                   "--warmup", str(args.warmup), "--haystack-gib", "%g" % args.haystack_gib, "--needle-len", str(args.needle_len),
+                   "--settle-seconds", "%g" % args.settle_seconds, "--variant", str(args.variant), "--grid", str(args.grid)]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                      "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
             try:
-                single = run_single_process(args, None, share)
-            except BaseException as e:                          # (SystemExit from fail() included: the multi-process line still stands)
+                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=float(os.environ.get("SS_BENCH_SINGLE_TIMEOUT", "600")))
+                lines = [l for l in r.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+                if r.returncode == 0 and lines:
+                    single = json.loads(lines[-1])
+                else:
+                    out["config"]["other_form"] = {"launcher": "single-process", "error": "exit code %d, no line" % r.returncode}
+            except Exception as e:                              # (TimeoutExpired included)
                 log("bench.py: the single-process form failed: %r" % (e,))
                 out["config"]["other_form"] = {"launcher": "single-process", "error": repr(e)[:300]}
         dist.barrier(group=cpu_group)
         if rank == 0 and single is not None:
             best, other = (single, out) if single["value"] > out["value"] else (out, single)
             best["config"]["other_form"] = other_form_summary(other)
-            best["config"]["forms_run"] = "one rank per GPU, then all GPUs from one process; this line is the better of the two"
+            best["config"]["forms_run"] = ("one rank per GPU, then all GPUs from one process (a child of rank 0, the ranks parked on a CPU "
+                                           "barrier); this line is the better of the two")
             out = best
     if rank == 0:
         write_line(real_stdout, out)

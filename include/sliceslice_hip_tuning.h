@@ -74,8 +74,9 @@ SS_API int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
 SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
 /* The candidate census of (`s`, d_haystack, len) on the current device, if its counts are in: counts[0] = wave-tiles sampled (0:
  * no census yet), [1] = tiles with a candidate of the device's three filter bytes, [2] = tiles with a candidate of the first two
- * alone, [3] = tiles in which a candidate's first 64 bytes equal the needle's, [4] = candidate lanes.  Launches nothing. */
-SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[5]);
+ * alone, [3] = tiles in which a candidate's first 64 bytes equal the needle's, [4] = candidate lanes; and [5] = the kernel family of
+ * the searcher's latest launch on the device (0 single stream, 2 / 3 cross-lane with / without the third byte).  Launches nothing. */
+SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[6]);
 
 /* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */
 SS_API int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches, uint64_t *settled);

@@ -111,6 +111,7 @@ struct PerDevice {
     unsigned long long *h_census = nullptr;     // pinned: [0] sums, [1] tag of the launch they belong to
     int last_occ = 0, last_found = 0;           // workgroups per CU of the latest launch; the latest synchronous search found the needle
     unsigned last_grid = 0;
+    int last_mode = 0;                          // kernel family of the latest launch: 0 single stream, 2 / 3 cross-lane with / without the third byte
     uint32_t done_low[64] = {0}, done_hi[64] = {0};
     uint32_t find_tag[64] = {0};            // next key of the slot; counts down from kFindTagMax
     uint64_t free_mask = 0;

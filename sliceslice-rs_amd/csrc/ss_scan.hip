@@ -444,6 +444,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     if (blocks < 1) blocks = 1;
     __atomic_store_n(&pd->last_occ, s->variant == 0 ? occ : 0, __ATOMIC_RELAXED);
     __atomic_store_n(&pd->last_grid, (unsigned)blocks, __ATOMIC_RELAXED);
+    __atomic_store_n(&pd->last_mode, l.mode, __ATOMIC_RELAXED);
     const ss::Shape shape = {(unsigned)blocks, l.block, tpb, l.dyn_lds};
     if (used_done) *used_done = false;
     if (done_slot >= 0 && used_done && blocks <= kDoneMaxBlocks && (!find || len < (1ull << ss::kFindOffsetBits))) {
@@ -560,7 +561,7 @@ int ss_searcher_last_launch(const ss_searcher *s, int *workgroups_per_cu, unsign
 }
 
 #ifdef SS_TEST_HOOKS
-int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[5])
+int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[6])
 {
     if (!s || !counts) return fail(SS_ERR_ARGUMENT, "NULL argument");
     PerDevice *pd = nullptr;
@@ -586,6 +587,7 @@ int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, ui
     counts[2] = cc.tiles2;
     counts[3] = cc.match_tiles;
     counts[4] = cc.lanes;
+    counts[5] = (uint32_t)__atomic_load_n(&pd->last_mode, __ATOMIC_RELAXED);
     return SS_OK;
 }
 #endif

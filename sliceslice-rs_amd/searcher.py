@@ -392,9 +392,10 @@ class DynamicHipSearcher:
 
     def census(self, haystack):
         """Hooks builds: the candidate census of (this searcher, haystack) as a dict, or None when its counts are not in."""
-        c = (ctypes.c_uint32 * 5)()
+        c = (ctypes.c_uint32 * 6)()
         ptr, n = haystack.data_ptr(), haystack.numel()
         self._ck(_hooks(self._L).ss_debug_census(self._h, ptr, n, c))
+        self.last_mode = int(c[5])                          # kernel family of the latest launch (0, 2 or 3)
         if c[0] == 0:
             return None
         return {"tiles": c[0], "tiles3": c[1], "tiles2": c[2], "match_tiles": c[3], "lanes": c[4]}

@@ -48,6 +48,14 @@ def main():
                 s.set_grid(grid)
                 assert s.search_in(t) == want, (len(nd), variant, grid)
                 checked += 1
+            if len(nd) >= 16 and variant in (2040, 2041, 2080, 2081, 302041):
+                # the 8-byte layout's THREE-byte first phase: all three filter bytes within four bytes (filter_half3_near)
+                for a, b, c in ((0, 1, 2), (0, 3, 2), (5, 8, 6), (len(nd) - 4, len(nd) - 1, len(nd) - 3)):
+                    s = ss.DynamicHipSearcher.new(nd)
+                    s.set_filter(a, b, c)
+                    s.set_variant(variant)
+                    assert s.search_in(t) == want, (len(nd), variant, a, b, c)
+                    checked += 1
             if len(nd) > 16:
                 # the reference's pair (needle[0], needle[n-1]), which no constructor picks at this distance: cross-lane kernels up
                 # to a distance of 1,007, beyond that the first byte + two partners with the far byte checked in memory

@@ -55,3 +55,12 @@ def corpus():
     if words[-1] == b"":
         words.pop()
     return {"i386": rd("i386.txt"), "words": words, "haystack": rd("haystack"), "needle": rd("needle")}
+
+
+def timing_log(test, **values):
+    """Timing tests report what they measured (SS_TIMING_LOG=<file>: one JSON line per test run), so that the spread over repeated
+    runs - the noise model their thresholds are set against - can be recorded: tools/timing_spread.py, profiles/r05/timing_test_spread.jsonl."""
+    path = os.environ.get("SS_TIMING_LOG")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(json.dumps(dict(test=test, **values)) + "\n")

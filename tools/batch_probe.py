@@ -52,6 +52,13 @@ def main():
         for rnd in range(2):
             row["call_ms_%d" % rnd], row["call_min_%d" % rnd] = [round(x, 4) for x in events_ms(call, reps)]
             row["plan_ms_%d" % rnd], row["plan_min_%d" % rnd] = [round(x, 4) for x in events_ms(lambda: plan.run(out), reps)]
+        # the yardstick: the SAME bytes as ONE haystack through the single-problem kernel (ss_search_device_async: launch only, like
+        # a plan run), bracketed the same way - what a batched call could at best cost
+        if not find:
+            one = ss.DynamicHipSearcher.new(bytes(nd[:16]))
+            flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+            row["single_problem_ms"], row["single_problem_min"] = [round(x, 4) for x in events_ms(lambda: one.search_in_async(hay, flag), reps)]
+            row["single_problem_gbps"] = round(count * each / row["single_problem_ms"] / 1e6, 1)
         nb = count * each
         row["call_gbps"] = round(nb / min(row["call_ms_0"], row["call_ms_1"]) / 1e6, 1)
         row["plan_gbps"] = round(nb / min(row["plan_ms_0"], row["plan_ms_1"]) / 1e6, 1)

@@ -7,6 +7,7 @@ rocprofv3 median is the median of the same launches the hipEvent median printed 
 the kernel family expected, the algorithmic bytes per launch and the kernel time by hipEvents (median, min).
 
   cases:  headline1g   1 GiB random, 16-byte absent needle, new()              (scan_kernel<3,0,...>)
+          near16       the same needle with set_filter(0, 1, 2); with variant 42041 (tuning build) the 8-byte first phase's three-byte filter
           onebyte      1 GiB random, 1-byte absent needle (8-byte loads)       (scan_kernel<0,0,true,...,L8>)
           mode2        1 GiB random, 128-byte needle, set_filter(0, 127)       (scan_kernel<.,2,...> cross-lane)
           far_pair     1 GiB random, 2000-byte needle, set_filter(0, 1999)     (rounds 1-3: the two-stream kernels, case "mode1"; now the
@@ -96,8 +97,13 @@ def main():
             e = ss.DynamicHipSearcher.new(nd)
             e.set_filter(0, len(nd) - 1)
             return e
+        def near(nd):                                    # all three filter bytes within four bytes (the L8 three-byte experiment)
+            e = ss.DynamicHipSearcher.new(nd)
+            e.set_filter(0, 1, 2)
+            return e
         s = {
             "headline1g": lambda: ss.DynamicHipSearcher.new(absent(16)),
+            "near16": lambda: near(absent(16)),
             "onebyte": lambda: ss.DynamicHipSearcher.new(absent(1)),
             "mode2": lambda: exact(absent(128)),
             "mode1": lambda: exact(absent(2000)),
