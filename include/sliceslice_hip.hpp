@@ -238,6 +238,15 @@ public:
     }
     // SS_COMBINE_RCCL (default): one grouped ncclAllReduce; SS_COMBINE_HOST: the host ORs the pinned flag mirrors
     void set_combine(int mode) { check(ss_comm_set_combine(set_, mode)); }
+    // SS_ISSUE_THREADS (default from two devices up): one issue thread per device; SS_ISSUE_SERIAL: the calling thread issues everything
+    void set_issue(int mode) { check(ss_comm_set_issue(set_, mode)); }
+    // ncclCommCount of every communicator of the set (they must agree)
+    int rccl_ranks() const
+    {
+        int n = 0;
+        check(ss_comm_set_count(set_, &n));
+        return n;
+    }
 
     // shards[g]: device pointer + length of shard g, resident on device(g)
     bool search_in(const DeviceSlice *shards) const

@@ -225,6 +225,12 @@ impl<N: Needle> NodeSearcher<N> {
         check(unsafe { ss_shard_range(len, n, self.ndev as c_int, g as c_int, &mut b, &mut e) });
         (b, e)
     }
+    /// `ncclCommCount` of every communicator of the set (they must agree).
+    pub fn rccl_ranks(&self) -> usize {
+        let mut n = 0;
+        check(unsafe { ss_comm_set_count(self.set, &mut n) });
+        n as usize
+    }
     pub fn search_in(&self, haystack: &NodeHaystack) -> bool {
         assert_eq!(haystack.shards.len(), self.ndev);
         let ptrs: Vec<*const c_void> = haystack.shards.iter().map(|s| s.ptr).collect();

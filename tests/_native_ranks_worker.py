@@ -181,8 +181,13 @@ def set_main(G):
     def shards():
         return [logical[b:e].clone() for b, e in ranges]  # every shard its own allocation, like on G devices
     checked = 0
-    for mode in (ss.NodeSearcher.COMBINE_RCCL, ss.NodeSearcher.COMBINE_HOST):
+    assert node.rccl_ranks() == G                        # ncclCommCount of every communicator of the set
+    # both combines, each with one issue thread per device (the default from two devices up) and with everything issued from
+    # the calling thread (the all-reduces as one group)
+    for mode, issue in ((ss.NodeSearcher.COMBINE_RCCL, ss.NodeSearcher.ISSUE_THREADS), (ss.NodeSearcher.COMBINE_HOST, ss.NodeSearcher.ISSUE_THREADS),
+                        (ss.NodeSearcher.COMBINE_RCCL, ss.NodeSearcher.ISSUE_SERIAL), (ss.NodeSearcher.COMBINE_HOST, ss.NodeSearcher.ISSUE_SERIAL)):
         node.set_combine(mode)
+        node.set_issue(issue)
         assert node.search_in(shards()) is False and node.find(shards(), begins) is None
         spots = [0, total - n, total // 2] + [r * S - k for r in range(1, G) for k in (1, n // 2, n - 1)] + [r * S for r in range(1, G)]
         for at in spots:
@@ -205,6 +210,26 @@ def set_main(G):
             assert node.search_in(sh) is False, it
         tiny = [s[:5] for s in sh]
         assert node.search_in(tiny) is False and node.find(tiny, begins) is None
+        node._searcher.set_timing(True)
+        assert node.search_in(sh) is False
+        ms, us = node.last_kernel_ms(), node.last_issue_us()
+        assert len(ms) == G and all(m > 0 for m in ms) and len(us) == 4 and us[3] >= us[0] > 0, (ms, us)
+        node._searcher.set_timing(False)
+        if node._L.has_hooks:
+            # a device whose scan cannot be enqueued: the others still get through their collective (nobody hangs), the call
+            # fails, and the next search finds every device in step again
+            logical[total - n:] = pn
+            sh2 = shards()
+            for fails in (1, 2):
+                node._L.ss_debug_fail_next_scans(node._searcher._h, fails)
+                try:
+                    node.search_in(sh2)
+                    raise AssertionError("a search with an injected scan failure returned an answer")
+                except ss.SlicesliceError as e:
+                    assert e.code == ss.SS_ERR_HIP, e
+                node._L.ss_debug_fail_next_scans(node._searcher._h, 0)
+                assert node.search_in(sh2) is True and node.search_in(sh) is False
+            ss.fill_random_device(logical, SEED)
     if node._L.has_hooks:
         node.set_combine(ss.NodeSearcher.COMBINE_RCCL)
         node.set_epoch(2**31 - 3)
@@ -214,7 +239,7 @@ def set_main(G):
             assert node.search_in(shards()) is True
             ss.fill_random_device(logical, SEED)
     node.close()
-    print("set of %d ok: %d spots per combine mode" % (G, checked // 2), flush=True)
+    print("set of %d ok: %d spots per combine and issue mode" % (G, checked // 4), flush=True)
 
 
 def relay_main():
