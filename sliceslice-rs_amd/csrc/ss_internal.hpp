@@ -101,6 +101,7 @@ struct PerDevice {
         uint32_t gen = 0;           // the searcher's filter generation the counts were taken with
         uint32_t state = 0;         // 0 = empty, 1 = launched (tag `tag`), 2 = counts are in
         uint32_t tag = 0;
+        uint32_t uses = 0;          // scans that went by these counts (the census is repeated every 256: a buffer may be refilled in place)
         uint64_t sums = 0;          // tiles3 | tiles2 << 11 | match tiles << 22 | candidate lanes << 33 (aux_kernels.hpp)
         uint64_t stamp = 0;
     } census[4];

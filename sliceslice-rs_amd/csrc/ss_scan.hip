@@ -129,6 +129,7 @@ constexpr uint32_t kCensusDenseTiles = 48, kCensusDenseLanes = 256;
 // where the reference's own pair (0, n-1) passes at percent rates, and costs 2-3 % where the pair alone rarely matches.  The pair
 // runs alone (MODE 3) when at most this many of the sampled tiles hold a candidate of the PAIR (random bytes: ~63 of 1,024).
 constexpr uint32_t kCensusSparsePairTiles = 128;
+constexpr uint32_t kCensusRefreshEvery = 256;      // scans of one (searcher, haystack) pair between two censuses of it
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 
@@ -320,23 +321,28 @@ bool census_lookup(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_
         if (c.state != 0 && c.hay == d_hay && c.len == len && c.gen == s->filter_gen) hit = &c;
         if (c.state != 1 && (victim->state == 1 || c.stamp < victim->stamp)) victim = &c;
     }
+    PerDevice::Census *target = victim;
+    bool have = false;
     if (hit) {
         hit->stamp = ++pd->census_clock;
         if (hit->state != 2) return false;
         *out = census_counts(hit->sums);
-        return true;
+        have = true;
+        // A buffer may be refilled in place: the counts are taken again every kCensusRefreshEvery scans (the old ones serve until
+        // the new ones are in).
+        if (++hit->uses % kCensusRefreshEvery != 0) return true;
+        target = hit;
     }
-    if (pd->census_pending >= 0 || victim->state == 1) return false;                         // one census in flight per searcher and device
+    if (pd->census_pending >= 0 || (!hit && victim->state == 1)) return have;                 // one census in flight per searcher and device
     const size_t n = s->n, end = len - n + 1;
-    const size_t reach = std::max(s->db, s->dc) + 4;                                          // the last dword a lane loads ends here
-    if (end < 2 * (size_t)ss::kCensusTileBytes + 8 || reach > n + 3) return false;
+    if (end < 2 * (size_t)ss::kCensusTileBytes + 8) return have;
     const uint64_t room = end - 4 - ss::kCensusTileBytes;                                     // latest start of a sampled tile
     const uint64_t stride = (room / (ss::kCensusTiles - 1)) & ~(uint64_t)(ss::kCensusTileBytes - 1);
-    if (stride < ss::kCensusTileBytes) return false;
+    if (stride < ss::kCensusTileBytes) return have;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
-        return false;                                                                          // a graph would replay the census for nobody
+        return have;                                                                           // a graph would replay the census for nobody
     }
     ss::CensusArgs a;
     a.hay = static_cast<const uint8_t *>(d_hay);
@@ -353,16 +359,19 @@ bool census_lookup(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_
     a.d_acc = pd->d_census;
     a.h_out = pd->h_census;
     ss::census_kernel<<<dim3(a.nblocks), dim3(ss::kBlock), 0, st>>>(a);
-    if (hipGetLastError() != hipSuccess) return false;
-    victim->hay = d_hay;
-    victim->len = len;
-    victim->gen = s->filter_gen;
-    victim->state = 1;
-    victim->tag = a.tag;
-    victim->sums = 0;
-    victim->stamp = ++pd->census_clock;
-    pd->census_pending = (int)(victim - pd->census);
-    return false;
+    if (hipGetLastError() != hipSuccess) return have;
+    if (!hit) {
+        target->hay = d_hay;
+        target->len = len;
+        target->gen = s->filter_gen;
+        target->state = 1;
+        target->sums = 0;
+        target->uses = 0;
+        target->stamp = ++pd->census_clock;
+    }
+    target->tag = a.tag;
+    pd->census_pending = (int)(target - pd->census);
+    return have;
 }
 
 // Four or six workgroups per CU from the census counts (see "Workgroups per CU" above).

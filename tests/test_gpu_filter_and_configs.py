@@ -590,3 +590,13 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             s.set_filter(a, b, c)
             assert s.census(h) is None
             assert s.search_in(h) is False and s.census(h) == got
+        # a buffer refilled IN PLACE: the census of a (searcher, haystack) pair is repeated every 256 scans, so the choice follows
+        s = ss.DynamicHipSearcher.new(b"segment descriptor table entries are")
+        for _ in range(3):
+            assert s.search_in(text) is False
+        assert s.last_launch()[0] == 6
+        ss.fill_random_device(text, 0x5EED0001)            # the same bytes as `hay`: no candidates at all
+        for _ in range(260):
+            assert s.search_in(text) is False
+        assert s.census(text) == _census_model(rnd_host, b"segment descriptor table entries are", s.filter3)
+        assert s.search_in(text) is False and s.last_launch()[0] == 4
