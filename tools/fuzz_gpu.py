@@ -19,9 +19,9 @@ import sliceslice_rs_amd as ss  # noqa: E402
 # variant, ss_searcher_set_variant / _set_grid).  The product library has neither the variants nor the overrides: there the campaign
 # draws haystacks, needles, positions and filter triples only, and every search runs the automatic choice.
 TUNING = ss.lib().has_hooks and b"tuning" in ss.lib().ss_version()
-VARIANTS = [0, 40, 41, 80, 81, 241, 281, 1041, 2041, 2081, 100041, 300041, 100241, 40041] if TUNING else [0]
+VARIANTS = [0, 40, 41, 80, 81, 241, 281, 341, 381, 1041, 2041, 2081, 100041, 300041, 100241, 100341, 40041, 60041] if TUNING else [0]
 FIND_VARIANTS = [0, 40, 41, 241] if TUNING else [0]
-BIG_VARIANTS = [0, 0, 41, 241, 1041] if TUNING else [0]
+BIG_VARIANTS = [0, 0, 0, 41, 241, 341, 1041, 60041] if TUNING else [0]
 GRIDS = [0, 0, 0, 1, 3, 64, 4096, -1, -2, -3, -7, -64] if TUNING else [0]
 BIG_GRIDS = [0, 0, 0, -1, -2, -5, 8192] if TUNING else [0]
 
