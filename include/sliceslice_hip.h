@@ -274,7 +274,7 @@ SS_API int ss_find_sharded(const ss_searcher *s, const void *d_shard, size_t sha
  * Who issues the per-device work: SS_ISSUE_THREADS (the default for sets of two or more devices) - the set keeps one thread per
  * device, parked on that device; each enqueues its device's scan, its ncclAllReduce (RCCL's one-thread-per-communicator form, no
  * group) and the answer word, so the G chains start side by side.  SS_ISSUE_SERIAL - everything from the calling thread, the
- * all-reduces as one group (SLICESLICE_SET_THREADS=0 makes it the default).  ss_find_sharded_all is always issued serially.
+ * all-reduces as one group (SLICESLICE_SET_THREADS=0 makes it the default).  ss_find_sharded_all is issued the same way.
  * Diagnostics (read-only; what a benchmark line reports): ss_comm_set_count = ncclCommCount of EVERY communicator of the set
  * (SS_ERR_RCCL if they disagree); ss_comm_set_last_kernel_ms = every device's scan-kernel time of the latest search (needs
  * ss_searcher_set_timing on its searcher; ms[count >= devices]); ss_comm_set_last_issue_us = host time the latest search spent

@@ -138,7 +138,8 @@ struct ss_comm_set {
 // side, and RCCL's "one thread per communicator" form needs no group - and reports back.  A thread spins for kWorkerSpinUs after
 // its latest job (back-to-back searches find it awake), then sleeps on a condition variable.
 struct SetJob {
-    int kind = 0;                       // 1 = one shard of a search, 2 = read the thread's kernel time
+    int kind = 0;                       // 1 = one shard of a search, 2 = read the thread's kernel time, 3 = one shard of a find
+    uint64_t begin = 0;                 // find: the shard's global offset
     const ss_searcher *s = nullptr;
     const void *shard = nullptr;
     size_t len = 0;
@@ -290,6 +291,30 @@ void run_job(SetWorker *w)
     w->msg[0] = 0;
     if (w->job.kind == 2) {
         w->rc = thread_last_kernel_ms(w->job.s, set->devs[w->g], &w->kernel_ms);
+    } else if (w->job.kind == 3) {
+        // one device's chain of a find: minimum reset -> scan (atomicMin of begin + offset) -> all-reduce(MIN) -> read-back -> wait.
+        // A chain whose scan cannot be enqueued still enters the collective (its minimum stays all ones); the caller sees its error.
+        const int g = w->g;
+        hipStream_t st = set->streams[g];
+        hipError_t e = hipMemsetAsync(set->d_best[g], 0xFF, sizeof(uint64_t), st);
+        if (e != hipSuccess) w->rc = fail(SS_ERR_HIP, "device %d: %s", set->devs[g], hipGetErrorString(e));
+        else w->rc = ss_find_device_async(w->job.s, w->job.shard, w->job.len, w->job.begin, st, set->d_best[g]);
+        if (w->rc != SS_OK) snprintf(w->msg, sizeof w->msg, "%s", last_error());
+        if (w->job.rccl) {
+            Rccl *r = rccl();
+            const int nrc = r->AllReduce(set->d_best[g], set->d_best_recv[g], 1, kNcclUint64, kNcclMin, set->comms[g], st);
+            if (nrc != 0 && w->rc == SS_OK) {
+                w->rc = rccl_fail(r, nrc, "ncclAllReduce");
+                snprintf(w->msg, sizeof w->msg, "%s", last_error());
+            }
+        }
+        if (!w->job.rccl || g == 0)
+            e = hipMemcpyAsync(set->h_best + g, w->job.rccl ? set->d_best_recv[g] : set->d_best[g], sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess && w->rc == SS_OK) {
+            w->rc = fail(SS_ERR_HIP, "device %d: %s", set->devs[g], hipGetErrorString(e));
+            snprintf(w->msg, sizeof w->msg, "%s", last_error());
+        }
     } else {
         w->rc = issue_chain(set, w->g, w->job, true, w->issue_us);
         if (w->rc != SS_OK) snprintf(w->msg, sizeof w->msg, "%s", last_error());
@@ -918,6 +943,34 @@ int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards, const
     SearchGate gate(s);
     DeviceGuard guard;
     int rc = SS_OK;
+    if (set->issue == SS_ISSUE_THREADS && (int)set->workers.size() == G) {
+        // every device's chain from that device's issue thread (see SetWorker); the threads wait for their streams themselves
+        std::vector<uint32_t> posted(G);
+        for (int g = 0; g < G; ++g) {
+            SetJob &j = set->workers[g]->job;
+            j.kind = 3;
+            j.s = s;
+            j.shard = d_shards[g];
+            j.len = shard_lens[g];
+            j.begin = shard_begins[g];
+            j.rccl = set->combine == SS_COMBINE_RCCL;
+            posted[g] = post_job(set->workers[g]);
+        }
+        char msg[256] = "";
+        for (int g = 0; g < G; ++g) {
+            wait_job(set->workers[g], posted[g]);
+            if (set->workers[g]->rc != SS_OK && rc == SS_OK) {
+                rc = set->workers[g]->rc;
+                snprintf(msg, sizeof msg, "%s", set->workers[g]->msg);
+            }
+        }
+        if (rc != SS_OK) return fail(rc, "%s", msg);
+        uint64_t best = set->h_best[0];
+        if (set->combine != SS_COMBINE_RCCL)
+            for (int g = 1; g < G; ++g) best = set->h_best[g] < best ? set->h_best[g] : best;
+        *position = best;
+        return SS_OK;
+    }
     for (int g = 0; g < G && rc == SS_OK; ++g) {
         hipError_t e = hipSetDevice(set->devs[g]);
         if (e == hipSuccess) e = hipMemsetAsync(set->d_best[g], 0xFF, sizeof(uint64_t), set->streams[g]);

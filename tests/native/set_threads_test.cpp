@@ -46,6 +46,8 @@ int main(int argc, char **argv)
     std::vector<uint8_t *> bufs(G, nullptr);
     std::vector<const void *> shards(G);
     std::vector<size_t> lens(G, len);
+    std::vector<uint64_t> begins(G);
+    for (int g = 0; g < G; ++g) begins[g] = (uint64_t)g * len;
     for (int g = 0; g < G; ++g) {
         CHECK(hipMalloc((void **)&bufs[g], len) == hipSuccess);
         CHECK(hipMemcpy(bufs[g], h_no.data(), len, hipMemcpyHostToDevice) == hipSuccess);
@@ -64,6 +66,9 @@ int main(int argc, char **argv)
                     if (it % 3 == 0) CHECK(hipMemcpy(bufs[where], h_yes.data(), len, hipMemcpyHostToDevice) == hipSuccess);
                     int found = -1;
                     CHECK(ss_search_sharded_all(s, shards.data(), lens.data(), set, &found) == SS_OK && found == (it % 3 == 0));
+                    uint64_t pos = 1;
+                    CHECK(ss_find_sharded_all(s, shards.data(), lens.data(), begins.data(), set, &pos) == SS_OK);
+                    CHECK(pos == (it % 3 == 0 ? (uint64_t)where * len + len - sizeof needle : SS_NPOS));
                     if (it % 3 == 0) CHECK(hipMemcpy(bufs[where], h_no.data(), len, hipMemcpyHostToDevice) == hipSuccess);
                 }
                 // a member whose scan cannot be enqueued: everybody still gets through the collective, the call fails, the next one is in step
