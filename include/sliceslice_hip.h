@@ -29,11 +29,15 @@
  * immutable after construction (ss_searcher_set_filter3 aside, which is refused
  * while a search runs); any number of threads may call ss_search_* on one handle
  * concurrently (each call uses its own flag slot).  What a handle does carry as
- * mutable state, per device, is LAUNCH TUNING: the candidate census of the
- * haystacks it has been used on and whether its latest synchronous search found
- * the needle decide between four and six workgroups per CU for scans of 256 MiB
- * and more (ss_searcher_last_launch reports the choice).  No result depends on it;
- * for a given haystack and needle the choice is the same from the second scan on.
+ * mutable state, per device, is LAUNCH TUNING for scans of 256 MiB and more: the
+ * candidate census of the haystacks it has been used on and whether its latest
+ * synchronous search found the needle decide between four and six workgroups per
+ * CU (ss_searcher_last_launch reports the choice), and for searchers built by
+ * ss_searcher_new - whose caller chose no filter bytes - a sampled byte histogram
+ * of the haystack may replace the three filter bytes FOR THAT HAYSTACK by rarer
+ * bytes of the needle (ss_searcher_filter3 keeps reporting the searcher's own).
+ * No result depends on any of it; for a given haystack and needle the choices are
+ * the same from the third scan on.
  * A call synchronises only the stream it was given.
  *
  * No CPU fallback exists: every ss_search_* that has to look at haystack bytes
@@ -102,7 +106,10 @@ SS_API int ss_searcher_info(const ss_searcher *s, size_t *needle_len, size_t *po
  *     byte at most 15 in front of `position`, so that one 16-byte load serves all three.
  *   ss_searcher_new - whose caller did not choose - picks all three by a static rarity ranking of the needle's
  *     bytes (first byte + the two rarest of the 15 bytes behind it, over the first 1024 needle bytes), so that
- *     text-like haystacks rarely pass the filter.  ss_searcher_info still reports position n-1.
+ *     text-like haystacks rarely pass the filter.  ss_searcher_info still reports position n-1.  On a haystack of 256 MiB or more
+ *     the library samples the haystack's byte histogram in front of the first scan and filters THAT haystack with the needle's
+ *     rarest bytes under it when that promises 16 x fewer candidates (non-Latin UTF-8 text, padding patterns: bytes the static
+ *     ranking takes for rare); ss_searcher_filter3 keeps reporting the static choice.
  *   ss_searcher_set_filter3 sets the triple verbatim (third == second: a plain two-byte filter, e.g. the reference's own
  *     pair (0, n-1)).  A pair 16 or more apart has no third byte and runs on the cross-lane kernels; beyond 16 * 63 bytes
  *     apart the device filters with `first` and two bytes close behind it and tests the caller's `second` first thing when a

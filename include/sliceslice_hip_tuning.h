@@ -75,8 +75,10 @@ SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
 /* The candidate census of (`s`, d_haystack, len) on the current device, if its counts are in: counts[0] = wave-tiles sampled (0:
  * no census yet), [1] = tiles with a candidate of the device's three filter bytes, [2] = tiles with a candidate of the first two
  * alone, [3] = tiles in which a candidate's first 64 bytes equal the needle's, [4] = candidate lanes; and [5] = the kernel family of
- * the searcher's latest launch on the device (0 single stream, 2 / 3 cross-lane with / without the third byte).  Launches nothing. */
-SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[6]);
+ * the searcher's latest launch on the device (0 single stream, 2 / 3 cross-lane with / without the third byte); [6..8] = the three
+ * filter bytes the device tests on THIS haystack (the searcher's own, or the triple chosen from the haystack's histogram); [9] = 0 not
+ * decided / 1 the searcher's own / 2 the histogram's; [10] = histogram triples put on trial so far.  Launches nothing. */
+SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[11]);
 
 /* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */
 SS_API int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches, uint64_t *settled);

@@ -26,7 +26,7 @@ _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_CSRC, "libsliceslice_hip.so")
 _TOOLS_SO = os.path.join(_CSRC, "libsliceslice_hip_tools.so")
 # host-side translation units (ss_internal.hpp lists what each holds) ...
-_HOST_SOURCES = ["ss_core.hip", "ss_scan.hip", "ss_host.hip", "ss_batched.hip", "ss_service.hip", "ss_comm.hip"]
+_HOST_SOURCES = ["ss_core.hip", "ss_scan.hip", "ss_census.hip", "ss_host.hip", "ss_batched.hip", "ss_service.hip", "ss_comm.hip"]
 # ... and the scan kernel family, one explicit-instantiation unit per (U, load flavour, search / find).  The product holds what
 # the constructors and ss_searcher_set_filter3 can select (scan_launch.hpp::kernel_built): U = 4, non-temporal loads.
 _KERNEL_SOURCES = ["scan_inst_u4_nt1.hip", "scan_inst_find_nt1.hip"]

@@ -442,6 +442,7 @@ int store_filter(ss_searcher *s, size_t fa, size_t fb, size_t fc)
     s->fa = fa;
     s->fb = fb;
     s->fc = fc;
+    s->auto_filter = false;         // the caller chose
     ++s->filter_gen;
     derive_device_filter(s);
     s->gate.store(0, std::memory_order_release);
@@ -469,6 +470,7 @@ int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_fi
     if (auto_filter) choose_filter_triple(s->needle.data(), n, &s->fa, &s->fb, &s->fc, cost);
     else filter_for_position(s->needle.data(), n, position, &s->fa, &s->fb, &s->fc, cost);
     derive_device_filter(s);
+    s->auto_filter = auto_filter;
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) {      // uploads the needle to the current device now
         delete s;

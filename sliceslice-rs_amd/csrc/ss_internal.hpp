@@ -3,6 +3,7 @@
 //
 //   ss_core.hip     errors, device info, control-block pools, ss_searcher (constructors, filter-byte choice, accessors)
 //   ss_scan.hip     kernel selection, the Problem of a (searcher, haystack), enqueue_scan, ss_search_device / ss_find_device
+//   ss_census.hip   what a searcher learns about a haystack by asking it: candidate census, byte histogram -> launch hints
 //   ss_host.hip     host-slice and host-file front ends, the byte histogram (rows f2, f3 of SURVEY.md 8f)
 //   ss_batched.hip  batched search / find, batch plans, short-haystack pairs (config 5, row f4)
 //   ss_service.hip  the resident search service
@@ -103,6 +104,11 @@ struct PerDevice {
         uint32_t tag = 0;
         uint32_t uses = 0;          // scans that went by these counts (the census is repeated every 256: a buffer may be refilled in place)
         uint64_t sums = 0;          // tiles3 | tiles2 << 11 | match tiles << 22 | candidate lanes << 33 (aux_kernels.hpp)
+        uint32_t triple_state = 0;  // the filter bytes on THIS haystack: 0 = not decided, 1 = the searcher's own, 2 = tri[] (ss_census.hip)
+        size_t tri[3] = {0, 0, 0};
+        bool trial = false;         // tri[] has not been counted yet; sums_own = the counts of the searcher's own triple
+        uint64_t sums_own = 0;
+        uint32_t trials = 0;        // triples from the histogram that have been put on trial (diagnostics)
         uint64_t stamp = 0;
     } census[4];
     uint32_t census_lock = 0, census_tag = 0;
@@ -147,6 +153,7 @@ struct ss_searcher {
     size_t da = 0, db = 0, dc = 0;  // the triple the device tests (derive_device_filter): == fa, fb, fc unless the pair is too far apart
     size_t far = 0;                 // ... then: the caller's far byte (== fb), tested first when a candidate reaches memory; else 0
     uint32_t filter_gen = 0;        // bumped by every rewrite of the triple: census counts taken with an older triple are stale
+    bool auto_filter = false;       // built by ss_searcher_new and not touched since: the library chose the triple and may choose again per haystack
     int variant = 0;          // tuning builds only (ss_searcher_set_variant / _set_grid); 0 = automatic
     int grid = 0;
     bool timing = false;
@@ -207,6 +214,20 @@ struct ByteCost {
 };
 size_t choose_third(const uint8_t *needle, size_t n, size_t fa, size_t fb, const ByteCost &cost, size_t other = ~(size_t)0);
 
+// ---- ss_census.hip ----------------------------------------------------------------------------------------------------
+// What the haystack has told this searcher so far (launch tuning only).  Scans of less than kCensusMinBytes are not asked.
+constexpr size_t kCensusMinBytes = (size_t)256 << 20;
+struct LaunchHints {
+    bool have_counts;           // the census of (searcher, haystack) is in:
+    int workgroups_per_cu;      //   four or six
+    bool sparse_pair;           //   the first two filter bytes alone rarely match (cross-lane kernels: no third byte needed)
+    bool have_triple;           // filter bytes chosen from the haystack's histogram (ss_searcher_new searchers only):
+    size_t tri[3];              //   first <= second, third, all within 15 of the first
+};
+// Looks up - and, when nothing is known and the stream is not being captured, starts - the census and the histogram sampling in
+// front of the caller's scan on `st`.  Never waits.
+void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, LaunchHints *out);
+
 // ---- ss_scan.hip ------------------------------------------------------------------------------------------------------
 // What a launch needs to know about a Problem besides the Problem itself.
 struct ProblemShape {
@@ -216,8 +237,9 @@ struct ProblemShape {
 };
 // The Problem of (searcher, haystack): everything but the sink-side fields (epoch, host_flag, completion word), which the caller
 // sets.  Preconditions: 1 <= n <= len.
+// `triple` != nullptr: filter bytes chosen for this haystack instead of the searcher's own (all within 16 bytes of the first).
 void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_hay, size_t len, uint64_t find_base, ss::Problem *out,
-                  ProblemShape *shape);
+                  ProblemShape *shape, const size_t *triple = nullptr);
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, set to `epoch` by the wave that
 // finds the needle, never cleared.  find == true: *d_sink is a uint64, atomicMin'ed with find_base + offset of every match the grid
 // sees (the leftmost one survives).  Preconditions: 1 <= n <= len.  done_slot >= 0: the call owns flag slot `done_slot` and would

@@ -10,7 +10,6 @@
 #include <algorithm>
 
 #define SS_AUX_PUBLISH 1
-#define SS_AUX_CENSUS 1
 #include "aux_kernels.hpp"
 #include "scan_launch.hpp"
 
@@ -105,31 +104,7 @@ struct Launch {
 // transposition into the 16-byte layout on top of the regular filter.  Automatic choice: one-byte needles
 // only; 2xxx variants force it for tuning.
 
-// Workgroups per CU.  Four suit a scan that rarely meets a candidate, six one that keeps meeting them (pick_variant has the
-// measurements), and which of the two a haystack is cannot be told from the needle: a text-like needle on binary data gave up 3-5 %
-// under the needle-byte guess, a stock phrase of the manual with rare-looking bytes 15-20 % the other way.  Round 4 LEARNED the
-// setting from the wall-clock time of a searcher's own full scans; its own records showed it misjudging by up to 10 % (a 1.5 %
-// threshold against 1 % timing noise and 2-3 % drift), its explorations landed inside timed regions, and a call's cost depended on
-// the calls before it.  Now the haystack is ASKED, once: the first scan of a (searcher, haystack) pair of at least kCensusMinBytes
-// is preceded - on the same stream, the host does not wait - by census_kernel (aux_kernels.hpp), which puts kCensusTiles sampled
-// wave-tiles through the searcher's own filter bytes and counts the tiles that hold a candidate.  From the second scan on the
-// count decides (census_choice): deterministic for a given haystack and needle, nothing in the scan kernels, nothing timed.  The
-// first scan, and every scan of less than kCensusMinBytes, goes by the needle-byte guess.  A searcher whose latest synchronous
-// search FOUND the needle launches with four: a grid that leaves early drains faster with fewer workgroups resident (`the` on 1 GiB
-// of text: 0.035 ms at four, 0.060 at six).
-constexpr size_t kCensusMinBytes = (size_t)256 << 20;
-// Six workgroups per CU when at least kCensusDenseTiles of the kCensusTiles sampled tiles hold a candidate of the device's filter,
-// or when the candidates crowd (kCensusDenseLanes candidate lanes in the sample).  Read from 96 (phrase, filter) cases on 1 GiB of
-// the i386 text and on random bytes, each timed at forced four and six in one process (tools/occ_census.py,
-// profiles/r05/occ_census.jsonl): below ~40 candidate tiles in 1,024 four is 3-8 % faster, above ~70 six is - by 3 % at 70, 10-30 %
-// from 150 on - and in between the two are within 3 % of each other; any threshold from 40 to 56 loses 0.3 % on average over the
-// set against always picking the faster one (four everywhere: 7 %, six everywhere: 3 %).
-constexpr uint32_t kCensusDenseTiles = 48, kCensusDenseLanes = 256;
-// Filter pairs 16 or more apart (ss_searcher_set_filter3 only; the cross-lane kernels): the third first-phase byte pays on text,
-// where the reference's own pair (0, n-1) passes at percent rates, and costs 2-3 % where the pair alone rarely matches.  The pair
-// runs alone (MODE 3) when at most this many of the sampled tiles hold a candidate of the PAIR (random bytes: ~63 of 1,024).
-constexpr uint32_t kCensusSparsePairTiles = 128;
-constexpr uint32_t kCensusRefreshEvery = 256;      // scans of one (searcher, haystack) pair between two censuses of it
+// (Workgroups per CU, the pair-alone kernels and the filter bytes of `new`-built searchers on large haystacks: ss_census.hip.)
 constexpr int kAutoU = 4;
 constexpr int kAutoTilesPerBlock = 2;    // 32 KiB contiguous per workgroup at U = 4 (profiles/r01/tiles_per_block_sweep.jsonl)
 
@@ -222,7 +197,7 @@ constexpr uint64_t kDoneMaxBlocks = 256;         // one atomic per workgroup on 
 }  // namespace
 
 void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_hay, size_t len, uint64_t find_base, ss::Problem *out,
-                  ProblemShape *shape)
+                  ProblemShape *shape, const size_t *triple)
 {
     ss::Problem &pr = *out;
     const size_t n = s->n;
@@ -231,7 +206,9 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     // and hay[fb + i] == needle[fb], so the kernel's aligned coordinates are those of hay + fa, while matches
     // are verified (and reported) at hay + i.  Bytes in front of hay + fa are never candidates (their index
     // wraps and fails `i < end`), and the last byte either stream touches is hay[len - n + fb] <= hay[len - 1].
-    const size_t fa = one_byte ? 0 : s->da, fb = one_byte ? 0 : s->db;      // the triple the DEVICE tests (derive_device_filter)
+    // the triple the DEVICE tests: the searcher's (derive_device_filter), or the one chosen for this haystack (ss_census.hip)
+    const size_t fa = one_byte ? 0 : (triple ? triple[0] : s->da), fb = one_byte ? 0 : (triple ? triple[1] : s->db);
+    const size_t fc = triple ? triple[2] : s->dc;
     const uint8_t *hf = static_cast<const uint8_t *>(d_hay) + fa;
     pr.hay = static_cast<const uint8_t *>(d_hay);
     pr.mis = (uint32_t)((uintptr_t)hf & 15);
@@ -245,8 +222,8 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.d = position / 16;
     // third first-phase byte, at most 15 behind the first; "none" (needles of two bytes) = needle[fa + position % 16] once more -
     // any (byte, offset) of the needle is a valid condition
-    const bool three = !one_byte && s->dc > fa && s->dc - fa <= 15 && s->dc < n && s->dc != fb;
-    size_t position3 = three ? s->dc - fa : position % 16;
+    const bool three = !one_byte && fc > fa && fc - fa <= 15 && fc < n && fc != fb;
+    size_t position3 = three ? fc - fa : position % 16;
     // The two further bytes are interchangeable; the kernels are instantiated for "the third byte's dword is not behind
     // the second's" only (10 copies of the first phase instead of 16 - and two of the six others, second byte in dword 0
     // with the third in dword 1 or 3, came out of the compiler waiting for all four loads of a tile before the first
@@ -270,7 +247,7 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     pr.done_target = pr.done_hi = 0;
     pr.flags = 0;
     pr.q = (uint32_t)(sh / 4);
-    pr.far_off = one_byte ? 0 : (uint64_t)s->far;
+    pr.far_off = one_byte || triple ? 0 : (uint64_t)s->far;
     // exact in-register verification: the needle ends at most 16 bytes behind the first filter byte (lib.rs:222-241)
     pr.exact_len = 0;
     pr.tail16[0] = pr.tail16[1] = pr.tail16[2] = pr.tail16[3] = 0;
@@ -288,101 +265,6 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
     shape->one_byte = one_byte;
 }
 
-// ---- the candidate census ---------------------------------------------------------------------------------------------
-namespace {
-
-struct CensusCounts {
-    uint32_t tiles3, tiles2, match_tiles, lanes;
-};
-CensusCounts census_counts(uint64_t sums)
-{
-    return {(uint32_t)(sums & 2047u), (uint32_t)((sums >> 11) & 2047u), (uint32_t)((sums >> 22) & 2047u), (uint32_t)(sums >> 33)};
-}
-
-// What is known about (hay, len) under the searcher's current filter bytes; launches the census in front of the caller's scan
-// when nothing is, nothing else is in flight and the stream is not being captured.  Returns true with the counts when they are in.
-bool census_lookup(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, CensusCounts *out)
-{
-    if (__atomic_exchange_n(&pd->census_lock, 1u, __ATOMIC_ACQUIRE) != 0) return false;     // another thread is at it
-    struct Unlock {
-        uint32_t *w;
-        ~Unlock() { __atomic_store_n(w, 0u, __ATOMIC_RELEASE); }
-    } unlock{&pd->census_lock};
-    if (pd->census_pending >= 0) {
-        PerDevice::Census &c = pd->census[pd->census_pending];
-        if (__atomic_load_n(pd->h_census + 1, __ATOMIC_ACQUIRE) == (unsigned long long)c.tag) {
-            c.sums = __atomic_load_n(pd->h_census, __ATOMIC_RELAXED);
-            c.state = 2;
-            pd->census_pending = -1;
-        }
-    }
-    PerDevice::Census *hit = nullptr, *victim = &pd->census[0];
-    for (auto &c : pd->census) {
-        if (c.state != 0 && c.hay == d_hay && c.len == len && c.gen == s->filter_gen) hit = &c;
-        if (c.state != 1 && (victim->state == 1 || c.stamp < victim->stamp)) victim = &c;
-    }
-    PerDevice::Census *target = victim;
-    bool have = false;
-    if (hit) {
-        hit->stamp = ++pd->census_clock;
-        if (hit->state != 2) return false;
-        *out = census_counts(hit->sums);
-        have = true;
-        // A buffer may be refilled in place: the counts are taken again every kCensusRefreshEvery scans (the old ones serve until
-        // the new ones are in).
-        if (++hit->uses % kCensusRefreshEvery != 0) return true;
-        target = hit;
-    }
-    if (pd->census_pending >= 0 || (!hit && victim->state == 1)) return have;                 // one census in flight per searcher and device
-    const size_t n = s->n, end = len - n + 1;
-    if (end < 2 * (size_t)ss::kCensusTileBytes + 8) return have;
-    const uint64_t room = end - 4 - ss::kCensusTileBytes;                                     // latest start of a sampled tile
-    const uint64_t stride = (room / (ss::kCensusTiles - 1)) & ~(uint64_t)(ss::kCensusTileBytes - 1);
-    if (stride < ss::kCensusTileBytes) return have;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return have;                                                                           // a graph would replay the census for nobody
-    }
-    ss::CensusArgs a;
-    a.hay = static_cast<const uint8_t *>(d_hay);
-    a.needle = pd->d_needle;
-    a.stride = stride;
-    a.oa = (uint32_t)s->da;
-    a.ob = (uint32_t)s->db;
-    a.oc = (uint32_t)s->dc;
-    a.bytes = (uint32_t)s->needle[s->da] | ((uint32_t)s->needle[s->db] << 8) | ((uint32_t)s->needle[s->dc] << 16);
-    a.ncheck = (uint32_t)std::min<size_t>(n, ss::kCensusCheck);
-    a.nblocks = ss::kCensusTiles / ss::kWavesPerBlock;
-    if (++pd->census_tag == 0) pd->census_tag = 1;
-    a.tag = pd->census_tag;
-    a.d_acc = pd->d_census;
-    a.h_out = pd->h_census;
-    ss::census_kernel<<<dim3(a.nblocks), dim3(ss::kBlock), 0, st>>>(a);
-    if (hipGetLastError() != hipSuccess) return have;
-    if (!hit) {
-        target->hay = d_hay;
-        target->len = len;
-        target->gen = s->filter_gen;
-        target->state = 1;
-        target->sums = 0;
-        target->uses = 0;
-        target->stamp = ++pd->census_clock;
-    }
-    target->tag = a.tag;
-    pd->census_pending = (int)(target - pd->census);
-    return have;
-}
-
-// Four or six workgroups per CU from the census counts (see "Workgroups per CU" above).
-int census_choice(const CensusCounts &c)
-{
-    if (c.match_tiles != 0) return 4;                   // the needle (or its first kCensusCheck bytes) is in the sample: an early answer
-    return c.tiles3 >= kCensusDenseTiles || c.lanes >= kCensusDenseLanes ? 6 : 4;
-}
-
-}  // namespace
-
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find,
                  uint64_t find_base, int *host_flag, int epoch, int done_slot, bool *used_done)
 {
@@ -391,30 +273,30 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
         return fail(SS_ERR_HIP, "injected scan failure (ss_debug_fail_next_scans)");
 #endif
     void *d_flag = d_sink;
+    // what the haystack has said so far (ss_census.hip): candidate counts of this searcher's filter, perhaps better filter bytes
+    LaunchHints hints;
+    launch_hints(s, pd, d_hay, len, st, &hints);
     ss::Problem pr;
     ProblemShape ps;
-    fill_problem(s, pd->d_needle, d_hay, len, find_base, &pr, &ps);
+    fill_problem(s, pd->d_needle, d_hay, len, find_base, &pr, &ps, hints.have_triple ? hints.tri : nullptr);
     pr.host_flag = host_flag;
     pr.epoch = epoch;
     const bool one_byte = ps.one_byte;
     const size_t fa = ps.fa, position = ps.position, position3 = ps.position3;
     const uint32_t sh = (uint32_t)(position % 16);
 
-    // Workgroups per CU (see "Workgroups per CU" above).  Without census counts: a guess from the NEEDLE (every filter byte
-    // text-like -> the haystack is presumably text; single-stream kernels only).
+    // Workgroups per CU.  Without census counts: a guess from the NEEDLE (every filter byte text-like -> the haystack is
+    // presumably text; single-stream kernels only) - or four, when the filter bytes have just been chosen for being rare HERE.
     const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
                            ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
-    int occ = !one_byte && text_like && pr.d == 0 ? 6 : 4;
+    int occ = !one_byte && text_like && pr.d == 0 && !hints.have_triple ? 6 : 4;
     bool pair_alone = false;
-    if (!one_byte && len >= kCensusMinBytes) {
-        CensusCounts cc;
-        if (census_lookup(s, pd, d_hay, len, st, &cc)) {
-            occ = census_choice(cc);
-            // a pair 16 or more apart that rarely matches on this haystack needs no third byte in the first phase (MODE 3)
-            pair_alone = pr.d != 0 && !find && cc.tiles2 <= kCensusSparsePairTiles;
-        }
-        if (__atomic_load_n(&pd->last_found, __ATOMIC_RELAXED) != 0) occ = 4;
+    if (hints.have_counts) {
+        occ = hints.workgroups_per_cu;
+        // a pair 16 or more apart that rarely matches on this haystack needs no third byte in the first phase (MODE 3)
+        pair_alone = pr.d != 0 && !find && hints.sparse_pair;
     }
+    if (!one_byte && len >= kCensusMinBytes && __atomic_load_n(&pd->last_found, __ATOMIC_RELAXED) != 0) occ = 4;
     Launch l = pick_variant(s->variant, pr.d, one_byte, occ, pair_alone);
     if (find && l.mode == 3) l.mode = 2;                     // find() has no pair-alone kernels
     if (l.mode == 3)                                        // the third byte goes back into the second level's schedule
@@ -568,38 +450,6 @@ int ss_searcher_last_launch(const ss_searcher *s, int *workgroups_per_cu, unsign
     *grid = __atomic_load_n(&pd->last_grid, __ATOMIC_RELAXED);
     return SS_OK;
 }
-
-#ifdef SS_TEST_HOOKS
-int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[6])
-{
-    if (!s || !counts) return fail(SS_ERR_ARGUMENT, "NULL argument");
-    PerDevice *pd = nullptr;
-    if (int rc = get_per_device(s, &pd)) return rc;
-    CensusCounts cc = {0, 0, 0, 0};
-    counts[0] = 0;
-    // (enqueue nothing: a null stream is never captured, but this call must not launch - look the entry up by hand)
-    while (__atomic_exchange_n(&pd->census_lock, 1u, __ATOMIC_ACQUIRE) != 0) cpu_relax();
-    for (auto &c : pd->census) {
-        if (c.state == 1 && pd->census_pending == (int)(&c - pd->census) &&
-            __atomic_load_n(pd->h_census + 1, __ATOMIC_ACQUIRE) == (unsigned long long)c.tag) {
-            c.sums = __atomic_load_n(pd->h_census, __ATOMIC_RELAXED);
-            c.state = 2;
-            pd->census_pending = -1;
-        }
-        if (c.state == 2 && c.hay == d_haystack && c.len == len && c.gen == s->filter_gen) {
-            cc = census_counts(c.sums);
-            counts[0] = ss::kCensusTiles;
-        }
-    }
-    __atomic_store_n(&pd->census_lock, 0u, __ATOMIC_RELEASE);
-    counts[1] = cc.tiles3;
-    counts[2] = cc.tiles2;
-    counts[3] = cc.match_tiles;
-    counts[4] = cc.lanes;
-    counts[5] = (uint32_t)__atomic_load_n(&pd->last_mode, __ATOMIC_RELAXED);
-    return SS_OK;
-}
-#endif
 
 int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms)
 {

@@ -392,10 +392,12 @@ class DynamicHipSearcher:
 
     def census(self, haystack):
         """Hooks builds: the candidate census of (this searcher, haystack) as a dict, or None when its counts are not in."""
-        c = (ctypes.c_uint32 * 6)()
+        c = (ctypes.c_uint32 * 11)()
         ptr, n = haystack.data_ptr(), haystack.numel()
         self._ck(_hooks(self._L).ss_debug_census(self._h, ptr, n, c))
         self.last_mode = int(c[5])                          # kernel family of the latest launch (0, 2 or 3)
+        self.device_filter = (int(c[6]), int(c[7]), int(c[8]))      # the bytes the device tests on this haystack
+        self.triple_state, self.triple_trials = int(c[9]), int(c[10])  # 0 undecided / 1 own / 2 from the histogram; trials so far
         if c[0] == 0:
             return None
         return {"tiles": c[0], "tiles3": c[1], "tiles2": c[2], "match_tiles": c[3], "lanes": c[4]}

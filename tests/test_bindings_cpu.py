@@ -305,7 +305,7 @@ def _family(name):
 def test_kernels_the_library_launches_by_default_keep_four_waves_per_simd():
     """build() records what the register allocator did with every kernel (csrc/kernel_resources.json).  The product library
     holds exactly what the constructors and ss_searcher_set_filter3 can select - 22 scan kernels (scan_launch.hpp::kernel_built),
-    34 kernels in all; the tuning residue (U = 8, plain loads, two-byte 8-byte phases) lives in the tuning build, and the
+    35 kernels in all; the tuning residue (U = 8, plain loads, two-byte 8-byte phases) lives in the tuning build, and the
     two-stream kernels of rounds 1-3 (MODE 1) are gone.  Every one of them keeps >= 4 waves per SIMD, without scratch and without
     spilled vector registers - which side of a register-count step a kernel lands on has moved with unrelated edits before (at
     three waves the scan runs at 6.3 TB/s) - and within its family's ceiling of spilled scalar registers."""

@@ -600,3 +600,85 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             assert s.search_in(text) is False
         assert s.census(text) == _census_model(rnd_host, b"segment descriptor table entries are", s.filter3)
         assert s.search_in(text) is False and s.last_launch()[0] == 4
+
+
+def _non_latin_haystack(n_bytes, seed):
+    """UTF-8-like text in a non-Latin script: two-byte letters (lead 0xD0 / 0xD1, trail 0x80..0xBF with a skewed distribution),
+    blanks, a few digits.  Every other byte is a lead byte - which the static rarity ranking takes for rare."""
+    rng = np.random.default_rng(seed)
+    pairs = n_bytes // 2
+    lead = rng.choice(np.array([0xD0, 0xD1], dtype=np.uint8), size=pairs, p=[0.6, 0.4])
+    trail = (0x80 + np.minimum(rng.geometric(0.08, size=pairs) - 1, 63)).astype(np.uint8)
+    a = np.empty(pairs * 2, dtype=np.uint8)
+    a[0::2], a[1::2] = lead, trail
+    blanks = rng.integers(0, pairs, size=pairs // 7)
+    a[2 * blanks] = 0x20
+    a[2 * blanks + 1] = 0x20
+    digits = rng.integers(0, pairs * 2, size=pairs // 200)
+    a[digits] = rng.integers(0x30, 0x3A, size=digits.size).astype(np.uint8)
+    return a
+
+
+@pytest.mark.gpu
+def test_filter_bytes_follow_the_haystacks_histogram(O):
+    """Row f3 of SURVEY.md 8f without the caller asking: a searcher built by `new` starts with the static, corpus-free choice of filter
+    bytes; on a haystack of 256 MiB or more the library samples the haystack's byte histogram next to the candidate census
+    (ss_census.hip) and, when the histogram promises 16 x fewer candidates for other bytes of the needle, filters THIS haystack with
+    those - on trial: if the census then counts MORE candidate tiles than the searcher's own triple had, the own triple stays.
+    Answers never change; `filter3` keeps reporting the searcher's own choice; `with_position` / `set_filter` searchers keep theirs."""
+    import sliceslice_rs_amd as ss
+    n_bytes = 512 << 20
+    with ss.tuning_build():
+        host = _non_latin_haystack(n_bytes, 7)
+        hay = torch.from_numpy(host).cuda()
+        word = bytes(host[1000:1016]) + b"e" + bytes(host[2000:2008])           # 'e' never occurs in this haystack
+        assert b"e"[0] not in host[: 1 << 20]
+        s = ss.DynamicHipSearcher.new(word)
+        own = s.filter3
+        assert 16 not in own, "the static ranking takes 'e' for the needle's most common byte"
+        assert s.search_in(hay) is False                       # first scan: the searcher's own triple; census + histogram sampled
+        first = s.census(hay)
+        assert s.device_filter == own and first == _census_model(host, word, own) and first["tiles3"] > 48
+        assert s.search_in(hay) is False                       # second scan: the histogram is in -> a triple with the 'e', on trial
+        s.census(hay)
+        assert 16 in s.device_filter and s.filter3 == own and s.triple_trials == 1 and s.triple_state == 2
+        assert s.search_in(hay) is False                       # third: its own census is in
+        settled = s.census(hay)
+        assert settled == _census_model(host, word, s.device_filter) and settled["tiles3"] == 0
+        assert 16 in s.device_filter and s.last_launch()[0] == 4
+        # answers: planted at the end, found; find() agrees; the caller's choices are not overridden
+        host2 = host.copy()
+        host2[n_bytes - len(word):] = np.frombuffer(word, dtype=np.uint8)
+        hay2 = torch.from_numpy(host2).cuda()
+        for _ in range(3):
+            assert s.search_in(hay2) is True and s.find(hay2) == n_bytes - len(word)
+        wp = ss.DynamicHipSearcher.with_position(word, len(word) - 1)
+        sf = ss.DynamicHipSearcher.new(word)
+        sf.set_filter(*own)
+        for t in (wp, sf):
+            for _ in range(3):
+                assert t.search_in(hay) is False
+            t.census(hay)
+            assert t.device_filter == t.filter3, "with_position / set_filter searchers keep their bytes"
+        del hay2
+
+        # the trial: a byte that is rare overall but comes in RUNS.  The histogram prefers it, the census says no, the own triple stays.
+        # (another length: the histogram is remembered per (pointer, length), and the allocator may hand out the same pointer again)
+        n_bytes += 1 << 20
+        rng = np.random.default_rng(11)
+        letters = np.frombuffer(b"bcdfghjklmnopqrstuvwxyz", dtype=np.uint8)
+        host = letters[rng.integers(0, letters.size, size=n_bytes)]
+        runs = rng.integers(0, n_bytes // 64 - 1, size=n_bytes // 6400)
+        for r in runs[:200000]:
+            host[64 * r:64 * r + 64] = ord("e")
+        hay = torch.from_numpy(host).cuda()
+        word = b"eeeb" + bytes(letters[rng.integers(0, letters.size, size=12)])
+        want = O.OracleSearcher(word).search_in(host[: 64 << 20])      # (a 16-byte needle of random letters: absent in practice)
+        s = ss.DynamicHipSearcher.new(word)
+        own = s.filter3
+        assert not {0, 1, 2} & set(own), "the static ranking avoids 'e'"
+        for _ in range(4):
+            assert s.search_in(hay) is want
+        s.census(hay)                                       # (the trial is settled by the time a synchronous search has returned)
+        assert s.triple_trials == 1 and s.triple_state == 1 and s.device_filter == own, (s.triple_trials, s.triple_state, s.device_filter)
+        assert s.census(hay) == _census_model(host, word, own)
