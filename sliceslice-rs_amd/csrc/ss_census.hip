@@ -225,7 +225,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     // the filter bytes themselves (searchers built by ss_searcher_new only): decided once per (searcher, haystack), when the
     // haystack's histogram is in
     bool recount = false;
-    if (s->auto_filter && s->n >= 3) {
+    if (s->auto_filter && s->n >= 3 && (!hit || hit->triple_state == 0)) {       // (decided once per census entry)
         uint64_t hist[256];
         const bool have_hist = stats_lookup(pd->dev, d_hay, len, st, hist);
         if (have_hist && hit && hit->triple_state == 0 && hit->state == 2) {
