@@ -423,6 +423,48 @@ int main(int argc, char **argv)
         (void)hipFree(d_rng);
     }
 
+    // ---- what a searcher learns about a large haystack (ss_census.hip): the candidate census and the per-device byte histogram,
+    // looked up and started by many threads on ONE handle and by several handles on one haystack at once; a haystack whose most
+    // frequent bytes look rare to the static ranking, so that the histogram's triple is adopted while the others keep searching
+    {
+        const size_t big = (260u << 20) + 17;
+        uint8_t *d_big = nullptr;
+        CHECK(hipMalloc((void **)&d_big, big) == hipSuccess);
+        std::vector<uint8_t> h_big(big);
+        for (size_t i = 0; i < big; ++i) h_big[i] = (i & 1) ? (uint8_t)(0x80 + ((i * 2654435761u) >> 27)) : (uint8_t)(0xD0 + ((i >> 1) & 1));
+        const uint8_t word[] = {0xD0, 0x81, 0xD1, 0x9C, 0xD0, 0xBE, 0xD1, 0x83, 0xD0, 0x80, 0xD1, 0x8F, 0xD0, 0x99, 0xD1, 0x82, 'e', 0xD0, 0x85};
+        std::memcpy(h_big.data() + big - sizeof word, word, sizeof word);
+        CHECK(hipMemcpy(d_big, h_big.data(), big, hipMemcpyHostToDevice) == hipSuccess);
+        ss_searcher *shared = nullptr;
+        CHECK(ss_searcher_new(word, sizeof word, &shared) == SS_OK);
+        std::vector<std::thread> many;
+        for (int t = 0; t < 12; ++t)
+            many.emplace_back([&, t]() {
+                ss_searcher *mine = nullptr;
+                uint8_t w2[sizeof word];
+                std::memcpy(w2, word, sizeof word);
+                w2[1] = (uint8_t)(0x80 + t);                    // twelve more needles on the same haystack: one histogram serves all
+                TCHECK(ss_searcher_new(w2, sizeof w2, &mine) == SS_OK);
+                for (int it = 0; it < 6; ++it) {
+                    int found = -1;
+                    uint64_t pos = 1;
+                    TCHECK(ss_search_device(shared, d_big, big, nullptr, &found) == SS_OK && found == 1);
+                    TCHECK(ss_find_device(shared, d_big, big, nullptr, &pos) == SS_OK && pos == big - sizeof word);
+                    TCHECK(ss_search_device(shared, d_big, big - 1, nullptr, &found) == SS_OK && found == 0);      // (another length: another census)
+                    TCHECK(ss_search_device(mine, d_big, big, nullptr, &found) == SS_OK && found == (t == 1));
+                }
+                ss_searcher_free(mine);
+            });
+        for (auto &t : many) t.join();
+        CHECK(g_failures == 0);
+        int wg = 0;
+        unsigned grid = 0;
+        CHECK(ss_searcher_last_launch(shared, &wg, &grid) == SS_OK && (wg == 4 || wg == 6) && grid > 0);
+        ss_searcher_free(shared);
+        (void)hipFree(d_big);
+        std::puts("census and histogram from 12 threads ok");
+    }
+
     ss_searcher_free(s);
     (void)hipFree(d_no);
     (void)hipFree(d_yes);
