@@ -385,6 +385,43 @@ def other_configs(ss, shard, reps=20):
     except Exception as e:      # pragma: no cover
         out["text_error"] = repr(e)
 
+    # row f3 made automatic: a haystack whose most frequent bytes LOOK rare to the static ranking (UTF-8-like text in a non-Latin
+    # script: lead bytes 0xD0 / 0xD1, trail bytes 0x80..0xBF, blanks) - `new` (filter bytes re-chosen from the haystack's own
+    # histogram, ss_census.hip) next to the same needles with the static triple pinned
+    try:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(7)
+        pairs = gib // 2
+        lead = (0xD0 + (torch.rand(pairs, device="cuda", generator=g) < 0.4).to(torch.uint8))
+        trail = (0x80 + torch.clamp((torch.log(torch.rand(pairs, device="cuda", generator=g).clamp_min(1e-9)) / np.log(1 - 0.08)).floor(), 0, 63)).to(torch.uint8)
+        nl = torch.stack((lead, trail), dim=1).reshape(-1).contiguous()
+        blanks = torch.randint(0, pairs, (pairs // 7,), device="cuda", generator=g)
+        nl[2 * blanks] = 0x20
+        nl[2 * blanks + 1] = 0x20
+        del lead, trail, blanks
+        rows = []
+        for k, ln in enumerate((12, 16, 32)):
+            w = bytearray(nl[2 * (1000 + 77 * k):2 * (1000 + 77 * k) + ln].cpu().numpy().tobytes())
+            w[ln // 2 | 1] = w[1] = 0xBF                       # the rarest trail byte, twice: the word is absent
+            auto = ss.DynamicHipSearcher.new(bytes(w))
+            pinned = ss.DynamicHipSearcher.new(bytes(w))
+            pinned.set_filter(*pinned.filter3)                  # the same static triple, the histogram-driven choice switched off
+            for s_ in (auto, pinned):
+                for _ in range(4):
+                    s_.search_in(nl)
+            ra, ma = median_kernel_ms(auto, nl, reps)
+            rp, mp = median_kernel_ms(pinned, nl, reps)
+            rows.append({"needle_len": ln, "found": ra, "static_filter_bytes": list(pinned.filter3),
+                         "automatic": _row(gib, ma, workgroups_per_cu=auto.last_launch()[0]),
+                         "static_triple_pinned": _row(gib, mp, workgroups_per_cu=pinned.last_launch()[0])})
+            assert ra is rp
+        out["text_non_latin"] = {"workload": "1 GiB of UTF-8-like text in a non-Latin script (every other byte a 0xD0 / 0xD1 lead byte), absent words of "
+                                             "its alphabet: `new` - filter bytes re-chosen per haystack from a sampled byte histogram - against "
+                                             "the static, corpus-free triple pinned with ss_searcher_set_filter3", "rows": rows}
+        del nl
+    except Exception as e:      # pragma: no cover
+        out["text_non_latin_error"] = repr(e)
+
     # config 5 and its shapes
     def batched(count, each, total_blob):
         blob = total_blob[:count * each]

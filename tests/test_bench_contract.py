@@ -7,7 +7,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-@pytest.mark.parametrize("rnd", ["r02", "r03"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r05"])
 def test_committed_bench_line_has_the_contract_fields(rnd):
     with open(os.path.join(ROOT, "profiles", rnd, "bench64g.json")) as fh:
         d = json.loads(fh.read())
@@ -26,6 +26,14 @@ def test_committed_bench_line_has_the_contract_fields(rnd):
     assert c["kind"] == "port" and c["unit"] == "GB/s" and c["cores"] >= 1 and "sample" in c and c["value"] > 0
     assert c["cores"] == c["threads_used"] <= c["host_hardware_threads"] and c["host_physical_cores"] >= 1
     assert d["config"]["ranks"] == d["n_gpus"] == 1
+    if rnd == "r05":
+        # round 5: the line says which workgroups-per-CU setting the timed launches ran with (the candidate census decides, not a clock)
+        # and how close the scan came to the box's plain read; the other box's line carries the non-Latin text rows
+        assert d["config"]["workgroups_per_cu_timed"] == {"4": d["steps"]} and r["frac_of_read_ceiling"] >= 0.97
+        other = json.load(open(os.path.join(ROOT, "profiles", rnd, "bench64g_second_box.json")))
+        rows = other["configs"]["text_non_latin"]["rows"]
+        assert len(rows) == 3 and all(x["found"] is False and x["automatic"]["frac"] > 0.9 for x in rows)
+        assert all(x["automatic"]["frac"] >= x["static_triple_pinned"]["frac"] for x in rows)
     if rnd == "r02":
         assert r["traffic_source"].startswith("stored ratio")
     else:                       # since round 3 the counter pass runs inside the bench run, and the launch time is the median

@@ -46,7 +46,7 @@ def main():
         ln = int(rng.choice([8, 12, 16, 24, 32]))
         at = 2 * int(rng.integers(0, n // 2 - 64))
         w = bytearray(host[at:at + ln].tobytes())
-        w[ln // 2 | 1] = 0xBF                                    # the rarest trail byte of the generator
+        w[ln // 2 | 1] = w[1] = 0xBF                             # the rarest trail byte of the generator, twice: absent
         cases.append(("non-latin", bytes(w)))
     for ph in (b"segment descriptor table entries are", b"privilege level zero!", b"there is not another one of these"):
         cases.append(("i386 text", ph))
