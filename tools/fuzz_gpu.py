@@ -105,9 +105,65 @@ def big(seconds, seed, gib):
                       "searches": 4 * rounds}))
 
 
+def nonlatin(seconds, seed):
+    """Haystacks on which the library re-chooses the filter bytes (ss_census.hip): 512 MiB of UTF-8-like text in a non-Latin script
+    (the static rarity ranking is wrong about it), needles cut from the haystack - whole, with one byte changed, with a byte that
+    never occurs - through `new` (automatic: histogram-driven triple, on trial against the census) and `with_position`; six scans
+    per searcher, search_in and find alternating, so that the static triple, the trial and the settled choice all answer."""
+    rng = random.Random(seed)
+    nrng = np.random.default_rng(seed)
+    n_bytes = 512 << 20
+    t_end = time.time() + seconds
+    rounds = searches = adopted = 0
+    while time.time() < t_end:
+        pairs = n_bytes // 2
+        lead = nrng.choice(np.array([0xD0, 0xD1], dtype=np.uint8), size=pairs, p=[0.6, 0.4])
+        trail = (0x80 + np.minimum(nrng.geometric(0.08, size=pairs) - 1, 63)).astype(np.uint8)
+        host = np.empty(n_bytes, dtype=np.uint8)
+        host[0::2], host[1::2] = lead, trail
+        blanks = nrng.integers(0, pairs, size=pairs // 7)
+        host[2 * blanks] = 0x20
+        host[2 * blanks + 1] = 0x20
+        hb = host.tobytes()
+        hay = torch.from_numpy(host).cuda()
+        for _ in range(10):
+            if time.time() >= t_end:
+                break
+            n = rng.choice([3, 4, 8, 12, 16, 17, 24, 32, 64, 200])
+            at = rng.choice([0, n_bytes - n, rng.randrange(n_bytes - n + 1)])
+            nd = bytearray(hb[at:at + n])
+            r = rng.random()
+            if r < 0.35:                                               # near miss: one byte changed
+                k = rng.randrange(n)
+                nd[k] = (nd[k] + 1 + rng.randrange(254)) & 0xFF
+            elif r < 0.55:                                             # a byte that never occurs in the haystack
+                nd[rng.randrange(n)] = rng.choice([0xFF, ord("e"), 0x00])
+            nd = bytes(nd)
+            want = hb.find(nd)
+            pos = None if rng.random() < 0.7 else rng.randrange(n)
+            s = ss.DynamicHipSearcher(nd, pos)
+            for it in range(6):
+                got = s.search_in(hay) if it % 2 == 0 else s.find(hay)
+                ok = got == (want >= 0) if it % 2 == 0 else got == (want if want >= 0 else None)
+                searches += 1
+                if not ok:
+                    print(json.dumps({"MISMATCH": True, "mode": "nonlatin", "needle_len": n, "position": pos, "at": at, "want": want, "scan": it,
+                                      "got": got, "seed": seed, "round": rounds}))
+                    sys.exit(1)
+            if ss.lib().has_hooks:
+                s.census(hay)
+                adopted += s.triple_state == 2
+            rounds += 1
+        del hay
+    print(json.dumps({"fuzz": "ok", "mode": "nonlatin", "seconds": seconds, "seed": seed, "searchers": rounds, "searches": searches,
+                      "triples_from_the_histogram": adopted if ss.lib().has_hooks else None}))
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "nonlatin":               # fuzz_gpu.py SECONDS SEED nonlatin: histogram-driven filter bytes
+        return nonlatin(seconds, seed)
     if len(sys.argv) > 3:                                             # fuzz_gpu.py SECONDS SEED GIB: the large-haystack mode
         return big(seconds, seed, float(sys.argv[3]))
     rng = random.Random(seed)
