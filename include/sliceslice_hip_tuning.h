@@ -8,7 +8,7 @@
  *   2. Tuning knobs and test hooks, exported only by builds with -DSS_TEST_HOOKS (libsliceslice_hip_tuning.so and the
  *      sanitizer builds; the product library has neither the symbols nor the code behind them): kernel-variant and grid
  *      overrides, fault injection, epoch / counter setters, the pure filter-choice helper, service counters.  Hooks builds
- *      also read a few more environment variables (tuning: SLICESLICE_BATCH_WGS, _BATCH_MIN_TILES, _BATCH_OCC;
+ *      also read a few more environment variables (tuning: SLICESLICE_BATCH_WGS, _BATCH_MIN_TILES, _BATCH_OCC, _BATCH_STATIC_CLASSES;
  *      measurement: SLICESLICE_CROSS_EXIT=0, SLICESLICE_SERVICE_HDP_FLUSH=0, SLICESLICE_SERVICE_DEBUG).
  */
 #ifndef SLICESLICE_HIP_TUNING_H
@@ -79,6 +79,11 @@ SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
  * filter bytes the device tests on THIS haystack (the searcher's own, or the triple chosen from the haystack's histogram); [9] = 0 not
  * decided / 1 the searcher's own / 2 the histogram's; [10] = histogram triples put on trial so far.  Launches nothing. */
 SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[11]);
+
+/* What a plan's descriptor of `problem` filters on: out[0..2] = the indices in the needle of the three first-phase bytes (first <=
+ * the other two), out[3] = the bytes themselves (first | second << 8 | third << 16 | one-byte needle << 24), out[4] = the slices
+ * that scan the problem (0: answered without a scan; the indices are 0 then).  Copies 64 bytes from the device. */
+SS_API int ss_debug_plan_filter(const ss_batch_plan *p, size_t problem, uint32_t out[5]);
 
 /* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */
 SS_API int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches, uint64_t *settled);

@@ -65,6 +65,68 @@ constexpr ClassPlanes make_class_planes()
     return p;
 }
 
+// ---- the rarity classes of a PLAN come from its haystacks' own bytes (row f3 of SURVEY.md 8f for config 5) -------------------
+// The static classes above are a corpus-free guess (letters common, everything outside text rare) - right for English text and
+// binaries, exactly wrong where the "rare-looking" bytes are the haystacks' most frequent ones (UTF-8 text in a non-Latin script:
+// every other byte is 0xD0 / 0xD1).  ss_batch_plan_create therefore has batch_sample_kernel take a byte histogram of
+// kPlanSampleTiles pieces of 4 KiB - sample j reads problem (j * count / kPlanSampleTiles) (or j mod count when there are fewer
+// problems than samples) at a pseudo-random offset of its haystack, so aliased ranges (many needles, one text) are sampled all
+// over the text and not kPlanSampleTiles times at its start - and the plan kernel turns the counts into SIXTEEN classes: the
+// number of whole bits in total / count, 15 = every second byte and more, 0 = never seen (or rarer than 1 in 32,768).  Per-wave
+// LDS histograms, one global atomic per non-zero counter and workgroup.  Results never depend on the classes (lib.rs:375-378).
+constexpr uint32_t kPlanSampleTiles = 1024, kPlanSampleBytes = 4096, kPlanSampleBlocks = 64;
+__global__ void __launch_bounds__(kBlock) batch_sample_kernel(const uint8_t *haystacks, const uint64_t *hay_begin, const uint64_t *hay_end,
+                                                               uint64_t count, uint32_t *hist)
+{
+    __shared__ uint32_t h[kWavesPerBlock][256];
+    for (int k = threadIdx.x; k < kWavesPerBlock * 256; k += kBlock) (&h[0][0])[k] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    constexpr uint32_t kPerWave = kPlanSampleTiles / (kPlanSampleBlocks * kWavesPerBlock);
+    for (uint32_t t = 0; t < kPerWave; ++t) {
+        const uint64_t j = ((uint64_t)blockIdx.x * kWavesPerBlock + wave) * kPerWave + t;
+        if (count < kPlanSampleTiles && j >= count * ((kPlanSampleTiles + count - 1) / count)) break;
+        const uint64_t prob = count >= kPlanSampleTiles ? j * count / kPlanSampleTiles : j % count;
+        const uint64_t h0 = hay_begin[prob], h1 = hay_end[prob];
+        if (h1 <= h0) continue;
+        const uint64_t len = h1 - h0;
+        uint64_t off = 0, take = len;
+        if (len > kPlanSampleBytes) {
+            const uint64_t frac = ((uint32_t)j * 2654435761u) >> 8;                 // 24 pseudo-random bits per sample
+            off = (uint64_t)(((unsigned __int128)(len - kPlanSampleBytes) * frac) >> 24);
+            take = kPlanSampleBytes;
+        } else if (count < kPlanSampleTiles && j >= count) {
+            continue;                                                               // a short haystack is read once
+        }
+        const uint8_t *p = haystacks + h0 + off + (uint64_t)lane * 64;
+        const uint64_t mine = (uint64_t)lane * 64 < take ? take - (uint64_t)lane * 64 : 0;
+        if (mine >= 64) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t w = reinterpret_cast<const UnalignedU32 *>(p + 4 * q)->v;
+                atomicAdd(&h[wave][w & 0xFF], 1u);
+                atomicAdd(&h[wave][(w >> 8) & 0xFF], 1u);
+                atomicAdd(&h[wave][(w >> 16) & 0xFF], 1u);
+                atomicAdd(&h[wave][w >> 24], 1u);
+            }
+        } else {
+            for (uint64_t q = 0; q < mine; ++q) atomicAdd(&h[wave][p[q]], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t total = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    if (total) atomicAdd(&hist[threadIdx.x], total);
+}
+// 16 classes from a sampled histogram: whole bits of total / count, rarest = 0.
+__device__ __forceinline__ uint8_t class_from_count(uint32_t cnt, uint32_t total)
+{
+    if (cnt == 0) return 0;
+    const uint32_t ratio = total / cnt;                                            // >= 1
+    const uint32_t bits = 31u - (uint32_t)__builtin_clz(ratio);
+    return (uint8_t)(15u - (bits < 15u ? bits : 15u));
+}
+constexpr uint32_t kClassNone = 255;            // above every class of either table
+
 // What the plan kernel tells the host about a plan's problems (ss_batch_plan_create sizes the grid of the runs from it).
 struct PlanStats {
     uint32_t max_slices;       // the most active slices any problem got
@@ -75,7 +137,7 @@ struct PlanStats {
 // One problem's descriptor (and, for the unplanned calls, its initial output); returns its number of active slices.
 __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, uint64_t h0, uint64_t h1, uint64_t n0, uint64_t n1, uint64_t given,
                                              BatchDesc *descs, uint32_t nslices, uint32_t min_tiles, int tile_pieces, const uint8_t *s_class,
-                                             uint64_t *tiles_out)
+                                             uint64_t *tiles_out, bool free_pair)
 {
     *tiles_out = 0;
     const uint64_t len = h1 - h0, n = n1 - n0;
@@ -102,7 +164,7 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
             for (int k = 0; k < 15; ++k) cls[k] = needle[position - 15 + k];
 #pragma unroll
             for (int k = 0; k < 15; ++k) cls[k] = s_class[cls[k]];
-            uint32_t best_cls = 4;
+            uint32_t best_cls = kClassNone;
 #pragma unroll
             for (int k = 0; k < 15; ++k) {          // later bytes win ties: the partner closest to `position`
                 const bool better = cls[k] <= best_cls;
@@ -117,7 +179,18 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
         for (uint32_t k = 0; k < 16; ++k) fb[k] = needle[anchor + (k < lim ? k : 0u)];
 #pragma unroll
         for (uint32_t k = 0; k < 16; ++k) cls[k] = s_class[fb[k]];
-        uint32_t p3 = s2, best_cls = 4;
+        if (free_pair && anchor == 0 && position == n - 1) {
+            // nobody chose `position` (it is the default, the last byte) and the classes are the haystacks' own: the partner of
+            // needle[0] is the rarest of the 15 bytes behind it, as ss_searcher_new would have it, the later one among equals
+            uint32_t bc = kClassNone;
+#pragma unroll
+            for (uint32_t k = 1; k < 16; ++k) {
+                const bool better = k < lim && cls[k] <= bc;
+                bc = better ? cls[k] : bc;
+                s2 = better ? k : s2;
+            }
+        }
+        uint32_t p3 = s2, best_cls = kClassNone;
 #pragma unroll
         for (uint32_t k = 1; k < 16; ++k) {         // the rarest of the 15 bytes behind the anchor, later ones winning ties
             const bool better = k < lim && k != s2 && cls[k] <= best_cls && n - anchor >= 3;
@@ -167,7 +240,8 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
 // load-rank loop ran 8-12 us, one memory round trip per byte.
 // `stats` (plans only, else null): see PlanStats.
 __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
-                                                             uint32_t nslices, uint32_t min_tiles, int tile_pieces, PlanStats *stats)
+                                                             uint32_t nslices, uint32_t min_tiles, int tile_pieces, PlanStats *stats,
+                                                             const uint32_t *hist)
 {
     __shared__ uint8_t s_class[256];
     __shared__ uint32_t s_max, s_maxt;
@@ -176,7 +250,18 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         s_max = s_maxt = 0;
         s_sum = 0;
     }
-    {
+    if (hist) {                                                                // (uniform: a kernel argument) classes from the
+        __shared__ uint32_t s_total;                                           // haystacks' own sampled histogram: batch_sample_kernel
+        const uint32_t mine = hist[threadIdx.x];
+        if (threadIdx.x == 0) s_total = 0;
+        __syncthreads();
+        uint32_t part = mine;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&s_total, part);
+        __syncthreads();
+        s_class[threadIdx.x] = class_from_count(mine, s_total);
+    } else {
         constexpr ClassPlanes P = make_class_planes();                         // compile-time constants, selected by wave
         const uint32_t t = threadIdx.x, w = t >> 5;                            // kBlock == 256: one table entry per thread
         uint32_t lo = P.lo[0], hi = P.hi[0];
@@ -195,9 +280,10 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
     const uint64_t given = a.position ? a.position[pi] : 0;
     __syncthreads();
     uint64_t tiles = 0;
+    const bool free_pair = hist != nullptr && a.position == nullptr;
     if (stats) {                                                               // (uniform: a kernel argument)
         uint32_t eff = 0;
-        if (live) eff = plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles);
+        if (live) eff = plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles, free_pair);
         if (eff != 0) {
             atomicMax(&s_max, eff);
             atomicMax(&s_maxt, tiles > 0xffffffffull ? 0xffffffffu : (uint32_t)tiles);
@@ -211,7 +297,7 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         }
         return;
     }
-    if (live) (void)plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles);
+    if (live) (void)plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles, free_pair);
 }
 
 // The cold fields of a planned problem, re-read from its descriptor by the waves that need them (scan_tiles' ColdT).

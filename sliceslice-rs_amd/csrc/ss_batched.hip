@@ -154,12 +154,14 @@ int batch_shape(int dev, size_t count, BatchShape *out, bool counted = false)
     return SS_OK;
 }
 
+// `hist` (plans only, else null): the sampled byte histogram of the plan's haystacks (batch_sample_kernel) - the rarity classes
+// the filter bytes are chosen by come from it instead of the static, corpus-free table.
 hipError_t launch_plan_kernel(const ss::BatchArgs &a, size_t count, ss::BatchDesc *descs, const BatchShape &sh, hipStream_t st,
-                              ss::PlanStats *stats = nullptr)
+                              ss::PlanStats *stats = nullptr, const uint32_t *hist = nullptr)
 {
     const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
     ss::batch_plan_kernel<<<dim3((unsigned)pblocks), dim3(ss::kBlock), 0, st>>>(a, (uint64_t)count, descs, sh.slices, sh.min_tiles,
-                                                                               ss::kWavesPerBlock * 4, stats);
+                                                                               ss::kWavesPerBlock * 4, stats, hist);
     return hipGetLastError();
 }
 
@@ -198,7 +200,8 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
 
 using namespace ssh;
 
-// The plan's own memory: descriptors | state words (uint64 each; the bool plans use the low int) | the plan kernel's PlanStats.
+// The plan's own memory: descriptors | state words (uint64 each; the bool plans use the low int) | the plan kernel's PlanStats
+// (64 bytes) | the sampled byte histogram of the haystacks (256 x uint32).
 struct ss_batch_plan {
     int dev = 0;
     size_t count = 0;
@@ -209,6 +212,7 @@ struct ss_batch_plan {
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
     void *state() const { return mem + count * sizeof(ss::BatchDesc); }
     ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t))); }
+    uint32_t *hist() const { return reinterpret_cast<uint32_t *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64); }
 };
 
 extern "C" {
@@ -259,7 +263,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     if (rc == SS_OK && (e = hipGetDevice(&p->dev)) != hipSuccess) rc = fail(SS_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
     if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape, true);
     if (rc == SS_OK) {
-        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64;
+        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64 + 256 * sizeof(uint32_t);
         if ((e = hipMalloc((void **)&p->mem, bytes)) != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
@@ -269,11 +273,25 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
         // count and reports what it saw; the host then sizes the slices for about kPlanTilesPerWg tiles per workgroup (bounded:
         // one huge haystack among many short ones must not multiply everybody's surplus slices) and, if that changes anything,
         // has the descriptors rebuilt.  The runs launch as many slices per problem as the busiest problem uses.
+        // Which needle bytes the scan filters on is decided by how rare they are IN THESE HAYSTACKS: a sampled histogram first
+        // (4 MiB read at most; batched_kernels.hpp, batch_sample_kernel).
         ss::PlanStats seen = {0, 0, 0};
         e = hipMemsetAsync(p->state(), p->find ? 0xFF : 0, count * sizeof(uint64_t), st);
+        const uint32_t *hist = p->hist();
+#ifdef SS_TEST_HOOKS
+        if (const char *v = getenv("SLICESLICE_BATCH_STATIC_CLASSES")) { if (atoi(v) != 0) hist = nullptr; }   // A/B: the static table
+#endif
+        if (e == hipSuccess && hist) {
+            e = hipMemsetAsync(p->hist(), 0, 256 * sizeof(uint32_t), st);
+            if (e == hipSuccess) {
+                ss::batch_sample_kernel<<<dim3(ss::kPlanSampleBlocks), dim3(ss::kBlock), 0, st>>>(p->args.haystacks, p->args.hay_begin, p->args.hay_end,
+                                                                                              (uint64_t)count, p->hist());
+                e = hipGetLastError();
+            }
+        }
         for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
             e = hipMemsetAsync(p->stats(), 0, 64, st);
-            if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs(), p->shape, st, p->stats());
+            if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs(), p->shape, st, p->stats(), hist);
             if (e == hipSuccess) e = hipMemcpyAsync(&seen, p->stats(), sizeof(seen), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess || pass == 1 || seen.max_slices == 0) break;
@@ -335,6 +353,23 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     }
     return SS_OK;
 }
+
+#ifdef SS_TEST_HOOKS
+int ss_debug_plan_filter(const ss_batch_plan *p, size_t problem, uint32_t out[5])
+{
+    if (!p || !out || problem >= p->count) return fail(SS_ERR_ARGUMENT, "bad argument");
+    ss::BatchDesc d;
+    HIP_TRY(hipMemcpy(&d, p->descs() + problem, sizeof d, hipMemcpyDeviceToHost));
+    const uint32_t r = (d.shifts >> 4) & 3, q = (d.shifts >> 6) & 3, r3 = (d.shifts >> 8) & 3, q3 = (d.shifts >> 10) & 3;
+    const bool scanned = (d.per >> 32) != 0;
+    out[0] = scanned ? (uint32_t)d.anchor : 0;
+    out[1] = scanned ? (uint32_t)d.anchor + 4 * q + r : 0;
+    out[2] = scanned ? (uint32_t)d.anchor + 4 * q3 + r3 : 0;
+    out[3] = d.bytes;
+    out[4] = (uint32_t)(d.per >> 32);
+    return SS_OK;
+}
+#endif
 
 void ss_batch_plan_free(ss_batch_plan *p)
 {

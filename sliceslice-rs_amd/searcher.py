@@ -108,6 +108,7 @@ HOOKS_ABI = {
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
     "ss_debug_census": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
+    "ss_debug_plan_filter": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
 
@@ -839,6 +840,13 @@ class BatchPlan:
         st = stream if stream is not None else _current_stream_handle()
         _check(self._L.ss_batch_plan_run(self._h, st, out.data_ptr()), self._L)
         return out
+
+    def filter_of(self, problem):
+        """((first, second, third) indices in the needle, the packed bytes, slices that scan the problem) of one problem's
+        descriptor - hooks builds (ss_debug_plan_filter)."""
+        out = (ctypes.c_uint32 * 5)()
+        _check(_hooks(self._L).ss_debug_plan_filter(self._h, int(problem), out), self._L)
+        return (out[0], out[1], out[2]), out[3], out[4]
 
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:

@@ -213,3 +213,141 @@ def test_batch_plan_trivial_problems_positions_and_graph_replay(ss):
         assert out.tolist() == [1 if rep % 2 == 0 else 0, 1, 0, -1, 0], rep
     plan.close()
     fplan.close()
+
+
+def _non_latin(n_bytes, seed):
+    """UTF-8-like text in a non-Latin script (as tests/test_gpu_filter_and_configs.py): every other byte is a lead byte 0xD0 / 0xD1 -
+    which the static, corpus-free rarity table takes for rare."""
+    rng = np.random.default_rng(seed)
+    pairs = n_bytes // 2
+    lead = rng.choice(np.array([0xD0, 0xD1], dtype=np.uint8), size=pairs, p=[0.6, 0.4])
+    trail = (0x80 + np.minimum(rng.geometric(0.08, size=pairs) - 1, 63)).astype(np.uint8)
+    a = np.empty(pairs * 2, dtype=np.uint8)
+    a[0::2], a[1::2] = lead, trail
+    blanks = rng.integers(0, pairs, size=pairs // 7)
+    a[2 * blanks] = 0x20
+    a[2 * blanks + 1] = 0x20
+    return a
+
+
+def _plan_sample_model(host, begins, ends):
+    """numpy restatement of batch_sample_kernel + class_from_count (batched_kernels.hpp): 1,024 samples of 4 KiB, sample j from
+    problem j * count / 1024 (j mod count when there are fewer problems than samples) at a pseudo-random offset; 16 classes =
+    15 - min(15, whole bits of total / count), never seen = 0 (the rarest)."""
+    count = len(begins)
+    hist = np.zeros(256, dtype=np.int64)
+    reps = (1024 + count - 1) // count
+    for j in range(1024):
+        if count < 1024 and j >= count * reps:
+            break
+        prob = j * count // 1024 if count >= 1024 else j % count
+        h0, h1 = begins[prob], ends[prob]
+        if h1 <= h0:
+            continue
+        ln = h1 - h0
+        off, take = 0, ln
+        if ln > 4096:
+            frac = ((j * 2654435761) & 0xFFFFFFFF) >> 8
+            off, take = ((ln - 4096) * frac) >> 24, 4096
+        elif count < 1024 and j >= count:
+            continue
+        hist += np.bincount(host[h0 + off:h0 + off + take], minlength=256)
+    total = int(hist.sum())
+    cls = [0 if c == 0 else 15 - min(15, (total // int(c)).bit_length() - 1) for c in hist]
+    return hist, cls
+
+
+def _plan_pair_model(needle, cls):
+    """plan_one's choice for a needle of 3..16 bytes whose `position` nobody chose: needle[0] + the two rarest (class) of the bytes
+    behind it, the later one among equals."""
+    lim = min(len(needle), 16)
+    s2, bc = len(needle) - 1, 255
+    for k in range(1, lim):
+        if cls[needle[k]] <= bc:
+            bc, s2 = cls[needle[k]], k
+    p3, bc = s2, 255
+    for k in range(1, lim):
+        if k != s2 and cls[needle[k]] <= bc:
+            bc, p3 = cls[needle[k]], k
+    return {0, s2, p3}
+
+
+def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
+    """Row f3 of SURVEY.md 8f for config 5: ss_batch_plan_create samples a byte histogram of the plan's haystacks and the plan kernel
+    ranks the needle bytes by it (16 classes) instead of by the static, corpus-free table - on text in a non-Latin script the static
+    table filters on the lead bytes that make up half the haystack.  The sampled counts and the chosen bytes equal a numpy
+    restatement; a caller's `position` is kept; answers (bool and find) equal Python's on every problem, whichever table chose."""
+    count, hay_len = 96, 1 << 20
+    host = _non_latin(count * hay_len, 5)
+    assert ord("e") not in host
+    rng = random.Random(9)
+    needles, noff, want = bytearray(), [0], []
+    for i in range(count):
+        at = 2 * rng.randrange(8, hay_len // 2 - 64) + i * hay_len
+        n = rng.choice((6, 12, 16))
+        w = bytearray(host[at:at + n].tobytes())
+        if i % 3:
+            w[rng.randrange(1, n - 1)] = ord("e")          # absent: no 'e' in this haystack - and the static table's most common letter
+        needles += w
+        noff.append(len(needles))
+        want.append(host[i * hay_len:(i + 1) * hay_len].tobytes().find(bytes(w)))
+    assert any(w >= 0 for w in want) and any(w < 0 for w in want)
+    hay = torch.from_numpy(host).cuda()
+    hoff = torch.arange(0, (count + 1) * hay_len, hay_len, dtype=torch.int64, device="cuda")
+    nbuf = torch.from_numpy(np.frombuffer(bytes(needles), dtype=np.uint8).copy()).cuda()
+    noff_t = torch.tensor(noff, dtype=torch.int64, device="cuda")
+    begins = [i * hay_len for i in range(count)]
+    _, cls = _plan_sample_model(host, begins, [b + hay_len for b in begins])
+    assert cls[ord("e")] == 0 and cls[0xD0] >= 13 and cls[0xD1] >= 12
+
+    with ss.tuning_build():
+        for find in (False, True):
+            plan = ss.BatchPlan(hay, hoff, nbuf, noff_t, find=find)
+            os.environ["SLICESLICE_BATCH_STATIC_CLASSES"] = "1"
+            try:
+                static = ss.BatchPlan(hay, hoff, nbuf, noff_t, find=find)
+            finally:
+                del os.environ["SLICESLICE_BATCH_STATIC_CLASSES"]
+            with_e = 0
+            for i in range(count):
+                nd = bytes(needles[noff[i]:noff[i + 1]])
+                tri, packed, slices = plan.filter_of(i)
+                assert slices >= 1 and set(tri) == _plan_pair_model(nd, cls), (i, nd, tri)
+                assert [packed & 0xFF, (packed >> 8) & 0xFF, (packed >> 16) & 0xFF] == [nd[k] for k in tri]
+                stri = static.filter_of(i)[0]
+                assert stri[0] == 0 and len(nd) - 1 in stri, "the static table keeps the reference's pair (0, n-1)"
+                if ord("e") in nd:
+                    e_at = nd.index(b"e")
+                    with_e += 1
+                    assert e_at in tri and e_at not in stri, (i, nd, tri, stri)
+            assert with_e > count // 2
+            for p in (plan, static):
+                out = p.run()
+                torch.cuda.synchronize()
+                assert out.tolist() == (want if find else [1 if w >= 0 else 0 for w in want])
+                p.close()
+        # a caller's position is the caller's: needle[position] stays a first-phase byte, the histogram ranks the others
+        pos = torch.tensor([(noff[i + 1] - noff[i]) // 2 for i in range(count)], dtype=torch.int64, device="cuda")
+        plan = ss.BatchPlan(hay, hoff, nbuf, noff_t, position=pos)
+        for i in range(0, count, 7):
+            tri = plan.filter_of(i)[0]
+            assert tri[0] == 0 and (noff[i + 1] - noff[i]) // 2 in tri
+        assert plan.run().tolist() == [1 if w >= 0 else 0 for w in want]
+        plan.close()
+
+    # aliased ranges (many needles, one text: the reference's i386 loop) are sampled all over the text, not 1,024 times at its start
+    text = np.concatenate([np.full(1 << 20, ord("a"), dtype=np.uint8), _non_latin(3 << 20, 6)])
+    words = [bytes(text[(1 << 20) + 2 * k * 100:(1 << 20) + 2 * k * 100 + 12]) for k in range(2000)]
+    tb = torch.from_numpy(text).cuda()
+    hb = torch.zeros(len(words), dtype=torch.int64, device="cuda")
+    he = torch.full((len(words),), text.size, dtype=torch.int64, device="cuda")
+    wb = torch.from_numpy(np.frombuffer(b"".join(words), dtype=np.uint8).copy()).cuda()
+    wo = torch.arange(0, 12 * len(words) + 1, 12, dtype=torch.int64, device="cuda")
+    hist, cls = _plan_sample_model(text, [0] * len(words), [text.size] * len(words))
+    assert 0 < hist[ord("a")] < hist.sum() // 2 and hist[0xD0] > hist.sum() // 8, "the sample reaches behind the first MiB"
+    with ss.tuning_build():
+        plan = ss.BatchPlan(tb, None, wb, wo, hay_ranges=(hb, he))
+        for i in range(0, len(words), 97):
+            assert set(plan.filter_of(i)[0]) == _plan_pair_model(words[i], cls)
+        assert plan.run().tolist() == [1] * len(words)
+        plan.close()
