@@ -206,8 +206,9 @@ SS_API int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin,
 
 /* Plan once, search many: the reference builds its 4,585 searchers ONCE and times only the searches
  * (bench/benches/i386.rs:246-256).  ss_batch_plan_create does for a batch what the constructors do for one needle: it reads
- * the range arrays and the NEEDLE bytes (on `hip_stream`, and waits for it) and keeps one descriptor per problem in memory of
- * its own; ss_batch_plan_run is then the scan launch alone, which writes the outputs itself (a plan in which some problem is
+ * the range arrays and the NEEDLE bytes (on `hip_stream`, and waits for it), samples a byte histogram of the haystacks (at most
+ * 4 MiB read) so that the needle bytes the scan filters on are the ones that are rare IN THESE HAYSTACKS (row f3 of SURVEY.md 8f;
+ * a caller's `position` is kept; no result depends on the choice), and keeps one descriptor per problem in memory of its own; ss_batch_plan_run is then the scan launch alone, which writes the outputs itself (a plan in which some problem is
  * scanned by several workgroups adds one small kernel behind it that copies those problems' answers out) - no plan kernel, no
  * scratch acquire, nothing allocated, capturable into a hipGraph.  `find` != 0: the plan answers leftmost offsets (d_out = `count`
  * uint64, as ss_find_batched), else flags (d_out = `count` int32, as ss_search_batched).  The caller vouches that ranges,

@@ -451,9 +451,12 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         pr.q = (d.shifts >> 6) & 3;
         const ColdInDesc cold = {dp, a.needles};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
-        void *wg_sink = COUNTED && eff == 1 ? static_cast<void *>(&s_wg[threadIdx.x / kWave]) : nullptr;
-        if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
-        else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
+        const bool single = COUNTED && eff == 1;        // (wave-uniform: from the descriptor's scalar registers)
+        void *wg_sink = single ? static_cast<void *>(&s_wg[threadIdx.x / kWave]) : nullptr;
+        // (-DSS_SIBLING_POLL A/B builds: the waves poll each other's words between tiles - their initial values must be in place first)
+        if (kSiblingPoll && single) __syncthreads();
+        if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink, s_wg, single);
+        else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink, s_wg, single);
     }
     if (COUNTED && eff == 1) {
         // the only workgroup of its problem: the answer is in the LDS word (a bare barrier settles it), one store publishes it

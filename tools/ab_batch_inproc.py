@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""In-process A/B of library builds on BATCH PLANS: every build is dlopen()ed (RTLD_LOCAL) into one process, a plan of each is
+made on the same device buffers, and their runs take turns (events around single runs; median / min of --reps per round, two
+rounds).  Shapes as tools/batch_probe.py (COUNTxBYTES); `--present K`: every K-th needle is cut out of its haystack (early
+exit inside a problem matters), else all absent.
+    python tools/ab_batch_inproc.py --libs cur=...so old=...so --shapes 16384x65536 65536x16384 1024x1048576 [--find] [--present 2]"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sliceslice_rs_amd as ss  # noqa: E402
+from batch_probe import events_ms  # noqa: E402
+
+vp, sz = ctypes.c_void_p, ctypes.c_size_t
+
+
+def load(path):
+    L = ctypes.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    L.ss_batch_plan_create.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, ctypes.c_int, vp, ctypes.POINTER(vp)]
+    L.ss_batch_plan_run.argtypes = [vp, vp, vp]
+    L.ss_batch_plan_free.argtypes = [vp]
+    L.ss_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--libs", nargs="+", required=True)
+    ap.add_argument("--shapes", nargs="+", required=True)
+    ap.add_argument("--find", action="store_true")
+    ap.add_argument("--present", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=30)
+    args = ap.parse_args()
+    libs = [(s.split("=", 1)[0], load(s.split("=", 1)[1])) for s in args.libs]
+    shapes = [tuple(int(x) for x in a.split("x")) for a in args.shapes]
+    blob = torch.empty(max(c * e for c, e in shapes), dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(blob, 0x5EED0001)
+    st = torch.cuda.current_stream().cuda_stream
+    for count, each in shapes:
+        hay = blob[:count * each]
+        nd = bytearray(ss.fill_random_host(16 * count, 0x5EED0003).tobytes())
+        nd[8::16] = b"\xff" * count
+        want = 0
+        if args.present:
+            rng = np.random.default_rng(5)
+            idx = np.arange(0, count, args.present)
+            at = rng.integers(0, each - 16, size=idx.size)
+            src = (idx * each + at)[:, None] + np.arange(16)[None, :]
+            cut = hay.cpu().numpy()[src.reshape(-1)].reshape(-1, 16)
+            arr = np.frombuffer(bytes(nd), dtype=np.uint8).reshape(count, 16).copy()
+            arr[idx] = cut
+            nd = bytearray(arr.tobytes())
+            want = idx.size
+        nblob = torch.from_numpy(np.frombuffer(bytes(nd), dtype=np.uint8).copy()).cuda()
+        hoff = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
+        noff = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
+        out = torch.empty(count, dtype=torch.int64 if args.find else torch.int32, device="cuda")
+        plans = []
+        for name, L in libs:
+            h = vp()
+            rc = L.ss_batch_plan_create(hay.data_ptr(), hoff.data_ptr(), hoff.data_ptr() + 8, nblob.data_ptr(), noff.data_ptr(), noff.data_ptr() + 8,
+                                        None, count, int(args.find), st, ctypes.byref(h))
+            assert rc == 0, L.ss_last_error()
+            plans.append((name, L, h))
+        row = {"problems": count, "each": each, "find": args.find, "present_every": args.present}
+        for rnd in range(2):
+            for name, L, h in plans:
+                ms, mn = events_ms(lambda: L.ss_batch_plan_run(h, st, out.data_ptr()), args.reps)
+                row["%s_ms_%d" % (name, rnd)], row["%s_min_%d" % (name, rnd)] = round(ms, 4), round(mn, 4)
+                torch.cuda.synchronize()
+                got = int((out >= 0).sum().item()) if args.find else int(out.sum().item())
+                assert got == want, (name, got, want)
+        for name, L, h in plans:
+            row[name + "_gbps"] = round(count * each / min(row[name + "_ms_0"], row[name + "_ms_1"]) / 1e6, 1)
+            L.ss_batch_plan_free(h)
+        print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
