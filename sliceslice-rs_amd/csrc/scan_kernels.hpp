@@ -245,6 +245,17 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 if (THREE) {
                     // lane 63's next lane: lane 0 of the next piece (raw dwords, rotated in), or the halo chunk
                     constexpr int QM = QQ > Q3 ? QQ : Q3;
+#ifdef SS_PHASE1_FOLDED
+                    const uint32_t k2 = pr.nlx4 ^ pr.n0x4, k3 = pr.n3x4 ^ pr.n0x4;
+                    const u32x4 &NP = u + 1 < U ? A[u + 1] : H;
+                    const uint32_t a[4] = {A[u].x ^ pr.n0x4, A[u].y ^ pr.n0x4, A[u].z ^ pr.n0x4, A[u].w ^ pr.n0x4};
+                    uint32_t nxa[4] = {NP.x ^ pr.n0x4, QM >= 1 ? NP.y ^ pr.n0x4 : 0u, QM >= 2 ? NP.z ^ pr.n0x4 : 0u, QM >= 3 ? NP.w ^ pr.n0x4 : 0u};
+                    if (u + 1 < U) {
+#pragma unroll
+                        for (int j = 0; j <= QM; ++j) nxa[j] = rotate_from_next_lane(nxa[j]);
+                    }
+                    filter_piece3_folded<QQ, Q3>(a, nxa, k2, k3, pr.r, pr.r3, g);
+#else
                     uint32_t nx[4] = {0, 0, 0, 0};
                     if (u + 1 < U) {
                         nx[0] = rotate_from_next_lane(A[u + 1].x);
@@ -255,6 +266,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         nx[0] = H.x; nx[1] = H.y; nx[2] = H.z; nx[3] = H.w;
                     }
                     filter_piece3<QQ, Q3>(A[u], nx, pr, g);
+#endif
                 } else if (SHIFTED) {
                     // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
                     position_diffs(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
