@@ -451,12 +451,12 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         pr.q = (d.shifts >> 6) & 3;
         const ColdInDesc cold = {dp, a.needles};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
-        const bool single = COUNTED && eff == 1;        // (wave-uniform: from the descriptor's scalar registers)
-        void *wg_sink = single ? static_cast<void *>(&s_wg[threadIdx.x / kWave]) : nullptr;
-        // (-DSS_SIBLING_POLL A/B builds: the waves poll each other's words between tiles - their initial values must be in place first)
-        if (kSiblingPoll && single) __syncthreads();
-        if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink, s_wg, single);
-        else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink, s_wg, single);
+        // (Measured and not adopted - commit 7511606 (-DSS_SIBLING_POLL), profiles/r05/ab_sibling_poll.jsonl: the waves of such a workgroup polling EACH
+        // OTHER'S words between tiles, so that a match by one stops the other three.  It takes a barrier in front of the scan - a
+        // wave must not read a sibling's word before its initial value is in place - and 10-15 more scalar registers at entry.)
+        void *wg_sink = COUNTED && eff == 1 ? static_cast<void *>(&s_wg[threadIdx.x / kWave]) : nullptr;
+        if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
+        else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
     }
     if (COUNTED && eff == 1) {
         // the only workgroup of its problem: the answer is in the LDS word (a bare barrier settles it), one store publishes it

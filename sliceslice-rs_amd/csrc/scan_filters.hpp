@@ -263,31 +263,6 @@ __device__ __forceinline__ void filter_piece3(const u32x4 &A, const uint32_t NX[
                                __builtin_amdgcn_alignbyte(z[j + 1], z[j], pr.r3));
 }
 
-// The same filter on FOLDED differences (-DSS_PHASE1_FOLDED): a = A ^ splat(needle[first]) is computed once per dword in the lane
-// that loaded it and THAT is what moves to the previous lane; the second and third byte's differences are a ^ splat(first ^ second)
-// and a ^ splat(first ^ third) (a byte splat commutes with v_alignbyte), so per output dword: two v_alignbyte, two v_bitop3
-// (t = a | (ab2 ^ k2) | (ab3 ^ k3)) and the zero-byte test - four xors per piece instead of ten.  NXa = lane 63's next chunk,
-// folded like a.
-template <int Q, int Q3>
-__device__ __forceinline__ void filter_piece3_folded(const uint32_t a[4], const uint32_t NXa[4], uint32_t k2, uint32_t k3, uint32_t r,
-                                                     uint32_t r3, uint32_t g[4])
-{
-    constexpr int QM = Q > Q3 ? Q : Q3;
-    uint32_t x[8];
-    x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
-    x[4] = from_next_lane_or(NXa[0], a[0]);
-    x[5] = QM >= 1 ? from_next_lane_or(NXa[1], a[1]) : 0u;
-    x[6] = QM >= 2 ? from_next_lane_or(NXa[2], a[2]) : 0u;
-    x[7] = QM >= 3 ? from_next_lane_or(NXa[3], a[3]) : 0u;
-    // (v_bitop3 by name, 0xF6 = s0 | (s1 ^ s2): left to itself the compiler reassociates to xor + bitop3 + or, one operation more)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t t2 = __builtin_amdgcn_bitop3_b32(a[j], __builtin_amdgcn_alignbyte(x[Q + j + 1], x[Q + j], r), k2, 0xF6);
-        const uint32_t t3 = __builtin_amdgcn_bitop3_b32(t2, __builtin_amdgcn_alignbyte(x[Q3 + j + 1], x[Q3 + j], r3), k3, 0xF6);
-        g[j] = __builtin_amdgcn_bitop3_b32(t3 - 0x01010101u, t3, t3, 0x30);                // (t - 0x01010101) & ~t
-    }
-}
-
 // ---- second-level filter ------------------------------------------------------------------------------
 // Run only by waves that have candidates: AND the candidate flags with the flags of needle[K] at byte
 // offset K, for up to 15 further needle bytes, still entirely in registers.  Text-like haystacks pass

@@ -48,37 +48,6 @@
 
 namespace ss {
 
-// Sibling poll - measured and NOT adopted (profiles/r05/ab_sibling_poll.jsonl; A/B builds with -DSS_SIBLING_POLL only,
-// tools/ab_batch_inproc.py): in a plan run the four waves of a problem's ONLY workgroup poll each other's LDS match words between
-// tiles instead of the plan's idle state word in memory, so that a match by one wave stops the other three.  It needs
-// a barrier in front of the scan (a wave must not read a sibling's word before its initial value is in place) and 10-15 more scalar
-// registers at entry: absent needles 0-2 % slower on workgroup-per-problem shapes, present ones from 2 % faster (8,192 x 128 KiB)
-// to 2-4 % slower (65,536 x 16 KiB; find).
-#ifdef SS_SIBLING_POLL
-constexpr bool kSiblingPoll = true;
-#else
-constexpr bool kSiblingPoll = false;
-#endif
-// The four per-wave match words of a workgroup (batched plan runs, a problem scanned by ONE workgroup): has a sibling wave found
-// the needle (bool: a word is non-zero) / the leftmost match so far (FIND: the minimum; idle = all ones).  LDS, wave-uniform.
-__device__ __forceinline__ int wg_words_any(const unsigned long long *w)
-{
-    unsigned long long v = 0;
-#pragma unroll
-    for (int k = 0; k < kWavesPerBlock; ++k) v |= __hip_atomic_load(w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return __builtin_amdgcn_readfirstlane((int)((uint32_t)v | (uint32_t)(v >> 32))) != 0;
-}
-__device__ __forceinline__ uint64_t wg_words_min(const unsigned long long *w)
-{
-    unsigned long long v = ~0ull;
-#pragma unroll
-    for (int k = 0; k < kWavesPerBlock; ++k) {
-        const unsigned long long x = __hip_atomic_load(w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        v = x < v ? x : v;
-    }
-    return v;
-}
-
 // MODE selects where the position-byte flags of a candidate come from (position = 16*d + 4*Q + r):
 //   0  d == 0: same chunk / next lane (DPP) - every needle of <= 16 bytes with the default position;
 //   2  0 < d < 64, small: ONE (non-temporal) load stream; the flags computed by the lane that owns chunk
@@ -92,8 +61,7 @@ __device__ __forceinline__ uint64_t wg_words_min(const unsigned long long *w)
 template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false,
           typename ColdT = ColdInRegisters>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_t *s_needle_block, uint64_t tile0,
-                                           uint64_t tile_step, uint64_t tile_end, void *sink, void *wg_sink = nullptr,
-                                           const unsigned long long *wg_words = nullptr, bool wg_poll = false)
+                                           uint64_t tile_step, uint64_t tile_end, void *sink, void *wg_sink = nullptr)
 {
     static_assert(!L8 || (MODE == 0 && !FIND), "the 8-byte layout covers the single-stream bool kernels");
     static_assert(Q != kQDynamic || (MODE == 0 && !L8), "a run-time window is for the single-stream kernels' three-byte phase");
@@ -104,8 +72,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     uint64_t *best = static_cast<uint64_t *>(sink);
     // `wg_sink`, when given: a word in the workgroup's LDS that takes the match INSTEAD of the global sink (bool: int 0 -> 1;
     // FIND, batched kernels only: uint64 minimum) - for launches whose epilogue carries the answer on, so that no wave queues a
-    // device-scope atomic in front of it.  `wg_poll` (batched plan runs, wave-uniform): the workgroup is the only one of its problem,
-    // `wg_words` are its waves' four sink words - they are polled between tiles instead of the global sink.
+    // device-scope atomic in front of it.
     int *wg_found = static_cast<int *>(wg_sink);
     constexpr bool WG_FIND = LAZY_ORDER;            // (compiled into scan_kernel's FIND path it would be dead code that still moves registers)
     constexpr bool NTA = NTMODE >= 1;
@@ -136,13 +103,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         const uint64_t chunk0 = (tile * (uint64_t)(wpb * U) + (uint64_t)wave * U) * 64;   // wave-uniform
         // FIND polls first (oldest load, so waiting for it does not drain the data loads behind it); the value
         // is only made wave-uniform (readfirstlane = the wait) after the tile's data loads have been issued
-        // (a plan's single-workgroup problem - LAZY_ORDER with a workgroup sink - has nobody but its own four waves to hear from:
-        // the sibling waves' LDS words are polled, not the plan's idle state word in memory)
-        uint64_t best_raw = 0;
-        if (FIND) {
-            if (kSiblingPoll && LAZY_ORDER && wg_poll) best_raw = wg_words_min(wg_words);
-            else best_raw = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const uint64_t best_raw = FIND ? __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         uint64_t best_now = 0;
         // last chunk this wave touches: the halo chunk (MODE 0) or the d+1 halo chunks (MODE 2)
         const uint64_t halo = chunk0 + 64 * U + pr.d;
@@ -230,10 +191,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 }
             }
             // the poll is issued behind the data loads and consumed after them
-            if (!FIND) {
-                if (kSiblingPoll && LAZY_ORDER && wg_poll) stop = wg_words_any(wg_words);
-                else stop = poll_found(found, pr.epoch);
-            }
+            stop = FIND ? 0 : poll_found(found, pr.epoch);
             if (FIND) best_now = uniform64(best_raw);
 
             // ---- phase 1: the two-byte filter for all U pieces, straight-line (loads are consumed in order) ----
@@ -245,17 +203,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 if (THREE) {
                     // lane 63's next lane: lane 0 of the next piece (raw dwords, rotated in), or the halo chunk
                     constexpr int QM = QQ > Q3 ? QQ : Q3;
-#ifdef SS_PHASE1_FOLDED
-                    const uint32_t k2 = pr.nlx4 ^ pr.n0x4, k3 = pr.n3x4 ^ pr.n0x4;
-                    const u32x4 &NP = u + 1 < U ? A[u + 1] : H;
-                    const uint32_t a[4] = {A[u].x ^ pr.n0x4, A[u].y ^ pr.n0x4, A[u].z ^ pr.n0x4, A[u].w ^ pr.n0x4};
-                    uint32_t nxa[4] = {NP.x ^ pr.n0x4, QM >= 1 ? NP.y ^ pr.n0x4 : 0u, QM >= 2 ? NP.z ^ pr.n0x4 : 0u, QM >= 3 ? NP.w ^ pr.n0x4 : 0u};
-                    if (u + 1 < U) {
-#pragma unroll
-                        for (int j = 0; j <= QM; ++j) nxa[j] = rotate_from_next_lane(nxa[j]);
-                    }
-                    filter_piece3_folded<QQ, Q3>(a, nxa, k2, k3, pr.r, pr.r3, g);
-#else
                     uint32_t nx[4] = {0, 0, 0, 0};
                     if (u + 1 < U) {
                         nx[0] = rotate_from_next_lane(A[u + 1].x);
@@ -266,7 +213,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         nx[0] = H.x; nx[1] = H.y; nx[2] = H.z; nx[3] = H.w;
                     }
                     filter_piece3<QQ, Q3>(A[u], nx, pr, g);
-#endif
                 } else if (SHIFTED) {
                     // flags of the following piece (or of the halo chunks), then the 8-dword window by lane distance
                     position_diffs(u + 1 < U ? A[u + 1] : H, pr.nlx4, wnext);
