@@ -80,6 +80,11 @@ SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
  * decided / 1 the searcher's own / 2 the histogram's; [10] = histogram triples put on trial so far.  Launches nothing. */
 SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[11]);
 
+/* What the library remembers of an UNPLANNED batch (ss_search_batched / ss_find_batched with these haystacks, this range array and
+ * this count) on the current device: *state = 0 unknown, 1 named once, 2 sampling in flight, 3 classes in - and then cls[0..256) =
+ * the sixteen rarity classes (0 = rarest) its calls choose their filter bytes by. */
+SS_API int ss_debug_batch_classes(const void *d_haystacks, const uint64_t *d_hay_begin, size_t count, uint32_t *state, uint8_t cls[256]);
+
 /* What a plan's descriptor of `problem` filters on: out[0..2] = the indices in the needle of the three first-phase bytes (first <=
  * the other two), out[3] = the bytes themselves (first | second << 8 | third << 16 | one-byte needle << 24), out[4] = the slices
  * that scan the problem (0: answered without a scan; the indices are 0 then).  Copies 64 bytes from the device. */

@@ -71,15 +71,38 @@ constexpr ClassPlanes make_class_planes()
 // every other byte is 0xD0 / 0xD1).  ss_batch_plan_create therefore has batch_sample_kernel take a byte histogram of
 // kPlanSampleTiles pieces of 4 KiB - sample j reads problem (j * count / kPlanSampleTiles) (or j mod count when there are fewer
 // problems than samples) at a pseudo-random offset of its haystack, so aliased ranges (many needles, one text) are sampled all
-// over the text and not kPlanSampleTiles times at its start - and the plan kernel turns the counts into SIXTEEN classes: the
-// number of whole bits in total / count, 15 = every second byte and more, 0 = never seen (or rarer than 1 in 32,768).  Per-wave
-// LDS histograms, one global atomic per non-zero counter and workgroup.  Results never depend on the classes (lib.rs:375-378).
+// over the text and not kPlanSampleTiles times at its start - and the workgroup that finishes last turns the counts into SIXTEEN
+// classes: the number of whole bits in total / count, 15 = every second byte and more, 0 = never seen (or rarer than 1 in
+// 32,768).  Per-wave LDS histograms, one global atomic per non-zero counter and workgroup.  The unplanned calls do the same without
+// ever waiting: the sampling goes in front of the SECOND call that names the same haystacks, later calls use its classes once
+// they are in (ss_batched.hip).  Results never depend on the classes (lib.rs:375-378).
 constexpr uint32_t kPlanSampleTiles = 1024, kPlanSampleBytes = 4096, kPlanSampleBlocks = 64;
+// 16 classes from a sampled histogram: whole bits of total / count, rarest = 0.
+__device__ __forceinline__ uint8_t class_from_count(uint32_t cnt, uint32_t total)
+{
+    if (cnt == 0) return 0;
+    const uint32_t ratio = total / cnt;                                            // >= 1
+    const uint32_t bits = 31u - (uint32_t)__builtin_clz(ratio);
+    return (uint8_t)(15u - (bits < 15u ? bits : 15u));
+}
+// The sampling's memory: 256 counters and the count of finished workgroups (all zero between launches: the workgroup that
+// completes the count puts them back), and the 256 classes it leaves behind.
+struct BatchClasses {
+    uint32_t hist[256];
+    uint32_t done, pad[15];
+    uint8_t cls[256];
+};
+// `h_tag` (may be null): a pinned word that takes `tag` when the classes are in place - how the unplanned calls, which never wait,
+// learn that a sampling launched in front of an earlier call has finished (ss_batched.hip).
 __global__ void __launch_bounds__(kBlock) batch_sample_kernel(const uint8_t *haystacks, const uint64_t *hay_begin, const uint64_t *hay_end,
-                                                               uint64_t count, uint32_t *hist)
+                                                               uint64_t count, BatchClasses *out, unsigned long long *h_tag,
+                                                               unsigned long long tag)
 {
     __shared__ uint32_t h[kWavesPerBlock][256];
+    __shared__ uint32_t s_total;
+    __shared__ int s_last;
     for (int k = threadIdx.x; k < kWavesPerBlock * 256; k += kBlock) (&h[0][0])[k] = 0;
+    if (threadIdx.x == 0) s_total = 0;
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     constexpr uint32_t kPerWave = kPlanSampleTiles / (kPlanSampleBlocks * kWavesPerBlock);
@@ -114,16 +137,29 @@ __global__ void __launch_bounds__(kBlock) batch_sample_kernel(const uint8_t *hay
         }
     }
     __syncthreads();
-    const uint32_t total = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
-    if (total) atomicAdd(&hist[threadIdx.x], total);
-}
-// 16 classes from a sampled histogram: whole bits of total / count, rarest = 0.
-__device__ __forceinline__ uint8_t class_from_count(uint32_t cnt, uint32_t total)
-{
-    if (cnt == 0) return 0;
-    const uint32_t ratio = total / cnt;                                            // >= 1
-    const uint32_t bits = 31u - (uint32_t)__builtin_clz(ratio);
-    return (uint8_t)(15u - (bits < 15u ? bits : 15u));
+    const uint32_t part = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    if (part) __hip_atomic_fetch_add(&out->hist[threadIdx.x], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&out->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == kPlanSampleBlocks;
+    __syncthreads();
+    if (!s_last) return;
+    // the workgroup that completes the count: counts -> classes, and everything back to zero for the next launch
+    __threadfence();
+    const uint32_t mine = __hip_atomic_exchange(&out->hist[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t sum = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) atomicAdd(&s_total, sum);
+    __syncthreads();
+    out->cls[threadIdx.x] = class_from_count(mine, s_total);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&out->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h_tag) __hip_atomic_store(h_tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 constexpr uint32_t kClassNone = 255;            // above every class of either table
 
@@ -241,7 +277,7 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
 // `stats` (plans only, else null): see PlanStats.
 __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
                                                              uint32_t nslices, uint32_t min_tiles, int tile_pieces, PlanStats *stats,
-                                                             const uint32_t *hist)
+                                                             const uint8_t *cls)
 {
     __shared__ uint8_t s_class[256];
     __shared__ uint32_t s_max, s_maxt;
@@ -250,17 +286,8 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         s_max = s_maxt = 0;
         s_sum = 0;
     }
-    if (hist) {                                                                // (uniform: a kernel argument) classes from the
-        __shared__ uint32_t s_total;                                           // haystacks' own sampled histogram: batch_sample_kernel
-        const uint32_t mine = hist[threadIdx.x];
-        if (threadIdx.x == 0) s_total = 0;
-        __syncthreads();
-        uint32_t part = mine;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if ((threadIdx.x & (kWave - 1)) == 0) atomicAdd(&s_total, part);
-        __syncthreads();
-        s_class[threadIdx.x] = class_from_count(mine, s_total);
+    if (cls) {                                                                 // (uniform: a kernel argument) the classes of the
+        s_class[threadIdx.x] = cls[threadIdx.x];                               // haystacks' own sampled histogram: batch_sample_kernel
     } else {
         constexpr ClassPlanes P = make_class_planes();                         // compile-time constants, selected by wave
         const uint32_t t = threadIdx.x, w = t >> 5;                            // kBlock == 256: one table entry per thread
@@ -280,7 +307,7 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
     const uint64_t given = a.position ? a.position[pi] : 0;
     __syncthreads();
     uint64_t tiles = 0;
-    const bool free_pair = hist != nullptr && a.position == nullptr;
+    const bool free_pair = cls != nullptr && a.position == nullptr;
     if (stats) {                                                               // (uniform: a kernel argument)
         uint32_t eff = 0;
         if (live) eff = plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles, free_pair);

@@ -154,15 +154,111 @@ int batch_shape(int dev, size_t count, BatchShape *out, bool counted = false)
     return SS_OK;
 }
 
-// `hist` (plans only, else null): the sampled byte histogram of the plan's haystacks (batch_sample_kernel) - the rarity classes
-// the filter bytes are chosen by come from it instead of the static, corpus-free table.
+// `cls` (may be null): the 256 rarity classes batch_sample_kernel derived from the haystacks' own bytes - the filter bytes are
+// chosen by them instead of the static, corpus-free table.
 hipError_t launch_plan_kernel(const ss::BatchArgs &a, size_t count, ss::BatchDesc *descs, const BatchShape &sh, hipStream_t st,
-                              ss::PlanStats *stats = nullptr, const uint32_t *hist = nullptr)
+                              ss::PlanStats *stats = nullptr, const uint8_t *cls = nullptr)
 {
     const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
     ss::batch_plan_kernel<<<dim3((unsigned)pblocks), dim3(ss::kBlock), 0, st>>>(a, (uint64_t)count, descs, sh.slices, sh.min_tiles,
-                                                                               ss::kWavesPerBlock * 4, stats, hist);
+                                                                               ss::kWavesPerBlock * 4, stats, cls);
     return hipGetLastError();
+}
+
+// Row f3 of SURVEY.md 8f for the UNPLANNED calls, without a wait and without a cost for callers that come once: per device a few
+// remembered batches (haystack blob, range array, count).  The first call that names a batch only leaves its name; the second has
+// batch_sample_kernel launched in front of it, on its stream (4 MiB read at most); calls after that use the classes once the
+// kernel's tag has arrived in pinned memory - the host never waits for it.  Sampled again every kClassRefreshEvery uses (a blob
+// may be refilled in place).  An entry that is evicted while a plan kernel of another stream still reads its classes hands that
+// kernel another batch's classes: a slower choice of filter bytes at worst, never another answer.
+constexpr int kClassEntries = 4;
+constexpr uint32_t kClassRefreshEvery = 1024;
+struct ClassEntry {
+    const void *hay = nullptr, *begin = nullptr;
+    size_t count = 0;
+    uint32_t state = 0;             // 0 = empty, 1 = named once, 2 = sampling launched (tag), 3 = classes in
+    uint32_t uses = 0;
+    unsigned long long tag = 0;
+    uint64_t stamp = 0;
+    ss::BatchClasses *mem = nullptr;
+};
+struct ClassTable {
+    std::mutex mu;
+    ClassEntry e[kClassEntries];
+    int pending = -1;
+    unsigned long long tag = 0;
+    uint64_t clock = 0;
+    unsigned long long *h_tag = nullptr;    // pinned
+    bool broken = false;
+};
+ClassTable *class_tables()          // never destroyed (a call may come from a thread that outlives main)
+{
+    static ClassTable *const t = new ClassTable[kMaxDevices];
+    return t;
+}
+
+// The classes of this batch if they are in; launches the sampling in front of the caller's kernels when the batch has been seen
+// before and nothing is in flight on the device.
+const uint8_t *batch_classes(int dev, const ss::BatchArgs &a, size_t count, hipStream_t st)
+{
+    if (dev < 0 || dev >= kMaxDevices) return nullptr;
+#ifdef SS_TEST_HOOKS
+    if (const char *v = getenv("SLICESLICE_BATCH_STATIC_CLASSES")) { if (atoi(v) != 0) return nullptr; }
+#endif
+    ClassTable &t = class_tables()[dev];
+    std::unique_lock<std::mutex> lock(t.mu, std::try_to_lock);
+    if (!lock.owns_lock() || t.broken) return nullptr;
+    if (t.pending >= 0 && __atomic_load_n(t.h_tag, __ATOMIC_ACQUIRE) == t.e[t.pending].tag) {
+        t.e[t.pending].state = 3;
+        t.pending = -1;
+    }
+    ClassEntry *hit = nullptr, *victim = nullptr;
+    for (auto &c : t.e) {
+        if (c.state != 0 && c.hay == a.haystacks && c.begin == a.hay_begin && c.count == count) hit = &c;
+        if ((int)(&c - t.e) != t.pending && (!victim || c.stamp < victim->stamp)) victim = &c;     // (never the entry being sampled)
+    }
+    if (!hit) {
+        victim->hay = a.haystacks;
+        victim->begin = a.hay_begin;
+        victim->count = count;
+        victim->state = 1;
+        victim->uses = 0;
+        victim->stamp = ++t.clock;
+        return nullptr;
+    }
+    hit->stamp = ++t.clock;
+    const uint8_t *have = hit->state == 3 ? hit->mem->cls : nullptr;
+    if (hit->state == 2) return nullptr;
+    if (hit->state == 3 && ++hit->uses % kClassRefreshEvery != 0) return have;
+    if (t.pending >= 0) return have;
+    if (!t.h_tag) {
+        if (hipHostMalloc((void **)&t.h_tag, sizeof(unsigned long long), hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            t.broken = true;
+            return have;
+        }
+        *t.h_tag = 0;
+    }
+    if (!hit->mem) {
+        hipError_t e = hipMalloc((void **)&hit->mem, sizeof(ss::BatchClasses));
+        if (e == hipSuccess) e = hipMemset(hit->mem, 0, sizeof(ss::BatchClasses));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            hit->mem = nullptr;
+            t.broken = true;
+            return have;
+        }
+    }
+    if (++t.tag == 0) t.tag = 1;
+    ss::batch_sample_kernel<<<dim3(ss::kPlanSampleBlocks), dim3(ss::kBlock), 0, st>>>(a.haystacks, a.hay_begin, a.hay_end, (uint64_t)count, hit->mem,
+                                                                                  t.h_tag, t.tag);
+    if (hipGetLastError() != hipSuccess) return have;
+    // (a refresh overwrites the classes in place while this very call's plan kernel - behind it on the same stream - reads them:
+    // stream order makes that the NEW classes; a call on another stream may see a mix of old and new: any classes are valid)
+    hit->tag = t.tag;
+    if (hit->state != 3) hit->state = 2;                        // (a refresh leaves the old classes in use until the new ones are in)
+    t.pending = (int)(hit - t.e);
+    return have;
 }
 
 // batch_plan_kernel turns the range arrays into one 64-byte descriptor per problem and writes the initial outputs (no memset
@@ -181,7 +277,8 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
     PlanScratch *ps = plan_scratch_acquire(dev, st, count);
     if (!ps) return fail(SS_ERR_NOMEM, "no device memory for %zu problem descriptors", count);
     ss::BatchDesc *descs = ps->buf;
-    hipError_t e = launch_plan_kernel(a, count, descs, sh, st);
+    const uint8_t *cls = batch_classes(dev, a, count, st);
+    hipError_t e = launch_plan_kernel(a, count, descs, sh, st, nullptr, cls);
     if (e == hipSuccess) {
         const dim3 grid((unsigned)((uint64_t)count * sh.slices));
         if (a.best)
@@ -201,7 +298,7 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
 using namespace ssh;
 
 // The plan's own memory: descriptors | state words (uint64 each; the bool plans use the low int) | the plan kernel's PlanStats
-// (64 bytes) | the sampled byte histogram of the haystacks (256 x uint32).
+// (64 bytes) | the sampling's counters and the rarity classes of the haystacks' bytes (ss::BatchClasses).
 struct ss_batch_plan {
     int dev = 0;
     size_t count = 0;
@@ -212,7 +309,7 @@ struct ss_batch_plan {
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
     void *state() const { return mem + count * sizeof(ss::BatchDesc); }
     ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t))); }
-    uint32_t *hist() const { return reinterpret_cast<uint32_t *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64); }
+    ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64); }
 };
 
 extern "C" {
@@ -263,7 +360,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     if (rc == SS_OK && (e = hipGetDevice(&p->dev)) != hipSuccess) rc = fail(SS_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
     if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape, true);
     if (rc == SS_OK) {
-        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64 + 256 * sizeof(uint32_t);
+        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64 + sizeof(ss::BatchClasses);
         if ((e = hipMalloc((void **)&p->mem, bytes)) != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
@@ -277,21 +374,21 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
         // (4 MiB read at most; batched_kernels.hpp, batch_sample_kernel).
         ss::PlanStats seen = {0, 0, 0};
         e = hipMemsetAsync(p->state(), p->find ? 0xFF : 0, count * sizeof(uint64_t), st);
-        const uint32_t *hist = p->hist();
+        const uint8_t *cls = p->classes()->cls;
 #ifdef SS_TEST_HOOKS
-        if (const char *v = getenv("SLICESLICE_BATCH_STATIC_CLASSES")) { if (atoi(v) != 0) hist = nullptr; }   // A/B: the static table
+        if (const char *v = getenv("SLICESLICE_BATCH_STATIC_CLASSES")) { if (atoi(v) != 0) cls = nullptr; }   // A/B: the static table
 #endif
-        if (e == hipSuccess && hist) {
-            e = hipMemsetAsync(p->hist(), 0, 256 * sizeof(uint32_t), st);
+        if (e == hipSuccess && cls) {
+            e = hipMemsetAsync(p->classes(), 0, sizeof(ss::BatchClasses), st);
             if (e == hipSuccess) {
                 ss::batch_sample_kernel<<<dim3(ss::kPlanSampleBlocks), dim3(ss::kBlock), 0, st>>>(p->args.haystacks, p->args.hay_begin, p->args.hay_end,
-                                                                                              (uint64_t)count, p->hist());
+                                                                                              (uint64_t)count, p->classes(), nullptr, 0ull);
                 e = hipGetLastError();
             }
         }
         for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
             e = hipMemsetAsync(p->stats(), 0, 64, st);
-            if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs(), p->shape, st, p->stats(), hist);
+            if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs(), p->shape, st, p->stats(), cls);
             if (e == hipSuccess) e = hipMemcpyAsync(&seen, p->stats(), sizeof(seen), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess || pass == 1 || seen.max_slices == 0) break;
@@ -355,6 +452,26 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
 }
 
 #ifdef SS_TEST_HOOKS
+int ss_debug_batch_classes(const void *d_haystacks, const uint64_t *d_hay_begin, size_t count, uint32_t *state, uint8_t cls[256])
+{
+    if (!state || !cls) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    *state = 0;
+    ClassTable &t = class_tables()[dev];
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (t.pending >= 0 && __atomic_load_n(t.h_tag, __ATOMIC_ACQUIRE) == t.e[t.pending].tag) {
+        t.e[t.pending].state = 3;
+        t.pending = -1;
+    }
+    for (auto &c : t.e) {
+        if (c.state == 0 || c.hay != d_haystacks || c.begin != d_hay_begin || c.count != count) continue;
+        *state = c.state;
+        if (c.state == 3) HIP_TRY(hipMemcpy(cls, c.mem->cls, 256, hipMemcpyDeviceToHost));
+    }
+    return SS_OK;
+}
+
 int ss_debug_plan_filter(const ss_batch_plan *p, size_t problem, uint32_t out[5])
 {
     if (!p || !out || problem >= p->count) return fail(SS_ERR_ARGUMENT, "bad argument");

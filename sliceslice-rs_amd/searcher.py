@@ -109,6 +109,7 @@ HOOKS_ABI = {
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
     "ss_debug_census": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_plan_filter": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
+    "ss_debug_batch_classes": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)]),
     "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
 
@@ -858,6 +859,16 @@ class BatchPlan:
             self.close()
         except Exception:
             pass
+
+
+def batch_classes(haystacks, hay_off=None, hay_ranges=None):
+    """(state, classes) the library remembers for the UNPLANNED batch calls on these haystacks / ranges: state 0 unknown, 1 named
+    once, 2 sampling in flight, 3 classes in (then a list of 256 rarity classes, 0 = rarest) - hooks builds (ss_debug_batch_classes)."""
+    hb, _, count = _ranges(hay_off, *(hay_ranges or (None, None)))
+    st, cls = ctypes.c_uint32(0), (ctypes.c_uint8 * 256)()
+    L = lib()
+    _check(_hooks(L).ss_debug_batch_classes(haystacks.data_ptr(), hb, count, ctypes.byref(st), cls), L)
+    return st.value, (list(cls) if st.value == 3 else None)
 
 
 def _ranges(off, begin, end):

@@ -326,6 +326,16 @@ def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
                 torch.cuda.synchronize()
                 assert out.tolist() == (want if find else [1 if w >= 0 else 0 for w in want])
                 p.close()
+        # the UNPLANNED calls never wait: the first call names the batch, the second has the sampling launched in front of it, the
+        # ones after that choose by its classes - the same classes a plan gets; answers are the same at every stage
+        assert ss.batch_classes(hay, hoff)[0] == 0
+        for call in range(4):
+            assert ss.search_batched(hay, hoff, nbuf, noff_t).tolist() == [1 if w >= 0 else 0 for w in want], call
+            torch.cuda.synchronize()
+            state, got = ss.batch_classes(hay, hoff)
+            assert state == (1 if call == 0 else 3), (call, state)
+        assert got == cls
+        assert ss.find_batched(hay, hoff, nbuf, noff_t).tolist() == want
         # a caller's position is the caller's: needle[position] stays a first-phase byte, the histogram ranks the others
         pos = torch.tensor([(noff[i + 1] - noff[i]) // 2 for i in range(count)], dtype=torch.int64, device="cuda")
         plan = ss.BatchPlan(hay, hoff, nbuf, noff_t, position=pos)

@@ -62,6 +62,17 @@ def one_round(rng, count):
                 print(json.dumps({"MISMATCH": True, "pairs": pairs, "with_positions": p is not None, "problem": k, "needle_len": len(needles[k]),
                                   "haystack_len": len(hays[k]), "position": positions[k], "want": want[k], "needle": needles[k][:40].hex()}))
                 sys.exit(1)
+    # the unplanned call twice more on the SAME batch: the library samples the haystacks in front of the second call that names a batch
+    # and later calls choose their filter bytes by the sampled classes (ss_batched.hip, batch_classes) - the answers must not move
+    for rep in range(2):
+        got = [bool(x) for x in ss.search_batched(blob, ho, nblob, no).cpu().tolist()]
+        gotf = ss.find_batched(blob, ho, nblob, no).cpu().tolist()
+        bad = [k for k in range(count) if got[k] != want[k] or gotf[k] != where[k]]
+        if bad:
+            k = bad[0]
+            print(json.dumps({"MISMATCH": True, "repeated_call": rep, "problem": k, "needle_len": len(needles[k]), "haystack_len": len(hays[k]),
+                              "want": where[k], "got": gotf[k], "got_bool": got[k], "needle": needles[k][:40].hex()}))
+            sys.exit(1)
     # plans: the same problems, set up once, run twice; outputs start as garbage
     for find in (False, True):
         plan = ss.BatchPlan(blob, ho, nblob, no, find=find)
@@ -78,7 +89,7 @@ def one_round(rng, count):
                 sys.exit(1)
             out.fill_(-7)
         plan.close()
-    return 8 * count
+    return 12 * count
 
 
 def main():
