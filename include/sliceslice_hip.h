@@ -199,7 +199,10 @@ SS_API int ss_search_batched(const void *d_haystacks, const uint64_t *d_hay_begi
 
 /* Row f1 for a whole batch: the LEFTMOST offset of needle i in haystack i (SS_NPOS: absent; the empty needle: 0) - the
  * `Option<usize>` shape of bench/sse4-strstr/src/lib.rs:4-15 for many problems in one call.  Same ranges, same plan kernel and
- * scan grid as ss_search_batched (the `new` position for every problem); d_position: `count` uint64 in device memory. */
+ * scan grid as ss_search_batched (the `new` position for every problem); d_position: `count` uint64 in device memory.
+ * Both calls remember a few batches per device (blob, range array, count): in front of the SECOND call that names a batch a byte
+ * histogram of its haystacks is sampled on the call's stream (at most 4 MiB read, never waited for), and later calls choose the
+ * needle bytes they filter on by it (row f3 of SURVEY.md 8f; no result depends on the choice). */
 SS_API int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
                            const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
                            size_t count, void *hip_stream, uint64_t *d_position);
