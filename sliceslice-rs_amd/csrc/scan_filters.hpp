@@ -309,15 +309,6 @@ constexpr uint32_t kFarFirst = 10;
 #endif
 constexpr uint32_t kExactRefineSteps = SS_EXACT_REFINE_STEPS;     // schedule bytes in front of the exact in-register compare
 constexpr uint32_t kExactSparseLanes = 24;                        // ... none at all with this few candidate lanes in a tile
-// Needles too long for the exact compare: with at most this many candidate lanes in a tile only kSparseVerifySteps schedule bytes
-// are tried before the candidates go to memory (A/B: -DSS_SPARSE_VERIFY_LANES=N; 0 = the full schedule always)
-#ifndef SS_SPARSE_VERIFY_LANES
-#define SS_SPARSE_VERIFY_LANES 0
-#endif
-#ifndef SS_SPARSE_VERIFY_STEPS
-#define SS_SPARSE_VERIFY_STEPS 2
-#endif
-constexpr uint32_t kSparseVerifyLanes = SS_SPARSE_VERIFY_LANES, kSparseVerifySteps = SS_SPARSE_VERIFY_STEPS;
 constexpr uint32_t kRefineBytesPerBallot = SS_REFINE_BYTES_PER_BALLOT;   // schedule bytes applied between two wave ballots
 
 __host__ __device__ inline uint32_t build_refine_order(const uint8_t *needle, uint64_t n, uint64_t position,
@@ -500,15 +491,14 @@ __device__ __forceinline__ bool refine_tile(const u32x4 (&A)[U], const u32x4 &H,
 // since the cold fields left the registers both fit, and tile-wide is worth 4.5-4.9 -> 6.1-6.2 TB/s for the reference's
 // pair on text: profiles/r03/ab_refine_bytes_per_ballot.jsonl, `m2pp` = per piece.)
 // Returns false when no lane of the wave has a candidate left in this piece.
-__device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4], uint32_t max_steps = 15)
+__device__ __forceinline__ bool refine_piece(const u32x4 &A, const NextPiece &np, const RefineOrder &ro, uint32_t g[4])
 {
     bool any = __ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) != 0;
     uint32_t t = 0;
-    const uint32_t n = ro.n < max_steps ? ro.n : max_steps;
 #pragma unroll 1
-    while (t < n && any) {
+    while (t < ro.n && any) {
 #pragma unroll 1
-        for (uint32_t k = 0; k < kRefineBytesPerBallot && t < n; ++k, ++t) {     // two bytes per ballot: see refine_tile
+        for (uint32_t k = 0; k < kRefineBytesPerBallot && t < ro.n; ++k, ++t) {     // two bytes per ballot: see refine_tile
             const uint32_t sh = 8 * (t & 7);
             const int K = (int)(((t < 8 ? ro.idx[0] : ro.idx[1]) >> sh) & 0xFF);
             const uint32_t v = (uint32_t)(((t < 8 ? ro.val[0] : ro.val[1]) >> sh) & 0xFF);

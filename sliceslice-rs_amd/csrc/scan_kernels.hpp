@@ -419,8 +419,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // ... and with few candidate lanes in the tile (every piece of this text holds a true match or two) not
                     // even those: the compare costs a lane ~40 operations per candidate, a schedule byte ~24 per PIECE.
                     const bool exact = EXACT_OK && exact_len != 0;
-                    const uint32_t max_steps = exact ? (cand_lanes <= kExactSparseLanes ? 0u : kExactRefineSteps)
-                                                     : (cand_lanes <= kSparseVerifyLanes ? kSparseVerifySteps : 15u);
+                    const uint32_t max_steps = exact ? (cand_lanes <= kExactSparseLanes ? 0u : kExactRefineSteps) : 15u;
                     if (max_steps != 0 && !refine_tile<U, MODE>(A, H, ro, G, max_steps)) continue;
                 }
             }
@@ -438,7 +437,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // With the needle's dwords at hand the exact compare below settles a lane's candidates in ~50 VALU
                     // operations, all lanes at once - about what TWO steps of the byte-wise schedule cost - and a true match
                     // would sit through every one of its up to 13 steps first (a microsecond of ballots and branches).
-                    if (!(EXACT_OK && exact_len != 0) && !refine_piece(A[u], np, ro, g, cand_lanes <= kSparseVerifyLanes ? kSparseVerifySteps : 15u)) continue;
+                    if (!(EXACT_OK && exact_len != 0) && !refine_piece(A[u], np, ro, g)) continue;
                 } else if (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) == 0) {
                     continue;
                 }
