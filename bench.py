@@ -418,6 +418,30 @@ def other_configs(ss, shard, reps=20):
         out["text_non_latin"] = {"workload": "1 GiB of UTF-8-like text in a non-Latin script (every other byte a 0xD0 / 0xD1 lead byte), absent words of "
                                              "its alphabet: `new` - filter bytes re-chosen per haystack from a sampled byte histogram - against "
                                              "the static, corpus-free triple pinned with ss_searcher_set_filter3", "rows": rows}
+        # ... and the same text as config 5 cuts it: 1,024 haystacks of 1 MiB, an absent 16-byte word of the alphabet each - the call and the
+        # plan choose their filter bytes by a byte histogram of the haystacks that the library samples itself (ss_batched.hip)
+        cnt, each = 1024, gib // 1024
+        at = torch.arange(cnt, device="cuda", dtype=torch.int64) * each + 2 * 1000
+        wd = nl[(at[:, None] + torch.arange(16, device="cuda", dtype=torch.int64)[None, :]).reshape(-1)].reshape(cnt, 16).clone()
+        wd[:, 1] = 0xBF
+        wd[:, 9] = 0xBF
+        nblob = wd.reshape(-1).contiguous()
+        hay_off = (torch.arange(cnt + 1, dtype=torch.int64) * each).cuda()
+        nd_off = (torch.arange(cnt + 1, dtype=torch.int64) * 16).cuda()
+        for _ in range(4):
+            found = ss.search_batched(nl, hay_off, nblob, nd_off)
+        med, steady = _events_ms(lambda: ss.search_batched(nl, hay_off, nblob, nd_off), 15)
+        plan = ss.BatchPlan(nl, hay_off, nblob, nd_off)
+        flags = torch.empty(cnt, dtype=torch.int32, device="cuda")
+        pmed, psteady = _events_ms(lambda: plan.run(flags), 15)
+        assert torch.equal(flags, found)
+        plan.close()
+        out["5_text_non_latin"] = {"workload": "the same text as 1,024 haystacks of 1 MiB, an absent 16-byte word of its alphabet each: one "
+                                               "ss_search_batched call / one run of a plan (filter bytes chosen by the haystacks' own sampled "
+                                               "byte histogram; the static classes filter this text at 2.7-3.5 TB/s: profiles/r05/batch_triple_probe.jsonl)",
+                                   "problems": cnt, "found": int(found.sum().item()), "call_ms": round(med, 4), "frac": round(gib / med / 1e6 / HBM_PEAK_GBPS, 4),
+                                   "plan_run_ms": round(pmed, 4), "plan_gbps": round(gib / pmed / 1e6, 1), "plan_frac": round(gib / pmed / 1e6 / HBM_PEAK_GBPS, 4),
+                                   "plan_frac_steady": round(gib / psteady / 1e6 / HBM_PEAK_GBPS, 4)}
         del nl
     except Exception as e:      # pragma: no cover
         out["text_non_latin_error"] = repr(e)

@@ -27,5 +27,6 @@ python tools/batch_probe.py --find --reps 20 1024x1048576 64x16777216 16384x6553
 for k in 1 2 3; do SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/occ_probe.py --gib 1,8 > $X/occ_probe_run$k.jsonl 2>/dev/null; done
 SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/mode3_probe.py --gib 1,8 > $X/mode3_probe.jsonl 2>/dev/null
 SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/triple_probe.py > $X/triple_probe.jsonl 2>/dev/null
+SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/batch_triple_probe.py > $X/batch_triple_probe.jsonl 2>/dev/null
 SLICESLICE_RCCL_LIB=$R/tests/native/libfake_rccl.so tools/native_bench set 8 8 200 2>/dev/null | grep '^{' > $X/native_set8.json
 tail -3 $X/capture.log
