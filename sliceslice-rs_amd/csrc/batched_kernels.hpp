@@ -339,6 +339,7 @@ struct ColdFields {
     __device__ __forceinline__ const ColdFields *operator->() const { return this; }
 };
 struct ColdInDesc {
+    static constexpr bool kHasOrder = false;        // the wave that meets a candidate builds the schedule itself
     const BatchDesc *dp;
     const uint8_t *needles;
     __device__ __forceinline__ ColdFields operator()() const
@@ -358,6 +359,132 @@ struct ColdInDesc {
         return f;
     }
 };
+
+// A PLAN carries the cold part ready-made: what a wave of the unplanned kernel builds when it first meets a candidate - the
+// second-level schedule (up to 15 further needle bytes, rarest first) and, for needles that end within 16 bytes of the first filter
+// byte, the needle's dwords for the in-register compare - costs it a dependent round trip to the needle bytes plus a few hundred
+// operations, once per wave and WORKGROUP: nothing on random bytes, where next to no wave meets a candidate, but on text, where
+// every other workgroup does, the batched scan ran at 5.2 TB/s (unplanned, shorter slices: 4.3) where the single-problem kernel,
+// whose Problem arrives complete in the kernel arguments, reaches 6.1-6.9.  batch_cold_kernel (one LANE per problem, once per plan)
+// writes one 64-byte BatchCold per problem; a wave then needs one more scalar load.
+struct __attribute__((aligned(64))) BatchCold {
+    uint64_t order_idx[2], order_val[2];       // as Problem::order_idx / order_val (build_refine_order)
+    uint32_t tail16[4];                        // as Problem::tail16
+    uint32_t norder, exact_len;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BatchCold) == 64, "one scalar load");
+struct ColdInPlan {
+    static constexpr bool kHasOrder = true;
+    const BatchDesc *dp;
+    const BatchCold *cp;
+    const uint8_t *needles;
+    __device__ __forceinline__ ColdFields operator()() const
+    {
+        const BatchDesc *q = dp;
+        const BatchCold *c = cp;
+        __asm__ volatile("" : "+s"(q), "+s"(c));    // opaque: the loads stay in the cold path
+        ColdFields f;
+        f.hay = q->base + (q->shifts & 15) - q->anchor;
+        f.needle = needles + q->needle_off;
+        f.n = q->n;
+        f.end = q->end;
+        f.norder = c->norder;
+        f.exact_len = c->exact_len;
+        f.order_idx[0] = c->order_idx[0]; f.order_idx[1] = c->order_idx[1];
+        f.order_val[0] = c->order_val[0]; f.order_val[1] = c->order_val[1];
+        f.tail16[0] = c->tail16[0]; f.tail16[1] = c->tail16[1]; f.tail16[2] = c->tail16[2]; f.tail16[3] = c->tail16[3];
+        f.host_flag = nullptr;
+        f.far_off = 0;
+        return f;
+    }
+};
+
+// One LANE per problem, once per plan, behind the plan kernel: the cold part of every problem that is scanned.  The schedule follows
+// build_refine_order's rules - the bytes 16..31 behind the first filter byte first, rarest first, at most kFarFirst of them; then
+// the bytes 1..15, rarest first; then what is left of the far ones; fifteen in all, the first-phase bytes left out - with the
+// rarity classes the plan's filter bytes were chosen by (`cls`: the haystacks' own, else the static four).  Only the ORDER of the
+// checks depends on the classes; the dwords of the exact compare are the needle's bytes.
+__global__ void __launch_bounds__(kBlock) batch_cold_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint64_t count,
+                                                             BatchCold *colds, const uint8_t *cls)
+{
+    __shared__ uint8_t s_class[256];
+    if (cls) {
+        s_class[threadIdx.x] = cls[threadIdx.x];
+    } else {
+        s_class[threadIdx.x] = (uint8_t)rarity_class4((uint8_t)threadIdx.x);
+    }
+    __syncthreads();
+    const uint64_t prob = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (prob >= count) return;
+    const BatchDesc d = descs[prob];
+    BatchCold c;
+    c.order_idx[0] = c.order_idx[1] = c.order_val[0] = c.order_val[1] = 0;
+    c.tail16[0] = c.tail16[1] = c.tail16[2] = c.tail16[3] = 0;
+    c.norder = c.exact_len = 0;
+    c.pad[0] = c.pad[1] = 0;
+    if ((d.per >> 32) != 0 && ((d.bytes >> 24) & 1) == 0) {
+        const uint8_t *needle = a.needles + d.needle_off + d.anchor;         // from the first filter byte on
+        const uint64_t nrel = d.n - d.anchor;
+        const uint32_t lim = nrel < (uint64_t)kRefineWindow ? (uint32_t)nrel : (uint32_t)kRefineWindow;
+        const uint32_t pos2 = 4 * ((d.shifts >> 6) & 3) + ((d.shifts >> 4) & 3), pos3 = 4 * ((d.shifts >> 10) & 3) + ((d.shifts >> 8) & 3);
+        uint32_t b[kRefineWindow], k[kRefineWindow];
+#pragma unroll
+        for (int K = 0; K < kRefineWindow; ++K) b[K] = needle[(uint32_t)K < lim ? K : 0];     // (all in flight together)
+#pragma unroll
+        for (int K = 0; K < kRefineWindow; ++K) k[K] = s_class[b[K]];
+        uint32_t valid = 0;                         // bit K: a byte the schedule may use
+#pragma unroll
+        for (int K = 1; K < kRefineWindow; ++K)
+            if ((uint32_t)K < lim && (uint32_t)K != pos2 && (uint32_t)K != pos3) valid |= 1u << K;
+        uint64_t i0 = 0, i1 = 0, v0 = 0, v1 = 0;
+        uint32_t m = 0, used = 0, far_used = 0;
+        auto emit = [&](uint32_t K, uint32_t byte) {
+            const uint32_t sh = 8 * (m & 7);
+            if (m < 8) { i0 |= (uint64_t)K << sh; v0 |= (uint64_t)byte << sh; }
+            else { i1 |= (uint64_t)K << sh; v1 |= (uint64_t)byte << sh; }
+            ++m;
+            used |= 1u << K;
+        };
+        // three passes, each class by class (rarest = 0 first), stable in K
+#pragma unroll 1
+        for (uint32_t cl = 0; cl < 16; ++cl) {
+#pragma unroll
+            for (int K = 16; K < kRefineWindow; ++K)
+                if (((valid >> K) & 1u) && k[K] == cl && far_used < kFarFirst) { emit(K, b[K]); ++far_used; }
+        }
+#pragma unroll 1
+        for (uint32_t cl = 0; cl < 16; ++cl) {
+#pragma unroll
+            for (int K = 1; K < 16; ++K)
+                if (((valid >> K) & 1u) && k[K] == cl && m < 15) emit(K, b[K]);
+        }
+#pragma unroll 1
+        for (uint32_t cl = 0; cl < 16; ++cl) {
+#pragma unroll
+            for (int K = 16; K < kRefineWindow; ++K)
+                if (((valid >> K) & 1u) && !((used >> K) & 1u) && k[K] == cl && m < 15) emit(K, b[K]);
+        }
+        c.norder = m;
+        c.order_idx[0] = i0; c.order_idx[1] = i1;
+        c.order_val[0] = v0; c.order_val[1] = v1;
+        if (nrel <= 16) {
+            // the bytes from the first filter byte on, plus what sixteen leave room for of those in front of it (scan_tiles)
+            const uint32_t behind = (uint32_t)nrel;
+            const uint32_t back = (uint32_t)(d.anchor < 16 - behind ? d.anchor : 16 - behind);
+            const uint32_t el = behind + back;
+            c.exact_len = el | (back << 8);
+            uint32_t t[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) t[j] = (needle - back)[j < el ? j : 0];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) t[j] = j < el ? t[j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c.tail16[j] = t[4 * j] | (t[4 * j + 1] << 8) | (t[4 * j + 2] << 16) | (t[4 * j + 3] << 24);
+        }
+    }
+    colds[prob] = c;
+}
 
 // Grid: ONE dimension, nslices workgroups per problem; two ways of laying them out, chosen by the host from the slice count
 // (the lengths live on the device; the count of problems is all the host knows):
@@ -398,7 +525,8 @@ constexpr uint32_t kPlanSliceMajorMax = 8;
 #endif
 template <int U, bool FIND = false, bool PLAN = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, SS_BATCH_WAVES_MAX))) __launch_bounds__(kBlock)
-scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state)
+scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state,
+                         const BatchCold *__restrict__ colds)
 {
     constexpr bool COUNTED = PLAN;                  // (the name the code below grew up with)
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
@@ -476,7 +604,15 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         pr.epoch = 1;
         pr.flags = 0;
         pr.q = (d.shifts >> 6) & 3;
-        const ColdInDesc cold = {dp, a.needles};
+        // (a plan's problems come with their cold part ready-made; the unplanned kernel's waves build it when they need it)
+#ifdef SS_NO_PLAN_COLD       // A/B builds only (tools/ab_batch_inproc.py): a plan's waves build their cold part like the unplanned kernel's
+        constexpr bool READY = PLAN && U == 0;
+#else
+        constexpr bool READY = PLAN;
+#endif
+        typename std::conditional<READY, ColdInPlan, ColdInDesc>::type cold;
+        if constexpr (READY) cold = ColdInPlan{dp, colds + prob, a.needles};
+        else cold = ColdInDesc{dp, a.needles};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
         // (Measured and not adopted - commit 7511606 (-DSS_SIBLING_POLL), profiles/r05/ab_sibling_poll.jsonl: the waves of such a workgroup polling EACH
         // OTHER'S words between tiles, so that a match by one stops the other three.  It takes a barrier in front of the scan - a

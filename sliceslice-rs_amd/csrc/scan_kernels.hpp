@@ -75,6 +75,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     // device-scope atomic in front of it.
     int *wg_found = static_cast<int *>(wg_sink);
     constexpr bool WG_FIND = LAZY_ORDER;            // (compiled into scan_kernel's FIND path it would be dead code that still moves registers)
+    // LAZY_ORDER kernels fetch the cold part once per wave; whether the wave then BUILDS the schedule and the needle's dwords or
+    // finds them there depends on where the cold part comes from (a plan's descriptors carry them: batched_kernels.hpp, BatchCold)
+    constexpr bool BUILD_ORDER = LAZY_ORDER && !ColdT::kHasOrder;
     constexpr bool NTA = NTMODE >= 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
@@ -335,7 +338,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 va.needle = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(uintptr_t)c->needle));
                 va.n = uniform64(c->n);
                 va.end = uniform64(c->end);
-                if (!ONE_BYTE && !LAZY_ORDER) {
+                if (!ONE_BYTE && !BUILD_ORDER) {
                     ro.n = c->norder;
                     ro.idx[0] = c->order_idx[0]; ro.idx[1] = c->order_idx[1];
                     ro.val[0] = c->order_val[0]; ro.val[1] = c->order_val[1];
@@ -344,8 +347,22 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
 #pragma unroll
                         for (int j = 0; j < 4; ++j) tail16[j] = c->tail16[j];
                     }
+                    if (LAZY_ORDER) {
+                        // (a plan's cold part arrives through memory behind the kernel's first stores, i.e. by vector loads: what
+                        // steers the second level must sit in scalar registers all the same)
+                        ro.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)ro.n);
+                        for (int t = 0; t < 2; ++t) {
+                            ro.idx[t] = uniform64(ro.idx[t]);
+                            ro.val[t] = uniform64(ro.val[t]);
+                        }
+                        if (EXACT_OK) {
+                            exact_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)exact_len);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) tail16[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail16[j]);
+                        }
+                    }
                 }
-                if (!ONE_BYTE && LAZY_ORDER) {
+                if (!ONE_BYTE && BUILD_ORDER) {
                     // the descriptor came without the schedule (and without the needle's dwords): built here, by the waves
                     // that need them, not on every workgroup's way in
                     const uint64_t position = pr.d * 16 + 4 * (Q == kQDynamic ? pr.q : (uint32_t)Q) + pr.r;

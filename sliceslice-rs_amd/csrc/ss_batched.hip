@@ -282,9 +282,9 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
     if (e == hipSuccess) {
         const dim3 grid((unsigned)((uint64_t)count * sh.slices));
         if (a.best)
-            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr);
+            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
         else
-            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr);
+            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
         e = hipGetLastError();
     }
     ps->mu.unlock();
@@ -297,8 +297,9 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
 
 using namespace ssh;
 
-// The plan's own memory: descriptors | state words (uint64 each; the bool plans use the low int) | the plan kernel's PlanStats
-// (64 bytes) | the sampling's counters and the rarity classes of the haystacks' bytes (ss::BatchClasses).
+// The plan's own memory: descriptors | cold parts (64 bytes each, like the descriptors) | state words (uint64 each; the bool plans
+// use the low int) | the plan kernel's PlanStats (64 bytes) | the sampling's counters and the rarity classes of the haystacks'
+// bytes (ss::BatchClasses).
 struct ss_batch_plan {
     int dev = 0;
     size_t count = 0;
@@ -306,10 +307,12 @@ struct ss_batch_plan {
     ss::BatchArgs args;
     BatchShape shape = {1, 1};
     uint8_t *mem = nullptr;
+    static constexpr size_t kPerProblem = sizeof(ss::BatchDesc) + sizeof(ss::BatchCold) + sizeof(uint64_t);
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
-    void *state() const { return mem + count * sizeof(ss::BatchDesc); }
-    ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t))); }
-    ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64); }
+    ss::BatchCold *colds() const { return reinterpret_cast<ss::BatchCold *>(mem + count * sizeof(ss::BatchDesc)); }
+    void *state() const { return mem + count * (sizeof(ss::BatchDesc) + sizeof(ss::BatchCold)); }
+    ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * kPerProblem); }
+    ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * kPerProblem + 64); }
 };
 
 extern "C" {
@@ -360,7 +363,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     if (rc == SS_OK && (e = hipGetDevice(&p->dev)) != hipSuccess) rc = fail(SS_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
     if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape, true);
     if (rc == SS_OK) {
-        const size_t bytes = count * (sizeof(ss::BatchDesc) + sizeof(uint64_t)) + 64 + sizeof(ss::BatchClasses);
+        const size_t bytes = count * ss_batch_plan::kPerProblem + 64 + sizeof(ss::BatchClasses);
         if ((e = hipMalloc((void **)&p->mem, bytes)) != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
@@ -412,6 +415,12 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
         if (e == hipSuccess) {
             const uint32_t most = seen.max_slices;
             p->shape.slices = most < 1 ? 1 : (most < p->shape.slices ? most : p->shape.slices);
+            // the cold part of every problem (second-level schedule, the needle's dwords): once, here, instead of by every wave that
+            // meets a candidate (batched_kernels.hpp, BatchCold)
+            ss::batch_cold_kernel<<<dim3((unsigned)((count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(p->args, p->descs(), (uint64_t)count,
+                                                                                                                        p->colds(), cls);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
         }
         if (e != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan set-up: %s", hipGetErrorString(e));
@@ -437,10 +446,10 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     const dim3 grid((unsigned)((uint64_t)p->count * p->shape.slices));
     if (p->find) {
         a.best = static_cast<uint64_t *>(d_out);
-        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state());
+        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state(), p->colds());
     } else {
         a.found = static_cast<int *>(d_out);
-        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state());
+        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state(), p->colds());
     }
     HIP_TRY(hipGetLastError());
     // problems scanned by several workgroups leave their answer in the plan's state words: one lane per problem publishes

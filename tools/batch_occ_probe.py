@@ -47,9 +47,17 @@ def main():
             for occ in (4, 5, 6):
                 os.environ["SLICESLICE_BATCH_OCC"] = str(occ)
                 row["occ%d_ms_%d" % (occ, rnd)] = round(events_ms(lambda: plan.run(out), args.reps)[0], 4)
+        # the unplanned call's scan kernel needs 80 vector registers (six waves per SIMD fit), the plan's 81-82 (five)
+        for _ in range(4):
+            ss.search_batched(hay, hoff, nb, noff)
+        for rnd in range(2):
+            for occ in (4, 5, 6):
+                os.environ["SLICESLICE_BATCH_OCC"] = str(occ)
+                row["call_occ%d_ms_%d" % (occ, rnd)] = round(events_ms(lambda: ss.search_batched(hay, hoff, nb, noff), args.reps)[0], 4)
         del os.environ["SLICESLICE_BATCH_OCC"]
         for occ in (4, 5, 6):
             row["occ%d_gbps" % occ] = round(n / min(row["occ%d_ms_0" % occ], row["occ%d_ms_1" % occ]) / 1e6, 1)
+            row["call_occ%d_gbps" % occ] = round(n / min(row["call_occ%d_ms_0" % occ], row["call_occ%d_ms_1" % occ]) / 1e6, 1)
         row["found"] = int(out.sum().item())
         print(json.dumps(row), flush=True)
         plan.close()
