@@ -363,10 +363,11 @@ struct ColdInDesc {
 // A PLAN carries the cold part ready-made: what a wave of the unplanned kernel builds when it first meets a candidate - the
 // second-level schedule (up to 15 further needle bytes, rarest first) and, for needles that end within 16 bytes of the first filter
 // byte, the needle's dwords for the in-register compare - costs it a dependent round trip to the needle bytes plus a few hundred
-// operations, once per wave and WORKGROUP: nothing on random bytes, where next to no wave meets a candidate, but on text, where
-// every other workgroup does, the batched scan ran at 5.2 TB/s (unplanned, shorter slices: 4.3) where the single-problem kernel,
-// whose Problem arrives complete in the kernel arguments, reaches 6.1-6.9.  batch_cold_kernel (one LANE per problem, once per plan)
-// writes one 64-byte BatchCold per problem; a wave then needs one more scalar load.
+// operations, once per wave and WORKGROUP: nothing on random bytes, where next to no wave meets a candidate; where the needles ARE
+// there (the reference's bench: every word occurs in the text) it sits on the path of every problem's answer - 65,536 problems of
+// 16 KiB, every second needle present: 0.447 ms a run, 0.271 with the cold part ready-made - and on text full of near misses it is
+// paid by every other workgroup.  batch_cold_kernel (one LANE per problem, once per plan) writes one 64-byte BatchCold per
+// problem; a wave then needs one more load.
 struct __attribute__((aligned(64))) BatchCold {
     uint64_t order_idx[2], order_val[2];       // as Problem::order_idx / order_val (build_refine_order)
     uint32_t tail16[4];                        // as Problem::tail16
@@ -605,11 +606,10 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         pr.flags = 0;
         pr.q = (d.shifts >> 6) & 3;
         // (a plan's problems come with their cold part ready-made; the unplanned kernel's waves build it when they need it)
-#ifdef SS_NO_PLAN_COLD       // A/B builds only (tools/ab_batch_inproc.py): a plan's waves build their cold part like the unplanned kernel's
-        constexpr bool READY = PLAN && U == 0;
-#else
+        // (measured against plans whose waves build it like the unplanned kernel's, in one process - commit 21a0590 with
+        // -DSS_NO_PLAN_COLD, profiles/r05/ab_plan_cold.jsonl: absent needles on random bytes the same to +-1 %, every second needle
+        // present 16,384 x 64 KiB 0.154 ms instead of 0.183, 65,536 x 16 KiB 0.271 instead of 0.447)
         constexpr bool READY = PLAN;
-#endif
         typename std::conditional<READY, ColdInPlan, ColdInDesc>::type cold;
         if constexpr (READY) cold = ColdInPlan{dp, colds + prob, a.needles};
         else cold = ColdInDesc{dp, a.needles};
