@@ -74,8 +74,9 @@ def one_round(rng, count):
                               "want": where[k], "got": gotf[k], "got_bool": got[k], "needle": needles[k][:40].hex()}))
             sys.exit(1)
     # plans: the same problems, set up once, run twice; outputs start as garbage
-    for find in (False, True):
-        plan = ss.BatchPlan(blob, ho, nblob, no, find=find)
+    for find, with_pos in ((False, False), (True, False), (False, True)):
+        # (plans with the caller's positions too: a first filter byte that is not needle[0], cold parts with bytes in front of it)
+        plan = ss.BatchPlan(blob, ho, nblob, no, find=find, position=pos if with_pos else None)
         out = torch.full((count,), 0x5a5a5a5a, dtype=torch.int64 if find else torch.int32, device="cuda")
         for run in range(2):
             plan.run(out)
@@ -84,12 +85,12 @@ def one_round(rng, count):
             bad = [k for k in range(count) if got[k] != exp[k]]
             if bad:
                 k = bad[0]
-                print(json.dumps({"MISMATCH": True, "plan": True, "find": find, "run": run, "problem": k, "needle_len": len(needles[k]),
+                print(json.dumps({"MISMATCH": True, "plan": True, "find": find, "with_positions": with_pos, "run": run, "problem": k, "needle_len": len(needles[k]),
                                   "haystack_len": len(hays[k]), "want": exp[k], "got": got[k], "needle": needles[k][:40].hex()}))
                 sys.exit(1)
             out.fill_(-7)
         plan.close()
-    return 12 * count
+    return 14 * count
 
 
 def main():
