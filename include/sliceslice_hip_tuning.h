@@ -90,6 +90,12 @@ SS_API int ss_debug_batch_classes(const void *d_haystacks, const uint64_t *d_hay
  * that scan the problem (0: answered without a scan; the indices are 0 then).  Copies 64 bytes from the device. */
 SS_API int ss_debug_plan_filter(const ss_batch_plan *p, size_t problem, uint32_t out[5]);
 
+/* A plan's ready-made cold part of `problem` (batched_kernels.hpp, BatchCold): out[0] = bytes in the second-level schedule, out[1] =
+ * exact_len (bytes of the in-register compare | bytes in front of the first filter byte << 8; 0: the needle is too long for it),
+ * out[2..5] = the schedule's indices (relative to the first filter byte), one byte each, low dword first; out[6..9] = the needle's
+ * bytes at those indices; out[10..13] = the needle's dwords for the compare. */
+SS_API int ss_debug_plan_cold(const ss_batch_plan *p, size_t problem, uint32_t out[14]);
+
 /* requests served / kernel launches so far (a burst of requests shares one residency) / requests that skipped the acquire */
 SS_API int ss_service_counters(ss_service *sv, uint64_t *requests, uint64_t *kernel_launches, uint64_t *settled);
 

@@ -481,6 +481,23 @@ int ss_debug_batch_classes(const void *d_haystacks, const uint64_t *d_hay_begin,
     return SS_OK;
 }
 
+int ss_debug_plan_cold(const ss_batch_plan *p, size_t problem, uint32_t out[14])
+{
+    if (!p || !out || problem >= p->count) return fail(SS_ERR_ARGUMENT, "bad argument");
+    ss::BatchCold c;
+    HIP_TRY(hipMemcpy(&c, p->colds() + problem, sizeof c, hipMemcpyDeviceToHost));
+    out[0] = c.norder;
+    out[1] = c.exact_len;
+    for (int t = 0; t < 2; ++t) {
+        out[2 + 2 * t] = (uint32_t)c.order_idx[t];
+        out[3 + 2 * t] = (uint32_t)(c.order_idx[t] >> 32);
+        out[6 + 2 * t] = (uint32_t)c.order_val[t];
+        out[7 + 2 * t] = (uint32_t)(c.order_val[t] >> 32);
+    }
+    for (int j = 0; j < 4; ++j) out[10 + j] = c.tail16[j];
+    return SS_OK;
+}
+
 int ss_debug_plan_filter(const ss_batch_plan *p, size_t problem, uint32_t out[5])
 {
     if (!p || !out || problem >= p->count) return fail(SS_ERR_ARGUMENT, "bad argument");

@@ -109,6 +109,7 @@ HOOKS_ABI = {
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
     "ss_debug_census": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_plan_filter": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
+    "ss_debug_plan_cold": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_batch_classes": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)]),
     "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
@@ -848,6 +849,17 @@ class BatchPlan:
         out = (ctypes.c_uint32 * 5)()
         _check(_hooks(self._L).ss_debug_plan_filter(self._h, int(problem), out), self._L)
         return (out[0], out[1], out[2]), out[3], out[4]
+
+    def cold_of(self, problem):
+        """(schedule indices, schedule bytes, exact_len, bytes in front, the compare's 16 bytes) of one problem's ready-made cold
+        part - hooks builds (ss_debug_plan_cold)."""
+        out = (ctypes.c_uint32 * 14)()
+        _check(_hooks(self._L).ss_debug_plan_cold(self._h, int(problem), out), self._L)
+        n = out[0]
+        idx = b"".join(int(out[2 + t]).to_bytes(4, "little") for t in range(4))[:n]
+        val = b"".join(int(out[6 + t]).to_bytes(4, "little") for t in range(4))[:n]
+        tail = b"".join(int(out[10 + t]).to_bytes(4, "little") for t in range(4))
+        return list(idx), val, out[1] & 0xFF, out[1] >> 8, tail
 
     def close(self):
         if getattr(self, "_h", None) and _lib is not None:

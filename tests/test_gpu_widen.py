@@ -258,18 +258,49 @@ def _plan_sample_model(host, begins, ends):
 
 
 def _plan_pair_model(needle, cls):
-    """plan_one's choice for a needle of 3..16 bytes whose `position` nobody chose: needle[0] + the two rarest (class) of the bytes
-    behind it, the later one among equals."""
-    lim = min(len(needle), 16)
-    s2, bc = len(needle) - 1, 255
-    for k in range(1, lim):
-        if cls[needle[k]] <= bc:
-            bc, s2 = cls[needle[k]], k
+    """plan_one's choice for a needle of 3 bytes or more whose `position` nobody chose.  Up to 16 bytes: needle[0] + the two rarest
+    (class) of the bytes behind it, the later one among equals.  Longer: the last byte, the rarest of the 15 in front of it as the
+    first filter byte, and the rarest other byte of the 15 behind that."""
+    n = len(needle)
+    position, anchor = n - 1, 0
+    if position >= 16:
+        bc = 255
+        for k in range(15):
+            if cls[needle[position - 15 + k]] <= bc:
+                bc, anchor = cls[needle[position - 15 + k]], position - 15 + k
+    lim = min(n - anchor, 16)
+    s2 = position - anchor
+    if anchor == 0:
+        bc = 255
+        for k in range(1, lim):
+            if cls[needle[k]] <= bc:
+                bc, s2 = cls[needle[k]], k
     p3, bc = s2, 255
     for k in range(1, lim):
-        if k != s2 and cls[needle[k]] <= bc:
-            bc, p3 = cls[needle[k]], k
-    return {0, s2, p3}
+        if k != s2 and cls[needle[anchor + k]] <= bc:
+            bc, p3 = cls[needle[anchor + k]], k
+    return {anchor, anchor + s2, anchor + p3}
+
+
+def _cold_model(needle, tri, cls):
+    """numpy-free restatement of batch_cold_kernel: the schedule (indices relative to the first filter byte: the bytes 16..31 first,
+    rarest class first, at most ten; then 1..15; then the far ones left over; fifteen in all, the other two filter bytes left out)
+    and the needle's bytes for the in-register compare (needles that end within 16 bytes of the first filter byte)."""
+    anchor = min(tri)
+    rel = needle[anchor:]
+    lim = min(len(rel), 32)
+    skip = {t - anchor for t in tri}
+    ok = [k for k in range(1, lim) if k not in skip]
+    far = sorted((k for k in ok if k >= 16), key=lambda k: cls[rel[k]])
+    near = sorted((k for k in ok if k < 16), key=lambda k: cls[rel[k]])
+    order = far[:10] + near
+    order = (order + far[10:])[:15] if len(order) < 15 else order[:15]
+    exact, back, tail = 0, 0, bytes(16)
+    if len(rel) <= 16:
+        back = min(anchor, 16 - len(rel))
+        exact = len(rel) + back
+        tail = (needle[anchor - back:] + bytes(16))[:16]
+    return order, bytes(rel[k] for k in order), exact, back, tail
 
 
 def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
@@ -284,7 +315,7 @@ def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
     needles, noff, want = bytearray(), [0], []
     for i in range(count):
         at = 2 * rng.randrange(8, hay_len // 2 - 64) + i * hay_len
-        n = rng.choice((6, 12, 16))
+        n = rng.choice((6, 12, 16, 40))                    # (40: too long for the in-register compare, bytes 16..31 in the schedule)
         w = bytearray(host[at:at + n].tobytes())
         if i % 3:
             w[rng.randrange(1, n - 1)] = ord("e")          # absent: no 'e' in this haystack - and the static table's most common letter
@@ -314,13 +345,14 @@ def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
                 tri, packed, slices = plan.filter_of(i)
                 assert slices >= 1 and set(tri) == _plan_pair_model(nd, cls), (i, nd, tri)
                 assert [packed & 0xFF, (packed >> 8) & 0xFF, (packed >> 16) & 0xFF] == [nd[k] for k in tri]
+                assert plan.cold_of(i) == _cold_model(nd, tri, cls), (i, nd, tri)        # the ready-made cold part
                 stri = static.filter_of(i)[0]
-                assert stri[0] == 0 and len(nd) - 1 in stri, "the static table keeps the reference's pair (0, n-1)"
-                if ord("e") in nd:
+                assert len(nd) - 1 in stri and (stri[0] == 0 or len(nd) > 16), "the static table keeps the reference's pair (0, n-1)"
+                if ord("e") in nd and len(nd) <= 16:
                     e_at = nd.index(b"e")
                     with_e += 1
                     assert e_at in tri and e_at not in stri, (i, nd, tri, stri)
-            assert with_e > count // 2
+            assert with_e > count // 3
             for p in (plan, static):
                 out = p.run()
                 torch.cuda.synchronize()
@@ -341,7 +373,8 @@ def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
         plan = ss.BatchPlan(hay, hoff, nbuf, noff_t, position=pos)
         for i in range(0, count, 7):
             tri = plan.filter_of(i)[0]
-            assert tri[0] == 0 and (noff[i + 1] - noff[i]) // 2 in tri
+            assert (tri[0] == 0 or noff[i + 1] - noff[i] > 16) and (noff[i + 1] - noff[i]) // 2 in tri
+            assert plan.cold_of(i) == _cold_model(bytes(needles[noff[i]:noff[i + 1]]), tri, cls)
         assert plan.run().tolist() == [1 if w >= 0 else 0 for w in want]
         plan.close()
 

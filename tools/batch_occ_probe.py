@@ -39,7 +39,34 @@ def main():
     ndr = bytearray(ss.fill_random_host(16 * count, 0x5EED0003).tobytes())
     ndr[8::16] = b"\xff" * count
     work.append(("random bytes", blob, torch.from_numpy(np.frombuffer(bytes(ndr), dtype=np.uint8).copy()).cuda(), (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()))
-    for name, hay, nb, noff in work:
+    # the reference's i386 loop: 4,585 words, one text (aliased ranges), every word present - bound by how many short-lived workgroups
+    # the chip keeps in flight, not by bytes
+    words = [w for w in open(os.path.join(gd, "words.txt"), "rb").read().split(b"\n") if w]
+    i386 = torch.from_numpy(raw.copy()).cuda()
+    hb = torch.zeros(len(words), dtype=torch.int64, device="cuda")
+    he = torch.full((len(words),), raw.size, dtype=torch.int64, device="cuda")
+    wb = torch.from_numpy(np.frombuffer(b"".join(words), dtype=np.uint8).copy()).cuda()
+    wo = torch.from_numpy(np.cumsum(np.array([0] + [len(w) for w in words], dtype=np.int64))).cuda()
+    work.append(("the reference's i386 loop", i386, wb, wo, (hb, he), len(words), raw.size * len(words)))
+    for item in work:
+        name, hay, nb, noff = item[:4]
+        ranges = item[4] if len(item) > 4 else None
+        count = item[5] if len(item) > 4 else args.mib
+        n = item[6] if len(item) > 4 else count * each
+        if ranges is not None:
+            plan = ss.BatchPlan(hay, None, nb, noff, hay_ranges=ranges)
+            out = torch.empty(count, dtype=torch.int32, device="cuda")
+            row = {"workload": name, "problems": count, "bytes": n}
+            for rnd in range(2):
+                for occ in (4, 5, 6):
+                    os.environ["SLICESLICE_BATCH_OCC"] = str(occ)
+                    row["occ%d_ms_%d" % (occ, rnd)] = round(events_ms(lambda: plan.run(out), args.reps)[0], 4)
+                    row["call_occ%d_ms_%d" % (occ, rnd)] = round(events_ms(lambda: ss.search_batched(hay, None, nb, noff, hay_ranges=ranges), args.reps)[0], 4)
+            del os.environ["SLICESLICE_BATCH_OCC"]
+            row["found"] = int(out.sum().item())
+            print(json.dumps(row), flush=True)
+            plan.close()
+            continue
         plan = ss.BatchPlan(hay, hoff, nb, noff)
         out = torch.empty(count, dtype=torch.int32, device="cuda")
         row = {"workload": name, "problems": count, "bytes": n}
