@@ -576,6 +576,9 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     uint64_t t0, te, step;
     bool work = true;
     if (slice_major) {
+        // (run = dispatch order on purpose.  Letting problem p's first-dispatched workgroup take run (p mod eff) - so that many
+        // needles over ONE text do not all read the same place at the same time - was tried: the i386 loop 0.180 ms instead of
+        // 0.134, its words are found in the first run; the other shapes the same.  tools/ab_batch_inproc.py --i386)
         t0 = (uint64_t)slice * per;
         te = t0 + per < ntiles ? t0 + per : ntiles;
         step = 1;

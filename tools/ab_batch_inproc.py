@@ -33,16 +33,45 @@ def load(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", nargs="+", required=True)
-    ap.add_argument("--shapes", nargs="+", required=True)
+    ap.add_argument("--shapes", nargs="+", default=[])
+    ap.add_argument("--i386", action="store_true")
     ap.add_argument("--find", action="store_true")
     ap.add_argument("--present", type=int, default=0)
     ap.add_argument("--reps", type=int, default=30)
     args = ap.parse_args()
     libs = [(s.split("=", 1)[0], load(s.split("=", 1)[1])) for s in args.libs]
     shapes = [tuple(int(x) for x in a.split("x")) for a in args.shapes]
-    blob = torch.empty(max(c * e for c, e in shapes), dtype=torch.uint8, device="cuda")
-    ss.fill_random_device(blob, 0x5EED0001)
     st = torch.cuda.current_stream().cuda_stream
+    blob = torch.empty(max([c * e for c, e in shapes] + [16]), dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(blob, 0x5EED0001)
+    if args.i386:
+        # the reference's i386 loop: 4,585 words, one text (aliased ranges), every word present
+        gd = os.path.join(ROOT, "tests", "golden", "data")
+        raw = np.frombuffer(open(os.path.join(gd, "i386.txt"), "rb").read(), dtype=np.uint8)
+        words = [w for w in open(os.path.join(gd, "words.txt"), "rb").read().split(b"\n") if w]
+        text = torch.from_numpy(raw.copy()).cuda()
+        hb = torch.zeros(len(words), dtype=torch.int64, device="cuda")
+        he = torch.full((len(words),), raw.size, dtype=torch.int64, device="cuda")
+        wb = torch.from_numpy(np.frombuffer(b"".join(words), dtype=np.uint8).copy()).cuda()
+        wo = torch.from_numpy(np.cumsum(np.array([0] + [len(w) for w in words], dtype=np.int64))).cuda()
+        out = torch.empty(len(words), dtype=torch.int64 if args.find else torch.int32, device="cuda")
+        plans = []
+        for name, L in libs:
+            h = vp()
+            rc = L.ss_batch_plan_create(text.data_ptr(), hb.data_ptr(), he.data_ptr(), wb.data_ptr(), wo.data_ptr(), wo.data_ptr() + 8,
+                                        None, len(words), int(args.find), st, ctypes.byref(h))
+            assert rc == 0, L.ss_last_error()
+            plans.append((name, L, h))
+        row = {"workload": "the reference's i386 loop", "problems": len(words), "find": args.find}
+        for rnd in range(3):
+            for name, L, h in plans:
+                ms, mn = events_ms(lambda: L.ss_batch_plan_run(h, st, out.data_ptr()), args.reps)
+                row["%s_ms_%d" % (name, rnd)] = round(ms, 4)
+                torch.cuda.synchronize()
+                assert int((out >= 0).sum().item() if args.find else out.sum().item()) == len(words)
+        for name, L, h in plans:
+            L.ss_batch_plan_free(h)
+        print(json.dumps(row), flush=True)
     for count, each in shapes:
         hay = blob[:count * each]
         nd = bytearray(ss.fill_random_host(16 * count, 0x5EED0003).tobytes())
