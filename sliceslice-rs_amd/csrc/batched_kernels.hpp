@@ -20,6 +20,7 @@ struct BatchArgs {
     int *found;                 // search: one int32 flag per problem
     uint64_t *best;             // find (ss_find_batched): one uint64 leftmost offset per problem (all ones = absent); else null
 };
+constexpr uint32_t kPlanSliceMajorMax = 8;   // launches with at most this many slices per problem use the slice-major layout (scan_batched_plan_kernel)
 constexpr int kBadPosition = -1;   // SS_BATCH_BAD_POSITION: flag of a problem whose position breaks the with_position rules
 
 // ---- K4, planned form: a one-lane-per-problem plan kernel + the scan grid ------------------------------------
@@ -43,6 +44,14 @@ struct __attribute__((aligned(64))) BatchDesc {
     uint32_t shifts;           // mis | r << 4 | Q << 6 | r3 << 8 | q3 << 10
 };
 static_assert(sizeof(BatchDesc) == 64, "one scalar load (s_load_dwordx16) per workgroup");
+// The cold part of a problem - what verification needs - where it is written ahead of the scan (see ColdInPlan / ColdInCall below).
+struct __attribute__((aligned(64))) BatchCold {
+    uint64_t order_idx[2], order_val[2];       // as Problem::order_idx / order_val (build_refine_order)
+    uint32_t tail16[4];                        // as Problem::tail16
+    uint32_t norder, exact_len;
+    uint32_t pad[2];                           // [0]: (unplanned calls) the record is usable as it is - ColdInCall
+};
+static_assert(sizeof(BatchCold) == 64, "one scalar load");
 
 __host__ __device__ constexpr inline int rarity_class4(uint8_t b)
 {
@@ -173,7 +182,7 @@ struct PlanStats {
 // One problem's descriptor (and, for the unplanned calls, its initial output); returns its number of active slices.
 __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, uint64_t h0, uint64_t h1, uint64_t n0, uint64_t n1, uint64_t given,
                                              BatchDesc *descs, uint32_t nslices, uint32_t min_tiles, int tile_pieces, const uint8_t *s_class,
-                                             uint64_t *tiles_out, bool free_pair)
+                                             uint64_t *tiles_out, bool free_pair, BatchCold *colds)
 {
     *tiles_out = 0;
     const uint64_t len = h1 - h0, n = n1 - n0;
@@ -186,6 +195,11 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
     d.anchor = 0;
     d.per = 0;                                      // no active slice
     d.bytes = d.shifts = 0;
+    BatchCold lite;                                 // (unplanned calls) the needle's dwords where they are at hand: see ColdInCall
+    lite.order_idx[0] = lite.order_idx[1] = lite.order_val[0] = lite.order_val[1] = 0;
+    lite.tail16[0] = lite.tail16[1] = lite.tail16[2] = lite.tail16[3] = 0;
+    lite.norder = lite.exact_len = 0;
+    lite.pad[0] = lite.pad[1] = 0;
     int flag = 0;
     if (n == 0) {
         flag = 1;                                   // N0: found everywhere (x86.rs:500)
@@ -244,6 +258,21 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
             b2 = k == s2 ? fb[k] : b2;
             b3 = k == p3 ? fb[k] : b3;
         }
+        if (anchor == 0 && n >= 2 && n <= 16 && nslices <= kPlanSliceMajorMax) {
+            // the whole needle sits in fb[0 .. n): the dwords of the in-register compare, no byte in front of the first filter byte.
+            // (Only for launches in the slice-major layout - many problems, few slices each.  Measured against the lazy form in one
+            // process, profiles/r05/ab_call_cold.jsonl: the reference's i386 loop 0.135 ms a call instead of 0.145; every second
+            // needle present, 16,384 x 64 KiB 0.168 instead of 0.207, 65,536 x 16 KiB 0.336 instead of 0.492; without matches the
+            // same.  In round-robin launches - few problems scanned by two dozen workgroups each - a match that is confirmed
+            // sooner made 1,024 x 1 MiB with every second needle present 4-8 % SLOWER, a layout whose found problems already
+            // cost more than its absent ones: 0.170 ms against 0.154, where eight slices of contiguous runs take 0.145.)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                lite.tail16[j] = (4u * j + 0 < n ? fb[4 * j] : 0u) | ((4u * j + 1 < n ? fb[4 * j + 1] : 0u) << 8) |
+                                 ((4u * j + 2 < n ? fb[4 * j + 2] : 0u) << 16) | ((4u * j + 3 < n ? fb[4 * j + 3] : 0u) << 24);
+            lite.exact_len = (uint32_t)n;
+            lite.pad[0] = 1;
+        }
         const uint8_t *hf = a.haystacks + h0 + anchor;
         const uint32_t mis = (uint32_t)((uintptr_t)hf & 15);
         d.base = hf - mis;
@@ -259,6 +288,7 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
         d.per = (eff << 32) | ((ntiles + eff - 1) / eff);
         *tiles_out = ntiles;
     }
+    if (colds) colds[prob] = lite;                         // (unplanned calls: ColdInCall)
     if (d.per == 0) d.shifts = (uint32_t)flag;             // no scan: the answer travels in the descriptor too (plan runs)
     if (a.best) a.best[prob] = n == 0 ? 0ull : ~0ull;      // the empty needle matches at offset 0 of every haystack
     else if (a.found) a.found[prob] = flag;
@@ -277,7 +307,7 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
 // `stats` (plans only, else null): see PlanStats.
 __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, uint64_t count, BatchDesc *descs,
                                                              uint32_t nslices, uint32_t min_tiles, int tile_pieces, PlanStats *stats,
-                                                             const uint8_t *cls)
+                                                             const uint8_t *cls, BatchCold *colds)
 {
     __shared__ uint8_t s_class[256];
     __shared__ uint32_t s_max, s_maxt;
@@ -310,7 +340,7 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
     const bool free_pair = cls != nullptr && a.position == nullptr;
     if (stats) {                                                               // (uniform: a kernel argument)
         uint32_t eff = 0;
-        if (live) eff = plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles, free_pair);
+        if (live) eff = plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles, free_pair, colds);
         if (eff != 0) {
             atomicMax(&s_max, eff);
             atomicMax(&s_maxt, tiles > 0xffffffffull ? 0xffffffffu : (uint32_t)tiles);
@@ -324,7 +354,7 @@ __global__ void __launch_bounds__(kBlock) batch_plan_kernel(const BatchArgs a, u
         }
         return;
     }
-    if (live) (void)plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles, free_pair);
+    if (live) (void)plan_one(a, pi, h0, h1, n0, n1, given, descs, nslices, min_tiles, tile_pieces, s_class, &tiles, free_pair, colds);
 }
 
 // The cold fields of a planned problem, re-read from its descriptor by the waves that need them (scan_tiles' ColdT).
@@ -336,30 +366,9 @@ struct ColdFields {
     uint32_t tail16[4];
     int *host_flag;
     uint64_t far_off;
+    uint32_t ready;                               // (ColdInCall) the record holds the needle's dwords: nothing to build
     __device__ __forceinline__ const ColdFields *operator->() const { return this; }
 };
-struct ColdInDesc {
-    static constexpr bool kHasOrder = false;        // the wave that meets a candidate builds the schedule itself
-    const BatchDesc *dp;
-    const uint8_t *needles;
-    __device__ __forceinline__ ColdFields operator()() const
-    {
-        const BatchDesc *q = dp;
-        __asm__ volatile("" : "+s"(q));             // opaque: the loads stay in the cold path
-        ColdFields f;
-        f.hay = q->base + (q->shifts & 15) - q->anchor;
-        f.needle = needles + q->needle_off;
-        f.n = q->n;
-        f.end = q->end;
-        f.norder = f.exact_len = 0;                 // LAZY_ORDER: built by the wave
-        f.order_idx[0] = f.order_idx[1] = f.order_val[0] = f.order_val[1] = 0;
-        f.tail16[0] = f.tail16[1] = f.tail16[2] = f.tail16[3] = 0;
-        f.host_flag = nullptr;
-        f.far_off = 0;
-        return f;
-    }
-};
-
 // A PLAN carries the cold part ready-made: what a wave of the unplanned kernel builds when it first meets a candidate - the
 // second-level schedule (up to 15 further needle bytes, rarest first) and, for needles that end within 16 bytes of the first filter
 // byte, the needle's dwords for the in-register compare - costs it a dependent round trip to the needle bytes plus a few hundred
@@ -368,15 +377,39 @@ struct ColdInDesc {
 // 16 KiB, every second needle present: 0.447 ms a run, 0.271 with the cold part ready-made - and on text full of near misses it is
 // paid by every other workgroup.  batch_cold_kernel (one LANE per problem, once per plan) writes one 64-byte BatchCold per
 // problem; a wave then needs one more load.
-struct __attribute__((aligned(64))) BatchCold {
-    uint64_t order_idx[2], order_val[2];       // as Problem::order_idx / order_val (build_refine_order)
-    uint32_t tail16[4];                        // as Problem::tail16
-    uint32_t norder, exact_len;
-    uint32_t pad[2];
+// The unplanned calls' form: the plan kernel of a call writes a record too, but only what costs it nothing - for a needle of up to
+// 16 bytes whose first filter byte is needle[0] (every needle of that length unless the caller chose a position of 16 or more) the
+// needle's dwords are already in its registers: tail16, exact_len, an empty schedule, `ready`.  A wave that meets a candidate looks
+// there first and builds the cold part itself (scan_tiles, BUILD_ORDER) only when the record says it must.
+struct ColdInCall {
+    static constexpr bool kHasOrder = false;
+    static constexpr bool kMaybeOrder = true;
+    const BatchDesc *dp;
+    const BatchCold *cp;
+    const uint8_t *needles;
+    __device__ __forceinline__ ColdFields operator()() const
+    {
+        const BatchDesc *q = dp;
+        const BatchCold *c = cp;
+        __asm__ volatile("" : "+s"(q), "+s"(c));    // opaque: the loads stay in the cold path
+        ColdFields f;
+        f.hay = q->base + (q->shifts & 15) - q->anchor;
+        f.needle = needles + q->needle_off;
+        f.n = q->n;
+        f.end = q->end;
+        f.norder = 0;
+        f.exact_len = c->exact_len;
+        f.order_idx[0] = f.order_idx[1] = f.order_val[0] = f.order_val[1] = 0;
+        f.tail16[0] = c->tail16[0]; f.tail16[1] = c->tail16[1]; f.tail16[2] = c->tail16[2]; f.tail16[3] = c->tail16[3];
+        f.host_flag = nullptr;
+        f.far_off = 0;
+        f.ready = c->pad[0];
+        return f;
+    }
 };
-static_assert(sizeof(BatchCold) == 64, "one scalar load");
 struct ColdInPlan {
     static constexpr bool kHasOrder = true;
+    static constexpr bool kMaybeOrder = false;
     const BatchDesc *dp;
     const BatchCold *cp;
     const uint8_t *needles;
@@ -397,6 +430,7 @@ struct ColdInPlan {
         f.tail16[0] = c->tail16[0]; f.tail16[1] = c->tail16[1]; f.tail16[2] = c->tail16[2]; f.tail16[3] = c->tail16[3];
         f.host_flag = nullptr;
         f.far_off = 0;
+        f.ready = 1;
         return f;
     }
 };
@@ -499,7 +533,6 @@ __global__ void __launch_bounds__(kBlock) batch_cold_kernel(const BatchArgs a, c
 //     by side - consecutive addresses in flight, where slice-major puts 1,024 separate streams a haystack apart in flight
 //     (1,024 x 1 MiB: 150 us instead of 162, kernel time) - and when one of them finds the needle the others are at the same
 //     depth and stop at their next poll.
-constexpr uint32_t kPlanSliceMajorMax = 8;
 // FIND: the sink is the problem's uint64 (leftmost offset, atomicMin); a workgroup skips only what lies right of the best so far
 // (scan_tiles does that tile by tile, so the slice-major entry poll is not needed).
 // PLAN (ss_batch_plan_run: descriptors built once, searched many times - the reference builds its searchers once and times the
@@ -613,9 +646,9 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         // -DSS_NO_PLAN_COLD, profiles/r05/ab_plan_cold.jsonl: absent needles on random bytes the same to +-1 %, every second needle
         // present 16,384 x 64 KiB 0.154 ms instead of 0.183, 65,536 x 16 KiB 0.271 instead of 0.447)
         constexpr bool READY = PLAN;
-        typename std::conditional<READY, ColdInPlan, ColdInDesc>::type cold;
+        typename std::conditional<READY, ColdInPlan, ColdInCall>::type cold;
         if constexpr (READY) cold = ColdInPlan{dp, colds + prob, a.needles};
-        else cold = ColdInDesc{dp, a.needles};
+        else cold = ColdInCall{dp, colds + prob, a.needles};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
         // (Measured and not adopted - commit 7511606 (-DSS_SIBLING_POLL), profiles/r05/ab_sibling_poll.jsonl: the waves of such a workgroup polling EACH
         // OTHER'S words between tiles, so that a match by one stops the other three.  It takes a barrier in front of the scan - a

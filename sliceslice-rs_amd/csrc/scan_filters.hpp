@@ -90,6 +90,7 @@ constexpr int kQDynamic = -1;                     // scan_tiles<Q = kQDynamic, .
 // Where a wave finds the COLD fields of its Problem.
 struct ColdInKernarg {        // scan_kernel: the Problem is the kernel's FIRST argument, i.e. offset 0 of the kernarg segment
     static constexpr bool kHasOrder = true;           // the second-level schedule and the needle's dwords come with the Problem
+    static constexpr bool kMaybeOrder = false;
     typedef const Problem __attribute__((address_space(4))) *Ptr;
     __device__ __forceinline__ Ptr operator()() const
     {
@@ -100,6 +101,7 @@ struct ColdInKernarg {        // scan_kernel: the Problem is the kernel's FIRST 
 };
 struct ColdInRegisters {      // kernels that build their Problem themselves (batched)
     static constexpr bool kHasOrder = true;
+    static constexpr bool kMaybeOrder = false;
     const Problem *p;
     __device__ __forceinline__ const Problem *operator()() const { return p; }
 };

@@ -78,6 +78,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
     // LAZY_ORDER kernels fetch the cold part once per wave; whether the wave then BUILDS the schedule and the needle's dwords or
     // finds them there depends on where the cold part comes from (a plan's descriptors carry them: batched_kernels.hpp, BatchCold)
     constexpr bool BUILD_ORDER = LAZY_ORDER && !ColdT::kHasOrder;
+    // ... or MAY find them there: the unplanned batched kernel, whose plan kernel leaves the needle's dwords where they cost it
+    // nothing (needles of up to 16 bytes with the first filter byte at index 0) and says so in the record
+    constexpr bool MAYBE_ORDER = BUILD_ORDER && ColdT::kMaybeOrder;
     constexpr bool NTA = NTMODE >= 1;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR
@@ -338,7 +341,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 va.needle = reinterpret_cast<const uint8_t *>(uniform64((uint64_t)(uintptr_t)c->needle));
                 va.n = uniform64(c->n);
                 va.end = uniform64(c->end);
-                if (!ONE_BYTE && !BUILD_ORDER) {
+                bool take = !BUILD_ORDER;
+                if constexpr (MAYBE_ORDER) take = __builtin_amdgcn_readfirstlane((int)c->ready) != 0;
+                if (!ONE_BYTE && (MAYBE_ORDER || !BUILD_ORDER) && take) {
                     ro.n = c->norder;
                     ro.idx[0] = c->order_idx[0]; ro.idx[1] = c->order_idx[1];
                     ro.val[0] = c->order_val[0]; ro.val[1] = c->order_val[1];
@@ -362,7 +367,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         }
                     }
                 }
-                if (!ONE_BYTE && BUILD_ORDER) {
+                if (!ONE_BYTE && BUILD_ORDER && !take) {
                     // the descriptor came without the schedule (and without the needle's dwords): built here, by the waves
                     // that need them, not on every workgroup's way in
                     const uint64_t position = pr.d * 16 + 4 * (Q == kQDynamic ? pr.q : (uint32_t)Q) + pr.r;

@@ -39,7 +39,7 @@ struct PlanScratch {
     hipStream_t stream = nullptr;
     bool used = false;
     ss::BatchDesc *buf = nullptr;
-    size_t cap = 0;             // descriptors
+    size_t cap = 0;             // descriptors (and as many cold records behind them)
     uint64_t stamp = 0;
     std::mutex mu;              // held across the plan + scan launches of one call
 };
@@ -86,7 +86,7 @@ PlanScratch *plan_scratch_acquire(int dev, hipStream_t st, size_t count)
         if (e->buf) (void)hipFree(e->buf);
         e->buf = nullptr;
         e->cap = 0;
-        if (hipMalloc((void **)&e->buf, want * sizeof(ss::BatchDesc)) != hipSuccess) {
+        if (hipMalloc((void **)&e->buf, want * (sizeof(ss::BatchDesc) + sizeof(ss::BatchCold))) != hipSuccess) {
             (void)hipGetLastError();
             e->buf = nullptr;
             e->mu.unlock();
@@ -157,11 +157,11 @@ int batch_shape(int dev, size_t count, BatchShape *out, bool counted = false)
 // `cls` (may be null): the 256 rarity classes batch_sample_kernel derived from the haystacks' own bytes - the filter bytes are
 // chosen by them instead of the static, corpus-free table.
 hipError_t launch_plan_kernel(const ss::BatchArgs &a, size_t count, ss::BatchDesc *descs, const BatchShape &sh, hipStream_t st,
-                              ss::PlanStats *stats = nullptr, const uint8_t *cls = nullptr)
+                              ss::PlanStats *stats = nullptr, const uint8_t *cls = nullptr, ss::BatchCold *colds = nullptr)
 {
     const uint64_t pblocks = ((uint64_t)count + ss::kBlock - 1) / ss::kBlock;
     ss::batch_plan_kernel<<<dim3((unsigned)pblocks), dim3(ss::kBlock), 0, st>>>(a, (uint64_t)count, descs, sh.slices, sh.min_tiles,
-                                                                               ss::kWavesPerBlock * 4, stats, cls);
+                                                                               ss::kWavesPerBlock * 4, stats, cls, colds);
     return hipGetLastError();
 }
 
@@ -277,14 +277,15 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
     PlanScratch *ps = plan_scratch_acquire(dev, st, count);
     if (!ps) return fail(SS_ERR_NOMEM, "no device memory for %zu problem descriptors", count);
     ss::BatchDesc *descs = ps->buf;
+    ss::BatchCold *colds = reinterpret_cast<ss::BatchCold *>(ps->buf + ps->cap);        // (behind the descriptors: ColdInCall)
     const uint8_t *cls = batch_classes(dev, a, count, st);
-    hipError_t e = launch_plan_kernel(a, count, descs, sh, st, nullptr, cls);
+    hipError_t e = launch_plan_kernel(a, count, descs, sh, st, nullptr, cls, colds);
     if (e == hipSuccess) {
         const dim3 grid((unsigned)((uint64_t)count * sh.slices));
         if (a.best)
-            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
+            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, colds);
         else
-            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, nullptr);
+            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, colds);
         e = hipGetLastError();
     }
     ps->mu.unlock();

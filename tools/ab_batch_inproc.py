@@ -26,6 +26,8 @@ def load(path):
     L.ss_batch_plan_create.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, ctypes.c_int, vp, ctypes.POINTER(vp)]
     L.ss_batch_plan_run.argtypes = [vp, vp, vp]
     L.ss_batch_plan_free.argtypes = [vp]
+    L.ss_search_batched.argtypes = [vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]
+    L.ss_find_batched.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp]
     L.ss_last_error.restype = ctypes.c_char_p
     return L
 
@@ -35,6 +37,7 @@ def main():
     ap.add_argument("--libs", nargs="+", required=True)
     ap.add_argument("--shapes", nargs="+", default=[])
     ap.add_argument("--i386", action="store_true")
+    ap.add_argument("--call", action="store_true", help="the UNPLANNED calls (ss_search_batched / ss_find_batched) instead of plan runs")
     ap.add_argument("--find", action="store_true")
     ap.add_argument("--present", type=int, default=0)
     ap.add_argument("--reps", type=int, default=30)
@@ -58,19 +61,28 @@ def main():
         plans = []
         for name, L in libs:
             h = vp()
-            rc = L.ss_batch_plan_create(text.data_ptr(), hb.data_ptr(), he.data_ptr(), wb.data_ptr(), wo.data_ptr(), wo.data_ptr() + 8,
-                                        None, len(words), int(args.find), st, ctypes.byref(h))
-            assert rc == 0, L.ss_last_error()
+            if not args.call:
+                rc = L.ss_batch_plan_create(text.data_ptr(), hb.data_ptr(), he.data_ptr(), wb.data_ptr(), wo.data_ptr(), wo.data_ptr() + 8,
+                                            None, len(words), int(args.find), st, ctypes.byref(h))
+                assert rc == 0, L.ss_last_error()
             plans.append((name, L, h))
-        row = {"workload": "the reference's i386 loop", "problems": len(words), "find": args.find}
+
+        def run386(L, h):
+            if not args.call:
+                return L.ss_batch_plan_run(h, st, out.data_ptr())
+            if args.find:
+                return L.ss_find_batched(text.data_ptr(), hb.data_ptr(), he.data_ptr(), wb.data_ptr(), wo.data_ptr(), wo.data_ptr() + 8, len(words), st, out.data_ptr())
+            return L.ss_search_batched(text.data_ptr(), hb.data_ptr(), he.data_ptr(), wb.data_ptr(), wo.data_ptr(), wo.data_ptr() + 8, None, len(words), st, out.data_ptr())
+        row = {"workload": "the reference's i386 loop", "problems": len(words), "find": args.find, "unplanned_call": args.call}
         for rnd in range(3):
             for name, L, h in plans:
-                ms, mn = events_ms(lambda: L.ss_batch_plan_run(h, st, out.data_ptr()), args.reps)
+                ms, mn = events_ms(lambda: run386(L, h), args.reps)
                 row["%s_ms_%d" % (name, rnd)] = round(ms, 4)
                 torch.cuda.synchronize()
                 assert int((out >= 0).sum().item() if args.find else out.sum().item()) == len(words)
         for name, L, h in plans:
-            L.ss_batch_plan_free(h)
+            if not args.call:
+                L.ss_batch_plan_free(h)
         print(json.dumps(row), flush=True)
     for count, each in shapes:
         hay = blob[:count * each]
@@ -94,21 +106,32 @@ def main():
         plans = []
         for name, L in libs:
             h = vp()
-            rc = L.ss_batch_plan_create(hay.data_ptr(), hoff.data_ptr(), hoff.data_ptr() + 8, nblob.data_ptr(), noff.data_ptr(), noff.data_ptr() + 8,
-                                        None, count, int(args.find), st, ctypes.byref(h))
-            assert rc == 0, L.ss_last_error()
+            if not args.call:
+                rc = L.ss_batch_plan_create(hay.data_ptr(), hoff.data_ptr(), hoff.data_ptr() + 8, nblob.data_ptr(), noff.data_ptr(), noff.data_ptr() + 8,
+                                            None, count, int(args.find), st, ctypes.byref(h))
+                assert rc == 0, L.ss_last_error()
             plans.append((name, L, h))
-        row = {"problems": count, "each": each, "find": args.find, "present_every": args.present}
+
+        def run(L, h):
+            if not args.call:
+                return L.ss_batch_plan_run(h, st, out.data_ptr())
+            if args.find:
+                return L.ss_find_batched(hay.data_ptr(), hoff.data_ptr(), hoff.data_ptr() + 8, nblob.data_ptr(), noff.data_ptr(), noff.data_ptr() + 8,
+                                         count, st, out.data_ptr())
+            return L.ss_search_batched(hay.data_ptr(), hoff.data_ptr(), hoff.data_ptr() + 8, nblob.data_ptr(), noff.data_ptr(), noff.data_ptr() + 8,
+                                       None, count, st, out.data_ptr())
+        row = {"problems": count, "each": each, "find": args.find, "present_every": args.present, "unplanned_call": args.call}
         for rnd in range(2):
             for name, L, h in plans:
-                ms, mn = events_ms(lambda: L.ss_batch_plan_run(h, st, out.data_ptr()), args.reps)
+                ms, mn = events_ms(lambda: run(L, h), args.reps)
                 row["%s_ms_%d" % (name, rnd)], row["%s_min_%d" % (name, rnd)] = round(ms, 4), round(mn, 4)
                 torch.cuda.synchronize()
                 got = int((out >= 0).sum().item()) if args.find else int(out.sum().item())
                 assert got == want, (name, got, want)
         for name, L, h in plans:
             row[name + "_gbps"] = round(count * each / min(row[name + "_ms_0"], row[name + "_ms_1"]) / 1e6, 1)
-            L.ss_batch_plan_free(h)
+            if not args.call:
+                L.ss_batch_plan_free(h)
         print(json.dumps(row), flush=True)
 
 
