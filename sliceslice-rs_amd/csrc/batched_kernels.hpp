@@ -49,7 +49,15 @@ struct __attribute__((aligned(64))) BatchCold {
     uint64_t order_idx[2], order_val[2];       // as Problem::order_idx / order_val (build_refine_order)
     uint32_t tail16[4];                        // as Problem::tail16
     uint32_t norder, exact_len;
-    uint32_t pad[2];                           // [0]: (unplanned calls) the record is usable as it is - ColdInCall
+    // The problem's STATE while a scan runs lives here too - a line of its own per pair of problems, not one of 16 or 32 words of
+    // an array: every wave polls its problem's word once per tile, the resident workgroups of a problem-major launch belong to a
+    // few dozen consecutive problems, and with their words in ONE cache line every match (an atomic on that line) sent the polls of
+    // all of them to memory - 1,024 x 1 MiB with every needle present ran 0.23-0.29 ms where the full scan takes 0.155.
+    //   unplanned bool calls: pad[1] = the found flag the waves poll and raise (the caller's output is written behind it)
+    //   unplanned find calls: pad[0..1] = one uint64, the leftmost offset so far (the caller's output is lowered behind it)
+    //   bool plans:           pad[1] = the flag (batch_publish_kernel copies it out and puts it back to 0)
+    //   find plans:           pad[0..1] = one uint64, the leftmost offset so far (idle: all ones)
+    uint32_t pad[2];
 };
 static_assert(sizeof(BatchCold) == 64, "one scalar load");
 
@@ -258,20 +266,17 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
             b2 = k == s2 ? fb[k] : b2;
             b3 = k == p3 ? fb[k] : b3;
         }
-        if (anchor == 0 && n >= 2 && n <= 16 && nslices <= kPlanSliceMajorMax) {
+        if (anchor == 0 && n >= 2 && n <= 16) {
             // the whole needle sits in fb[0 .. n): the dwords of the in-register compare, no byte in front of the first filter byte.
-            // (Only for launches in the slice-major layout - many problems, few slices each.  Measured against the lazy form in one
-            // process, profiles/r05/ab_call_cold.jsonl: the reference's i386 loop 0.135 ms a call instead of 0.145; every second
-            // needle present, 16,384 x 64 KiB 0.168 instead of 0.207, 65,536 x 16 KiB 0.336 instead of 0.492; without matches the
-            // same.  In round-robin launches - few problems scanned by two dozen workgroups each - a match that is confirmed
-            // sooner made 1,024 x 1 MiB with every second needle present 4-8 % SLOWER, a layout whose found problems already
-            // cost more than its absent ones: 0.170 ms against 0.154, where eight slices of contiguous runs take 0.145.)
+            // (Measured against the lazy form in one process, profiles/r05/ab_call_cold.jsonl: the reference's i386 loop 0.135 ms a
+            // call instead of 0.145; every second needle present, 16,384 x 64 KiB 0.168 instead of 0.207, 65,536 x 16 KiB 0.336
+            // instead of 0.492; without matches the same.  Round-robin launches - few problems, two dozen workgroups each - gain
+            // nothing from it, and lost 4-8 % as long as their state words shared cache lines: see BatchCold.)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 lite.tail16[j] = (4u * j + 0 < n ? fb[4 * j] : 0u) | ((4u * j + 1 < n ? fb[4 * j + 1] : 0u) << 8) |
                                  ((4u * j + 2 < n ? fb[4 * j + 2] : 0u) << 16) | ((4u * j + 3 < n ? fb[4 * j + 3] : 0u) << 24);
             lite.exact_len = (uint32_t)n;
-            lite.pad[0] = 1;
         }
         const uint8_t *hf = a.haystacks + h0 + anchor;
         const uint32_t mis = (uint32_t)((uintptr_t)hf & 15);
@@ -288,7 +293,10 @@ __device__ __forceinline__ uint32_t plan_one(const BatchArgs &a, uint64_t prob, 
         d.per = (eff << 32) | ((ntiles + eff - 1) / eff);
         *tiles_out = ntiles;
     }
-    if (colds) colds[prob] = lite;                         // (unplanned calls: ColdInCall)
+    if (colds) {                                           // (unplanned calls: ColdInCall; the state word idle)
+        lite.pad[0] = lite.pad[1] = a.best ? ~0u : 0u;
+        colds[prob] = lite;
+    }
     if (d.per == 0) d.shifts = (uint32_t)flag;             // no scan: the answer travels in the descriptor too (plan runs)
     if (a.best) a.best[prob] = n == 0 ? 0ull : ~0ull;      // the empty needle matches at offset 0 of every haystack
     else if (a.found) a.found[prob] = flag;
@@ -387,6 +395,7 @@ struct ColdInCall {
     const BatchDesc *dp;
     const BatchCold *cp;
     const uint8_t *needles;
+    void *out_word;                                 // the caller's output of this problem - int flag or uint64 offset: the wave that finds writes it
     __device__ __forceinline__ ColdFields operator()() const
     {
         const BatchDesc *q = dp;
@@ -401,9 +410,9 @@ struct ColdInCall {
         f.exact_len = c->exact_len;
         f.order_idx[0] = f.order_idx[1] = f.order_val[0] = f.order_val[1] = 0;
         f.tail16[0] = c->tail16[0]; f.tail16[1] = c->tail16[1]; f.tail16[2] = c->tail16[2]; f.tail16[3] = c->tail16[3];
-        f.host_flag = nullptr;
+        f.host_flag = static_cast<int *>(out_word);
         f.far_off = 0;
-        f.ready = c->pad[0];
+        f.ready = c->exact_len;                      // (the plan kernel sets it only where it left the dwords)
         return f;
     }
 };
@@ -441,7 +450,7 @@ struct ColdInPlan {
 // rarity classes the plan's filter bytes were chosen by (`cls`: the haystacks' own, else the static four).  Only the ORDER of the
 // checks depends on the classes; the dwords of the exact compare are the needle's bytes.
 __global__ void __launch_bounds__(kBlock) batch_cold_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint64_t count,
-                                                             BatchCold *colds, const uint8_t *cls)
+                                                             BatchCold *colds, const uint8_t *cls, int find)
 {
     __shared__ uint8_t s_class[256];
     if (cls) {
@@ -457,7 +466,7 @@ __global__ void __launch_bounds__(kBlock) batch_cold_kernel(const BatchArgs a, c
     c.order_idx[0] = c.order_idx[1] = c.order_val[0] = c.order_val[1] = 0;
     c.tail16[0] = c.tail16[1] = c.tail16[2] = c.tail16[3] = 0;
     c.norder = c.exact_len = 0;
-    c.pad[0] = c.pad[1] = 0;
+    c.pad[0] = c.pad[1] = find ? ~0u : 0u;          // the plan's state word of this problem, idle
     if ((d.per >> 32) != 0 && ((d.bytes >> 24) & 1) == 0) {
         const uint8_t *needle = a.needles + d.needle_off + d.anchor;         // from the first filter byte on
         const uint64_t nrel = d.n - d.anchor;
@@ -559,8 +568,7 @@ __global__ void __launch_bounds__(kBlock) batch_cold_kernel(const BatchArgs a, c
 #endif
 template <int U, bool FIND = false, bool PLAN = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, SS_BATCH_WAVES_MAX))) __launch_bounds__(kBlock)
-scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, void *state,
-                         const BatchCold *__restrict__ colds)
+scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, BatchCold *colds)
 {
     constexpr bool COUNTED = PLAN;                  // (the name the code below grew up with)
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
@@ -577,8 +585,10 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         prob = w / nslices;
         slice = w - prob * nslices;
     }
-    int *found = FIND ? nullptr : (COUNTED ? static_cast<int *>(state) + prob : a.found + prob);
-    void *sink = FIND ? static_cast<void *>((COUNTED ? static_cast<uint64_t *>(state) : a.best) + prob) : static_cast<void *>(found);
+    // the problem's state word sits in its cold record (BatchCold: a line per pair of problems), not in an array of words
+    BatchCold *rec = colds + prob;
+    int *found = FIND ? nullptr : reinterpret_cast<int *>(&rec->pad[1]);
+    void *sink = FIND ? static_cast<void *>(&rec->pad[0]) : static_cast<void *>(found);
     const BatchDesc *dp = descs + prob;
     // slice-major, later slices: the problem's flag (one coherent load) is requested together with the descriptor (one scalar
     // load, s_load_dwordx16) - one round trip decides whether and what to scan
@@ -648,7 +658,7 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         constexpr bool READY = PLAN;
         typename std::conditional<READY, ColdInPlan, ColdInCall>::type cold;
         if constexpr (READY) cold = ColdInPlan{dp, colds + prob, a.needles};
-        else cold = ColdInCall{dp, colds + prob, a.needles};
+        else cold = ColdInCall{dp, colds + prob, a.needles, FIND ? static_cast<void *>(a.best + prob) : static_cast<void *>(a.found + prob)};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
         // (Measured and not adopted - commit 7511606 (-DSS_SIBLING_POLL), profiles/r05/ab_sibling_poll.jsonl: the waves of such a workgroup polling EACH
         // OTHER'S words between tiles, so that a match by one stops the other three.  It takes a barrier in front of the scan - a
@@ -676,18 +686,18 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
 // Behind the scan of a plan that has problems of several workgroups: one LANE per problem copies the state word of such a
 // problem to the caller's output and puts it back to its idle value (the kernel boundary is the ordering; 4-5 us).
 __global__ void __launch_bounds__(kBlock) batch_publish_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count,
-                                                                void *state)
+                                                                BatchCold *colds)
 {
     const uint32_t prob = blockIdx.x * kBlock + threadIdx.x;
     if (prob >= count) return;
     if ((uint32_t)(descs[prob].per >> 32) <= 1) return;              // published by the scan itself
     if (a.best) {
-        uint64_t *st = static_cast<uint64_t *>(state) + prob;
+        uint64_t *st = reinterpret_cast<uint64_t *>(&colds[prob].pad[0]);
         const uint64_t v = *st;
         a.best[prob] = v;
         if (v != ~0ull) *st = ~0ull;
     } else {
-        int *st = static_cast<int *>(state) + prob;
+        int *st = reinterpret_cast<int *>(&colds[prob].pad[1]);
         const int v = *st;
         a.found[prob] = v != 0;
         if (v != 0) *st = 0;

@@ -496,6 +496,12 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                                 __hip_atomic_fetch_min(static_cast<uint64_t *>(wg_sink), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         } else if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if constexpr (LAZY_ORDER) {
+                                // (the unplanned batched find: `best` is the problem's state word in its cold record, which the
+                                // waves poll; the caller's output takes the minimum too - nobody polls that one)
+                                uint64_t *out_best = reinterpret_cast<uint64_t *>(cold()->host_flag);
+                                if (out_best) __hip_atomic_fetch_min(out_best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                         forget_scalar_cache_unless(small_grid);
                         return;                         // the wave's later pieces and tiles are further right

@@ -283,9 +283,9 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
     if (e == hipSuccess) {
         const dim3 grid((unsigned)((uint64_t)count * sh.slices));
         if (a.best)
-            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, colds);
+            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, colds);
         else
-            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, nullptr, colds);
+            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, colds);
         e = hipGetLastError();
     }
     ps->mu.unlock();
@@ -298,9 +298,9 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
 
 using namespace ssh;
 
-// The plan's own memory: descriptors | cold parts (64 bytes each, like the descriptors) | state words (uint64 each; the bool plans
-// use the low int) | the plan kernel's PlanStats (64 bytes) | the sampling's counters and the rarity classes of the haystacks'
-// bytes (ss::BatchClasses).
+// The plan's own memory: descriptors | cold parts (64 bytes each, like the descriptors; a problem's state word - flag or minimum -
+// sits in its cold part) | the plan kernel's PlanStats (64 bytes) | the sampling's counters and the rarity classes of the
+// haystacks' bytes (ss::BatchClasses).
 struct ss_batch_plan {
     int dev = 0;
     size_t count = 0;
@@ -308,10 +308,9 @@ struct ss_batch_plan {
     ss::BatchArgs args;
     BatchShape shape = {1, 1};
     uint8_t *mem = nullptr;
-    static constexpr size_t kPerProblem = sizeof(ss::BatchDesc) + sizeof(ss::BatchCold) + sizeof(uint64_t);
+    static constexpr size_t kPerProblem = sizeof(ss::BatchDesc) + sizeof(ss::BatchCold);
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
     ss::BatchCold *colds() const { return reinterpret_cast<ss::BatchCold *>(mem + count * sizeof(ss::BatchDesc)); }
-    void *state() const { return mem + count * (sizeof(ss::BatchDesc) + sizeof(ss::BatchCold)); }
     ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * kPerProblem); }
     ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * kPerProblem + 64); }
 };
@@ -369,7 +368,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     if (rc == SS_OK) {
-        // idle values: flags 0 / minima all ones; then the descriptors (the plan kernel writes no outputs here: args.found and
+        // The descriptors (the plan kernel writes no outputs here: args.found and
         // args.best are both null).  The lengths live on the device, so the first pass runs with the grid guessed from the problem
         // count and reports what it saw; the host then sizes the slices for about kPlanTilesPerWg tiles per workgroup (bounded:
         // one huge haystack among many short ones must not multiply everybody's surplus slices) and, if that changes anything,
@@ -377,7 +376,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
         // Which needle bytes the scan filters on is decided by how rare they are IN THESE HAYSTACKS: a sampled histogram first
         // (4 MiB read at most; batched_kernels.hpp, batch_sample_kernel).
         ss::PlanStats seen = {0, 0, 0};
-        e = hipMemsetAsync(p->state(), p->find ? 0xFF : 0, count * sizeof(uint64_t), st);
+        e = hipSuccess;
         const uint8_t *cls = p->classes()->cls;
 #ifdef SS_TEST_HOOKS
         if (const char *v = getenv("SLICESLICE_BATCH_STATIC_CLASSES")) { if (atoi(v) != 0) cls = nullptr; }   // A/B: the static table
@@ -419,7 +418,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
             // the cold part of every problem (second-level schedule, the needle's dwords): once, here, instead of by every wave that
             // meets a candidate (batched_kernels.hpp, BatchCold)
             ss::batch_cold_kernel<<<dim3((unsigned)((count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(p->args, p->descs(), (uint64_t)count,
-                                                                                                                        p->colds(), cls);
+                                                                                                                        p->colds(), cls, p->find ? 1 : 0);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(st);
         }
@@ -447,15 +446,15 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     const dim3 grid((unsigned)((uint64_t)p->count * p->shape.slices));
     if (p->find) {
         a.best = static_cast<uint64_t *>(d_out);
-        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state(), p->colds());
+        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->colds());
     } else {
         a.found = static_cast<int *>(d_out);
-        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->state(), p->colds());
+        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->colds());
     }
     HIP_TRY(hipGetLastError());
     // problems scanned by several workgroups leave their answer in the plan's state words: one lane per problem publishes
     if (p->shape.slices > 1) {
-        ss::batch_publish_kernel<<<dim3((unsigned)((p->count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(a, p->descs(), (uint32_t)p->count, p->state());
+        ss::batch_publish_kernel<<<dim3((unsigned)((p->count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(a, p->descs(), (uint32_t)p->count, p->colds());
         HIP_TRY(hipGetLastError());
     }
     return SS_OK;

@@ -282,7 +282,7 @@ SGPR_SPILL_CEILINGS = {
     "scan_kernel, single stream (MODE 0), find": 51,
     "scan_kernel, cross-lane (MODE 2)": 17,
     "scan_kernel, one-byte needles": 0,
-    "scan_batched_plan_kernel": 59,
+    "scan_batched_plan_kernel": 65,
     "service_kernel": 88,
 }
 

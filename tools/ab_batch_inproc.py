@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--call", action="store_true", help="the UNPLANNED calls (ss_search_batched / ss_find_batched) instead of plan runs")
     ap.add_argument("--find", action="store_true")
     ap.add_argument("--present", type=int, default=0)
+    ap.add_argument("--at", choices=["random", "start", "middle", "end"], default="random", help="where a present needle is cut out of its haystack")
     ap.add_argument("--reps", type=int, default=30)
     args = ap.parse_args()
     libs = [(s.split("=", 1)[0], load(s.split("=", 1)[1])) for s in args.libs]
@@ -93,6 +94,8 @@ def main():
             rng = np.random.default_rng(5)
             idx = np.arange(0, count, args.present)
             at = rng.integers(0, each - 16, size=idx.size)
+            if args.at != "random":
+                at[:] = {"start": 0, "middle": each // 2, "end": each - 16}[args.at]
             src = (idx * each + at)[:, None] + np.arange(16)[None, :]
             cut = hay.cpu().numpy()[src.reshape(-1)].reshape(-1, 16)
             arr = np.frombuffer(bytes(nd), dtype=np.uint8).reshape(count, 16).copy()
@@ -120,7 +123,7 @@ def main():
                                          count, st, out.data_ptr())
             return L.ss_search_batched(hay.data_ptr(), hoff.data_ptr(), hoff.data_ptr() + 8, nblob.data_ptr(), noff.data_ptr(), noff.data_ptr() + 8,
                                        None, count, st, out.data_ptr())
-        row = {"problems": count, "each": each, "find": args.find, "present_every": args.present, "unplanned_call": args.call}
+        row = {"problems": count, "each": each, "find": args.find, "present_every": args.present, "at": args.at, "unplanned_call": args.call}
         for rnd in range(2):
             for name, L, h in plans:
                 ms, mn = events_ms(lambda: run(L, h), args.reps)
