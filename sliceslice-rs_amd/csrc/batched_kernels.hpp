@@ -387,7 +387,7 @@ struct ColdFields {
 // problem; a wave then needs one more load.
 // The unplanned calls' form: the plan kernel of a call writes a record too, but only what costs it nothing - for a needle of up to
 // 16 bytes whose first filter byte is needle[0] (every needle of that length unless the caller chose a position of 16 or more) the
-// needle's dwords are already in its registers: tail16, exact_len, an empty schedule, `ready`.  A wave that meets a candidate looks
+// needle's dwords are already in its registers: tail16, exact_len (non-zero says: usable as it is), an empty schedule.  A wave that meets a candidate looks
 // there first and builds the cold part itself (scan_tiles, BUILD_ORDER) only when the record says it must.
 struct ColdInCall {
     static constexpr bool kHasOrder = false;
