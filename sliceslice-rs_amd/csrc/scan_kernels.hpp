@@ -58,6 +58,11 @@ namespace ss {
 // LAZY_ORDER (batched kernel): the descriptor arrives without the second-level schedule; a wave builds it
 // when it first meets a candidate, next to staging the needle - not on every workgroup's way in.
 // `pr` is read for its HOT fields only; `cold()` yields a pointer through which the cold ones are read where they are needed.
+// The kernels that serve many problems per grid have no workgroup that peeks at a flag through the scalar cache (their entry polls
+// are coherent loads), so a wave that leaves early has nothing to make visible there - and an invalidation costs the workgroups
+// that start on that CU next their descriptor and kernel-argument lines: plan runs with matches 2-5 % (the i386 loop 0.122 ms
+// instead of 0.128), the unplanned calls nothing (profiles/r05/ab_batch_no_dcache_inv.jsonl).
+template <bool BATCHED> constexpr bool kNoForget = BATCHED;
 template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false,
           typename ColdT = ColdInRegisters>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_t *s_needle_block, uint64_t tile0,
@@ -154,7 +159,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                 }
             }
             if (stop8) {                                      // somebody has already found the needle
-                forget_scalar_cache_unless(small_grid);
+                forget_scalar_cache_unless(small_grid || kNoForget<LAZY_ORDER>);
                 return;
             }
             if (__ballot((any8 & 0x80808080u) != 0) == 0) continue;   // nothing in this tile: the common case
@@ -318,7 +323,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         if (FIND) {
             const uint64_t first = chunk0 * 16 > pr.mis ? chunk0 * 16 - pr.mis : 0;   // lowest index this wave can report
             if (best_now <= pr.find_base + first) {                                     // all of it lies right of a match
-                forget_scalar_cache_unless(small_grid);
+                forget_scalar_cache_unless(small_grid || kNoForget<LAZY_ORDER>);
                 return;
             }
         }
@@ -327,7 +332,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         const bool cand_tile = __ballot((any_tile & 0x80808080u) != 0) != 0;
         if (L8) dense = cand_tile;      // stay in the 16-byte layout while tiles keep producing candidates
         if (stop) {                     // somebody has already found the needle: no point in verifying more
-            forget_scalar_cache_unless(small_grid);
+            forget_scalar_cache_unless(small_grid || kNoForget<LAZY_ORDER>);
             return;
         }
         if (cand_tile) {
@@ -503,7 +508,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                                 if (out_best) __hip_atomic_fetch_min(out_best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
-                        forget_scalar_cache_unless(small_grid);
+                        forget_scalar_cache_unless(small_grid || kNoForget<LAZY_ORDER>);
                         return;                         // the wave's later pieces and tiles are further right
                     }
                 }
@@ -529,7 +534,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         if (old != pr.epoch && host_flag)
                             __hip_atomic_store(host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
-                    forget_scalar_cache_unless(small_grid);
+                    forget_scalar_cache_unless(small_grid || kNoForget<LAZY_ORDER>);
                     return;
                 }
             }
