@@ -216,7 +216,8 @@ SS_API int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin,
  * scratch acquire, nothing allocated, capturable into a hipGraph.  `find` != 0: the plan answers leftmost offsets (d_out = `count`
  * uint64, as ss_find_batched), else flags (d_out = `count` int32, as ss_search_batched).  The caller vouches that ranges,
  * needle bytes and the haystacks' ADDRESSES are unchanged between create and the last run; haystack CONTENTS may change
- * freely.  ONE run at a time per plan (the plan's state words are the run's scratch; every run leaves them at their idle
+ * freely.  (A plan of long problems holds two launch layouts and picks by how many problems its previous run found - a tally the
+ * run leaves in pinned memory; a run never waits for it, and no result depends on it.)  ONE run at a time per plan (the plan's state words are the run's scratch; every run leaves them at their idle
  * values): runs must be ordered one behind the other - the same stream, or events.  d_out needs no
  * initialisation.  No run may be in flight when the plan is freed. */
 typedef struct ss_batch_plan ss_batch_plan;

@@ -8,7 +8,7 @@
  *   2. Tuning knobs and test hooks, exported only by builds with -DSS_TEST_HOOKS (libsliceslice_hip_tuning.so and the
  *      sanitizer builds; the product library has neither the symbols nor the code behind them): kernel-variant and grid
  *      overrides, fault injection, epoch / counter setters, the pure filter-choice helper, service counters.  Hooks builds
- *      also read a few more environment variables (tuning: SLICESLICE_BATCH_WGS, _BATCH_MIN_TILES, _BATCH_OCC, _BATCH_STATIC_CLASSES;
+ *      also read a few more environment variables (tuning: SLICESLICE_BATCH_WGS, _BATCH_MIN_TILES, _BATCH_OCC, _BATCH_STATIC_CLASSES, SLICESLICE_PLAN_ONE_LAYOUT;
  *      measurement: SLICESLICE_CROSS_EXIT=0, SLICESLICE_SERVICE_HDP_FLUSH=0, SLICESLICE_SERVICE_DEBUG).
  */
 #ifndef SLICESLICE_HIP_TUNING_H
@@ -89,6 +89,11 @@ SS_API int ss_debug_batch_classes(const void *d_haystacks, const uint64_t *d_hay
  * the other two), out[3] = the bytes themselves (first | second << 8 | third << 16 | one-byte needle << 24), out[4] = the slices
  * that scan the problem (0: answered without a scan; the indices are 0 then).  Copies 64 bytes from the device. */
 SS_API int ss_debug_plan_filter(const ss_batch_plan *p, size_t problem, uint32_t out[5]);
+
+/* A plan's layouts: out[0] = 1 if it holds two (plans of long problems), out[1] = slices per problem of the first (round robin where
+ * more than eight), out[2] = of the second (contiguous runs), out[3] = problems found in the latest run whose tally has arrived,
+ * out[4] = 1 if the next ss_batch_plan_run takes the second layout. */
+SS_API int ss_debug_plan_layout(const ss_batch_plan *p, uint32_t out[5]);
 
 /* A plan's ready-made cold part of `problem` (batched_kernels.hpp, BatchCold): out[0] = bytes in the second-level schedule, out[1] =
  * exact_len (bytes of the in-register compare | bytes in front of the first filter byte << 8; 0: the needle is too long for it),

@@ -686,21 +686,42 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
 // Behind the scan of a plan that has problems of several workgroups: one LANE per problem copies the state word of such a
 // problem to the caller's output and puts it back to its idle value (the kernel boundary is the ordering; 4-5 us).
 __global__ void __launch_bounds__(kBlock) batch_publish_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count,
-                                                                BatchCold *colds)
+                                                                BatchCold *colds, uint32_t *d_tally, unsigned long long *h_tally, uint32_t run)
 {
+    // `d_tally` / `h_tally` (plans that hold two layouts, else null): how many of the problems scanned by several workgroups were FOUND
+    // in this run - summed per workgroup, the workgroup that finishes last stores run << 32 | found to pinned memory, where the
+    // host reads it before a later run (never waiting for it) to choose the layout: ss_batch_plan_run.
+    __shared__ uint32_t s_found;
+    if (threadIdx.x == 0) s_found = 0;
+    __syncthreads();
     const uint32_t prob = blockIdx.x * kBlock + threadIdx.x;
-    if (prob >= count) return;
-    if ((uint32_t)(descs[prob].per >> 32) <= 1) return;              // published by the scan itself
-    if (a.best) {
-        uint64_t *st = reinterpret_cast<uint64_t *>(&colds[prob].pad[0]);
-        const uint64_t v = *st;
-        a.best[prob] = v;
-        if (v != ~0ull) *st = ~0ull;
-    } else {
-        int *st = reinterpret_cast<int *>(&colds[prob].pad[1]);
-        const int v = *st;
-        a.found[prob] = v != 0;
-        if (v != 0) *st = 0;
+    bool was_found = false;
+    if (prob < count && (uint32_t)(descs[prob].per >> 32) > 1) {       // (a single-workgroup problem is published by the scan itself)
+        if (a.best) {
+            uint64_t *st = reinterpret_cast<uint64_t *>(&colds[prob].pad[0]);
+            const uint64_t v = *st;
+            a.best[prob] = v;
+            if (v != ~0ull) *st = ~0ull;
+            was_found = v != ~0ull;
+        } else {
+            int *st = reinterpret_cast<int *>(&colds[prob].pad[1]);
+            const int v = *st;
+            a.found[prob] = v != 0;
+            if (v != 0) *st = 0;
+            was_found = v != 0;
+        }
+    }
+    if (d_tally == nullptr) return;                                        // (uniform: a kernel argument)
+    const uint32_t mine = (uint32_t)__builtin_popcountll(__ballot(was_found));
+    if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(&s_found, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_found) __hip_atomic_fetch_add(d_tally, s_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(d_tally + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+            const uint32_t total = __hip_atomic_exchange(d_tally, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d_tally + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(h_tally, ((unsigned long long)run << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -307,12 +307,27 @@ struct ss_batch_plan {
     bool find = false;
     ss::BatchArgs args;
     BatchShape shape = {1, 1};
+    // Plans of LONG problems hold a second layout.  Their workgroups scan a problem round robin, side by side - the fastest way
+    // through haystacks that do not hold the needle (consecutive addresses in flight), and one that gains nothing when they do:
+    // four tiles per workgroup leave no room for an early exit.  Eight contiguous runs per problem (the slice-major layout) are 6 %
+    // slower without matches and 2 to 25 times faster with them (256 x 4 MiB, every needle present at the start / in the middle:
+    // 0.014 / 0.087 ms against 0.196 / 0.160; profiles/r05/plan_layouts.jsonl) - the later runs of a found problem leave at their
+    // entry poll.  Which of the two a plan's problems want is not known when it is made, and is known after its first run: the
+    // publish kernel tallies the problems that were found into pinned memory, and a later run - which never waits for the tally -
+    // takes the contiguous runs when at least an eighth of the problems were found last time.  Deterministic for given inputs;
+    // no result depends on it.
+    bool has_alt = false;
+    BatchShape shape_alt = {1, 1};
+    unsigned long long *h_tally = nullptr;          // pinned: run << 32 | found problems of that run
+    mutable uint32_t runs = 0;
     uint8_t *mem = nullptr;
-    static constexpr size_t kPerProblem = sizeof(ss::BatchDesc) + sizeof(ss::BatchCold);
+    static constexpr size_t kPerProblem = 2 * sizeof(ss::BatchDesc) + sizeof(ss::BatchCold);
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
-    ss::BatchCold *colds() const { return reinterpret_cast<ss::BatchCold *>(mem + count * sizeof(ss::BatchDesc)); }
+    ss::BatchDesc *descs_alt() const { return reinterpret_cast<ss::BatchDesc *>(mem + count * sizeof(ss::BatchDesc)); }
+    ss::BatchCold *colds() const { return reinterpret_cast<ss::BatchCold *>(mem + 2 * count * sizeof(ss::BatchDesc)); }
     ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * kPerProblem); }
     ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * kPerProblem + 64); }
+    uint32_t *tally() const { return reinterpret_cast<uint32_t *>(mem + count * kPerProblem + 64 + sizeof(ss::BatchClasses)); }
 };
 
 extern "C" {
@@ -363,7 +378,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     if (rc == SS_OK && (e = hipGetDevice(&p->dev)) != hipSuccess) rc = fail(SS_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
     if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape, true);
     if (rc == SS_OK) {
-        const size_t bytes = count * ss_batch_plan::kPerProblem + 64 + sizeof(ss::BatchClasses);
+        const size_t bytes = count * ss_batch_plan::kPerProblem + 64 + sizeof(ss::BatchClasses) + 64;
         if ((e = hipMalloc((void **)&p->mem, bytes)) != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
@@ -421,6 +436,31 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
                                                                                                                         p->colds(), cls, p->find ? 1 : 0);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(st);
+            // the second layout (see ss_batch_plan): for plans whose problems are scanned round robin and are numerous enough for
+            // eight runs each to fill the device
+            bool alt_ok = p->shape.slices > ss::kPlanSliceMajorMax && (uint64_t)count * ss::kPlanSliceMajorMax >= 1024;
+#ifdef SS_TEST_HOOKS
+            if (getenv("SLICESLICE_BATCH_WGS")) alt_ok = false;
+            if (const char *v = getenv("SLICESLICE_PLAN_ONE_LAYOUT")) { if (atoi(v) != 0) alt_ok = false; }
+#endif
+            if (e == hipSuccess && alt_ok) {
+                ss::PlanStats alt = {0, 0, 0};
+                p->shape_alt.slices = ss::kPlanSliceMajorMax;
+                p->shape_alt.min_tiles = kPlanMinTilesCounted;
+                e = hipMemsetAsync(p->stats(), 0, 64, st);
+                if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs_alt(), p->shape_alt, st, p->stats(), cls);
+                if (e == hipSuccess) e = hipMemcpyAsync(&alt, p->stats(), sizeof(alt), hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipMemsetAsync(p->tally(), 0, 64, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e == hipSuccess && alt.max_slices > 1 &&
+                    hipHostMalloc((void **)&p->h_tally, sizeof(unsigned long long), hipHostMallocPortable) == hipSuccess) {
+                    *p->h_tally = 0;
+                    p->shape_alt.slices = alt.max_slices < p->shape_alt.slices ? alt.max_slices : p->shape_alt.slices;
+                    p->has_alt = true;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
         }
         if (e != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan set-up: %s", hipGetErrorString(e));
@@ -428,6 +468,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     if (rc != SS_OK) {
         (void)hipGetLastError();
         (void)hipFree(p->mem);
+        if (p->h_tally) (void)hipHostFree(p->h_tally);
         delete p;
         return rc;
     }
@@ -443,18 +484,29 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     if (dev != p->dev) return fail(SS_ERR_ARGUMENT, "the plan was made on device %d, the current device is %d", p->dev, dev);
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     ss::BatchArgs a = p->args;
-    const dim3 grid((unsigned)((uint64_t)p->count * p->shape.slices));
+    // which layout: the contiguous runs when the latest tally that has arrived says an eighth of the problems were found (see
+    // ss_batch_plan; runs of one plan are ordered one behind the other by contract, so `runs` needs no atomics)
+    bool alt = false;
+    if (p->has_alt) {
+        const unsigned long long t = __atomic_load_n(p->h_tally, __ATOMIC_RELAXED);
+        alt = (t >> 32) != 0 && (uint64_t)(uint32_t)t * 8 >= (uint64_t)p->count;
+    }
+    const ss::BatchDesc *descs = alt ? p->descs_alt() : p->descs();
+    const BatchShape &sh = alt ? p->shape_alt : p->shape;
+    const dim3 grid((unsigned)((uint64_t)p->count * sh.slices));
     if (p->find) {
         a.best = static_cast<uint64_t *>(d_out);
-        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->colds());
+        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds());
     } else {
         a.found = static_cast<int *>(d_out);
-        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, p->descs(), (uint32_t)p->count, p->shape.slices, p->colds());
+        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds());
     }
     HIP_TRY(hipGetLastError());
-    // problems scanned by several workgroups leave their answer in the plan's state words: one lane per problem publishes
-    if (p->shape.slices > 1) {
-        ss::batch_publish_kernel<<<dim3((unsigned)((p->count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(a, p->descs(), (uint32_t)p->count, p->colds());
+    // problems scanned by several workgroups leave their answer in their state words: one lane per problem publishes
+    if (sh.slices > 1) {
+        const uint32_t run = ++p->runs == 0 ? ++p->runs : p->runs;
+        ss::batch_publish_kernel<<<dim3((unsigned)((p->count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(
+            a, descs, (uint32_t)p->count, p->colds(), p->has_alt ? p->tally() : nullptr, p->h_tally, run);
         HIP_TRY(hipGetLastError());
     }
     return SS_OK;
@@ -478,6 +530,18 @@ int ss_debug_batch_classes(const void *d_haystacks, const uint64_t *d_hay_begin,
         *state = c.state;
         if (c.state == 3) HIP_TRY(hipMemcpy(cls, c.mem->cls, 256, hipMemcpyDeviceToHost));
     }
+    return SS_OK;
+}
+
+int ss_debug_plan_layout(const ss_batch_plan *p, uint32_t out[5])
+{
+    if (!p || !out) return fail(SS_ERR_ARGUMENT, "NULL argument");
+    const unsigned long long t = p->has_alt ? __atomic_load_n(p->h_tally, __ATOMIC_RELAXED) : 0ull;
+    out[0] = p->has_alt ? 1u : 0u;
+    out[1] = p->shape.slices;
+    out[2] = p->has_alt ? p->shape_alt.slices : 0u;
+    out[3] = (uint32_t)t;                                            // problems found in the latest tallied run
+    out[4] = p->has_alt && (t >> 32) != 0 && (uint64_t)(uint32_t)t * 8 >= (uint64_t)p->count ? 1u : 0u;   // the next run takes the second layout
     return SS_OK;
 }
 
@@ -518,6 +582,7 @@ void ss_batch_plan_free(ss_batch_plan *p)
 {
     if (!p) return;
     (void)hipFree(p->mem);          // (waits for the device: a run the caller forgot about cannot read freed memory)
+    if (p->h_tally) (void)hipHostFree(p->h_tally);
     delete p;
 }
 

@@ -110,6 +110,7 @@ HOOKS_ABI = {
     "ss_debug_census": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_plan_filter": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_plan_cold": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
+    "ss_debug_plan_layout": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_batch_classes": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)]),
     "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
@@ -849,6 +850,13 @@ class BatchPlan:
         out = (ctypes.c_uint32 * 5)()
         _check(_hooks(self._L).ss_debug_plan_filter(self._h, int(problem), out), self._L)
         return (out[0], out[1], out[2]), out[3], out[4]
+
+    def layout(self):
+        """{"two": the plan holds two layouts, "slices": (first, second), "found_last": problems found in the latest tallied run,
+        "next_is_second": the next run takes the contiguous-runs layout} - hooks builds (ss_debug_plan_layout)."""
+        out = (ctypes.c_uint32 * 5)()
+        _check(_hooks(self._L).ss_debug_plan_layout(self._h, out), self._L)
+        return {"two": bool(out[0]), "slices": (out[1], out[2]), "found_last": out[3], "next_is_second": bool(out[4])}
 
     def cold_of(self, problem):
         """(schedule indices, schedule bytes, exact_len, bytes in front, the compare's 16 bytes) of one problem's ready-made cold

@@ -394,3 +394,57 @@ def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
             assert set(plan.filter_of(i)[0]) == _plan_pair_model(words[i], cls)
         assert plan.run().tolist() == [1] * len(words)
         plan.close()
+
+
+def test_plans_of_long_problems_change_their_layout_with_what_the_last_run_found(ss):
+    """A plan of LONG problems holds two layouts: round robin (side by side through each haystack: the fastest full scan) and eight
+    contiguous runs per problem (later runs of a found problem leave at once).  The publish kernel tallies the problems a run found;
+    a later run takes the contiguous runs when at least an eighth were found.  Answers are the same through every switch, for flags
+    and offsets, with the needles present, removed and put back."""
+    count, each = 160, 2 << 20
+    hay = torch.empty(count * each, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, 0xA17)
+    at = [(i * 7919) % (each - 16) for i in range(count)]
+    idx = (torch.arange(count, device="cuda", dtype=torch.int64) * each + torch.tensor(at, device="cuda", dtype=torch.int64))[:, None] + \
+        torch.arange(16, device="cuda", dtype=torch.int64)[None, :]
+    needles = hay[idx.reshape(-1)].contiguous()
+    hoff = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
+    noff = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
+    host = hay.cpu().numpy()
+    nd = needles.cpu().numpy().tobytes()
+    want = [host[i * each:(i + 1) * each].tobytes().find(nd[16 * i:16 * i + 16]) for i in range(count)]
+    assert all(w >= 0 for w in want)
+    with ss.tuning_build():
+        for find in (False, True):
+            plan = ss.BatchPlan(hay, hoff, needles, noff, find=find)
+            lay = plan.layout()
+            assert lay["two"] and lay["slices"][0] > 8 and 1 < lay["slices"][1] <= 8 and not lay["next_is_second"], lay
+            expect = want if find else [1] * count
+            for run in range(3):
+                assert plan.run().tolist() == expect, (find, run)
+                torch.cuda.synchronize()
+                lay = plan.layout()
+                assert lay["found_last"] == count and lay["next_is_second"], (run, lay)
+            # the needles leave their haystacks (one byte of each occurrence changed): the next run - contiguous runs - finds nothing,
+            # the one after it goes round robin again
+            saved = hay[idx[:, 0]].clone()
+            hay[idx[:, 0]] ^= 0x5A
+            torch.cuda.synchronize()
+            h2 = hay.cpu().numpy()
+            want2 = [h2[i * each:(i + 1) * each].tobytes().find(nd[16 * i:16 * i + 16]) for i in range(count)]
+            expect2 = want2 if find else [1 if w >= 0 else 0 for w in want2]
+            assert plan.run().tolist() == expect2
+            torch.cuda.synchronize()
+            lay = plan.layout()
+            assert lay["found_last"] == sum(w >= 0 for w in want2) and not lay["next_is_second"], lay
+            assert plan.run().tolist() == expect2
+            hay[idx[:, 0]] = saved
+            torch.cuda.synchronize()
+            assert plan.run().tolist() == expect
+            torch.cuda.synchronize()
+            assert plan.layout()["next_is_second"]
+            plan.close()
+        # a plan of few, very long problems keeps ONE layout (eight runs each would not fill the device)
+        few = ss.BatchPlan(hay, (torch.arange(5, dtype=torch.int64) * (40 * each)).cuda(), needles[:64], noff[:5])
+        assert not few.layout()["two"]
+        few.close()
