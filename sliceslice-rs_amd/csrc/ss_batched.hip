@@ -320,11 +320,12 @@ struct ss_batch_plan {
     BatchShape shape_alt = {1, 1};
     unsigned long long *h_tally = nullptr;          // pinned: run << 32 | found problems of that run
     mutable uint32_t runs = 0;
+    ss::BatchDesc *mem_alt = nullptr;               // the second layout's descriptors (plans that hold two)
     uint8_t *mem = nullptr;
-    static constexpr size_t kPerProblem = 2 * sizeof(ss::BatchDesc) + sizeof(ss::BatchCold);
+    static constexpr size_t kPerProblem = sizeof(ss::BatchDesc) + sizeof(ss::BatchCold);
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
-    ss::BatchDesc *descs_alt() const { return reinterpret_cast<ss::BatchDesc *>(mem + count * sizeof(ss::BatchDesc)); }
-    ss::BatchCold *colds() const { return reinterpret_cast<ss::BatchCold *>(mem + 2 * count * sizeof(ss::BatchDesc)); }
+    ss::BatchDesc *descs_alt() const { return mem_alt; }
+    ss::BatchCold *colds() const { return reinterpret_cast<ss::BatchCold *>(mem + count * sizeof(ss::BatchDesc)); }
     ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * kPerProblem); }
     ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * kPerProblem + 64); }
     uint32_t *tally() const { return reinterpret_cast<uint32_t *>(mem + count * kPerProblem + 64 + sizeof(ss::BatchClasses)); }
@@ -443,6 +444,11 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
             if (getenv("SLICESLICE_BATCH_WGS")) alt_ok = false;
             if (const char *v = getenv("SLICESLICE_PLAN_ONE_LAYOUT")) { if (atoi(v) != 0) alt_ok = false; }
 #endif
+            if (e == hipSuccess && alt_ok && hipMalloc((void **)&p->mem_alt, count * sizeof(ss::BatchDesc)) != hipSuccess) {
+                (void)hipGetLastError();
+                p->mem_alt = nullptr;
+                alt_ok = false;                                    // (no memory for it: one layout)
+            }
             if (e == hipSuccess && alt_ok) {
                 ss::PlanStats alt = {0, 0, 0};
                 p->shape_alt.slices = ss::kPlanSliceMajorMax;
@@ -468,6 +474,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     if (rc != SS_OK) {
         (void)hipGetLastError();
         (void)hipFree(p->mem);
+        (void)hipFree(p->mem_alt);
         if (p->h_tally) (void)hipHostFree(p->h_tally);
         delete p;
         return rc;
@@ -582,6 +589,7 @@ void ss_batch_plan_free(ss_batch_plan *p)
 {
     if (!p) return;
     (void)hipFree(p->mem);          // (waits for the device: a run the caller forgot about cannot read freed memory)
+    (void)hipFree(p->mem_alt);
     if (p->h_tally) (void)hipHostFree(p->h_tally);
     delete p;
 }
