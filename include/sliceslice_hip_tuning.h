@@ -15,6 +15,7 @@
 #define SLICESLICE_HIP_TUNING_H
 
 #include "sliceslice_hip.h"
+#include "sliceslice_hip_service.h"
 
 #ifdef __cplusplus
 extern "C" {

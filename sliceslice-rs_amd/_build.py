@@ -1,6 +1,8 @@
 """Builds csrc/ into the in-tree C-ABI libraries with hipcc for gfx950 (cross-compiles without a GPU).
 
     libsliceslice_hip.so          the product: include/sliceslice_hip.h and nothing else (-fvisibility=hidden)
+    libsliceslice_hip_service.so  the product's objects plus the resident search service (include/sliceslice_hip_service.h): an
+                                  opt-in component outside the hot path - a process uses one library or the other
     libsliceslice_hip_tools.so    benchmark helpers (synthetic haystack generator, read ceiling, self-test): ss_tools.hip
     libsliceslice_hip_tuning.so   the product's sources with -DSS_TUNING_VARIANTS -DSS_TEST_HOOKS: every kernel variant,
                                   ss_searcher_set_variant / _set_grid, fault injection (tools/, the variant and hook tests)
@@ -25,16 +27,19 @@ _CSRC = os.path.join(_HERE, "csrc")
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_CSRC, "libsliceslice_hip.so")
 _TOOLS_SO = os.path.join(_CSRC, "libsliceslice_hip_tools.so")
+_SERVICE_SO = os.path.join(_CSRC, "libsliceslice_hip_service.so")
 # host-side translation units (ss_internal.hpp lists what each holds) ...
-_HOST_SOURCES = ["ss_core.hip", "ss_scan.hip", "ss_census.hip", "ss_host.hip", "ss_batched.hip", "ss_service.hip", "ss_comm.hip"]
+_HOST_SOURCES = ["ss_core.hip", "ss_scan.hip", "ss_census.hip", "ss_host.hip", "ss_batched.hip", "ss_comm.hip"]
+_SERVICE_SOURCES = ["ss_service.hip"]       # NOT in the product: libsliceslice_hip_service.so and the hooks builds
 # ... and the scan kernel family, one explicit-instantiation unit per (U, load flavour, search / find).  The product holds what
 # the constructors and ss_searcher_set_filter3 can select (scan_launch.hpp::kernel_built): U = 4, non-temporal loads.
 _KERNEL_SOURCES = ["scan_inst_u4_nt1.hip", "scan_inst_find_nt1.hip"]
 _SOURCES = _HOST_SOURCES + _KERNEL_SOURCES
 # The tuning build adds every variant ss_searcher_set_variant can name: plain loads, U = 8.
-_TUNING_SOURCES = _SOURCES + ["scan_inst_u4_nt0.hip", "scan_inst_find_nt0.hip", "scan_inst_u8_nt0.hip", "scan_inst_u8_nt1.hip"]
+_TUNING_SOURCES = _SOURCES + _SERVICE_SOURCES + ["scan_inst_u4_nt0.hip", "scan_inst_find_nt0.hip", "scan_inst_u8_nt0.hip", "scan_inst_u8_nt1.hip"]
 _HEADERS = ["scan_filters.hpp", "scan_kernels.hpp", "scan_launch.hpp", "batched_kernels.hpp", "service_kernels.hpp", "aux_kernels.hpp",
             "ss_internal.hpp", os.path.join("..", "..", "include", "sliceslice_hip.h"),
+            os.path.join("..", "..", "include", "sliceslice_hip_service.h"),
             os.path.join("..", "..", "include", "sliceslice_hip_tuning.h")]
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-fvisibility=hidden"]
 _HOOK_FLAGS = ["-DSS_TEST_HOOKS=1"]
@@ -54,6 +59,10 @@ def library_path():
 
 def tools_library_path():
     return _TOOLS_SO
+
+
+def service_library_path():
+    return _SERVICE_SO
 
 
 def native_bench_path():
@@ -196,6 +205,14 @@ def build(force=False, verbose=False):
     return so
 
 
+def build_service(force=False, verbose=False):
+    """The product's objects + csrc/ss_service.hip -> csrc/libsliceslice_hip_service.so (include/sliceslice_hip_service.h): the
+    resident search service is an opt-in component outside the hot path and ships apart from the drop-in library."""
+    build(verbose=verbose)                                  # the product's objects are shared
+    with _Lock(".build_service.lock"):
+        return _build_variant(_SERVICE_SO, ".o", [], [], force, verbose, _SOURCES + _SERVICE_SOURCES, own=_SERVICE_SOURCES)
+
+
 def build_tools(force=False, verbose=False):
     """csrc/ss_tools.hip -> csrc/libsliceslice_hip_tools.so: the benchmark helpers of include/sliceslice_hip_tuning.h, group 1."""
     with _Lock(".build_toolslib.lock"):
@@ -209,7 +226,7 @@ def build_sanitized(force=False, verbose=False):
     build(verbose=verbose)                                  # the kernel-instantiation objects are shared with the regular build
     with _Lock(".build_asan.lock"):
         return _build_variant(so, ".asan.o", _SAN_FLAGS + _HOOK_FLAGS, ["-fsanitize=address,undefined", "-shared-libsan"], force, verbose,
-                              _SOURCES, own=_HOST_SOURCES)
+                              _SOURCES + _SERVICE_SOURCES, own=_HOST_SOURCES + _SERVICE_SOURCES)
 
 
 def build_tsan(force=False, verbose=False):
@@ -218,7 +235,7 @@ def build_tsan(force=False, verbose=False):
     build(verbose=verbose)
     with _Lock(".build_tsan.lock"):
         return _build_variant(so, ".tsan.o", _TSAN_FLAGS + _HOOK_FLAGS, ["-fsanitize=thread", "-shared-libsan"], force, verbose,
-                              _SOURCES, own=_HOST_SOURCES)
+                              _SOURCES + _SERVICE_SOURCES, own=_HOST_SOURCES + _SERVICE_SOURCES)
 
 
 def tsan_runtime():
@@ -235,14 +252,15 @@ def asan_runtime():
 def build_native_bench(force=False, verbose=False):
     """tools/native_bench.cpp -> tools/native_bench: the measurements that must not have Python or torch in the
     loop (per-call latencies, the config-1 per-needle loop, the multi-rank overheads), linked against the in-tree libraries."""
-    so = build(verbose=verbose)
+    build(verbose=verbose)
+    so = build_service(verbose=verbose)         # (a superset of the product: the tool also times the resident service)
     with _Lock(".build_tools.lock"):
         if (not force and os.path.exists(_NATIVE_BENCH) and
                 os.path.getmtime(_NATIVE_BENCH) >= max(os.path.getmtime(_NATIVE_BENCH_SRC), os.path.getmtime(so), os.path.getmtime(_TOOLS_SO))):
             return _NATIVE_BENCH
         tmp = _NATIVE_BENCH + ".tmp%d" % os.getpid()
         _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(_ROOT, "include"), _NATIVE_BENCH_SRC, "-o", tmp,
-              "-L", _CSRC, "-lsliceslice_hip", "-lsliceslice_hip_tools", "-Wl,-rpath,$ORIGIN/../sliceslice-rs_amd/csrc",
+              "-L", _CSRC, "-lsliceslice_hip_service", "-lsliceslice_hip_tools", "-Wl,-rpath,$ORIGIN/../sliceslice-rs_amd/csrc",
               "-Wl,-rpath,/opt/rocm/lib", "-pthread"], verbose)
         os.replace(tmp, _NATIVE_BENCH)
         return _NATIVE_BENCH
@@ -280,4 +298,4 @@ def build_ab(name, defines, force=False, verbose=False):
     with SLICESLICE_HIP_LIB=<path>, see tools/ab_compare.py)."""
     so = os.path.join(_CSRC, "libsliceslice_hip_%s.so" % name)
     with _Lock(".build_ab_%s.lock" % name):
-        return _build_variant(so, ".%s.o" % name, ["-D" + d for d in defines] + _HOOK_FLAGS, [], force, verbose, _SOURCES)
+        return _build_variant(so, ".%s.o" % name, ["-D" + d for d in defines] + _HOOK_FLAGS, [], force, verbose, _SOURCES + _SERVICE_SOURCES)

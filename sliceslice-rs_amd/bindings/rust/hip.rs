@@ -12,11 +12,11 @@
 #![allow(non_camel_case_types, dead_code)]
 use crate::Needle;
 use std::os::raw::{c_char, c_float, c_int, c_uint, c_void};
+// (the resident search service - an opt-in component outside the hot path, in a library of its own - is src/hip_service.rs)
 
 #[repr(C)] pub struct ss_searcher { _private: [u8; 0] }
 #[repr(C)] pub struct ss_comm { _private: [u8; 0] }
 #[repr(C)] pub struct ss_comm_set { _private: [u8; 0] }
-#[repr(C)] pub struct ss_service { _private: [u8; 0] }
 #[repr(C)] pub struct ss_batch_plan { _private: [u8; 0] }
 
 pub const SS_OK: c_int = 0;
@@ -93,11 +93,6 @@ extern "C" {
     pub fn ss_search_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, set: *mut ss_comm_set, found: *mut c_int) -> c_int;
     pub fn ss_find_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, shard_begins: *const u64,
                                set: *mut ss_comm_set, position: *mut u64) -> c_int;
-    // resident search service
-    pub fn ss_service_start(workgroups: c_int, lease_ms: f64, out: *mut *mut ss_service) -> c_int;
-    pub fn ss_service_search(sv: *mut ss_service, s: *const ss_searcher, d_haystack: *const c_void, len: usize, found: *mut c_int) -> c_int;
-    pub fn ss_service_bind(sv: *mut ss_service, d_haystack: *const c_void, len: usize) -> c_int;
-    pub fn ss_service_stop(sv: *mut ss_service);
     // diagnostics
     pub fn ss_last_error() -> *const c_char;
     pub fn ss_device_info(name: *mut c_char, name_cap: usize, compute_units: *mut c_int, total_mem: *mut usize) -> c_int;
@@ -113,7 +108,7 @@ pub struct DynamicHipSearcher<N: Needle> { handle: *mut ss_searcher, needle: N }
 unsafe impl<N: Needle + Send> Send for DynamicHipSearcher<N> {}
 unsafe impl<N: Needle + Sync> Sync for DynamicHipSearcher<N> {}   // ss_search_* is re-entrant per handle
 
-fn check(rc: c_int) {
+pub(crate) fn check(rc: c_int) {
     if rc == SS_OK { return; }
     let msg = unsafe { std::ffi::CStr::from_ptr(ss_last_error()) }.to_string_lossy().into_owned();
     // contract violations panic exactly where the reference does (x86.rs:300, :473)
@@ -290,36 +285,4 @@ mod tests {
         assert!(DynamicHipSearcher::new(std::sync::Arc::<[u8]>::from(&b"ipsum"[..])).search_in(hay));
         assert!(DynamicHipSearcher::new(*b"ipsum").search_in(hay));
     }
-}
-
-/// A resident search service on the current device (`ss_service_*`): a kernel that stays on the GPU and answers one
-/// `search_in` at a time without a launch - 5 us per search instead of 8.5-9.5: the floor of the per-call shape (one PCIe
-/// round trip).  The shape of the reference's own bench loop (bench/benches/i386.rs:246-256): build the searchers FIRST,
-/// `bind` the text if it does not change between searches, then one `search_in` per needle.  The GPU's own answer to that
-/// loop is ONE call for all needles: `ss_batch_plan_create` once (the searchers), `ss_batch_plan_run` per iteration.
-pub struct SearchService { handle: *mut ss_service }
-
-unsafe impl Send for SearchService {}
-unsafe impl Sync for SearchService {}     // requests queue on a mutex inside the library
-
-impl SearchService {
-    /// `workgroups` = 0: 64; `lease_ms` = 0.0: 20 ms without a request, then the kernel leaves until the next one.
-    pub fn start(workgroups: i32, lease_ms: f64) -> Self {
-        let mut handle = std::ptr::null_mut();
-        check(unsafe { ss_service_start(workgroups as c_int, lease_ms, &mut handle) });
-        Self { handle }
-    }
-    /// The semantics of `DynamicHipSearcher::search_in_device` for a haystack that is COMPLETE in device memory.
-    pub fn search_in<N: Needle>(&self, searcher: &DynamicHipSearcher<N>, haystack: DeviceSlice) -> bool {
-        let mut found = 0;
-        check(unsafe { ss_service_search(self.handle, searcher.handle(), haystack.ptr, haystack.len, &mut found) });
-        found != 0
-    }
-    /// The caller vouches that `haystack` stays unchanged until `unbind` / the next `bind`.
-    pub fn bind(&self, haystack: DeviceSlice) { check(unsafe { ss_service_bind(self.handle, haystack.ptr, haystack.len) }) }
-    pub fn unbind(&self) { check(unsafe { ss_service_bind(self.handle, std::ptr::null(), 0) }) }
-}
-
-impl Drop for SearchService {
-    fn drop(&mut self) { unsafe { ss_service_stop(self.handle) } }
 }

@@ -240,8 +240,9 @@ const uint8_t *batch_classes(int dev, const ss::BatchArgs &a, size_t count, hipS
         *t.h_tag = 0;
     }
     if (!hit->mem) {
+        // (zeroed on the call's stream, in front of the sampling kernel: no null-stream work inside a search call)
         hipError_t e = hipMalloc((void **)&hit->mem, sizeof(ss::BatchClasses));
-        if (e == hipSuccess) e = hipMemset(hit->mem, 0, sizeof(ss::BatchClasses));
+        if (e == hipSuccess) e = hipMemsetAsync(hit->mem, 0, sizeof(ss::BatchClasses), st);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             hit->mem = nullptr;

@@ -153,8 +153,11 @@ bool stats_lookup(int dev, const void *d_hay, size_t len, hipStream_t st, uint64
     const uint64_t stride = ((len - 8 - ss::kCensusTileBytes) / (ss::kCensusTiles - 1)) & ~(uint64_t)(ss::kCensusTileBytes - 1);
     if (stride < ss::kCensusTileBytes || stream_is_capturing(st)) return have;
     if (!ds.d_partial) {                                                          // first use on this device
+        // (zeroed on the CALL'S stream, in front of the sampling kernel that follows on it: a null-stream memset would be a
+        // device-wide ordering point inside a search, whose contract is to synchronise nothing but the stream it was given.  The
+        // next sampling - possibly on another stream - is not launched before this one's tag has arrived: `pending`.)
         hipError_t e = hipMalloc((void **)&ds.d_partial, ss::kHistBlocks * 256 * sizeof(uint32_t) + 64);
-        if (e == hipSuccess) e = hipMemset(ds.d_partial, 0, ss::kHistBlocks * 256 * sizeof(uint32_t) + 64);
+        if (e == hipSuccess) e = hipMemsetAsync(ds.d_partial, 0, ss::kHistBlocks * 256 * sizeof(uint32_t) + 64, st);
         if (e == hipSuccess) e = hipHostMalloc((void **)&ds.h_out, sizeof(unsigned long long) + 256 * sizeof(uint32_t), hipHostMallocPortable);
         if (e != hipSuccess) {
             (void)hipGetLastError();

@@ -125,7 +125,7 @@ struct ss_comm_set {
     std::vector<volatile uint32_t *> hdp_flush;         // per device: HDP flush register (pushes the store out of the host data path)
     // One issue thread per device (SS_ISSUE_THREADS): see SetWorker below.  Created with the set, joined by ss_comm_set_free.
     std::vector<SetWorker *> workers;
-    const ss_searcher *timed = nullptr;                 // the searcher of the latest search (ss_comm_set_last_kernel_ms)
+    uint64_t timed = 0;                                 // uid of the searcher of the latest search (ss_comm_set_last_kernel_ms); 0: none
     float issue_us[4] = {0, 0, 0, 0};                   // the latest search's host time: scans, collective, answer words, all of it
 };
 
@@ -140,6 +140,7 @@ struct ss_comm_set {
 struct SetJob {
     int kind = 0;                       // 1 = one shard of a search, 2 = read the thread's kernel time, 3 = one shard of a find
     uint64_t begin = 0;                 // find: the shard's global offset
+    uint64_t uid = 0;                   // kind 2: the searcher whose time is asked for (its uid: it may have been freed since)
     const ss_searcher *s = nullptr;
     const void *shard = nullptr;
     size_t len = 0;
@@ -151,9 +152,9 @@ struct SetWorker {
     int g = 0;
     std::thread th;
     std::atomic<uint32_t> posted{0}, done{0};
-    std::atomic<bool> asleep{false}, quit{false};
+    std::atomic<bool> asleep{false}, quit{false}, caller_asleep{false};
     std::mutex mu;
-    std::condition_variable cv;
+    std::condition_variable cv, done_cv;
     SetJob job;
     int rc = SS_OK;
     char msg[256] = "";
@@ -161,6 +162,7 @@ struct SetWorker {
     float issue_us[3] = {0, 0, 0};
 };
 constexpr long long kWorkerSpinUs = 500;
+constexpr long long kCallerSpinUs = 200;     // how long the caller spins for a worker's report before it sleeps (wait_job)
 
 namespace {
 
@@ -290,7 +292,7 @@ void run_job(SetWorker *w)
     w->rc = SS_OK;
     w->msg[0] = 0;
     if (w->job.kind == 2) {
-        w->rc = thread_last_kernel_ms(w->job.s, set->devs[w->g], &w->kernel_ms);
+        w->rc = thread_last_kernel_ms(w->job.uid, set->devs[w->g], &w->kernel_ms);
     } else if (w->job.kind == 3) {
         // one device's chain of a find: minimum reset -> scan (atomicMin of begin + offset) -> all-reduce(MIN) -> read-back -> wait.
         // A chain whose scan cannot be enqueued still enters the collective (its minimum stays all ones); the caller sees its error.
@@ -348,7 +350,11 @@ void worker_main(SetWorker *w)
         if (p == seen) return;                                // quit
         run_job(w);
         seen = p;
-        w->done.store(p, std::memory_order_release);
+        w->done.store(p, std::memory_order_seq_cst);
+        if (w->caller_asleep.load(std::memory_order_seq_cst)) {      // (the caller gave up spinning: see wait_job)
+            std::lock_guard<std::mutex> lock(w->mu);
+            w->done_cv.notify_all();
+        }
         idle_since = std::chrono::steady_clock::now();
     }
 }
@@ -364,9 +370,33 @@ uint32_t post_job(SetWorker *w)
     return p;
 }
 
+// The caller's side of a job: a job that only enqueues is done in microseconds, so spin first; a worker that waits for its stream
+// inside the job (long shards, every find) - or sits in a collective another rank has not entered yet - is waited for on the
+// worker's condition variable instead of a burning core.
 void wait_job(SetWorker *w, uint32_t p)
 {
-    while (w->done.load(std::memory_order_acquire) != p) cpu_relax();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; w->done.load(std::memory_order_acquire) != p; ++spins) {
+        cpu_relax();
+        if ((spins & 255) == 255 && us_since(t0) > (double)kCallerSpinUs) {
+            std::unique_lock<std::mutex> lock(w->mu);
+            w->caller_asleep.store(true, std::memory_order_seq_cst);
+            w->done_cv.wait(lock, [&]() { return w->done.load(std::memory_order_seq_cst) == p; });
+            w->caller_asleep.store(false, std::memory_order_seq_cst);
+            return;
+        }
+    }
+}
+
+// std::thread's constructor throws std::system_error when the system is out of threads: not through an extern "C" boundary
+bool start_worker(SetWorker *w)
+{
+    try {
+        w->th = std::thread(worker_main, w);
+    } catch (...) {
+        return false;
+    }
+    return true;
 }
 
 bool threads_wanted()
@@ -652,7 +682,10 @@ int ss_comm_init_all(int ndev, const int *devs, ss_comm_set **out)
             w->set = set;
             w->g = g;
             set->workers.push_back(w);
-            w->th = std::thread(worker_main, w);
+            if (!start_worker(w)) {
+                free_comm_set(set);
+                return fail(SS_ERR_NOMEM, "an issue thread could not be started");
+            }
         }
     }
     *out = set;
@@ -685,7 +718,11 @@ int ss_comm_set_issue(ss_comm_set *set, int issue)
             w->set = set;
             w->g = g;
             set->workers.push_back(w);
-            w->th = std::thread(worker_main, w);
+            if (!start_worker(w)) {
+                stop_workers(set);                                // all or none: the set stays on the one-thread form
+                set->issue = SS_ISSUE_SERIAL;
+                return fail(SS_ERR_NOMEM, "an issue thread could not be started");
+            }
         }
     }
     set->issue = issue;
@@ -719,7 +756,8 @@ int ss_comm_set_last_kernel_ms(ss_comm_set *set, float *ms, int count)
         std::vector<uint32_t> posted(set->ndev);
         for (int g = 0; g < set->ndev; ++g) {
             set->workers[g]->job.kind = 2;
-            set->workers[g]->job.s = set->timed;
+            set->workers[g]->job.s = nullptr;
+            set->workers[g]->job.uid = set->timed;
             posted[g] = post_job(set->workers[g]);
         }
         int rc = SS_OK;
@@ -758,7 +796,7 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
     SearchGate gate(s);
     DeviceGuard guard;
     const int epoch = next_comm_epoch(&set->epoch, set->d_flag.data(), set->devs.data(), G, set->h_flag.data());
-    set->timed = s;
+    set->timed = s->uid;
     // Scans short enough to be waited for by spinning (spin_for_word) end with a one-lane kernel per device that stores the
     // device's answer word - behind the scan and the all-reduce, so a word that has arrived says its stream is done - and the
     // host collects the G words; longer ones are waited for on their streams.
@@ -919,7 +957,19 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
         return SS_OK;
     }
     int any = 0;
-    if (rccl_on) {
+    if (signal) {
+        // The spin ran out of its budget (a first ncclAllReduce that connects lazily, a device busy with other work) and the streams
+        // have been drained since: the G answer words ARE written now - every chain ends with its answer-word kernel, and only the
+        // non-signal chains enqueue the read-back into h_recv.  A word that is still missing is an error, never "not found".
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long v = (unsigned long long)__atomic_load_n(set->h_words + g, __ATOMIC_ACQUIRE);
+            if ((v >> 2) != (unsigned long long)(uint32_t)epoch)
+                return fail(SS_ERR_HIP, "device %d of the set did not write its answer word", set->devs[g]);
+            any |= (int)(v & 1);
+            any_failed |= (int)((v >> 1) & 1);
+        }
+        if (any_failed) return fail(SS_ERR_HIP, "a device of the set failed its part of this search; no answer");
+    } else if (rccl_on) {
         any = set->h_recv[0] == epoch;
         if (set->h_recv[1] == epoch) return fail(SS_ERR_HIP, "a device of the set failed its part of this search; no answer");
     } else {

@@ -463,6 +463,8 @@ int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_fi
     if (e != hipSuccess || ndev == 0) return fail(SS_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
     ss_searcher *s = new (std::nothrow) ss_searcher;
     if (!s) return fail(SS_ERR_NOMEM, "out of memory");
+    static std::atomic<uint64_t> next_uid{1};
+    s->uid = next_uid.fetch_add(1, std::memory_order_relaxed);
     s->needle.assign(needle, needle + n);
     s->n = n;
     s->position = position;

@@ -6,7 +6,7 @@
 //   ss_census.hip   what a searcher learns about a haystack by asking it: candidate census, byte histogram -> launch hints
 //   ss_host.hip     host-slice and host-file front ends, the byte histogram (rows f2, f3 of SURVEY.md 8f)
 //   ss_batched.hip  batched search / find, batch plans, short-haystack pairs (config 5, row f4)
-//   ss_service.hip  the resident search service
+//   ss_service.hip  the resident search service - NOT in libsliceslice_hip.so: libsliceslice_hip_service.so and the hooks builds
 //   ss_comm.hip     RCCL, the range-sharded searches (one process per GPU and all GPUs from one process), ss_shard_range
 //   ss_tools.hip    benchmark / tuning helpers and the test hooks (sliceslice_hip_tuning.h)
 // The scan kernels live in scan_filters.hpp / scan_kernels.hpp (instantiated in scan_inst_*.hip), the others next to their users.
@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/sliceslice_hip.h"
+#include "../../include/sliceslice_hip_service.h"      // (declarations only: ss_service.hip is linked into libsliceslice_hip_service.so and the hooks builds)
 #include "../../include/sliceslice_hip_tuning.h"
 #include "scan_filters.hpp"
 
@@ -140,6 +141,8 @@ bool bar_writes_allowed();              // SLICESLICE_NO_BAR_WRITES != 1
 }  // namespace ssh
 
 struct ss_searcher {
+    uint64_t uid = 0;         // unique for the life of the process (never 0): what timing records and communicator sets remember
+                              // a searcher by - an address may be handed out again after ss_searcher_free
     std::vector<uint8_t> needle;
     size_t n = 0;
     size_t position = 0;      // the API position (what ss_searcher_position reports; x86.rs:468)
@@ -247,7 +250,7 @@ void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_h
 int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t len, hipStream_t st, void *d_sink, bool find = false,
                  uint64_t find_base = 0, int *host_flag = nullptr, int epoch = 1, int done_slot = -1, bool *used_done = nullptr);
 void timer_forget(const ss_searcher *s);                         // ss_searcher_free: the calling thread's timing record
-int thread_last_kernel_ms(const ss_searcher *s, int dev, float *ms);   // the calling thread's latest timed scan on `dev` (< 0: its latest)
+int thread_last_kernel_ms(uint64_t uid, int dev, float *ms);     // the calling thread's latest timed scan of searcher `uid` on `dev` (< 0: its latest)
 
 // Scans too large for the workgroup count of the completion word still answer through a pinned word when the scan is short enough
 // to be waited for by spinning: a one-lane kernel behind the scan (behind the all-reduce, for a sharded search) stores the word.

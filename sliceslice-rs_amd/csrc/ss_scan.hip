@@ -21,7 +21,7 @@ namespace ssh {
 namespace {
 struct ThreadTimer {
     hipEvent_t ev0[kMaxDevices] = {nullptr}, ev1[kMaxDevices] = {nullptr};
-    const void *owner[kMaxDevices] = {nullptr};     // per device: the searcher of the most recent timed scan there
+    uint64_t owner[kMaxDevices] = {0};              // per device: the uid of the searcher of the most recent timed scan there (0: none)
     int dev = -1;                                   // the device of the most recent timed scan
     ~ThreadTimer()
     {
@@ -38,15 +38,17 @@ thread_local ThreadTimer g_timer;
 void timer_forget(const ss_searcher *s)
 {
     for (auto &o : g_timer.owner)
-        if (o == s) o = nullptr;
+        if (o == s->uid) o = 0;
 }
 
-// The calling thread's most recent timed scan through `s` on device `dev` (dev < 0: on the device it last launched on).
-int thread_last_kernel_ms(const ss_searcher *s, int dev, float *ms)
+// The calling thread's most recent timed scan through the searcher `uid` on device `dev` (dev < 0: on the device it last launched
+// on).  Keyed by the searcher's uid, not its address: a record that outlives its searcher (another thread's) can never pass for
+// a later searcher allocated at the same address, and nobody dereferences a searcher to read it.
+int thread_last_kernel_ms(uint64_t uid, int dev, float *ms)
 {
     ThreadTimer &tm = g_timer;
     if (dev < 0) dev = tm.dev;
-    if (dev < 0 || dev >= kMaxDevices || tm.owner[dev] != s)
+    if (dev < 0 || dev >= kMaxDevices || uid == 0 || tm.owner[dev] != uid)
         return fail(SS_ERR_ARGUMENT, "no timed scan has been launched through this searcher by the calling thread");
     HIP_TRY(hipEventSynchronize(tm.ev1[dev]));
     HIP_TRY(hipEventElapsedTime(ms, tm.ev0[dev], tm.ev1[dev]));
@@ -387,7 +389,7 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(tm.ev1[pd->dev], st));
-        tm.owner[pd->dev] = s;
+        tm.owner[pd->dev] = s->uid;
         tm.dev = pd->dev;
     }
     return SS_OK;
@@ -454,7 +456,7 @@ int ss_searcher_last_launch(const ss_searcher *s, int *workgroups_per_cu, unsign
 int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms)
 {
     if (!s || !ms) return fail(SS_ERR_ARGUMENT, "NULL argument");
-    return thread_last_kernel_ms(s, -1, ms);
+    return thread_last_kernel_ms(s->uid, -1, ms);
 }
 
 int ss_search_device_async(const ss_searcher *s, const void *d_haystack, size_t len, void *hip_stream,

@@ -82,12 +82,16 @@ ABI = {
     "ss_comm_set_last_issue_us": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "ss_search_sharded_all": (_int, [_vp, _pvp, _psz, _vp, _pint]),
     "ss_find_sharded_all": (_int, [_vp, _pvp, _psz, _pu64, _vp, _pu64]),
+    "ss_last_error": (ctypes.c_char_p, []),
+    "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, _psz]),
+}
+# include/sliceslice_hip_service.h: the resident search service, an opt-in component outside the hot path - NOT in the product
+# library: libsliceslice_hip_service.so (the product's objects plus the service) and the hooks builds hold it
+SERVICE_ABI = {
     "ss_service_start": (_int, [_int, ctypes.c_double, _pvp]),
     "ss_service_search": (_int, [_vp, _vp, _vp, _sz, _pint]),
     "ss_service_bind": (_int, [_vp, _vp, _sz]),
     "ss_service_stop": (None, [_vp]),
-    "ss_last_error": (ctypes.c_char_p, []),
-    "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, _psz]),
 }
 # include/sliceslice_hip_tuning.h, group 1: libsliceslice_hip_tools.so
 TOOLS_ABI = {
@@ -152,8 +156,10 @@ def _load(path):
     _preload_torch()
     L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
     _bind(L, ABI, strict=True)
+    _bind(L, SERVICE_ABI, strict=False)
     _bind(L, HOOKS_ABI, strict=False)
     L.has_hooks = hasattr(L, "ss_debug_fail_next_scans")
+    L.has_service = hasattr(L, "ss_service_start")
     return L
 
 
@@ -168,6 +174,7 @@ def lib():
 
 _tools = None
 _tuning = None
+_service = None
 
 
 def tools_lib():
@@ -191,6 +198,24 @@ class tuning_build:
             _tuning = _load(_build.build_tuning())
         self._saved, _lib = _lib, _tuning
         return _tuning
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+class service_build:
+    """``with ss.service_build():`` - inside the block ``lib()`` is libsliceslice_hip_service.so: every function of the product
+    library plus the resident search service (include/sliceslice_hip_service.h).  Searchers belong to the library that made
+    them, so the searchers a SearchService is asked about must be created inside the block too."""
+
+    def __enter__(self):
+        global _lib, _service
+        if _service is None:
+            _service = _load(_build.build_service())
+        self._saved, _lib = _lib, _service
+        return _service
 
     def __exit__(self, *a):
         global _lib
@@ -768,6 +793,10 @@ class SearchService:
     def __init__(self, workgroups=0, lease_ms=0.0):
         self._h = ctypes.c_void_p()
         L = self._L = lib()
+        if not getattr(L, "has_service", False):
+            raise SlicesliceError(SS_ERR_ARGUMENT, "the resident search service is not part of libsliceslice_hip.so: it lives in "
+                                                   "libsliceslice_hip_service.so (`with ss.service_build():`, or SLICESLICE_HIP_LIB=<path>) "
+                                                   "and in the hooks builds")
         _check(L.ss_service_start(int(workgroups), float(lease_ms), ctypes.byref(self._h)), L)
 
     def _ck(self, rc):

@@ -9,6 +9,9 @@
 #include <vector>
 
 #include "sliceslice_hip.hpp"
+#ifdef SS_VENEER_WITH_SERVICE       // built a second time against libsliceslice_hip_service.so (tests/test_gpu_native.py)
+#include "sliceslice_hip_service.hpp"
+#endif
 
 using sliceslice::hip::DeviceSlice;
 using sliceslice::hip::DynamicHipSearcher;
@@ -128,7 +131,8 @@ int main()
         CHECK(other.find(shards.data(), begins.data()) == DynamicHipSearcher::npos);
         for (int g = 0; g < ndev; ++g) (void)hipFree(bufs[g]);
     }
-    {   // SearchService: the shape of the reference's bench loop - searchers first, the text bound, one search per needle
+    {   // the shape of the reference's bench loop - searchers first, one search per needle (through the SearchService of
+        // sliceslice_hip_service.hpp, the text bound, when built against the service library)
         const std::string text = "the quick brown fox jumps over the lazy dog; pack my box with five dozen liquor jugs";
         uint8_t *dt = nullptr;
         CHECK(hipMalloc((void **)&dt, text.size()) == hipSuccess);
@@ -137,12 +141,17 @@ int main()
         const bool expect[] = {true, true, true, true, true, true, false, false, false};
         std::vector<DynamicHipSearcher> ss;
         for (const char *w : words) ss.push_back(DynamicHipSearcher::new_(w));
+#ifdef SS_VENEER_WITH_SERVICE
         sliceslice::hip::SearchService service;
         service.bind(DeviceSlice{dt, text.size()});
         for (int round = 0; round < 3; ++round)
             for (size_t k = 0; k < ss.size(); ++k) CHECK(service.search_in(ss[k], DeviceSlice{dt, text.size()}) == expect[k]);
         service.unbind();
         CHECK(service.search_in(ss[0], DeviceSlice{dt + 4, text.size() - 4}));
+        std::puts("service veneer ok");
+#else
+        for (size_t k = 0; k < ss.size(); ++k) CHECK(ss[k].search_in(DeviceSlice{dt, text.size()}) == expect[k]);
+#endif
 
         // BatchPlan: the same loop as ONE launch per iteration - the needles as ranges of a blob, every problem the whole text
         std::string blob;

@@ -61,8 +61,8 @@ def _rust_class(t):
     return {"c_int": "i32", "usize": "usize", "u64": "u64", "u32": "u32", "c_float": "f32", "f64": "f64"}[t]
 
 
-def rust_prototypes():
-    text = open(os.path.join(ROOT, "sliceslice-rs_amd", "bindings", "rust", "hip.rs")).read()
+def rust_prototypes(source="hip.rs"):
+    text = open(os.path.join(ROOT, "sliceslice-rs_amd", "bindings", "rust", source)).read()
     block = re.search(r'extern "C" \{(.*?)\n\}', text, flags=re.S).group(1)
     block = re.sub(r"//[^\n]*", "", block)
     protos = {}
@@ -79,6 +79,9 @@ def test_header_parser_sees_every_symbol():
     assert len(protos) <= 50 and not any(n.startswith("ss_debug_") for n in protos)       # the reference-facing surface stays small
     tuning = header_prototypes("sliceslice_hip_tuning.h")
     assert sorted(tuning) == sorted(list(ss.searcher.TOOLS_ABI) + list(ss.searcher.HOOKS_ABI))
+    # the resident search service is declared apart (a library of its own: libsliceslice_hip_service.so)
+    service = header_prototypes("sliceslice_hip_service.h")
+    assert sorted(service) == sorted(ss.searcher.SERVICE_ABI) and not any(n.startswith("ss_service_") for n in protos)
     assert protos["ss_searcher_new"] == ("i32", ["ptr", "usize", "ptr"])
     assert protos["ss_find_sharded"] == ("i32", ["ptr", "ptr", "usize", "u64", "ptr", "ptr", "ptr"])
     assert protos["ss_searcher_free"] == ("void", ["ptr"])
@@ -90,6 +93,11 @@ def test_rust_extern_block_matches_the_header():
     assert sorted(r) == sorted(c), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
     for name in c:
         assert r[name] == c[name], (name, r[name], c[name])
+    # ... and the service's module against the service's header
+    cs, rs = header_prototypes("sliceslice_hip_service.h"), rust_prototypes("hip_service.rs")
+    assert sorted(rs) == sorted(cs) == sorted(ss.searcher.SERVICE_ABI)
+    for name in cs:
+        assert rs[name] == cs[name], (name, rs[name], cs[name])
     text = open(os.path.join(ROOT, "sliceslice-rs_amd", "bindings", "rust", "hip.rs")).read()
     # constants the Rust side restates
     hdr = open(os.path.join(ROOT, "include", "sliceslice_hip.h")).read()
@@ -115,7 +123,8 @@ def test_ctypes_table_matches_the_header():
         return {ctypes.c_int: "i32", ctypes.c_size_t: "usize", ctypes.c_uint64: "u64", ctypes.c_uint32: "u32", ctypes.c_float: "f32",
                 ctypes.c_double: "f64"}[t]
     c.update(header_prototypes("sliceslice_hip_tuning.h"))
-    tables = dict(ss.searcher.ABI, **ss.searcher.TOOLS_ABI, **ss.searcher.HOOKS_ABI)
+    c.update(header_prototypes("sliceslice_hip_service.h"))
+    tables = dict(ss.searcher.ABI, **ss.searcher.TOOLS_ABI, **ss.searcher.HOOKS_ABI, **ss.searcher.SERVICE_ABI)
     for name, (res, args) in tables.items():
         got = (cls(res), [cls(a) for a in args])
         want = c[name]

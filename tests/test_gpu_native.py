@@ -17,7 +17,18 @@ def test_cpp_veneer(tmp_path):
                            "-L", os.path.dirname(so), "-lsliceslice_hip", "-Wl,-rpath," + os.path.dirname(so)])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "veneer_test ok" in out.stdout
+    assert "veneer_test ok" in out.stdout and "service veneer ok" not in out.stdout
+    # ... and once more with the service veneer (include/sliceslice_hip_service.hpp) against libsliceslice_hip_service.so, which a
+    # program links INSTEAD of the drop-in library
+    import sys
+    svc = sys.modules["sliceslice_rs_amd._build"].build_service()
+    exe2 = str(tmp_path / "veneer_service_test")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-DSS_VENEER_WITH_SERVICE=1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "veneer_test.cpp"), "-o", exe2,
+                           "-L", os.path.dirname(svc), "-lsliceslice_hip_service", "-Wl,-rpath," + os.path.dirname(svc)])
+    out = subprocess.run([exe2], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "veneer_test ok" in out.stdout and "service veneer ok" in out.stdout
 
 
 def test_c_grep_example(tmp_path):

@@ -1,7 +1,9 @@
 """The resident search service (ss_service_*): the same booleans as the launch path and the oracle, the lease and the cap that
 bound its residency, stopping it under traffic.  Every wait in the service is bounded on both sides; the tests carry a timeout all
 the same.  Tests that read the service's counters (ss_service_counters: a hooks-build entry point) take the `hooks` fixture and
-run against libsliceslice_hip_tuning.so - the same host code plus the hooks; the others run against the product library."""
+run against libsliceslice_hip_tuning.so - the same host code plus the hooks; the others take the `service` fixture and run against
+libsliceslice_hip_service.so (the product's objects plus the service: include/sliceslice_hip_service.h).  The product library
+itself holds no service: test_the_product_library_has_no_service."""
 import os
 import random
 import subprocess
@@ -35,6 +37,22 @@ def O():
 def hooks(ss):
     with ss.tuning_build():
         yield
+
+
+@pytest.fixture
+def service(ss):
+    with ss.service_build():
+        yield
+
+
+def test_the_product_library_has_no_service(ss):
+    """The drop-in library is the hot path's surface: the resident service ships apart (libsliceslice_hip_service.so)."""
+    assert not ss.lib().has_service and not hasattr(ss.lib(), "ss_service_start")
+    with pytest.raises(ss.SlicesliceError) as e:
+        ss.SearchService()
+    assert "libsliceslice_hip_service.so" in str(e.value)
+    with ss.service_build() as L:
+        assert L.has_service and not L.has_hooks
 
 
 def test_service_answers_like_the_launch_path_and_the_oracle(ss, O, hooks):
@@ -86,7 +104,7 @@ def test_service_answers_like_the_launch_path_and_the_oracle(ss, O, hooks):
         assert e.value.code == ss.SS_ERR_ARGUMENT
 
 
-def test_service_sees_haystack_bytes_written_between_requests(ss):
+def test_service_sees_haystack_bytes_written_between_requests(ss, service):
     """The kernel stays resident across requests, so nothing is invalidated for it by a kernel boundary: bytes written to the
     haystack between two requests (by a copy that has completed) must be seen by the next request all the same."""
     ln = 1 << 20

@@ -13,8 +13,8 @@ from oracle import oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "sliceslice_hip.h")).read()
+def declared_symbols(header="sliceslice_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", text)))
 
@@ -43,6 +43,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(H, name), name
     for name in ss.searcher.HOOKS_ABI:
         assert not hasattr(L, name), name
+    # The resident search service ships apart: libsliceslice_hip_service.so = the product's objects + the service.  The drop-in
+    # library exports none of it; the service library exports exactly the two headers.
+    svc_syms = [n for n in declared_symbols("sliceslice_hip_service.h") if n not in syms]
+    assert sorted(svc_syms) == sorted(ss.searcher.SERVICE_ABI) and all(n.startswith("ss_service_") for n in svc_syms)
+    assert not any(n.startswith("ss_service") for n in exported)
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build_service()], capture_output=True, text=True, check=True).stdout
+    assert sorted(l.split()[-1] for l in out.splitlines() if " T " in l) == sorted(syms + svc_syms)
 
 
 def test_the_rccl_stand_in_exports_what_the_library_resolves():

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "sliceslice_hip.h"
+#include "sliceslice_hip_service.h"     // the resident service is timed too: the tool links libsliceslice_hip_service.so (a superset of the product)
 #include "sliceslice_hip_tuning.h"      // the synthetic haystack generator (libsliceslice_hip_tools.so)
 
 #define CK(x)                                                                  \
