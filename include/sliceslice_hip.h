@@ -257,6 +257,10 @@ SS_API int ss_comm_unique_id(uint8_t id[SS_UNIQUE_ID_BYTES]);                   
 SS_API int ss_comm_init_rank(const uint8_t id[SS_UNIQUE_ID_BYTES], int nranks, int rank, ss_comm **out);
 SS_API void ss_comm_free(ss_comm *c);
 SS_API int ss_comm_count(const ss_comm *c, int *nranks);                            /* ncclCommCount: what RCCL itself sees */
+/* Which collective library this process' communicators are made of: the file the resolved ncclAllReduce lives in (dladdr) and what
+ * its ncclGetVersion says (e.g. 22606; 0: the library has none).  A process that has torch in it holds torch's bundled librccl next
+ * to the system's; a benchmark line names the one in use (bench.py: config.librccl_path / librccl_version). */
+SS_API int ss_comm_rccl_info(char *path, size_t path_cap, int *version);
 /* Scan + all-reduce + read-back on one stream: the whole sharded search_in.  The communicator's flag is
  * never cleared - "found" is the call's epoch (every rank makes the same sequence of calls on a communicator,
  * so the epochs agree) - which saves the memset launch per search.  Collective: every rank must call it, and a rank whose
@@ -310,6 +314,46 @@ SS_API int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards
 
 /* (The resident search service - ss_service_* - is NOT part of this library: it is an opt-in component outside the hot path,
  * built into a library of its own, libsliceslice_hip_service.so, and declared in sliceslice_hip_service.h.) */
+
+/* ---- launch tuning: what it is, how to see it, how to switch it off ------------------------------------------------------------
+ * No search RESULT depends on anything here (src/lib.rs:375-378: the reference asserts the same for every `position`).  What a
+ * handle learns about the haystacks it meets only moves necessary conditions around and picks launch shapes:
+ *   - per (searcher, device, haystack >= 256 MiB): a candidate census of 1,024 sampled 4 KiB tiles, taken by a small kernel in
+ *     front of the first scan (and every 256th after it) on the scan's own stream, never waited for: workgroups per CU (four /
+ *     six), the cross-lane kernels with or without a third byte, the THIRD first-phase byte where the library owns it and the near
+ *     bytes that stand in for a far pair (by the measured number of candidates each position lets through, on trial against the
+ *     next census), and the ORDER of the second level's schedule (the needle byte that kills most of the sampled candidates
+ *     first);
+ *   - per (device, haystack): a sampled byte histogram (searchers built by ss_searcher_new: the filter bytes themselves);
+ *   - per (device, batch) and per plan: the rarity classes of the haystacks' sampled bytes; a plan's layout by what its previous
+ *     run found;
+ *   - per searcher: whether its latest synchronous search found the needle.
+ * ss_set_autotune(0) (or SLICESLICE_AUTOTUNE=0 in the environment) switches ALL of it off, process-wide: the constructors' static
+ * filter bytes, a needle-byte guess for workgroups per CU, the static rarity classes, one plan layout (plans made while it is off),
+ * no sampling kernels - a call's cost then depends on its arguments alone.  Returns the previous setting.
+ * ss_searcher_tuning_state reports, without launching or waiting for anything, every tuning state the handle holds for one
+ * haystack on the current device. */
+typedef struct ss_tuning_state {
+    uint32_t autotune;              /* 1: on (the default) */
+    uint32_t census_state;          /* 0: no census of this haystack, 1: in flight, 2: counts are in */
+    uint32_t census_age;            /* scans that have gone by these counts (taken again every 256) */
+    uint32_t tiles, tiles3, tiles2, match_tiles, lanes;   /* sampled tiles; with a candidate of the triple / of the pair alone / with a
+                                       prefix match of up to 64 bytes; candidate lanes */
+    uint32_t pair_lanes, triple_lanes;                    /* sampled candidates the per-position match counts were taken from */
+    uint32_t triple_state;          /* the filter bytes on this haystack: 0 still being looked at, 1 the searcher's own, 2 in_force[] differs */
+    uint32_t on_trial, trials;      /* a proposal's census is in flight; proposals put on trial so far ... */
+    uint32_t accepted, settled;     /* ... and how many of them replaced the bytes in force; 1: no byte is being looked at any more */
+    uint32_t proposal;              /* the latest proposal: 1 from the haystack's histogram, 2 one byte moved by the census's match counts,
+                                       3 the near form of a pair 16 or more apart, 4 a jump to the needle byte that kills most of the sampled
+                                       candidates */
+    uint32_t own[3], in_force[3];   /* needle indices of the three first-phase bytes: the searcher's own / on this haystack */
+    uint32_t order_measured, norder;/* the second level's schedule is ordered by the census (else by the static rarity table) */
+    uint8_t order[16];              /* ... needle indices, first tested first (norder of them) */
+    uint32_t histogram_state;       /* the device's sampled histogram of this haystack: 0 none, 1 in flight, 2 in */
+    uint32_t workgroups_per_cu, grid, kernel_mode, last_found;   /* the handle's latest launch on this device (any haystack) */
+} ss_tuning_state;
+SS_API int ss_set_autotune(int enabled);
+SS_API int ss_searcher_tuning_state(const ss_searcher *s, const void *d_haystack, size_t len, ss_tuning_state *out);
 
 /* Diagnostics */
 SS_API const char *ss_last_error(void);      /* thread-local, static storage */

@@ -14,6 +14,6 @@ from ._build import build, library_path                      # noqa: F401
 from .searcher import (                                      # noqa: F401
     SS_OK, SS_ERR_POSITION, SS_ERR_ARGUMENT, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_RCCL, SS_ERR_NOMEM, SS_ERR_PEER,
     DynamicHipSearcher, HipSearcher, MemchrHipSearcher, PositionError, SlicesliceError, ShardedSearcher, NodeSearcher, shard_range,
-    SearchService, BatchPlan, tuning_build, tools_lib, selftest_dpp,
+    SearchService, BatchPlan, tuning_build, service_build, set_autotune, rccl_info, TuningState, tools_lib, selftest_dpp,
     search_batched, find_batched, batch_classes, search_file, byte_histogram, choose_position, choose_filter_pair, choose_filter_triple, choose_filter_for_position, fill_random_device, fill_random_host, read_ceiling_gbps, device_info, lib,
 )

@@ -18,6 +18,18 @@ use std::os::raw::{c_char, c_float, c_int, c_uint, c_void};
 #[repr(C)] pub struct ss_comm { _private: [u8; 0] }
 #[repr(C)] pub struct ss_comm_set { _private: [u8; 0] }
 #[repr(C)] pub struct ss_batch_plan { _private: [u8; 0] }
+/// `ss_tuning_state` (include/sliceslice_hip.h): every launch-tuning state a handle holds for one haystack.  No result depends on it.
+#[repr(C)] #[derive(Clone, Copy, Debug, Default)]
+pub struct ss_tuning_state {
+    pub autotune: u32, pub census_state: u32, pub census_age: u32,
+    pub tiles: u32, pub tiles3: u32, pub tiles2: u32, pub match_tiles: u32, pub lanes: u32,
+    pub pair_lanes: u32, pub triple_lanes: u32,
+    pub triple_state: u32, pub on_trial: u32, pub trials: u32, pub accepted: u32, pub settled: u32, pub proposal: u32,
+    pub own: [u32; 3], pub in_force: [u32; 3],
+    pub order_measured: u32, pub norder: u32, pub order: [u8; 16],
+    pub histogram_state: u32,
+    pub workgroups_per_cu: u32, pub grid: u32, pub kernel_mode: u32, pub last_found: u32,
+}
 
 pub const SS_OK: c_int = 0;
 pub const SS_ERR_POSITION: c_int = 1;
@@ -79,6 +91,7 @@ extern "C" {
     pub fn ss_comm_init_rank(id: *const u8, nranks: c_int, rank: c_int, out: *mut *mut ss_comm) -> c_int;
     pub fn ss_comm_free(c: *mut ss_comm);
     pub fn ss_comm_count(c: *const ss_comm, nranks: *mut c_int) -> c_int;
+    pub fn ss_comm_rccl_info(path: *mut c_char, path_cap: usize, version: *mut c_int) -> c_int;
     pub fn ss_search_sharded(s: *const ss_searcher, d_shard: *const c_void, shard_len: usize, c: *mut ss_comm, hip_stream: *mut c_void, found: *mut c_int) -> c_int;
     pub fn ss_find_sharded(s: *const ss_searcher, d_shard: *const c_void, shard_len: usize, shard_begin: u64, c: *mut ss_comm,
                            hip_stream: *mut c_void, position: *mut u64) -> c_int;
@@ -93,6 +106,9 @@ extern "C" {
     pub fn ss_search_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, set: *mut ss_comm_set, found: *mut c_int) -> c_int;
     pub fn ss_find_sharded_all(s: *const ss_searcher, d_shards: *const *const c_void, shard_lens: *const usize, shard_begins: *const u64,
                                set: *mut ss_comm_set, position: *mut u64) -> c_int;
+    // launch tuning: the switch and the read-only report
+    pub fn ss_set_autotune(enabled: c_int) -> c_int;
+    pub fn ss_searcher_tuning_state(s: *const ss_searcher, d_haystack: *const c_void, len: usize, out: *mut ss_tuning_state) -> c_int;
     // diagnostics
     pub fn ss_last_error() -> *const c_char;
     pub fn ss_device_info(name: *mut c_char, name_cap: usize, compute_units: *mut c_int, total_mem: *mut usize) -> c_int;

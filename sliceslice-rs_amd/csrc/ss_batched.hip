@@ -201,7 +201,7 @@ ClassTable *class_tables()          // never destroyed (a call may come from a t
 // before and nothing is in flight on the device.
 const uint8_t *batch_classes(int dev, const ss::BatchArgs &a, size_t count, hipStream_t st)
 {
-    if (dev < 0 || dev >= kMaxDevices) return nullptr;
+    if (dev < 0 || dev >= kMaxDevices || !autotune_enabled()) return nullptr;      // (ss_set_autotune(0): the static classes, no sampling)
 #ifdef SS_TEST_HOOKS
     if (const char *v = getenv("SLICESLICE_BATCH_STATIC_CLASSES")) { if (atoi(v) != 0) return nullptr; }
 #endif
@@ -394,7 +394,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
         // (4 MiB read at most; batched_kernels.hpp, batch_sample_kernel).
         ss::PlanStats seen = {0, 0, 0};
         e = hipSuccess;
-        const uint8_t *cls = p->classes()->cls;
+        const uint8_t *cls = autotune_enabled() ? p->classes()->cls : nullptr;      // (ss_set_autotune(0): the static classes)
 #ifdef SS_TEST_HOOKS
         if (const char *v = getenv("SLICESLICE_BATCH_STATIC_CLASSES")) { if (atoi(v) != 0) cls = nullptr; }   // A/B: the static table
 #endif
@@ -440,7 +440,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             // the second layout (see ss_batch_plan): for plans whose problems are scanned round robin and are numerous enough for
             // eight runs each to fill the device
-            bool alt_ok = p->shape.slices > ss::kPlanSliceMajorMax && (uint64_t)count * ss::kPlanSliceMajorMax >= 1024;
+            bool alt_ok = p->shape.slices > ss::kPlanSliceMajorMax && (uint64_t)count * ss::kPlanSliceMajorMax >= 1024 && autotune_enabled();
 #ifdef SS_TEST_HOOKS
             if (getenv("SLICESLICE_BATCH_WGS")) alt_ok = false;
             if (const char *v = getenv("SLICESLICE_PLAN_ONE_LAYOUT")) { if (atoi(v) != 0) alt_ok = false; }

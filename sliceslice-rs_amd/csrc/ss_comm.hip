@@ -27,6 +27,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
 };
 
 Rccl *rccl()
@@ -56,6 +57,7 @@ Rccl *rccl()
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.h, "ncclGroupEnd");
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
     });
     if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.CommCount || !r.GroupStart ||
         !r.GroupEnd || !r.AllReduce)
@@ -468,6 +470,25 @@ int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value)
     return SS_OK;
 }
 #endif
+
+// Which collective library the communicators of this process are made of: the file the resolved ncclAllReduce lives in (dladdr) and
+// what its ncclGetVersion says.  A process that has torch in it holds torch's bundled librccl as well as the system's; which one
+// "librccl.so.1" resolved to is otherwise invisible from a benchmark line.
+int ss_comm_rccl_info(char *path, size_t path_cap, int *version)
+{
+    Rccl *r = rccl();
+    if (!r) return fail(SS_ERR_RCCL, "librccl could not be loaded: %s", dlerror());
+    if (path && path_cap) {
+        Dl_info info;
+        path[0] = 0;
+        if (dladdr(reinterpret_cast<void *>(r->AllReduce), &info) && info.dli_fname) snprintf(path, path_cap, "%s", info.dli_fname);
+    }
+    if (version) {
+        *version = 0;
+        if (r->GetVersion) (void)r->GetVersion(version);
+    }
+    return SS_OK;
+}
 
 int ss_comm_count(const ss_comm *c, int *nranks)
 {

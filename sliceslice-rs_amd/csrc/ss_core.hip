@@ -64,8 +64,8 @@ bool process_exiting() { return g_exiting.load(std::memory_order_acquire); }
 namespace {
 
 // ---- control blocks ---------------------------------------------------------------------------------------------------
-// A searcher needs, per device, 1.8 KB of device memory (flag / minimum / completion slots), 1.3 KB of pinned host memory
-// (their mirrors) and its needle.  Allocated one by one that was five hipMalloc, three hipHostMalloc, four hipMemset and a
+// A searcher needs, per device, 2.3 KB of device memory (flag / minimum / completion slots, the census's counters), 1.8 KB of pinned
+// host memory (their mirrors) and its needle (up to 1.5 KB inside the block).  Allocated one by one that was five hipMalloc, three hipHostMalloc, four hipMemset and a
 // hipMemcpy per `new` - the better part of a millisecond for a constructor that costs the reference tens of nanoseconds, and
 // every one of those calls waits for the whole device (a resident search service: for its lease).  Blocks come from slabs
 // instead (512 blocks of 4 KiB device + 2 KiB pinned memory per slab, kept until the process ends), and a block is
@@ -73,10 +73,12 @@ namespace {
 // runtime call at all once a slab exists.  The writes are pushed through the device's host data path and waited for (bar_write);
 // a kernel's start drops the caches' copy of the block; a resident service kernel acquires what was uploaded after its last
 // look (upload tickets).  Without a large BAR (or with SLICESLICE_NO_BAR_WRITES=1) the image goes by one hipMemcpy.
-constexpr size_t kBlockDevBytes = 4096, kBlockHostBytes = 2048, kBlockNeedleOff = 2048, kBlockNeedleMax = 2048;
-constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kOffCensus = 1792, kCtlBytes = 1808;
-constexpr size_t kHostOffFlags = 0, kHostOffBest = 256, kHostOffDone = 768, kHostOffCensus = 1280;
-static_assert(kCtlBytes <= kBlockNeedleOff && kHostOffCensus + 16 <= kBlockHostBytes, "the control words fit their halves of a block");
+constexpr size_t kBlockDevBytes = 4096, kBlockHostBytes = 2048, kBlockNeedleOff = 2560, kBlockNeedleMax = kBlockDevBytes - kBlockNeedleOff;
+constexpr size_t kCensusStatBytes = 4 * (2 * 64 + 2);           // ss::kCensusStatWords counters (aux_kernels.hpp; checked in ss_census.hip)
+constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kOffCensus = 1792, kOffStats = 1808, kCtlBytes = 2336;
+constexpr size_t kHostOffFlags = 0, kHostOffBest = 256, kHostOffDone = 768, kHostOffCensus = 1280, kHostOffStats = 1296;
+static_assert(kOffStats + kCensusStatBytes <= kCtlBytes && kCtlBytes <= kBlockNeedleOff && kHostOffStats + kCensusStatBytes <= kBlockHostBytes,
+              "the control words fit their halves of a block");
 constexpr uint32_t kBlocksPerSlab = 512;        // 2 MiB of device memory per slab: one page-table fragment
 
 struct BlockPool {
@@ -185,9 +187,11 @@ int get_per_device(const ss_searcher *s, PerDevice **out)
     p.h_done = reinterpret_cast<long long *>(hb + kHostOffDone);
     p.d_census = reinterpret_cast<unsigned long long *>(db + kOffCensus);
     p.h_census = reinterpret_cast<unsigned long long *>(hb + kHostOffCensus);
+    p.d_stats = reinterpret_cast<uint32_t *>(db + kOffStats);
+    p.h_stats = reinterpret_cast<uint32_t *>(hb + kHostOffStats);
     memset(hb, 0, kBlockHostBytes);                    // blocks are recycled: a stale value must not equal an epoch
     for (int k = 0; k < kSlots; ++k) p.find_tag[k] = kFindTagMax;
-    // the block's image: flags 0 | minima all ones | completion counters 0 | keyed minima all ones | census word 0 | the needle
+    // the block's image: flags 0 | minima all ones | completion counters 0 | keyed minima all ones | census words and counters 0 | the needle
     const bool inside = s->n <= kBlockNeedleMax;
     alignas(16) uint8_t img[kBlockDevBytes];
     memset(img, 0, sizeof img);
@@ -443,6 +447,8 @@ int store_filter(ss_searcher *s, size_t fa, size_t fb, size_t fc)
     s->fb = fb;
     s->fc = fc;
     s->auto_filter = false;         // the caller chose
+    s->third_owned = fc == fb;      // ... a plain pair: the third byte stays the library's (derive_device_filter)
+    s->anchor_owned = false;
     ++s->filter_gen;
     derive_device_filter(s);
     s->gate.store(0, std::memory_order_release);
@@ -473,6 +479,8 @@ int make_searcher(const uint8_t *needle, size_t n, size_t position, bool auto_fi
     else filter_for_position(s->needle.data(), n, position, &s->fa, &s->fb, &s->fc, cost);
     derive_device_filter(s);
     s->auto_filter = auto_filter;
+    s->third_owned = true;
+    s->anchor_owned = !auto_filter && n >= 2 && position >= 16;
     PerDevice *pd = nullptr;
     if (int rc = get_per_device(s, &pd)) {      // uploads the needle to the current device now
         delete s;

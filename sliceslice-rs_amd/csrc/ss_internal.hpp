@@ -97,19 +97,39 @@ struct PerDevice {
     // device - launch tuning only; no search result depends on it.  A small table (the searcher's latest haystacks), the one census
     // that may be in flight, and the latest launch's shape for ss_searcher_last_launch.  census_lock is a try-lock: a thread that
     // finds it taken launches with what it has.
+    // One (searcher, haystack) pair's census state (ss_census.hip): the counts, and the filter bytes IN FORCE on this haystack -
+    // the searcher's own triple at first, then whatever a few rounds of measured, one-byte-at-a-time improvement arrive at.
     struct Census {
         const void *hay = nullptr;
         size_t len = 0;
-        uint32_t gen = 0;           // the searcher's filter generation the counts were taken with
-        uint32_t state = 0;         // 0 = empty, 1 = launched (tag `tag`), 2 = counts are in
-        uint32_t tag = 0;
-        uint32_t uses = 0;          // scans that went by these counts (the census is repeated every 256: a buffer may be refilled in place)
-        uint64_t sums = 0;          // tiles3 | tiles2 << 11 | match tiles << 22 | candidate lanes << 33 (aux_kernels.hpp)
-        uint32_t triple_state = 0;  // the filter bytes on THIS haystack: 0 = not decided, 1 = the searcher's own, 2 = tri[] (ss_census.hip)
-        size_t tri[3] = {0, 0, 0};
-        bool trial = false;         // tri[] has not been counted yet; sums_own = the counts of the searcher's own triple
-        uint64_t sums_own = 0;
-        uint32_t trials = 0;        // triples from the histogram that have been put on trial (diagnostics)
+        uint32_t gen = 0;           // the searcher's filter generation the entry belongs to
+        uint32_t state = 0;         // 0 = empty, 1 = a census is in flight and no counts of cur[] are in yet, 2 = counts of cur[] are in
+        uint32_t tag = 0;           // tag of the census in flight (inflight != 0)
+        uint32_t uses = 0;          // scans that went by these counts (everything is looked at again every 256: a buffer may be refilled in place)
+        uint64_t sums = 0;          // counts of cur[]: tiles3 | tiles2 << 11 | match tiles << 22 | candidate lanes << 33 (aux_kernels.hpp)
+        size_t cur[3] = {0, 0, 0};  // the first-phase bytes in force on this haystack (needle indices; cur[0] the smallest)
+        bool adopted = false;       // cur[] differs from the searcher's own triple
+        // the census in flight: of cur[] (inflight == 1) or of a proposal on TRIAL (inflight == 2: prop[]); `roles`: which coordinate the
+        // per-position counts are gathered FOR - the kernel's "pair" is the other two bytes, so pair_match[k] is what a first phase
+        // with k in that coordinate's place would let through
+        uint32_t inflight = 0;
+        int roles = 2;
+        size_t prop[3] = {0, 0, 0};
+        uint32_t prop_kind = 0;     // 1 = from the haystack's histogram, 2 = one coordinate moved by measurement, 3 = the near form of a far pair,
+                                    // 4 = a jump to the byte that kills most of today's candidates
+        uint32_t trials = 0, accepted = 0;
+        // the descent: coordinates the library may move (bit j), the next one to look at, coordinates looked at since the last improvement
+        uint32_t free_mask = 0, coord = 2, stale = 0, rounds = 0;
+        bool settled = false, hist_tried = false, near_tried = false, jump_tried = false;
+        // what the latest census of cur[] MEASURED about survival: how many of the sampled pair / triple candidates match the needle at
+        // position k (< 64); stats_roles = the coordinate they were gathered for (-1: none at hand)
+        int stats_roles = -1;
+        uint16_t pair_match[64] = {0}, triple_match[64] = {0};
+        uint32_t pair_lanes = 0, triple_lanes = 0;
+        // ... and the second level's schedule ordered by it (enqueue_scan takes it instead of the static rarity order)
+        bool have_order = false;
+        uint32_t norder = 0;
+        uint64_t order_idx[2] = {0, 0}, order_val[2] = {0, 0};
         uint64_t stamp = 0;
     } census[4];
     uint32_t census_lock = 0, census_tag = 0;
@@ -117,6 +137,8 @@ struct PerDevice {
     uint64_t census_clock = 0;
     unsigned long long *d_census = nullptr;     // the census kernel's accumulator word
     unsigned long long *h_census = nullptr;     // pinned: [0] sums, [1] tag of the launch they belong to
+    uint32_t *d_stats = nullptr;                // the census kernel's per-position match counters (ss::kCensusStatWords)
+    uint32_t *h_stats = nullptr;                // pinned: the counters of the launch h_census[1] names
     int last_occ = 0, last_found = 0;           // workgroups per CU of the latest launch; the latest synchronous search found the needle
     unsigned last_grid = 0;
     int last_mode = 0;                          // kernel family of the latest launch: 0 single stream, 2 / 3 cross-lane with / without the third byte
@@ -157,6 +179,10 @@ struct ss_searcher {
     size_t far = 0;                 // ... then: the caller's far byte (== fb), tested first when a candidate reaches memory; else 0
     uint32_t filter_gen = 0;        // bumped by every rewrite of the triple: census counts taken with an older triple are stale
     bool auto_filter = false;       // built by ss_searcher_new and not touched since: the library chose the triple and may choose again per haystack
+    bool anchor_owned = false;      // ss_searcher_with_position with position >= 16: the caller's byte has a partner close in front of it that
+                                    // the LIBRARY chose (choose_anchor) - the census may choose it again
+    bool third_owned = false;       // the THIRD first-phase byte is the library's choice (every constructor; ss_searcher_set_filter3 given a
+                                    // plain pair): the census may move it to the needle position that lets the fewest candidates through
     int variant = 0;          // tuning builds only (ss_searcher_set_variant / _set_grid); 0 = automatic
     int grid = 0;
     bool timing = false;
@@ -224,8 +250,11 @@ struct LaunchHints {
     bool have_counts;           // the census of (searcher, haystack) is in:
     int workgroups_per_cu;      //   four or six
     bool sparse_pair;           //   the first two filter bytes alone rarely match (cross-lane kernels: no third byte needed)
-    bool have_triple;           // filter bytes chosen from the haystack's histogram (ss_searcher_new searchers only):
+    bool have_triple;           // filter bytes chosen for this haystack (from its histogram, or from the census's own match counts):
     size_t tri[3];              //   first <= second, third, all within 15 of the first
+    bool have_order;            // the second level's schedule ordered by what the census measured (for the triple in force):
+    uint32_t norder;            //   as Problem::norder / order_idx / order_val
+    uint64_t order_idx[2], order_val[2];
 };
 // Looks up - and, when nothing is known and the stream is not being captured, starts - the census and the histogram sampling in
 // front of the caller's scan on `st`.  Never waits.
@@ -243,6 +272,7 @@ struct ProblemShape {
 // `triple` != nullptr: filter bytes chosen for this haystack instead of the searcher's own (all within 16 bytes of the first).
 void fill_problem(const ss_searcher *s, const uint8_t *d_needle, const void *d_hay, size_t len, uint64_t find_base, ss::Problem *out,
                   ProblemShape *shape, const size_t *triple = nullptr);
+bool autotune_enabled();          // ss_set_autotune / SLICESLICE_AUTOTUNE (ss_census.hip): off = static choices only, no sampling kernels
 // Builds the Problem for (hay, len) and enqueues the scan.  find == false: *d_sink is an int flag, set to `epoch` by the wave that
 // finds the needle, never cleared.  find == true: *d_sink is a uint64, atomicMin'ed with find_base + offset of every match the grid
 // sees (the leftmost one survives).  Preconditions: 1 <= n <= len.  done_slot >= 0: the call owns flag slot `done_slot` and would

@@ -281,6 +281,15 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     ss::Problem pr;
     ProblemShape ps;
     fill_problem(s, pd->d_needle, d_hay, len, find_base, &pr, &ps, hints.have_triple ? hints.tri : nullptr);
+    if (hints.have_order && pr.d == 0 && s->n >= 2) {
+        // the second level's schedule in the order the census MEASURED (ss_census.hip, build_measured_order): the needle byte that
+        // kills most of this haystack's candidates first - instead of the static rarity order fill_problem wrote
+        pr.norder = hints.norder;
+        pr.order_idx[0] = hints.order_idx[0];
+        pr.order_idx[1] = hints.order_idx[1];
+        pr.order_val[0] = hints.order_val[0];
+        pr.order_val[1] = hints.order_val[1];
+    }
     pr.host_flag = host_flag;
     pr.epoch = epoch;
     const bool one_byte = ps.one_byte;
@@ -291,14 +300,14 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
     // presumably text; single-stream kernels only) - or four, when the filter bytes have just been chosen for being rare HERE.
     const bool text_like = !one_byte && ss::byte_rarity_rank(s->needle[fa]) >= 64 && ss::byte_rarity_rank(s->needle[fa + position]) >= 64 &&
                            ss::byte_rarity_rank(s->needle[fa + position3]) >= 64;
-    int occ = !one_byte && text_like && pr.d == 0 && !hints.have_triple ? 6 : 4;
+    int occ = !one_byte && text_like && pr.d == 0 && !hints.have_triple ? 6 : 4;      // (autotune off: this guess is all there is)
     bool pair_alone = false;
     if (hints.have_counts) {
         occ = hints.workgroups_per_cu;
         // a pair 16 or more apart that rarely matches on this haystack needs no third byte in the first phase (MODE 3)
         pair_alone = pr.d != 0 && !find && hints.sparse_pair;
     }
-    if (!one_byte && len >= kCensusMinBytes && __atomic_load_n(&pd->last_found, __ATOMIC_RELAXED) != 0) occ = 4;
+    if (!one_byte && len >= kCensusMinBytes && autotune_enabled() && __atomic_load_n(&pd->last_found, __ATOMIC_RELAXED) != 0) occ = 4;
     Launch l = pick_variant(s->variant, pr.d, one_byte, occ, pair_alone);
     if (find && l.mode == 3) l.mode = 2;                     // find() has no pair-alone kernels
     if (l.mode == 3)                                        // the third byte goes back into the second level's schedule

@@ -71,6 +71,7 @@ ABI = {
     "ss_comm_init_rank": (_int, [_vp, _int, _int, _pvp]),
     "ss_comm_free": (None, [_vp]),
     "ss_comm_count": (_int, [_vp, _pint]),
+    "ss_comm_rccl_info": (_int, [ctypes.c_char_p, _sz, _pint]),
     "ss_search_sharded": (_int, [_vp, _vp, _sz, _vp, _vp, _pint]),
     "ss_find_sharded": (_int, [_vp, _vp, _sz, _u64, _vp, _vp, _pu64]),
     "ss_comm_init_all": (_int, [_int, _pint, _pvp]),
@@ -82,6 +83,8 @@ ABI = {
     "ss_comm_set_last_issue_us": (_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "ss_search_sharded_all": (_int, [_vp, _pvp, _psz, _vp, _pint]),
     "ss_find_sharded_all": (_int, [_vp, _pvp, _psz, _pu64, _vp, _pu64]),
+    "ss_set_autotune": (_int, [_int]),
+    "ss_searcher_tuning_state": (_int, [_vp, _vp, _sz, _vp]),
     "ss_last_error": (ctypes.c_char_p, []),
     "ss_device_info": (_int, [ctypes.c_char_p, _sz, _pint, _psz]),
 }
@@ -112,12 +115,43 @@ HOOKS_ABI = {
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
     "ss_debug_census": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
+    "ss_debug_census_stats": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), _pint]),
     "ss_debug_plan_filter": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_plan_cold": (_int, [_vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_plan_layout": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_batch_classes": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)]),
     "ss_service_counters": (_int, [_vp, _pu64, _pu64, _pu64]),
 }
+
+
+class TuningState(ctypes.Structure):
+    """ss_tuning_state (include/sliceslice_hip.h): every launch-tuning state a handle holds for one haystack."""
+    _fields_ = [(k, ctypes.c_uint32) for k in ("autotune", "census_state", "census_age", "tiles", "tiles3", "tiles2", "match_tiles", "lanes",
+                                               "pair_lanes", "triple_lanes", "triple_state", "on_trial", "trials", "accepted", "settled", "proposal")] + \
+               [("own", ctypes.c_uint32 * 3), ("in_force", ctypes.c_uint32 * 3), ("order_measured", ctypes.c_uint32), ("norder", ctypes.c_uint32),
+                ("order", ctypes.c_uint8 * 16), ("histogram_state", ctypes.c_uint32), ("workgroups_per_cu", ctypes.c_uint32),
+                ("grid", ctypes.c_uint32), ("kernel_mode", ctypes.c_uint32), ("last_found", ctypes.c_uint32)]
+
+    def as_dict(self):
+        d = {}
+        for k, _ in self._fields_:
+            v = getattr(self, k)
+            d[k] = list(v) if hasattr(v, "__len__") else int(v)
+        d["order"] = d["order"][:d["norder"]]
+        return d
+
+
+def rccl_info():
+    """(path of the librccl the native communicators use, its ncclGetVersion) - ss_comm_rccl_info."""
+    buf = ctypes.create_string_buffer(512)
+    ver = ctypes.c_int(0)
+    _check(lib().ss_comm_rccl_info(buf, len(buf), ctypes.byref(ver)))
+    return buf.value.decode("utf-8", "replace"), int(ver.value)
+
+
+def set_autotune(enabled):
+    """ss_set_autotune: launch tuning on (the default) or off, process-wide; returns the previous setting."""
+    return bool(lib().ss_set_autotune(1 if enabled else 0))
 
 
 class SlicesliceError(RuntimeError):
@@ -418,6 +452,29 @@ class DynamicHipSearcher:
         w, g = ctypes.c_int(0), ctypes.c_uint(0)
         self._ck(self._L.ss_searcher_last_launch(self._h, ctypes.byref(w), ctypes.byref(g)))
         return w.value, g.value
+
+    def device_triple(self):
+        """The three first-phase bytes the device tests by default (ss_searcher_tuning_state.own): the searcher's triple, with the third byte
+        the library adds to a plain pair."""
+        st = TuningState()
+        self._ck(self._L.ss_searcher_tuning_state(self._h, None, 0, ctypes.byref(st)))
+        return tuple(int(x) for x in st.own)
+
+    def tuning_state(self, haystack):
+        """ss_searcher_tuning_state as a dict: what this handle has learnt about `haystack` (a device tensor) and goes by."""
+        st = TuningState()
+        self._ck(self._L.ss_searcher_tuning_state(self._h, haystack.data_ptr(), haystack.numel(), ctypes.byref(st)))
+        return st.as_dict()
+
+    def census_stats(self, haystack):
+        """Hooks builds: the census's per-position match counts {pair_match, triple_match, pair_lanes, triple_lanes}, or None."""
+        c = (ctypes.c_uint32 * 130)()
+        have = ctypes.c_int(0)
+        self._ck(_hooks(self._L).ss_debug_census_stats(self._h, haystack.data_ptr(), haystack.numel(), c, ctypes.byref(have)))
+        if not have.value:
+            return None
+        self.stats_roles = have.value - 1                   # the slot the pair counts were gathered for
+        return {"pair_match": list(c[:64]), "triple_match": list(c[64:128]), "pair_lanes": int(c[128]), "triple_lanes": int(c[129])}
 
     def census(self, haystack):
         """Hooks builds: the candidate census of (this searcher, haystack) as a dict, or None when its counts are not in."""

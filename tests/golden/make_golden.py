@@ -19,7 +19,9 @@ What it writes
   asserted by the reference for EVERY ``position in 0..needle.len()``
   (``src/lib.rs:375-378``); the tests here do the same.
 * ``corpus_checksums.json`` - hit counts of the two corpus sweeps of
-  ``tests/i386.rs:46-70`` and of the ``bench/benches/random.rs:16`` size grid,
+  ``tests/i386.rs:46-70``, of the third criterion group's loop (the 4,585 words
+  in ``data/haystack``, ``bench/benches/i386.rs:286-289``) and of the
+  ``bench/benches/random.rs:16`` size grid,
   computed with Python's ``bytes.__contains__`` (a naive, independent scan; no
   reference code involved), plus sha256 of the data files.
 
@@ -159,6 +161,11 @@ def main():
         for h in sizes[i:]:
             grid.append({"needle_len": s, "haystack_len": h, "expected": ndl[:s] in hay[:h]})
 
+    # the reference's THIRD criterion group, search_random_haystack (bench/benches/i386.rs:286-289): the 4,585 words in data/haystack
+    # (1,000 bytes of [0-9A-Za-z] noise) - by the naive scan, like everything here
+    random_hits = sum(w in hay for w in words)
+    random_hit_words = sorted(w.decode("latin1") for w in words if w in hay)
+
     with open(os.path.join(HERE, "corpus_checksums.json"), "w") as fh:
         json.dump({
             "sha256": sha,
@@ -170,6 +177,9 @@ def main():
             "long_haystack_bytes_to_first_hit_raw": raw_traversed,
             "short_haystack_pairs": pairs,
             "short_haystack_hits": hits,
+            "random_haystack_len": len(hay),
+            "random_haystack_hits": random_hits,
+            "random_haystack_hit_words": random_hit_words,
             "random_grid": grid,
         }, fh, indent=1)
     print("wrote kat.json, corpus_checksums.json;", "pairs", pairs, "hits", hits,

@@ -46,6 +46,33 @@ def test_committed_bench_line_has_the_contract_fields(rnd):
     assert 0.9 * r["achieved"] <= d["value"] <= 1.001 * r["achieved"]
 
 
+def test_the_line_ends_with_a_summary_of_the_other_configs():
+    """a driver that keeps only the tail of stdout must still hold every fraction of configs 3 / text / 5 / 1:
+    `configs_summary` is the LAST key of the line and at most 600 bytes."""
+    import importlib.util
+    import io
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench64g.json")))
+    d.pop("configs_summary", None)
+    r, w = os.pipe()
+    bench.write_line(w, d)
+    os.close(w)
+    line = json.loads(io.open(r, "rb").read().decode())
+    assert list(line)[-1] == "configs_summary" and list(line)[-2] == "cpu_baseline"
+    cs = line["configs_summary"]
+    assert len(json.dumps(cs)) <= 600, len(json.dumps(cs))
+    assert set(cs["3"]) == {"1", "2", "4", "8", "16", "32", "128"} and len(cs["text"]) == 4 and cs["autotune"] == "on"
+    assert cs["text"] == [round(x["frac"], 3) for x in d["configs"]["text"]["rows"]]
+    assert cs["5"]["call"] == round(d["configs"]["5"]["frac"], 3) and cs["1_short_ms"] == round(d["configs"]["1_short"]["launch_ms"], 3)
+    for key in ("5_shapes_1gib", "1_long_ms", "1_random_ms"):
+        assert key in cs
+    # N > 1 lines name their collective library (asserted on a real multi-rank run in tests/test_gpu_sharded.py)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "librccl_path" in src and "librccl_version" in src and "ss.rccl_info()" in src
+
+
 def test_bench_source_keeps_exactly_one_stdout_line():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "os.dup2(2, 1)" in src and src.count("os.write(real_stdout") == 1           # write_line() is the only writer

@@ -517,21 +517,34 @@ def test_second_level_far_bytes_at_lane_piece_and_tile_edges(ss):
         assert s.search_in(hay) is False
 
 
-def _census_model(host, needle, filt):
-    """The census kernel's counts (aux_kernels.hpp: census_kernel; ss_scan.hip: census_lookup) restated with numpy: 1,024 tiles of
-    4 KiB candidate offsets spread evenly, a 'lane' = 64 consecutive offsets."""
+def _census_model(host, needle, filt, roles=None):
+    """The census kernel's counts (aux_kernels.hpp: census_kernel; ss_census.hip) restated with numpy: 1,024 tiles of 4 KiB
+    candidate offsets spread evenly, a 'lane' = 64 consecutive offsets.  `roles` given: also the per-position match counts
+    gathered FOR that slot of `filt` (the kernel's pair = the other two slots): for every lane's leftmost pair candidate and leftmost
+    triple candidate, at which of the needle's first 64 positions the haystack matches."""
     n, ln = len(needle), host.size
     end = ln - n + 1
     stride = ((end - 4 - 4096) // 1023) & ~4095
-    fa, fb, fc = filt
     nd = np.frombuffer(needle, dtype=np.uint8)
+    if roles is None:
+        fa, fb, fc = filt
+    else:
+        fa, fb, fc = filt[(roles + 1) % 3], filt[(roles + 2) % 3], filt[roles]
+    ncheck = min(n, 64)
     tiles3 = tiles2 = match = lanes = 0
+    pm, tm, pl, tl = np.zeros(64, dtype=np.int64), np.zeros(64, dtype=np.int64), 0, 0
     for k in range(1024):
         o = k * stride
         a, b, c = (host[o + f:o + f + 4096] == nd[f] for f in (fa, fb, fc))
         p2 = a & b
         p3 = p2 & c
         tiles2 += bool(p2.any())
+        if roles is not None and p2.any():
+            per2 = p2.reshape(64, 64)
+            for l in np.nonzero(per2.any(axis=1))[0]:
+                i = o + 64 * int(l) + int(np.argmax(per2[l]))
+                pm[:ncheck] += host[i:i + ncheck] == nd[:ncheck]
+                pl += 1
         if p3.any():
             tiles3 += 1
             per_lane = p3.reshape(64, 64)
@@ -539,19 +552,44 @@ def _census_model(host, needle, filt):
             m = False
             for l in np.nonzero(per_lane.any(axis=1))[0]:
                 i = o + 64 * int(l) + int(np.argmax(per_lane[l]))
-                m = m or bool((host[i:i + min(n, 64)] == nd[:min(n, 64)]).all())
+                eq = host[i:i + ncheck] == nd[:ncheck]
+                m = m or bool(eq.all())
+                tm[:ncheck] += eq
+                tl += 1
             match += m
-    return {"tiles": 1024, "tiles3": tiles3, "tiles2": tiles2, "match_tiles": match, "lanes": lanes}
+    counts = {"tiles": 1024, "tiles3": tiles3, "tiles2": tiles2, "match_tiles": match, "lanes": lanes}
+    if roles is None:
+        return counts
+    return counts, {"pair_match": [int(x) for x in np.minimum(pm, 0xFFFF)], "triple_match": [int(x) for x in np.minimum(tm, 0xFFFF)],
+                    "pair_lanes": pl, "triple_lanes": tl}
+
+
+def _settle(s, h, want_found=False, scans=16):
+    """Scans until the handle has stopped looking at its bytes on this haystack (ss_searcher_tuning_state.settled)."""
+    for _ in range(scans):
+        assert s.search_in(h) is want_found
+        st = s.tuning_state(h)
+        if st["settled"] and not st["on_trial"]:
+            break
+    assert s.search_in(h) is want_found                     # (one more: the census a settling scan launched has arrived)
+    st = s.tuning_state(h)
+    assert st["settled"] == 1 and st["census_state"] == 2, st
+    return st
+
+
+def _rule(st):
+    return 4 if st["match_tiles"] else (6 if st["tiles3"] >= 48 or st["lanes"] >= 256 else 4)
 
 
 @pytest.mark.gpu
 def test_workgroups_per_cu_follow_the_candidate_census(O):
-    """four or six workgroups per CU is decided by what a census of the HAYSTACK counts (ss_scan.hip:
-    census_lookup / census_choice; aux_kernels.hpp: census_kernel), not by the wall-clock time of earlier scans: deterministic for a
-    given haystack and needle from the second scan on, nothing timed, observable through ss_searcher_last_launch.  Hooks build for
-    ss_debug_census.  The counts equal a numpy restatement of the sampling; a text-like needle on RANDOM bytes starts at the
-    needle-byte guess (six) and goes to four; a stock phrase of the manual on text goes to six; scans below 256 MiB take no
-    census; a searcher that has just FOUND its needle launches with four; new filter bytes mean a new census."""
+    """VERDICT r04 item 2: four or six workgroups per CU is decided by what a census of the HAYSTACK counts (ss_census.hip;
+    aux_kernels.hpp: census_kernel), not by the wall-clock time of earlier scans: deterministic for a given haystack and needle,
+    nothing timed, observable through ss_searcher_last_launch and ss_searcher_tuning_state.  Hooks build for ss_debug_census.  The
+    counts equal a numpy restatement of the sampling - for the searcher's own bytes after the first scan and for the bytes in force
+    once the handle has settled (round 6: the census may move bytes the library owns to positions that let fewer candidates through);
+    a text-like needle on RANDOM bytes starts at the needle-byte guess (six) and goes to four; scans below 256 MiB take no census; a
+    searcher that has just FOUND its needle launches with four; new filter bytes mean a new census."""
     import sliceslice_rs_amd as ss
     gib = 1 << 30
     with ss.tuning_build():
@@ -561,9 +599,9 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
         text_host = np.tile(raw, gib // raw.size + 1)[:gib].copy()
         text = torch.from_numpy(text_host).cuda()
         rnd_host = O.fill_random(gib, 0x5EED0001)
-        for needle, h, host, want in ((b"there is not another one of these", hay, rnd_host, 4),
-                                      (b"segment descriptor table entries are", text, text_host, 6),
-                                      (b"privilege level zero!", text, text_host, 4)):
+        for needle, h, host in ((b"there is not another one of these", hay, rnd_host),
+                                (b"segment descriptor table entries are", text, text_host),
+                                (b"privilege level zero!", text, text_host)):
             s = ss.DynamicHipSearcher.new(needle)
             assert s.search_in(h[: 1 << 20]) is False and s.census(h[: 1 << 20]) is None, "a 1 MiB scan takes no census"
             guess = s.last_launch()[0]
@@ -572,11 +610,20 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             assert s.last_launch()[0] == guess, "the first scan of a haystack goes by the needle-byte guess"
             got = s.census(h)                               # the census ran in front of that scan: its counts are in
             assert got == _census_model(host, needle, s.filter3), (needle, got)
+            assert s.device_filter == s.filter3
+            st = _settle(s, h)
+            counts = {k: st[k] for k in ("tiles", "tiles3", "tiles2", "match_tiles", "lanes")}
+            assert counts["tiles3"] <= got["tiles3"] and counts["lanes"] <= got["lanes"], (got, st)       # bytes only move to fewer candidates
+            model = _census_model(host, needle, st["in_force"])
+            assert {k: counts[k] for k in ("tiles3", "match_tiles", "lanes")} == {k: model[k] for k in ("tiles3", "match_tiles", "lanes")}, (st, model)
+            want = _rule(st)
+            if h is hay:
+                assert want == 4 and st["tiles3"] == 0
             picks = set()
             for _ in range(5):
                 assert s.search_in(h) is False
                 picks.add(s.last_launch()[0])
-            assert picks == {want}, (needle, got, picks)
+            assert picks == {want}, (needle, st, picks)
             assert s.last_launch()[1] in (gib // 16384, gib // 16384 + 1), "one 16 KiB tile per workgroup at 1 GiB"
             # a needle that is found: the next launch is at four, whatever the census says; absent again: back to the census
             h2 = h[: 300 << 20].clone()
@@ -585,13 +632,16 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             assert s.search_in(h2) is True and s.last_launch()[0] == 4
             del h2
             assert s.search_in(h) is False and s.search_in(h) is False and s.last_launch()[0] == want
-            # new filter bytes: the old counts no longer describe the filter
+            # new filter bytes: the old counts no longer describe the filter; an explicit triple is the caller's, nothing moves
             a, b, c = s.filter3
             s.set_filter(a, b, c)
             assert s.census(h) is None
             assert s.search_in(h) is False and s.census(h) == got
-        # a buffer refilled IN PLACE: the census of a (searcher, haystack) pair is repeated every 256 scans, so the choice follows
+            st2 = _settle(s, h)
+            assert st2["in_force"] == [a, b, c] and st2["trials"] == 0 and st2["triple_state"] == 1
+        # a buffer refilled IN PLACE: everything is looked at again every 256 scans, so the choice follows
         s = ss.DynamicHipSearcher.new(b"segment descriptor table entries are")
+        s.set_filter(*s.filter3)                            # (the stock triple pinned: 209 candidate tiles in 1,024 on this text)
         for _ in range(3):
             assert s.search_in(text) is False
         assert s.last_launch()[0] == 6
@@ -600,6 +650,83 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             assert s.search_in(text) is False
         assert s.census(text) == _census_model(rnd_host, b"segment descriptor table entries are", s.filter3)
         assert s.search_in(text) is False and s.last_launch()[0] == 4
+
+
+@pytest.mark.gpu
+def test_census_measures_survival_and_moves_the_bytes_the_library_owns(O):
+    """what a candidate costs is how deep it survives - measured, not modelled.  The census counts, per needle
+    position, how many of the sampled pair / triple candidates MATCH the needle there (checked against a numpy restatement, for
+    whichever slot the counts were gathered for); the library moves a byte IT owns to the position that lets the fewest candidates
+    through (on trial against the next census), replaces the far byte of a pair 16 or more apart by near ones (one load stream), and
+    orders the second level's schedule by the counts.  A caller's bytes stay; answers never change; ss_set_autotune(0) switches it
+    all off."""
+    import sliceslice_rs_amd as ss
+    gib = 1 << 30
+    with ss.tuning_build():
+        raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
+        host = np.tile(raw, gib // raw.size + 1)[:gib].copy()
+        text = torch.from_numpy(host).cuda()
+        stock = b"\nSame exceptions as in Reel Address Mode"          # the manual says "Real": hundreds of candidates that survive 24 bytes
+        assert stock not in raw.tobytes() and stock.replace(b"Reel", b"Real") in raw.tobytes()
+        # (1) the counters themselves, first census: the searcher's own triple, gathered for slot 2
+        s = ss.DynamicHipSearcher.new(stock)
+        own = list(s.filter3)
+        assert s.search_in(text) is False
+        counts, stats = _census_model(host, stock, own, roles=2)
+        assert s.census(text) == counts
+        got = s.census_stats(text)
+        assert got == stats, (got, stats)
+        assert stats["triple_lanes"] >= 100 and min(stats["triple_match"][:len(stock)]) == 0
+        killer = stats["triple_match"].index(0)
+        assert stock[killer:killer + 1] == b"e" and killer == stock.index(b"Reel") + 2      # the byte that tells the needle from the manual's phrase
+        # (2) ... the order of the second level follows them: the killer byte first
+        assert s.search_in(text) is False
+        st = s.tuning_state(text)
+        assert st["order_measured"] == 1 and st["order"][0] == killer, st
+        # (3) ... and the bytes move: settled, the filter in force meets (far) fewer candidates than the static one, by the same model
+        st = _settle(s, text)
+        assert st["triple_state"] == 2 and st["accepted"] >= 1 and st["in_force"] != own and st["own"] == own, st
+        model = _census_model(host, stock, st["in_force"])
+        assert (st["tiles3"], st["lanes"]) == (model["tiles3"], model["lanes"]) and st["tiles3"] * 4 <= counts["tiles3"], (st, counts)
+        assert s.filter3 == tuple(own), "ss_searcher_filter3 keeps reporting the searcher's own choice"
+        # (4) a caller's bytes stay: with_position keeps its byte, an explicit triple everything
+        wp = ss.DynamicHipSearcher.with_position(stock, len(stock) - 1)
+        st = _settle(wp, text)
+        assert len(stock) - 1 in st["in_force"], st
+        ex = ss.DynamicHipSearcher.new(stock)
+        ex.set_filter(*own)
+        st = _settle(ex, text)
+        assert st["in_force"] == own and st["trials"] == 0 and st["order_measured"] == 1, st
+        # (5) the reference's pair (0, n-1) of a long needle: 16 or more apart -> the cross-lane kernels at first, then its near form
+        rp = ss.DynamicHipSearcher.new(b" the quick brown fox ")
+        rp.set_filter(0, 20)
+        assert rp.search_in(text) is False
+        rp.census(text)
+        assert rp.last_mode in (2, 3)
+        st = _settle(rp, text)
+        assert st["in_force"][0] == 0 and max(st["in_force"]) <= 15 and st["kernel_mode"] == 0 and st["proposal"] in (2, 3), st
+        assert rp.filter3[:2] == (0, 20)
+        # (6) answers: planted, found and located by every one of them, tuned or not
+        for needle, searchers in ((stock, (s, wp, ex)), (b" the quick brown fox ", (rp,))):
+            h2 = text[: 300 << 20].clone()
+            at = (299 << 20) + 12345
+            h2[at:at + len(needle)] = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+            for t in searchers:
+                for _ in range(3):
+                    assert t.search_in(h2) is True and t.find(h2) == at
+                assert t.search_in(text) is False
+            del h2
+        # (7) the switch: off, a fresh searcher samples nothing and keeps the static choices; on again, it learns
+        assert ss.set_autotune(False) is True
+        try:
+            off = ss.DynamicHipSearcher.new(stock)
+            for _ in range(4):
+                assert off.search_in(text) is False
+            st = off.tuning_state(text)
+            assert st["autotune"] == 0 and st["census_state"] == 0 and st["histogram_state"] in (0, 2) and st["in_force"] == own, st
+        finally:
+            assert ss.set_autotune(True) is False
+        assert off.search_in(text) is False and off.tuning_state(text)["census_state"] >= 1
 
 
 def _non_latin_haystack(n_bytes, seed):

@@ -559,6 +559,42 @@ def test_long_haystack_all_needles_one_launch(ss, corpus):
     assert [bool(x) for x in found.cpu().tolist()] == want
 
 
+def test_random_haystack_sweep(ss, corpus, checksums):
+    """The reference's THIRD criterion group, search_random_haystack (bench/benches/i386.rs:286-289): the 4,585 words in
+    data/haystack (1,000 bytes of noise).  As ONE batched call (4,585 ranges aliasing the same 1,000 bytes), through a plan, and - on a
+    100-word sample that holds every hit-or-miss kind - one ss_search_device per needle, the reference's own loop shape
+    (bench/benches/i386.rs:252-256).  Expected: the naive count of tests/golden/make_golden.py, word by word."""
+    hay = corpus["haystack"]
+    words = list(corpus["words"])
+    want = [w in hay for w in words]
+    assert sum(want) == checksums["random_haystack_hits"] == 106
+    assert sorted(w.decode("latin1") for w, h in zip(words, want) if h) == checksums["random_haystack_hit_words"]
+    lens = np.array([len(w) for w in words], dtype=np.int64)
+    nb = np.zeros(len(words), dtype=np.int64)
+    nb[1:] = np.cumsum(lens)[:-1]
+    nblob = torch.from_numpy(np.frombuffer(b"".join(words), dtype=np.uint8).copy()).cuda()
+    dh = dev(hay)
+    hb = torch.zeros(len(words), dtype=torch.int64, device="cuda")
+    he = torch.full((len(words),), len(hay), dtype=torch.int64, device="cuda")
+    nbd, ned = torch.from_numpy(nb).cuda(), torch.from_numpy(nb + lens).cuda()
+    for _ in range(3):                                   # (the second and third call go by the batch's sampled classes)
+        found = ss.search_batched(dh, None, nblob, None, hay_ranges=(hb, he), needle_ranges=(nbd, ned))
+        assert [bool(x) for x in found.cpu().tolist()] == want
+    plan = ss.BatchPlan(dh, None, nblob, None, hay_ranges=(hb, he), needle_ranges=(nbd, ned))
+    flags = torch.empty(len(words), dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        plan.run(flags)
+        assert [bool(x) for x in flags.cpu().tolist()] == want
+    plan.close()
+    at = ss.find_batched(dh, None, nblob, None, hay_ranges=(hb, he), needle_ranges=(nbd, ned)).cpu().tolist()
+    assert at == [hay.find(w) for w in words]            # (SS_NPOS reads as -1, which is what bytes.find says too)
+    rng = random.Random(3)
+    sample = [w for w, h in zip(words, want) if h][:50] + rng.sample([w for w, h in zip(words, want) if not h], 50)
+    for w in sample:
+        assert ss.DynamicHipSearcher.new(w).search_in(dh) is (w in hay), w
+        assert ss.DynamicHipSearcher.with_position(w, 0).search_in(dh) is (w in hay), w
+
+
 def test_find_leftmost_vs_python(ss, corpus):
     """Row f1: offset of the leftmost occurrence (tests/i386.rs:6-10 `find_subsequence`), bit-exact vs
     Python's bytes.find on text, boundaries, repeated matches and random data."""

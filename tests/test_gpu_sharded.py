@@ -337,6 +337,10 @@ def test_bench_with_eight_ranks_on_the_native_transport():
     assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8 and d["config"]["rccl_ranks"] == 8
     assert d["config"]["transport"].startswith("rccl") and d["config"]["transport_note"] is None
     assert d["config"]["ranks_share_one_gpu"] is True
+    # the line names the collective library its communicator is made of - here the stand-in, by path and by the
+    # version only it reports (a real run shows torch's or the system's librccl and RCCL's own version, e.g. 22606)
+    assert d["config"]["librccl_path"].endswith("libfake_rccl.so") and d["config"]["librccl_version"] == 1, d["config"]
+    assert d["config"]["librccl_env"] == env["SLICESLICE_RCCL_LIB"]
     assert d["config"]["haystack_bytes"] == 2 << 30 and d["config"]["shard_bytes"] == (2 << 30) // 8 + 15
     assert d["value"] > 0 and d["roofline"]["kernel_launches"] == 20
     # the N > 1 line explains itself.  Both forms ran - one rank per GPU (launched by bench.py itself) and all

@@ -58,7 +58,7 @@ def test_the_rccl_stand_in_exports_what_the_library_resolves():
     build = sys.modules["sliceslice_rs_amd._build"]
     src = open(os.path.join(ROOT, "sliceslice-rs_amd", "csrc", "ss_comm.hip")).read()
     wanted = sorted(set(re.findall(r'dlsym\(r\.h, "(nccl[A-Za-z]+)"\)', src)))
-    assert len(wanted) == 9, wanted
+    assert len(wanted) == 10, wanted
     F = ctypes.CDLL(build.build_fake_rccl())
     for name in wanted:
         assert hasattr(F, name), name

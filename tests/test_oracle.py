@@ -75,6 +75,17 @@ def test_long_haystack_sweep(corpus, checksums):
     assert O.sweep_long(lossy, corpus["words"], mode=2) == checksums["long_haystack_hits_lossy"] == 4585
 
 
+def test_random_haystack_sweep(corpus, checksums):
+    # the reference's THIRD criterion group, search_random_haystack (bench/benches/i386.rs:286-289 through :246-256): every word of
+    # words.txt in data/haystack (1,000 bytes of noise) - the restated searcher against the naive count of make_golden.py, word by word
+    hay = corpus["haystack"]
+    assert len(hay) == checksums["random_haystack_len"] == 1000
+    hit = [w for w in corpus["words"] if O.OracleSearcher(w).search_in(hay)]
+    assert len(hit) == checksums["random_haystack_hits"] == 106
+    assert sorted(w.decode("latin1") for w in hit) == checksums["random_haystack_hit_words"]
+    assert O.sweep_long(hay, corpus["words"], mode=2) == checksums["random_haystack_hits"]     # (mode 2: restatement == naive on every word)
+
+
 def test_random_grid(corpus, checksums):
     # bench/benches/random.rs:16 size grid over data/needle, data/haystack
     for row in checksums["random_grid"]:
