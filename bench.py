@@ -373,13 +373,33 @@ def other_configs(ss, shard, reps=20):
         rows = []
         for nd, how in ((b"privilege level zero!", "new"), (b"segment descriptor table entries are", "new"),
                         (b"segment descriptor table entries are", "with_position(n-1)"),
-                        (b" the quick brown fox ", "set_filter(0, n-1): the reference's pair, verbatim")):
+                        (b" the quick brown fox ", "set_filter(0, n-1): the reference's pair (on this haystack the census replaces its far byte "
+                                                    "by near ones - `bytes_in_force`; verbatim under `autotune_off`)")):
             s = ss.DynamicHipSearcher.with_position(nd, len(nd) - 1) if how.startswith("with_position") else ss.DynamicHipSearcher.new(nd)
             if how.startswith("set_filter"):
                 s.set_filter(0, len(nd) - 1)
+            for _ in range(12):                             # the handle settles on this haystack: census, trials, schedule order
+                s.search_in(text)
             res, ms = median_kernel_ms(s, text, reps)
-            rows.append(_row(gib, ms, needle=nd.decode("latin1"), how=how, found=res, filter_bytes=list(s.filter3)))
-        out["text"] = {"workload": "i386.txt (857,425 B of English) tiled to 1 GiB, absent phrases", "rows": rows}
+            st = s.tuning_state(text)
+            row = _row(gib, ms, needle=nd.decode("latin1"), how=how, found=res, filter_bytes=list(s.filter3),
+                       bytes_in_force=st["in_force"], candidate_tiles_of_1024=st["tiles3"], deep_candidates=st["deep_lanes"],
+                       schedule_by_census=bool(st["order_measured"]), workgroups_per_cu=s.last_launch()[0], kernel_mode=st["kernel_mode"])
+            # the same searcher with launch tuning OFF: the static bytes (a caller's pair verbatim, in the cross-lane kernels where it is
+            # 16 or more apart), the static schedule, the needle-byte guess for workgroups per CU
+            was = ss.set_autotune(False)
+            try:
+                s0 = ss.DynamicHipSearcher.with_position(nd, len(nd) - 1) if how.startswith("with_position") else ss.DynamicHipSearcher.new(nd)
+                if how.startswith("set_filter"):
+                    s0.set_filter(0, len(nd) - 1)
+                res0, ms0 = median_kernel_ms(s0, text, reps)
+                row["autotune_off"] = _row(gib, ms0, found=res0, workgroups_per_cu=s0.last_launch()[0])
+            finally:
+                ss.set_autotune(was)
+            rows.append(row)
+        out["text"] = {"workload": "i386.txt (857,425 B of English) tiled to 1 GiB, absent phrases; kernel time by hipEvents once the handle "
+                                   "has settled on the haystack (ss_searcher_tuning_state), and the same searcher with ss_set_autotune(0)",
+                       "rows": rows}
         del text
         fill = torch.full((gib,), 0x61, dtype=torch.uint8, device="cuda")
         rows = []
@@ -779,6 +799,19 @@ def librccl_fields(ss, native):
         return {"librccl_path": None, "librccl_version": None, "librccl_note": repr(e)}
 
 
+def tuning_fields(ss, searcher, shard):
+    """config.autotune / config.tuning: which way the timed steps ran - launch tuning on or off, and what the
+    handle held about the haystack when the timed region ended (ss_searcher_tuning_state: census counts, the bytes in force, whether
+    the second level's schedule is the census's)."""
+    try:
+        st = searcher.tuning_state(shard)
+        keep = ("census_state", "census_age", "tiles3", "tiles2", "lanes", "deep_lanes", "triple_state", "trials", "accepted", "settled", "own",
+                "in_force", "order_measured", "histogram_state", "workgroups_per_cu", "kernel_mode")
+        return {"autotune": "on" if st["autotune"] else "off", "tuning": {k: st[k] for k in keep}}
+    except Exception as e:      # pragma: no cover
+        return {"autotune": None, "tuning_note": repr(e)}
+
+
 def wg_histogram(seen):
     from collections import Counter
     return {str(k): v for k, v in sorted(Counter(seen).items())}
@@ -1043,7 +1076,7 @@ def run_multi_process(args, ctx):
                 launcher=os.environ.get("SS_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
                 ranks_share_one_gpu=bool(share and world > 1), prewarm_ms=round(prewarm_ms, 1), prewarm_steps=pw_steps,
                 waited_for_free_vram_s=round(waited_s, 2), vram_used_at_start=used_at_start,
-                workgroups_per_cu_timed=wg_histogram(wgs)),
+                workgroups_per_cu_timed=wg_histogram(wgs), **tuning_fields(ss, inner, shard)),
             "roofline": roofline_block(shard.numel(), kernel_ms, value, world, ratio, src),
         }
         if dist is not None:

@@ -211,15 +211,18 @@ SS_API int ss_find_batched(const void *d_haystacks, const uint64_t *d_hay_begin,
  * (bench/benches/i386.rs:246-256).  ss_batch_plan_create does for a batch what the constructors do for one needle: it reads
  * the range arrays and the NEEDLE bytes (on `hip_stream`, and waits for it), samples a byte histogram of the haystacks (at most
  * 4 MiB read) so that the needle bytes the scan filters on are the ones that are rare IN THESE HAYSTACKS (row f3 of SURVEY.md 8f;
- * a caller's `position` is kept; no result depends on the choice), and keeps one descriptor per problem in memory of its own; ss_batch_plan_run is then the scan launch alone, which writes the outputs itself (a plan in which some problem is
- * scanned by several workgroups adds one small kernel behind it that copies those problems' answers out) - no plan kernel, no
- * scratch acquire, nothing allocated, capturable into a hipGraph.  `find` != 0: the plan answers leftmost offsets (d_out = `count`
- * uint64, as ss_find_batched), else flags (d_out = `count` int32, as ss_search_batched).  The caller vouches that ranges,
- * needle bytes and the haystacks' ADDRESSES are unchanged between create and the last run; haystack CONTENTS may change
- * freely.  (A plan of long problems holds two launch layouts and picks by how many problems its previous run found - a tally the
- * run leaves in pinned memory; a run never waits for it, and no result depends on it.)  ONE run at a time per plan (the plan's state words are the run's scratch; every run leaves them at their idle
- * values): runs must be ordered one behind the other - the same stream, or events.  d_out needs no
- * initialisation.  No run may be in flight when the plan is freed. */
+ * a caller's `position` is kept; no result depends on the choice), and keeps one descriptor per problem in memory of its own;
+ * ss_batch_plan_run is then ONE kernel launch - the scan, which writes the outputs itself - for every plan: no plan kernel, no
+ * scratch acquire, nothing allocated, nothing initialised by the host, capturable into a hipGraph and replayable.  (Problems scanned
+ * by several workgroups keep their state in the plan; consecutive runs tell themselves apart by the identity the hardware gives
+ * every launch - the AQL dispatch id and the queue - so no second kernel is needed to re-arm anything: batched_kernels.hpp.)
+ * `find` != 0: the plan answers leftmost offsets (d_out = `count` uint64, as ss_find_batched), else flags (d_out = `count` int32, as
+ * ss_search_batched).  The caller vouches that ranges, needle bytes and the haystacks' ADDRESSES are unchanged between create and
+ * the last run; haystack CONTENTS may change freely.  (A plan of long problems holds two launch layouts and picks by how many
+ * problems an earlier run found - a tally the runs leave in pinned memory; a run never waits for it, no result depends on it, and
+ * the choice is made by the HOST when the launch is issued: a run captured into a hipGraph keeps the layout it was captured with.)
+ * ONE run at a time per plan (the plan's state words are the runs' scratch): runs must be ordered one behind the other - the same
+ * stream, or events.  d_out needs no initialisation.  No run may be in flight when the plan is freed. */
 typedef struct ss_batch_plan ss_batch_plan;
 SS_API int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, const uint64_t *d_hay_end,
                                 const void *d_needles, const uint64_t *d_needle_begin, const uint64_t *d_needle_end,
@@ -340,6 +343,7 @@ typedef struct ss_tuning_state {
     uint32_t tiles, tiles3, tiles2, match_tiles, lanes;   /* sampled tiles; with a candidate of the triple / of the pair alone / with a
                                        prefix match of up to 64 bytes; candidate lanes */
     uint32_t pair_lanes, triple_lanes;                    /* sampled candidates the per-position match counts were taken from */
+    uint32_t deep_lanes;            /* ... of them: candidates that only the compare in memory can tell from a match */
     uint32_t triple_state;          /* the filter bytes on this haystack: 0 still being looked at, 1 the searcher's own, 2 in_force[] differs */
     uint32_t on_trial, trials;      /* a proposal's census is in flight; proposals put on trial so far ... */
     uint32_t accepted, settled;     /* ... and how many of them replaced the bytes in force; 1: no byte is being looked at any more */

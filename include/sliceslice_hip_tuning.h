@@ -81,9 +81,10 @@ SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);
  * decided / 1 the searcher's own / 2 the histogram's; [10] = histogram triples put on trial so far.  Launches nothing. */
 SS_API int ss_debug_census(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t counts[11]);
 /* ... and its per-position match counters (aux_kernels.hpp, census_kernel): stats[k] = sampled PAIR candidates that match the needle
- * at position k (< 64), stats[64 + k] = sampled TRIPLE candidates that do, stats[128] / [129] = how many of each were sampled.
+ * at position k (< 64), stats[64 + k] = sampled TRIPLE candidates that do, stats[128] / [129] = how many of each were sampled, stats[130] = the deep ones among the
+ * triple candidates (match everywhere from the first filter byte on, yet no match).
  * *have = 0 while they are not in.  (What the product reports of it: ss_searcher_tuning_state.) */
-SS_API int ss_debug_census_stats(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t stats[130], int *have);
+SS_API int ss_debug_census_stats(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t stats[131], int *have);
 
 /* What the library remembers of an UNPLANNED batch (ss_search_batched / ss_find_batched with these haystacks, this range array and
  * this count) on the current device: *state = 0 unknown, 1 named once, 2 sampling in flight, 3 classes in - and then cls[0..256) =

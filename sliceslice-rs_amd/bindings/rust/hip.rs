@@ -23,7 +23,7 @@ use std::os::raw::{c_char, c_float, c_int, c_uint, c_void};
 pub struct ss_tuning_state {
     pub autotune: u32, pub census_state: u32, pub census_age: u32,
     pub tiles: u32, pub tiles3: u32, pub tiles2: u32, pub match_tiles: u32, pub lanes: u32,
-    pub pair_lanes: u32, pub triple_lanes: u32,
+    pub pair_lanes: u32, pub triple_lanes: u32, pub deep_lanes: u32,
     pub triple_state: u32, pub on_trial: u32, pub trials: u32, pub accepted: u32, pub settled: u32, pub proposal: u32,
     pub own: [u32; 3], pub in_force: [u32; 3],
     pub order_measured: u32, pub norder: u32, pub order: [u8; 16],

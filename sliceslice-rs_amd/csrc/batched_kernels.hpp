@@ -55,8 +55,7 @@ struct __attribute__((aligned(64))) BatchCold {
     // all of them to memory - 1,024 x 1 MiB with every needle present ran 0.23-0.29 ms where the full scan takes 0.155.
     //   unplanned bool calls: pad[1] = the found flag the waves poll and raise (the caller's output is written behind it)
     //   unplanned find calls: pad[0..1] = one uint64, the leftmost offset so far (the caller's output is lowered behind it)
-    //   bool plans:           pad[1] = the flag (batch_publish_kernel copies it out and puts it back to 0)
-    //   find plans:           pad[0..1] = one uint64, the leftmost offset so far (idle: all ones)
+    //   plans:                not here - a plan's problems have a PlanState of their own (two words, one per run parity: below)
     uint32_t pad[2];
 };
 static_assert(sizeof(BatchCold) == 64, "one scalar load");
@@ -373,6 +372,7 @@ struct ColdFields {
     uint64_t order_idx[2], order_val[2];
     uint32_t tail16[4];
     int *host_flag;
+    uint32_t *tally;                              // (ColdInPlan, plans that hold two layouts) the run's count of found problems; else null
     uint64_t far_off;
     uint32_t ready;                               // (ColdInCall) the record holds the needle's dwords: nothing to build
     __device__ __forceinline__ const ColdFields *operator->() const { return this; }
@@ -411,6 +411,7 @@ struct ColdInCall {
         f.order_idx[0] = f.order_idx[1] = f.order_val[0] = f.order_val[1] = 0;
         f.tail16[0] = c->tail16[0]; f.tail16[1] = c->tail16[1]; f.tail16[2] = c->tail16[2]; f.tail16[3] = c->tail16[3];
         f.host_flag = static_cast<int *>(out_word);
+        f.tally = nullptr;
         f.far_off = 0;
         f.ready = c->exact_len;                      // (the plan kernel sets it only where it left the dwords)
         return f;
@@ -419,9 +420,12 @@ struct ColdInCall {
 struct ColdInPlan {
     static constexpr bool kHasOrder = true;
     static constexpr bool kMaybeOrder = false;
+    static constexpr bool kSingleLaunchPlan = true;   // scan_tiles: state word first, the caller's output behind it, the tally
     const BatchDesc *dp;
     const BatchCold *cp;
     const uint8_t *needles;
+    void *out_word;                                 // problems scanned by several workgroups: the caller's output of this problem; else null
+    uint32_t *tally;
     __device__ __forceinline__ ColdFields operator()() const
     {
         const BatchDesc *q = dp;
@@ -437,7 +441,8 @@ struct ColdInPlan {
         f.order_idx[0] = c->order_idx[0]; f.order_idx[1] = c->order_idx[1];
         f.order_val[0] = c->order_val[0]; f.order_val[1] = c->order_val[1];
         f.tail16[0] = c->tail16[0]; f.tail16[1] = c->tail16[1]; f.tail16[2] = c->tail16[2]; f.tail16[3] = c->tail16[3];
-        f.host_flag = nullptr;
+        f.host_flag = static_cast<int *>(out_word);
+        f.tally = tally;
         f.far_off = 0;
         f.ready = 1;
         return f;
@@ -563,12 +568,56 @@ __global__ void __launch_bounds__(kBlock) batch_cold_kernel(const BatchArgs a, c
 // their slice-0 workgroup from the descriptor.
 // (-DSS_BATCH_WAVES_MAX=6 lets the register allocator aim at six waves per SIMD - tried with SLICESLICE_BATCH_OCC = 5 and 6 on
 // every batch shape: no difference, so four it stays)
+// ---- a plan run is ONE launch ------------------------------------------------------------------------------
+// What the second launch (batch_publish_kernel) did for problems scanned by several workgroups - copy the state word to the caller's
+// output, put it back to idle, tally - needs something that happens once per run and problem, in front of every finder.  Counting
+// workgroups out was built in round 4 and measured at 5-8 % (a returning atomic at the end of every short-lived workgroup).  What
+// works without any counting:
+//   * every run has an IDENTITY that all its workgroups see and no neighbouring run shares: the AQL dispatch id of the launch (the
+//     packet's index in its queue, 64 bits, from the hardware) and the id of the queue.  The plan's control word holds
+//     (identity << 1 | parity) of the latest run.  A workgroup that reads its own identity there takes the parity as it is; one that
+//     reads another identity - the previous run's - takes the OTHER parity; workgroup 0 stores (own identity, own parity).  Whichever
+//     of the two a workgroup reads, it computes the same parity: consistent within a run, flipped between consecutive runs, no
+//     atomics, nobody waits.  hipGraph replays get fresh dispatch ids like any launch.
+//   * a problem has TWO state words, one per parity.  The waves of a run poll and raise word[parity]; the workgroup of slice 0 puts
+//     word[parity ^ 1] back to idle - nobody looks at it in this run - for the run after.
+//   * the caller's output: the slice-0 workgroup stores the idle value at its entry; a wave that finds the needle raises the state
+//     word FIRST and writes the output behind it; the slice-0 workgroup re-reads the state word at its own end (behind a fence:
+//     its store has been performed) and writes the output again if it is set.  Either a finder's state update is seen by that
+//     re-read, or it came later - then so did its output store, behind the idle value.  FIND: the same with minima.
+//   * the tally of found problems (plans with two layouts): the first finder of a problem adds one to tally[parity]; workgroup 0 of
+//     the NEXT run stores the previous run's count to pinned memory and clears it.
+struct __attribute__((aligned(64))) PlanCtl {
+    unsigned long long run_word;                    // (identity of the latest run) << 1 | its parity
+    uint32_t tally[2];                              // by parity: problems found (scanned by several workgroups) in that run
+    uint32_t pad[12];
+};
+static_assert(sizeof(PlanCtl) == 64, "a line of its own");
+struct __attribute__((aligned(64))) PlanState {
+    uint64_t word[2];                               // by parity.  bool plans: 0 / 1; find plans: the leftmost offset so far (idle: all ones)
+    uint64_t pad[6];
+};
+static_assert(sizeof(PlanState) == 64, "a problem's state: half a cache line of its own");
+extern "C" __device__ unsigned long long ss_llvm_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");
+__device__ __forceinline__ unsigned long long plan_run_identity()
+{
+    // 20 bits that tell the queue - hsa_queue_t::id (byte 32 of the queue structure: "unique over the lifetime of the application")
+    // plus the structure's own page number, so that two live queues differ even where the runtime hands out equal ids - | 43 bits of
+    // the packet's index in that queue.  (profiles/r06/dispatch_id_probe.json: one value per launch, a new one per launch and per
+    // hipGraph replay; every stream its own queue structure.)
+    typedef const uint64_t __attribute__((address_space(4))) *QueuePtr;          // (constant address space: scalar loads)
+    const QueuePtr q = (QueuePtr)__builtin_amdgcn_queue_ptr();
+    const uint64_t queue = q[4] + ((uint64_t)(uintptr_t)__builtin_amdgcn_queue_ptr() >> 12);
+    return ((queue & 0xFFFFFull) << 43) | (ss_llvm_dispatch_id() & ((1ull << 43) - 1ull));
+}
+
 #ifndef SS_BATCH_WAVES_MAX
 #define SS_BATCH_WAVES_MAX 4
 #endif
 template <int U, bool FIND = false, bool PLAN = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, SS_BATCH_WAVES_MAX))) __launch_bounds__(kBlock)
-scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, BatchCold *colds)
+scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, BatchCold *colds,
+                         PlanCtl *ctl, PlanState *states, unsigned long long *h_tally, uint32_t run)
 {
     constexpr bool COUNTED = PLAN;                  // (the name the code below grew up with)
     __shared__ __attribute__((aligned(16))) uint8_t s_needle[kWavesPerBlock * kNeedleLds];
@@ -585,18 +634,30 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         prob = w / nslices;
         slice = w - prob * nslices;
     }
-    // the problem's state word sits in its cold record (BatchCold: a line per pair of problems), not in an array of words
+    // The problem's state word.  Unplanned calls: in its cold record (BatchCold: a line per pair of problems), not in an array of words.
+    // A plan's run: word[parity] of the problem's PlanState - the parity comes from the plan's control word and this launch's identity
+    // (see PlanCtl), requested here together with the descriptor: one scalar round trip.
     BatchCold *rec = colds + prob;
-    int *found = FIND ? nullptr : reinterpret_cast<int *>(&rec->pad[1]);
-    void *sink = FIND ? static_cast<void *>(&rec->pad[0]) : static_cast<void *>(found);
     const BatchDesc *dp = descs + prob;
-    // slice-major, later slices: the problem's flag (one coherent load) is requested together with the descriptor (one scalar
-    // load, s_load_dwordx16) - one round trip decides whether and what to scan
-    const int seen = !FIND && slice_major && slice != 0 ? __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    // slice-major, later slices: the problem's flag (one coherent load; a plan's run: both parities' words, chosen below) is requested
+    // together with the descriptor (one scalar load, s_load_dwordx16) - one round trip decides whether and what to scan
+    const bool peek = !FIND && slice_major && slice != 0;
+    int seen0 = 0, seen1 = 0;
+    if (PLAN) {
+        if (peek) {
+            seen0 = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].word[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen1 = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].word[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (peek) {
+        seen0 = __hip_atomic_load(reinterpret_cast<int *>(&rec->pad[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     BatchDesc d = *dp;
+    unsigned long long run_word = 0;
+    // (issued behind the descriptor's load and waited for together with it: one scalar round trip)
+    if (PLAN) __asm__ volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(run_word) : "s"(ctl) : "memory");
     if (COUNTED) {
         // The hot fields are pinned in scalar registers HERE, in front of the first store of the kernel (the LDS words'
-        // initial values, the trivial problem's answer below): a load the compiler sinks behind a store cannot go through the scalar cache any more, so it became a
+        // initial values, the control word, the trivial problem's answer below): a load the compiler sinks behind a store cannot go through the scalar cache any more, so it became a
         // per-lane load and everything computed from it - tile bounds, loop control, addresses - per-lane arithmetic under exec
         // masks (101 VGPRs, and 311 us where the uncounted kernel takes 154 on 1,024 x 1 MiB).
         uint64_t base = reinterpret_cast<uint64_t>(d.base);
@@ -605,6 +666,24 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         if ((threadIdx.x & (kWave - 1)) == 0)
             __hip_atomic_store(&s_wg[threadIdx.x / kWave], FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    uint32_t parity = 0;
+    if (PLAN) {
+        const unsigned long long me = plan_run_identity();
+        const bool mine = (run_word >> 1) == me;
+        parity = mine ? (uint32_t)(run_word & 1ull) : (uint32_t)(run_word & 1ull) ^ 1u;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !mine) {
+            // the first workgroup of a run: the previous run's tally to the host (plans with two layouts), the run's identity and parity
+            // into the control word.  Workgroups that still read the old word arrive at the same parity.
+            if (h_tally) {
+                const uint32_t total = __hip_atomic_exchange(&ctl->tally[parity ^ 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h_tally, ((unsigned long long)run << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(&ctl->run_word, (me << 1) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int seen = PLAN ? (parity ? seen1 : seen0) : seen0;
+    int *found = FIND ? nullptr : (PLAN ? reinterpret_cast<int *>(&states[prob].word[parity]) : reinterpret_cast<int *>(&rec->pad[1]));
+    void *sink = FIND ? (PLAN ? static_cast<void *>(&states[prob].word[parity]) : static_cast<void *>(&rec->pad[0])) : static_cast<void *>(found);
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
     const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
@@ -633,6 +712,15 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     }
     work = work && t0 < te;
     if (!work) return;                              // (a plan's single-workgroup problem always has work: t0 = 0 < te)
+    const bool opener = COUNTED && eff > 1 && slice == 0 && threadIdx.x == 0;      // (slice 0 always has work: its first tile is tile 0)
+    if (opener) {
+        // one lane per problem and run: the OTHER parity's state word back to idle for the run after this one (nobody looks at it in
+        // this run), and the caller's output to its idle value - every finder writes the output BEHIND its update of the state word
+        // that this lane re-reads at its own end (below)
+        __hip_atomic_store(&states[prob].word[parity ^ 1u], FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FIND) __hip_atomic_store(a.best + prob, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(a.found + prob, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     if (work) {
         Problem pr;                                 // hot fields only; the cold ones are re-read from the descriptor
@@ -657,7 +745,10 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         // present 16,384 x 64 KiB 0.154 ms instead of 0.183, 65,536 x 16 KiB 0.271 instead of 0.447)
         constexpr bool READY = PLAN;
         typename std::conditional<READY, ColdInPlan, ColdInCall>::type cold;
-        if constexpr (READY) cold = ColdInPlan{dp, colds + prob, a.needles};
+        // (a plan's problem scanned by several workgroups: the finding wave writes the caller's output behind the state word)
+        if constexpr (READY)
+            cold = ColdInPlan{dp, colds + prob, a.needles, eff > 1 ? (FIND ? static_cast<void *>(a.best + prob) : static_cast<void *>(a.found + prob)) : nullptr,
+                              eff > 1 && h_tally ? &ctl->tally[parity] : nullptr};
         else cold = ColdInCall{dp, colds + prob, a.needles, FIND ? static_cast<void *>(a.best + prob) : static_cast<void *>(a.found + prob)};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
         // (Measured and not adopted - commit 7511606 (-DSS_SIBLING_POLL), profiles/r05/ab_sibling_poll.jsonl: the waves of such a workgroup polling EACH
@@ -666,6 +757,18 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         void *wg_sink = COUNTED && eff == 1 ? static_cast<void *>(&s_wg[threadIdx.x / kWave]) : nullptr;
         if ((d.bytes >> 24) & 1) scan_tiles<0, 0, true, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
         else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
+    }
+    if (opener) {
+        // ... the wave's own scan is over: the idle value has been PERFORMED by now (the fence waits for it), so a state word that is
+        // still idle here means that whoever raises it later writes the output later too
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        if (FIND) {
+            const uint64_t v = __hip_atomic_load(&states[prob].word[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != ~0ull) __hip_atomic_fetch_min(a.best + prob, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const int v = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].word[parity]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0) __hip_atomic_store(a.found + prob, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (COUNTED && eff == 1) {
         // the only workgroup of its problem: the answer is in the LDS word (a bare barrier settles it), one store publishes it
@@ -679,48 +782,6 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
             }
             if (FIND) a.best[prob] = mine;
             else a.found[prob] = mine != 0;
-        }
-    }
-}
-
-// Behind the scan of a plan that has problems of several workgroups: one LANE per problem copies the state word of such a
-// problem to the caller's output and puts it back to its idle value (the kernel boundary is the ordering; 4-5 us).
-__global__ void __launch_bounds__(kBlock) batch_publish_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count,
-                                                                BatchCold *colds, uint32_t *d_tally, unsigned long long *h_tally, uint32_t run)
-{
-    // `d_tally` / `h_tally` (plans that hold two layouts, else null): how many of the problems scanned by several workgroups were FOUND
-    // in this run - summed per workgroup, the workgroup that finishes last stores run << 32 | found to pinned memory, where the
-    // host reads it before a later run (never waiting for it) to choose the layout: ss_batch_plan_run.
-    __shared__ uint32_t s_found;
-    if (threadIdx.x == 0) s_found = 0;
-    __syncthreads();
-    const uint32_t prob = blockIdx.x * kBlock + threadIdx.x;
-    bool was_found = false;
-    if (prob < count && (uint32_t)(descs[prob].per >> 32) > 1) {       // (a single-workgroup problem is published by the scan itself)
-        if (a.best) {
-            uint64_t *st = reinterpret_cast<uint64_t *>(&colds[prob].pad[0]);
-            const uint64_t v = *st;
-            a.best[prob] = v;
-            if (v != ~0ull) *st = ~0ull;
-            was_found = v != ~0ull;
-        } else {
-            int *st = reinterpret_cast<int *>(&colds[prob].pad[1]);
-            const int v = *st;
-            a.found[prob] = v != 0;
-            if (v != 0) *st = 0;
-            was_found = v != 0;
-        }
-    }
-    if (d_tally == nullptr) return;                                        // (uniform: a kernel argument)
-    const uint32_t mine = (uint32_t)__builtin_popcountll(__ballot(was_found));
-    if ((threadIdx.x & (kWave - 1)) == 0 && mine) atomicAdd(&s_found, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (s_found) __hip_atomic_fetch_add(d_tally, s_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(d_tally + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
-            const uint32_t total = __hip_atomic_exchange(d_tally, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(d_tally + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(h_tally, ((unsigned long long)run << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

@@ -63,6 +63,11 @@ namespace ss {
 // that start on that CU next their descriptor and kernel-argument lines: plan runs with matches 2-5 % (the i386 loop 0.122 ms
 // instead of 0.128), the unplanned calls nothing (profiles/r05/ab_batch_no_dcache_inv.jsonl).
 template <bool BATCHED> constexpr bool kNoForget = BATCHED;
+// ColdT::kSingleLaunchPlan (batched_kernels.hpp, ColdInPlan): the problem's state word is the plan's own, the CALLER'S output is
+// written behind it by the finding wave (state first, output second - see scan_batched_plan_kernel), and the first finder of a
+// problem counts it into the plan's tally.
+template <class T, class = void> struct SingleLaunchPlan : std::false_type {};
+template <class T> struct SingleLaunchPlan<T, std::void_t<decltype(T::kSingleLaunchPlan)>> : std::bool_constant<T::kSingleLaunchPlan> {};
 template <int Q, int MODE, bool ONE_BYTE, int U, int NTMODE, bool FIND = false, bool L8 = false, bool LAZY_ORDER = false,
           typename ColdT = ColdInRegisters>
 __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_t *s_needle_block, uint64_t tile0,
@@ -500,12 +505,24 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                             if (lane == 0)
                                 __hip_atomic_fetch_min(static_cast<uint64_t *>(wg_sink), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         } else if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if constexpr (LAZY_ORDER) {
-                                // (the unplanned batched find: `best` is the problem's state word in its cold record, which the
-                                // waves poll; the caller's output takes the minimum too - nobody polls that one)
-                                uint64_t *out_best = reinterpret_cast<uint64_t *>(cold()->host_flag);
+                            if constexpr (SingleLaunchPlan<ColdT>::value) {
+                                // a plan's run: the state word FIRST (the old value tells the first finder of the problem), the
+                                // caller's output behind it - in that order, settled by the fence: the workgroup that initialises
+                                // the output re-reads the state word afterwards (scan_batched_plan_kernel)
+                                const uint64_t old = __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                                const auto c = cold();
+                                uint64_t *out_best = reinterpret_cast<uint64_t *>(c->host_flag);
                                 if (out_best) __hip_atomic_fetch_min(out_best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (old == ~0ull && c->tally) __hip_atomic_fetch_add(c->tally, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if constexpr (LAZY_ORDER) {
+                                    // (the unplanned batched find: `best` is the problem's state word in its cold record, which the
+                                    // waves poll; the caller's output takes the minimum too - nobody polls that one)
+                                    uint64_t *out_best = reinterpret_cast<uint64_t *>(cold()->host_flag);
+                                    if (out_best) __hip_atomic_fetch_min(out_best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
                             }
                         }
                         forget_scalar_cache_unless(small_grid || kNoForget<LAZY_ORDER>);
@@ -530,9 +547,20 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     } else if (lane == __ffsll((unsigned long long)hits) - 1 &&
                                __hip_atomic_load(found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != pr.epoch) {
                         const int old = __hip_atomic_exchange(found, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        int *host_flag = cold()->host_flag;
-                        if (old != pr.epoch && host_flag)
-                            __hip_atomic_store(host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if constexpr (SingleLaunchPlan<ColdT>::value) {
+                            // a plan's run: the exchange has RETURNED (the state word is set) before the caller's output is
+                            // written behind it; the first finder of the problem counts it into the plan's tally
+                            if (old != pr.epoch) {
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                                const auto c = cold();
+                                if (c->host_flag) __hip_atomic_store(c->host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (c->tally) __hip_atomic_fetch_add(c->tally, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        } else {
+                            int *host_flag = cold()->host_flag;
+                            if (old != pr.epoch && host_flag)
+                                __hip_atomic_store(host_flag, pr.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
                     }
                     forget_scalar_cache_unless(small_grid || kNoForget<LAZY_ORDER>);
                     return;

@@ -284,9 +284,11 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
     if (e == hipSuccess) {
         const dim3 grid((unsigned)((uint64_t)count * sh.slices));
         if (a.best)
-            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, colds);
+            ss::scan_batched_plan_kernel<4, true, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, colds,
+                                                                                                          nullptr, nullptr, nullptr, 0u);
         else
-            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, colds);
+            ss::scan_batched_plan_kernel<4, false, false><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)count, sh.slices, colds,
+                                                                                                           nullptr, nullptr, nullptr, 0u);
         e = hipGetLastError();
     }
     ps->mu.unlock();
@@ -299,9 +301,10 @@ int launch_batched(const ss::BatchArgs &a, size_t count, hipStream_t st)
 
 using namespace ssh;
 
-// The plan's own memory: descriptors | cold parts (64 bytes each, like the descriptors; a problem's state word - flag or minimum -
-// sits in its cold part) | the plan kernel's PlanStats (64 bytes) | the sampling's counters and the rarity classes of the
-// haystacks' bytes (ss::BatchClasses).
+// The plan's own memory: descriptors | cold parts (64 bytes each, like the descriptors) | the problems' state words (ss::PlanState, 64
+// bytes each: one word per run parity) | the plan kernel's PlanStats (64 bytes) | the control word of the runs (ss::PlanCtl, 64 bytes:
+// the latest run's identity and parity, the tallies) | the sampling's counters and the rarity classes of the haystacks' bytes
+// (ss::BatchClasses).
 struct ss_batch_plan {
     int dev = 0;
     size_t count = 0;
@@ -314,22 +317,24 @@ struct ss_batch_plan {
     // slower without matches and 2 to 25 times faster with them (256 x 4 MiB, every needle present at the start / in the middle:
     // 0.014 / 0.087 ms against 0.196 / 0.160; profiles/r05/plan_layouts.jsonl) - the later runs of a found problem leave at their
     // entry poll.  Which of the two a plan's problems want is not known when it is made, and is known after its first run: the
-    // publish kernel tallies the problems that were found into pinned memory, and a later run - which never waits for the tally -
-    // takes the contiguous runs when at least an eighth of the problems were found last time.  Deterministic for given inputs;
-    // no result depends on it.
+    // first finder of every problem counts it into the run's tally, the first workgroup of the NEXT run stores that count to pinned
+    // memory, and a later run - which never waits for it - takes the contiguous runs when at least an eighth of the problems were
+    // found.  Deterministic for given inputs; no result depends on it.  (A run captured into a hipGraph keeps the layout - and the run
+    // number - it was captured with: the choice is the host's, made when the launch is issued.)
     bool has_alt = false;
     BatchShape shape_alt = {1, 1};
-    unsigned long long *h_tally = nullptr;          // pinned: run << 32 | found problems of that run
+    unsigned long long *h_tally = nullptr;          // pinned: run << 32 | found problems of the run before it
     mutable uint32_t runs = 0;
     ss::BatchDesc *mem_alt = nullptr;               // the second layout's descriptors (plans that hold two)
     uint8_t *mem = nullptr;
-    static constexpr size_t kPerProblem = sizeof(ss::BatchDesc) + sizeof(ss::BatchCold);
+    static constexpr size_t kPerProblem = sizeof(ss::BatchDesc) + sizeof(ss::BatchCold) + sizeof(ss::PlanState);
     ss::BatchDesc *descs() const { return reinterpret_cast<ss::BatchDesc *>(mem); }
     ss::BatchDesc *descs_alt() const { return mem_alt; }
     ss::BatchCold *colds() const { return reinterpret_cast<ss::BatchCold *>(mem + count * sizeof(ss::BatchDesc)); }
+    ss::PlanState *states() const { return reinterpret_cast<ss::PlanState *>(mem + count * (sizeof(ss::BatchDesc) + sizeof(ss::BatchCold))); }
     ss::PlanStats *stats() const { return reinterpret_cast<ss::PlanStats *>(mem + count * kPerProblem); }
-    ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * kPerProblem + 64); }
-    uint32_t *tally() const { return reinterpret_cast<uint32_t *>(mem + count * kPerProblem + 64 + sizeof(ss::BatchClasses)); }
+    ss::PlanCtl *ctl() const { return reinterpret_cast<ss::PlanCtl *>(mem + count * kPerProblem + 64); }
+    ss::BatchClasses *classes() const { return reinterpret_cast<ss::BatchClasses *>(mem + count * kPerProblem + 128); }
 };
 
 extern "C" {
@@ -380,7 +385,7 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
     if (rc == SS_OK && (e = hipGetDevice(&p->dev)) != hipSuccess) rc = fail(SS_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
     if (rc == SS_OK) rc = batch_shape(p->dev, count, &p->shape, true);
     if (rc == SS_OK) {
-        const size_t bytes = count * ss_batch_plan::kPerProblem + 64 + sizeof(ss::BatchClasses) + 64;
+        const size_t bytes = count * ss_batch_plan::kPerProblem + 128 + sizeof(ss::BatchClasses);
         if ((e = hipMalloc((void **)&p->mem, bytes)) != hipSuccess)
             rc = fail(e == hipErrorOutOfMemory ? SS_ERR_NOMEM : SS_ERR_HIP, "plan memory (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
@@ -437,6 +442,9 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
             ss::batch_cold_kernel<<<dim3((unsigned)((count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(p->args, p->descs(), (uint64_t)count,
                                                                                                                         p->colds(), cls, p->find ? 1 : 0);
             e = hipGetLastError();
+            // the runs' state: every problem's two state words idle (bool: 0, find: all ones), the control word naming no run
+            if (e == hipSuccess) e = hipMemsetAsync(p->states(), p->find ? 0xFF : 0, count * sizeof(ss::PlanState), st);
+            if (e == hipSuccess) e = hipMemsetAsync(p->ctl(), 0, sizeof(ss::PlanCtl), st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             // the second layout (see ss_batch_plan): for plans whose problems are scanned round robin and are numerous enough for
             // eight runs each to fill the device
@@ -457,7 +465,6 @@ int ss_batch_plan_create(const void *d_haystacks, const uint64_t *d_hay_begin, c
                 e = hipMemsetAsync(p->stats(), 0, 64, st);
                 if (e == hipSuccess) e = launch_plan_kernel(p->args, count, p->descs_alt(), p->shape_alt, st, p->stats(), cls);
                 if (e == hipSuccess) e = hipMemcpyAsync(&alt, p->stats(), sizeof(alt), hipMemcpyDeviceToHost, st);
-                if (e == hipSuccess) e = hipMemsetAsync(p->tally(), 0, 64, st);
                 if (e == hipSuccess) e = hipStreamSynchronize(st);
                 if (e == hipSuccess && alt.max_slices > 1 &&
                     hipHostMalloc((void **)&p->h_tally, sizeof(unsigned long long), hipHostMallocPortable) == hipSuccess) {
@@ -502,21 +509,21 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     const ss::BatchDesc *descs = alt ? p->descs_alt() : p->descs();
     const BatchShape &sh = alt ? p->shape_alt : p->shape;
     const dim3 grid((unsigned)((uint64_t)p->count * sh.slices));
+    // ONE launch: problems scanned by a single workgroup are published by it, problems scanned by several raise the plan's state
+    // word of this run's parity and write the caller's output behind it (batched_kernels.hpp, PlanCtl) - no publish kernel, nothing
+    // initialised by the host, so a run can be captured into a hipGraph and replayed.
+    const uint32_t run = ++p->runs == 0 ? ++p->runs : p->runs;
+    unsigned long long *h_tally = p->has_alt ? p->h_tally : nullptr;
     if (p->find) {
         a.best = static_cast<uint64_t *>(d_out);
-        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds());
+        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds(),
+                                                                                                     p->ctl(), p->states(), h_tally, run);
     } else {
         a.found = static_cast<int *>(d_out);
-        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds());
+        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds(),
+                                                                                                      p->ctl(), p->states(), h_tally, run);
     }
     HIP_TRY(hipGetLastError());
-    // problems scanned by several workgroups leave their answer in their state words: one lane per problem publishes
-    if (sh.slices > 1) {
-        const uint32_t run = ++p->runs == 0 ? ++p->runs : p->runs;
-        ss::batch_publish_kernel<<<dim3((unsigned)((p->count + ss::kBlock - 1) / ss::kBlock)), dim3(ss::kBlock), 0, st>>>(
-            a, descs, (uint32_t)p->count, p->colds(), p->has_alt ? p->tally() : nullptr, p->h_tally, run);
-        HIP_TRY(hipGetLastError());
-    }
     return SS_OK;
 }
 

@@ -65,9 +65,14 @@ constexpr uint32_t kThirdMinLanes = 16;
 // tiles than the pair did: the single-stream kernels are 2-3 % faster than the cross-lane ones before any candidate is met, which is
 // what some 64 candidate tiles in 1,024 cost (profiles/r06/survival_probe_v1.jsonl).
 constexpr uint32_t kNearFormSlackTiles = 64;
+// What a proposal is judged by: its candidate lanes, a DEEP candidate - one that only the compare in memory can tell from a match: a
+// dependent round trip with the workgroup's slot held - counting as kDeepWeight of them.  (profiles/r06/survival_probe_v2.jsonl: the
+// i386 phrase through with_position(n-1) lost 3 % to a third byte with a quarter of the candidates, every one of them deep.)
+constexpr uint32_t kDeepWeight = 8;
+constexpr uint32_t kCensusDeepLanes = 24;          // six workgroups per CU from this many deep candidates in the sample
 constexpr uint32_t kDescentMaxRounds = 12;         // censuses a (searcher, haystack) pair may spend on improving its bytes, per 256 scans
 constexpr uint32_t kOrderMinLanes = 4;             // triple candidates in the sample below which the static schedule order stays
-static_assert(ss::kCensusStatWords == 2 * 64 + 2 && ss::kCensusCheck == 64, "PerDevice::Census and the control blocks are laid out for 64 positions");
+static_assert(ss::kCensusStatWords == 2 * 64 + 3 && ss::kCensusCheck == 64, "PerDevice::Census and the control blocks are laid out for 64 positions");
 
 struct CensusCounts {
     uint32_t tiles3, tiles2, match_tiles, lanes;
@@ -142,10 +147,12 @@ void complete_pending(const ss_searcher *s, PerDevice *pd)
     bool take = what == 1;
     if (what == 2) {
         const CensusCounts now = census_counts(sums), was = census_counts(c.sums);
+        const uint32_t deep_now = __atomic_load_n(pd->h_stats + 2 * ss::kCensusCheck + 2, __ATOMIC_RELAXED);
+        const uint64_t cost_now = (uint64_t)now.lanes + (uint64_t)kDeepWeight * deep_now, cost_was = (uint64_t)was.lanes + (uint64_t)kDeepWeight * c.deep_lanes;
         bool better;
-        if (c.prop_kind == 3) better = now.tiles3 <= was.tiles3 + kNearFormSlackTiles;   // one load stream instead of the cross-lane kernels
-        else if (c.prop_kind == 1) better = now.tiles3 <= was.tiles3;
-        else better = now.tiles3 <= was.tiles3 && now.lanes <= was.lanes && (now.tiles3 < was.tiles3 || now.lanes < was.lanes);
+        if (c.prop_kind == 3) better = now.tiles3 <= was.tiles3 + kNearFormSlackTiles && deep_now <= c.deep_lanes + kNearFormSlackTiles / 4;   // one load stream instead of the cross-lane kernels
+        else if (c.prop_kind == 1) better = now.tiles3 <= was.tiles3 && cost_now <= cost_was;
+        else better = now.tiles3 <= was.tiles3 && cost_now < cost_was;
         if (better) {
             if (c.prop_kind == 3) c.free_mask = 6;      // the near form keeps the caller's first byte; the other two are the library's
             c.cur[0] = c.prop[0];
@@ -171,6 +178,7 @@ void complete_pending(const ss_searcher *s, PerDevice *pd)
     }
     c.pair_lanes = __atomic_load_n(pd->h_stats + 2 * ss::kCensusCheck, __ATOMIC_RELAXED);
     c.triple_lanes = __atomic_load_n(pd->h_stats + 2 * ss::kCensusCheck + 1, __ATOMIC_RELAXED);
+    c.deep_lanes = __atomic_load_n(pd->h_stats + 2 * ss::kCensusCheck + 2, __ATOMIC_RELAXED);
     c.stats_roles = c.roles;
     size_t tri[3];
     normalised(c.cur, tri);
@@ -574,7 +582,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     if (c->state != 2) return;                          // the first census is in flight
     const CensusCounts cc = census_counts(c->sums);
     out->have_counts = true;
-    out->workgroups_per_cu = cc.match_tiles != 0 ? 4 : (cc.tiles3 >= kCensusDenseTiles || cc.lanes >= kCensusDenseLanes ? 6 : 4);
+    out->workgroups_per_cu = cc.match_tiles != 0 ? 4 : (cc.tiles3 >= kCensusDenseTiles || cc.lanes >= kCensusDenseLanes || c->deep_lanes >= kCensusDeepLanes ? 6 : 4);
     out->sparse_pair = cc.tiles2 <= kCensusSparsePairTiles;
     // A buffer may be refilled in place: everything is looked at again every kCensusRefreshEvery scans, starting from the bytes in
     // force (the old counts serve until the new ones are in).
@@ -706,6 +714,7 @@ int ss_searcher_tuning_state(const ss_searcher *s, const void *d_haystack, size_
         if (c.stats_roles >= 0) {
             out->pair_lanes = c.pair_lanes;
             out->triple_lanes = c.triple_lanes;
+            out->deep_lanes = c.deep_lanes;
         }
         out->triple_state = c.adopted ? 2u : (c.settled ? 1u : 0u);
         out->on_trial = c.inflight == 2 ? 1u : 0u;
@@ -740,7 +749,7 @@ int ss_searcher_tuning_state(const ss_searcher *s, const void *d_haystack, size_
 #ifdef SS_TEST_HOOKS
 // the census's per-position match counters of (searcher, haystack): pair_match[64] | triple_match[64] | pair lanes | triple lanes;
 // *have = 0 when they are not in
-int ss_debug_census_stats(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t stats[130], int *have)
+int ss_debug_census_stats(const ss_searcher *s, const void *d_haystack, size_t len, uint32_t stats[131], int *have)
 {
     if (!s || !stats || !have) return fail(SS_ERR_ARGUMENT, "NULL argument");
     PerDevice *pd = nullptr;
@@ -756,6 +765,7 @@ int ss_debug_census_stats(const ss_searcher *s, const void *d_haystack, size_t l
         }
         stats[128] = c.pair_lanes;
         stats[129] = c.triple_lanes;
+        stats[130] = c.deep_lanes;
         *have = 1 + c.stats_roles;                      // (1 + the slot the pair counts were gathered for)
     }
     __atomic_store_n(&pd->census_lock, 0u, __ATOMIC_RELEASE);

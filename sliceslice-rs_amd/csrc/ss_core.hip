@@ -74,7 +74,7 @@ namespace {
 // a kernel's start drops the caches' copy of the block; a resident service kernel acquires what was uploaded after its last
 // look (upload tickets).  Without a large BAR (or with SLICESLICE_NO_BAR_WRITES=1) the image goes by one hipMemcpy.
 constexpr size_t kBlockDevBytes = 4096, kBlockHostBytes = 2048, kBlockNeedleOff = 2560, kBlockNeedleMax = kBlockDevBytes - kBlockNeedleOff;
-constexpr size_t kCensusStatBytes = 4 * (2 * 64 + 2);           // ss::kCensusStatWords counters (aux_kernels.hpp; checked in ss_census.hip)
+constexpr size_t kCensusStatBytes = 4 * (2 * 64 + 3);           // ss::kCensusStatWords counters (aux_kernels.hpp; checked in ss_census.hip)
 constexpr size_t kOffFlags = 0, kOffBest = 256, kOffDone = 768, kOffBestDone = 1280, kOffCensus = 1792, kOffStats = 1808, kCtlBytes = 2336;
 constexpr size_t kHostOffFlags = 0, kHostOffBest = 256, kHostOffDone = 768, kHostOffCensus = 1280, kHostOffStats = 1296;
 static_assert(kOffStats + kCensusStatBytes <= kCtlBytes && kCtlBytes <= kBlockNeedleOff && kHostOffStats + kCensusStatBytes <= kBlockHostBytes,

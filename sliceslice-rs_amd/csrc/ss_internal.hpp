@@ -126,6 +126,7 @@ struct PerDevice {
         int stats_roles = -1;
         uint16_t pair_match[64] = {0}, triple_match[64] = {0};
         uint32_t pair_lanes = 0, triple_lanes = 0;
+        uint32_t deep_lanes = 0;    // of cur[]: sampled candidates that only the compare in memory can tell from a match (aux_kernels.hpp)
         // ... and the second level's schedule ordered by it (enqueue_scan takes it instead of the static rarity order)
         bool have_order = false;
         uint32_t norder = 0;

@@ -127,7 +127,7 @@ HOOKS_ABI = {
 class TuningState(ctypes.Structure):
     """ss_tuning_state (include/sliceslice_hip.h): every launch-tuning state a handle holds for one haystack."""
     _fields_ = [(k, ctypes.c_uint32) for k in ("autotune", "census_state", "census_age", "tiles", "tiles3", "tiles2", "match_tiles", "lanes",
-                                               "pair_lanes", "triple_lanes", "triple_state", "on_trial", "trials", "accepted", "settled", "proposal")] + \
+                                               "pair_lanes", "triple_lanes", "deep_lanes", "triple_state", "on_trial", "trials", "accepted", "settled", "proposal")] + \
                [("own", ctypes.c_uint32 * 3), ("in_force", ctypes.c_uint32 * 3), ("order_measured", ctypes.c_uint32), ("norder", ctypes.c_uint32),
                 ("order", ctypes.c_uint8 * 16), ("histogram_state", ctypes.c_uint32), ("workgroups_per_cu", ctypes.c_uint32),
                 ("grid", ctypes.c_uint32), ("kernel_mode", ctypes.c_uint32), ("last_found", ctypes.c_uint32)]
@@ -468,13 +468,13 @@ class DynamicHipSearcher:
 
     def census_stats(self, haystack):
         """Hooks builds: the census's per-position match counts {pair_match, triple_match, pair_lanes, triple_lanes}, or None."""
-        c = (ctypes.c_uint32 * 130)()
+        c = (ctypes.c_uint32 * 131)()
         have = ctypes.c_int(0)
         self._ck(_hooks(self._L).ss_debug_census_stats(self._h, haystack.data_ptr(), haystack.numel(), c, ctypes.byref(have)))
         if not have.value:
             return None
         self.stats_roles = have.value - 1                   # the slot the pair counts were gathered for
-        return {"pair_match": list(c[:64]), "triple_match": list(c[64:128]), "pair_lanes": int(c[128]), "triple_lanes": int(c[129])}
+        return {"pair_match": list(c[:64]), "triple_match": list(c[64:128]), "pair_lanes": int(c[128]), "triple_lanes": int(c[129]), "deep_lanes": int(c[130])}
 
     def census(self, haystack):
         """Hooks builds: the candidate census of (this searcher, haystack) as a dict, or None when its counts are not in."""

@@ -171,7 +171,7 @@ def test_batch_plan_runs_equal_the_unplanned_calls(ss):
 
 def test_batch_plan_trivial_problems_positions_and_graph_replay(ss):
     """Problems without a scan (empty needle, haystack shorter than the needle, a position that breaks the with_position rules)
-    are answered from the plan on every run; and a run is one or two kernel launches with nothing allocated, so it can be captured into a
+    are answered from the plan on every run; and a run is ONE kernel launch with nothing allocated, so it can be captured into a
     hipGraph and replayed - which the unplanned call refuses (its per-stream scratch may be reallocated by a later call)."""
     hay = torch.zeros(4096, dtype=torch.uint8, device="cuda")
     hay[100:103] = torch.tensor([1, 2, 3], dtype=torch.uint8)
@@ -213,6 +213,75 @@ def test_batch_plan_trivial_problems_positions_and_graph_replay(ss):
         assert out.tolist() == [1 if rep % 2 == 0 else 0, 1, 0, -1, 0], rep
     plan.close()
     fplan.close()
+
+
+def test_plan_runs_of_many_workgroup_problems_are_one_launch_and_replay(ss):
+    """a plan run is ONE launch also where problems are scanned by several workgroups - no publish kernel behind the
+    scan.  The run's workgroups agree on a parity from the launch's dispatch identity (batched_kernels.hpp, PlanCtl): consecutive runs
+    use the two state words of a problem in turn, the slice-0 workgroup re-arms the other one and initialises the caller's output,
+    finders write the output behind the state word.  Answers - flags and leftmost offsets - through eager runs on two streams (two
+    hardware queues), hipGraph replays and back again, with the needles put in and taken out between runs; both layouts (contiguous
+    runs / round robin)."""
+    rng = np.random.default_rng(5)
+    for count, each in ((96, 1 << 20), (24, 8 << 20)):
+        hay = torch.empty(count * each, dtype=torch.uint8, device="cuda")
+        ss.fill_random_device(hay, 0xB0B + count)
+        nd = np.frombuffer(bytes(ss.fill_random_host(16 * count, 0xD1CE + count).tobytes()), dtype=np.uint8).copy()
+        nd[8::16] = 0xFF                                     # absent until planted: 0xFF never occurs in the haystack
+        needles = torch.from_numpy(nd).cuda()
+        hoff = (torch.arange(count + 1, dtype=torch.int64) * each).cuda()
+        noff = (torch.arange(count + 1, dtype=torch.int64) * 16).cuda()
+        where = [int(rng.integers(0, each - 16)) if i % 3 else (0 if i % 2 else each - 16) for i in range(count)]
+        idx = (torch.arange(count, device="cuda", dtype=torch.int64) * each + torch.tensor(where, device="cuda", dtype=torch.int64))[:, None] + \
+            torch.arange(16, device="cuda", dtype=torch.int64)[None, :]
+        saved = hay[idx.reshape(-1)].clone()
+        plans = {False: ss.BatchPlan(hay, hoff, needles, noff), True: ss.BatchPlan(hay, hoff, needles, noff, find=True)}
+        outs = {False: torch.full((count,), 7, dtype=torch.int32, device="cuda"), True: torch.full((count,), 7, dtype=torch.int64, device="cuda")}
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        graphs = {}
+        for find, plan in plans.items():
+            with torch.cuda.stream(streams[0]):
+                plan.run(outs[find], stream=streams[0].cuda_stream)
+            streams[0].synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=streams[0]):
+                plan.run(outs[find], stream=torch.cuda.current_stream().cuda_stream)
+                plan.run(outs[find], stream=torch.cuda.current_stream().cuda_stream)       # two runs per replay: the parity flips inside the graph too
+            graphs[find] = g
+        present = np.zeros(count, dtype=bool)
+        for rnd in range(10):
+            flip = rng.random(count) < (0.5 if rnd else 1.0)    # first round: every needle goes in
+            present ^= flip
+            hay[idx.reshape(-1)] = saved
+            sel = torch.from_numpy(np.nonzero(present)[0]).cuda()
+            if sel.numel():
+                hay[idx[sel].reshape(-1)] = needles.reshape(count, 16)[sel].reshape(-1)
+            torch.cuda.synchronize()
+            want_flag = [1 if p else 0 for p in present]
+            want_at = [where[i] if present[i] else -1 for i in range(count)]
+            for find, plan in plans.items():
+                out = outs[find]
+                how = rnd % 4
+                out.fill_(5)
+                torch.cuda.synchronize()
+                if how == 0:
+                    plan.run(out)
+                elif how == 1:
+                    with torch.cuda.stream(streams[1]):
+                        plan.run(out, stream=streams[1].cuda_stream)
+                    streams[1].synchronize()
+                elif how == 2:
+                    graphs[find].replay()
+                else:
+                    with torch.cuda.stream(streams[0]):
+                        plan.run(out, stream=streams[0].cuda_stream)
+                        plan.run(out, stream=streams[0].cuda_stream)
+                    streams[0].synchronize()
+                torch.cuda.synchronize()
+                assert out.tolist() == (want_at if find else want_flag), (count, each, rnd, how, find)
+        for plan in plans.values():
+            plan.close()
+        del hay
 
 
 def _non_latin(n_bytes, seed):
@@ -398,8 +467,8 @@ def test_batch_plan_filter_bytes_follow_the_haystacks_histogram(ss):
 
 def test_plans_of_long_problems_change_their_layout_with_what_the_last_run_found(ss):
     """A plan of LONG problems holds two layouts: round robin (side by side through each haystack: the fastest full scan) and eight
-    contiguous runs per problem (later runs of a found problem leave at once).  The publish kernel tallies the problems a run found;
-    a later run takes the contiguous runs when at least an eighth were found.  Answers are the same through every switch, for flags
+    contiguous runs per problem (later runs of a found problem leave at once).  A run tallies the problems it found; a later run
+    takes the contiguous runs when at least an eighth were found.  Answers are the same through every switch, for flags
     and offsets, with the needles present, removed and put back."""
     count, each = 160, 2 << 20
     hay = torch.empty(count * each, dtype=torch.uint8, device="cuda")
@@ -420,13 +489,18 @@ def test_plans_of_long_problems_change_their_layout_with_what_the_last_run_found
             lay = plan.layout()
             assert lay["two"] and lay["slices"][0] > 8 and 1 < lay["slices"][1] <= 8 and not lay["next_is_second"], lay
             expect = want if find else [1] * count
-            for run in range(3):
+            # (round 6: a run is ONE launch - the first finder of every problem counts it into the run's tally, and the first workgroup
+            # of the NEXT run hands that count to the host: what a run found is known to the host one run later)
+            for run in range(4):
                 assert plan.run().tolist() == expect, (find, run)
                 torch.cuda.synchronize()
                 lay = plan.layout()
-                assert lay["found_last"] == count and lay["next_is_second"], (run, lay)
-            # the needles leave their haystacks (one byte of each occurrence changed): the next run - contiguous runs - finds nothing,
-            # the one after it goes round robin again
+                if run == 0:
+                    assert lay["found_last"] == 0 and not lay["next_is_second"], (run, lay)
+                else:
+                    assert lay["found_last"] == count and lay["next_is_second"], (run, lay)
+            # the needles leave their haystacks (one byte of each occurrence changed): the next runs - contiguous runs - find nothing,
+            # and once the host has heard of it the plan goes round robin again
             saved = hay[idx[:, 0]].clone()
             hay[idx[:, 0]] ^= 0x5A
             torch.cuda.synchronize()
@@ -435,11 +509,15 @@ def test_plans_of_long_problems_change_their_layout_with_what_the_last_run_found
             expect2 = want2 if find else [1 if w >= 0 else 0 for w in want2]
             assert plan.run().tolist() == expect2
             torch.cuda.synchronize()
+            assert plan.layout()["next_is_second"]                  # (the tally at hand is still the run before's)
+            assert plan.run().tolist() == expect2
+            torch.cuda.synchronize()
             lay = plan.layout()
             assert lay["found_last"] == sum(w >= 0 for w in want2) and not lay["next_is_second"], lay
             assert plan.run().tolist() == expect2
             hay[idx[:, 0]] = saved
             torch.cuda.synchronize()
+            assert plan.run().tolist() == expect
             assert plan.run().tolist() == expect
             torch.cuda.synchronize()
             assert plan.layout()["next_is_second"]

@@ -72,6 +72,15 @@ for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
            "filter_bytes": line.get("filter_bytes"), "processes": len(proc), "process_medians_ms": [round(x / 1e6, 4) for x in proc],
            "frac_min_max_over_processes": [round(alg / max(proc) / 8000, 4), round(alg / min(proc) / 8000, 4)],
            "workgroups_per_cu": line.get("workgroups_per_cu"), "census": line.get("census")}
+    # the second clock: hipEvents around the same launches in a process WITHOUT the profiler (what a caller's own timing sees)
+    np_log = os.path.join(src, f"{tag}_{case}_noprof.log")
+    if os.path.exists(np_log):
+        for l in open(np_log, errors="replace"):
+            if l.startswith('{"case"'):
+                j = json.loads(l)
+                row["hipevent_no_profiler_ms"] = j["ms"]
+                row["frac_by_hipevents_no_profiler"] = round(alg / (j["ms"] * 1e6) / 8000, 4)
+                row["workgroups_per_cu_no_profiler"] = j.get("workgroups_per_cu")
     pmc = os.path.join(src, f"{tag}_{case}_pmc", "r_counter_collection.csv")
     if os.path.exists(pmc):
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(pmc)) if want in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
@@ -104,13 +113,16 @@ for kt in sorted(glob.glob(os.path.join(src, f"{tag}_*_kt"))):
 json.dump(rows, open(os.path.join(dst, "kernels.json"), "w"), indent=1)
 with open(os.path.join(dst, "kernels.md"), "w") as fh:
     fh.write("Three processes per case; ms = median over the processes of each process's median over its 24 measured launches; "
-             "`frac` the same, with the slowest and the fastest process behind it.\n\n")
-    fh.write("| case | kernel | median ms (per process) | GB/s | frac of 8 TB/s (min - max over the processes) | fetched / algorithmic | VGPRs allocated (waves per SIMD) | workgroups per CU | VALU / SALU / LDS / VMEM per KiB | wait |\n|---|---|---|---|---|---|---|---|---|---|\n")
+             "`frac` the same, with the slowest and the fastest process behind it.  TWO clocks: rocprofv3's kernel durations (kernel-trace: "
+             "begin to end of the dispatch), and hipEvents on the launch stream around the same launches in a process WITHOUT the profiler - "
+             "what a caller's own timing sees (bench.py's `configs.*` rows are that clock).\n\n")
+    fh.write("| case | kernel | median ms (per process) | GB/s | frac of 8 TB/s (min - max over the processes) | hipEvents, no profiler: ms / frac | fetched / algorithmic | VGPRs allocated (waves per SIMD) | workgroups per CU | VALU / SALU / LDS / VMEM per KiB | wait |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
         sqk = r.get("sq_per_kib", {})
-        fh.write("| %s | `%s` | %.4f (%s) | %.0f | %.3f (%.3f - %.3f) | %s | %s | %s | %s / %s / %s / %s | %s |\n" % (
+        fh.write("| %s | `%s` | %.4f (%s) | %.0f | %.3f (%.3f - %.3f) | %s / %s | %s | %s | %s | %s / %s / %s / %s | %s |\n" % (
             r["case"], r["kernel"].replace("void ", "")[:70], r["rocprof_median_ms"], ", ".join("%.4f" % x for x in r["process_medians_ms"]), r["gbps"], r["frac_of_8tbps"],
             r["frac_min_max_over_processes"][0], r["frac_min_max_over_processes"][1],
+            r.get("hipevent_no_profiler_ms", "-"), r.get("frac_by_hipevents_no_profiler", "-"),
             r.get("fetched_over_algorithmic", "-"), "%s (%s)" % (r.get("vgpr", "-"), r.get("waves_per_simd", "-")), r.get("workgroups_per_cu") or "-",
             sqk.get("valu", "-"), sqk.get("salu", "-"), sqk.get("lds", "-"),
             sqk.get("vmem_rd", "-"), r.get("wait_fraction", "-")))

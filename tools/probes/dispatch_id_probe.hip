@@ -17,7 +17,7 @@ __global__ void probe(Seen *out)
 {
     const unsigned long long id = ss_dispatch_id();
     const uint64_t *q = (const uint64_t *)__builtin_amdgcn_queue_ptr();
-    const unsigned long long qid = q[5];            // hsa_queue_t::id
+    const unsigned long long qid = q[4];            // hsa_queue_t::id (byte 32: type u32, features u32, base_address, doorbell_signal, size u32, reserved u32, id)
     if (threadIdx.x == 0) {
         atomicMin(&out->id_min, id);
         atomicMax(&out->id_max, id);

@@ -25,6 +25,9 @@ the kernel family expected, the algorithmic bytes per launch and the kernel time
           text_spaces  ' the quick brown fox ' with the reference's pair (' ', ' '), set verbatim
           text_spaces_new   the same needle through new(): filter bytes 'q', 'x', 'k'
           text_common_new   'there is not another one of these' through new(): common letters only
+          <case>_static     any of the above with launch tuning OFF (ss_set_autotune(0)): the constructors' static bytes, the static
+                            schedule order, the needle-byte guess for workgroups per CU - e.g. text_refpair_static keeps the caller's
+                            pair in the cross-lane kernels, where text_refpair (tuning on) runs its near form in the single-stream ones
 """
 import json
 import os
@@ -49,6 +52,10 @@ def absent(n, seed=SEED_NEEDLE):
 def main():
     case = sys.argv[1]
     launches = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    static = case.endswith("_static")
+    if static:
+        case = case[:-len("_static")]
+        ss.set_autotune(False)
 
     def spin(fn):
         t_end = time.perf_counter() + 0.05
@@ -56,7 +63,7 @@ def main():
             fn()
         torch.cuda.synchronize()
     n_bytes = 1 << 30
-    out = {"case": case, "launches": launches}
+    out = {"case": case + ("_static" if static else ""), "launches": launches, "autotune": not static}
     if case.startswith("text"):
         raw = np.frombuffer(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "data", "i386.txt"), "rb").read(), dtype=np.uint8)
         hay = torch.from_numpy(raw.copy()).cuda().repeat(n_bytes // raw.size)
@@ -131,6 +138,8 @@ def main():
         assert r in (False, None), r
         out.update(kernel="scan_kernel", filter_bytes=list(s.filter3), ms=round(float(np.median(ms)), 4), ms_min=round(float(np.min(ms)), 4))
         out["workgroups_per_cu"], out["grid"] = s.last_launch()
+        st = s.tuning_state(hay)
+        out["tuning"] = {k: st[k] for k in ("census_state", "tiles3", "lanes", "deep_lanes", "triple_state", "in_force", "own", "order_measured", "kernel_mode", "settled")}
         if ss.lib().has_hooks:
             out["census"] = s.census(hay)
     out["gbps"] = round(hay.numel() / out["ms"] / 1e6, 1)
