@@ -417,10 +417,11 @@ struct ColdInCall {
         return f;
     }
 };
-struct ColdInPlan {
+template <bool MULTI>
+struct ColdInPlanT {
     static constexpr bool kHasOrder = true;
     static constexpr bool kMaybeOrder = false;
-    static constexpr bool kSingleLaunchPlan = true;   // scan_tiles: state word first, the caller's output behind it, the tally
+    static constexpr bool kSingleLaunchPlan = MULTI;  // scan_tiles: state word first, the caller's output behind it, the tally
     const BatchDesc *dp;
     const BatchCold *cp;
     const uint8_t *needles;
@@ -441,8 +442,8 @@ struct ColdInPlan {
         f.order_idx[0] = c->order_idx[0]; f.order_idx[1] = c->order_idx[1];
         f.order_val[0] = c->order_val[0]; f.order_val[1] = c->order_val[1];
         f.tail16[0] = c->tail16[0]; f.tail16[1] = c->tail16[1]; f.tail16[2] = c->tail16[2]; f.tail16[3] = c->tail16[3];
-        f.host_flag = static_cast<int *>(out_word);
-        f.tally = tally;
+        f.host_flag = MULTI ? static_cast<int *>(out_word) : nullptr;
+        f.tally = MULTI ? tally : nullptr;
         f.far_off = 0;
         f.ready = 1;
         return f;
@@ -582,7 +583,7 @@ __global__ void __launch_bounds__(kBlock) batch_cold_kernel(const BatchArgs a, c
 //   * a problem has TWO state words, one per parity.  The waves of a run poll and raise word[parity]; the workgroup of slice 0 puts
 //     word[parity ^ 1] back to idle - nobody looks at it in this run - for the run after.
 //   * the caller's output: the slice-0 workgroup stores the idle value at its entry; a wave that finds the needle raises the state
-//     word FIRST and writes the output behind it; the slice-0 workgroup re-reads the state word at its own end (behind a fence:
+//     word FIRST and writes the output behind it; the slice-0 workgroup re-reads the state word at its own end (behind a wait:
 //     its store has been performed) and writes the output again if it is set.  Either a finder's state update is seen by that
 //     re-read, or it came later - then so did its output store, behind the idle value.  FIND: the same with minima.
 //   * the tally of found problems (plans with two layouts): the first finder of a problem adds one to tally[parity]; workgroup 0 of
@@ -593,28 +594,37 @@ struct __attribute__((aligned(64))) PlanCtl {
     uint32_t pad[12];
 };
 static_assert(sizeof(PlanCtl) == 64, "a line of its own");
-struct __attribute__((aligned(64))) PlanState {
-    uint64_t word[2];                               // by parity.  bool plans: 0 / 1; find plans: the leftmost offset so far (idle: all ones)
-    uint64_t pad[6];
+struct __attribute__((aligned(128))) PlanState {
+    // by parity, each word in a 64-byte half of its own: the word of THIS run is polled by every wave of the problem once per tile,
+    // and the other one is written (re-armed) during the run - in the polled line that store cost round-robin plans 10 %
+    // (profiles/r06/ab_plan_one_launch_parts.jsonl).  bool plans: 0 / 1; find plans: the leftmost offset so far (idle: all ones)
+    struct __attribute__((aligned(64))) Half {
+        uint64_t word;
+        uint64_t pad[7];
+    } half[2];
 };
-static_assert(sizeof(PlanState) == 64, "a problem's state: half a cache line of its own");
+static_assert(sizeof(PlanState) == 128, "a problem's state: a cache line of its own, one half per run parity");
 extern "C" __device__ unsigned long long ss_llvm_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");
 __device__ __forceinline__ unsigned long long plan_run_identity()
 {
-    // 20 bits that tell the queue - hsa_queue_t::id (byte 32 of the queue structure: "unique over the lifetime of the application")
-    // plus the structure's own page number, so that two live queues differ even where the runtime hands out equal ids - | 43 bits of
-    // the packet's index in that queue.  (profiles/r06/dispatch_id_probe.json: one value per launch, a new one per launch and per
-    // hipGraph replay; every stream its own queue structure.)
-    typedef const uint64_t __attribute__((address_space(4))) *QueuePtr;          // (constant address space: scalar loads)
-    const QueuePtr q = (QueuePtr)__builtin_amdgcn_queue_ptr();
-    const uint64_t queue = q[4] + ((uint64_t)(uintptr_t)__builtin_amdgcn_queue_ptr() >> 12);
-    return ((queue & 0xFFFFFull) << 43) | (ss_llvm_dispatch_id() & ((1ull << 43) - 1ull));
+    // 27 bits that tell the queue - the page number of its hsa_queue_t, an SGPR pair the hardware hands every wave: two live queues
+    // never share it (the structures are pages apart; the bits compared cover 512 GiB of address space) - | 36 bits of the packet's
+    // index in that queue.  NOTHING is read from the queue structure itself: it lives in host memory, and a first cut that loaded
+    // hsa_queue_t::id from it paid a PCIe round trip at every workgroup's entry (1,024 x 1 MiB: 0.221 ms a run instead of 0.157;
+    // profiles/r06/ab_plan_one_launch_queue_struct_read.jsonl).  (profiles/r06/dispatch_id_probe.json: one dispatch id per launch, a new
+    // one per launch and per hipGraph replay; every stream its own queue structure.)
+    const uint64_t queue = (uint64_t)(uintptr_t)__builtin_amdgcn_queue_ptr() >> 12;
+    return ((queue & 0x7FFFFFFull) << 36) | (ss_llvm_dispatch_id() & ((1ull << 36) - 1ull));
 }
 
 #ifndef SS_BATCH_WAVES_MAX
 #define SS_BATCH_WAVES_MAX 4
 #endif
-template <int U, bool FIND = false, bool PLAN = false>
+// MULTI (plans only): some problem of the plan is scanned by several workgroups - the run needs its parity, the state words, the
+// slice-0 duties.  A plan whose every problem is scanned by ONE workgroup (16,384 x 64 KiB; the short cuts of config 5) launches the
+// MULTI = false instantiation, which holds none of it: such problems publish from LDS, and the entry of their short-lived
+// workgroups is what it was before (3-6 % on those shapes: profiles/r06/ab_plan_one_launch.jsonl).
+template <int U, bool FIND = false, bool PLAN = false, bool MULTI = PLAN>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, SS_BATCH_WAVES_MAX))) __launch_bounds__(kBlock)
 scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs, uint32_t count, uint32_t nslices, BatchCold *colds,
                          PlanCtl *ctl, PlanState *states, unsigned long long *h_tally, uint32_t run)
@@ -643,10 +653,10 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     // together with the descriptor (one scalar load, s_load_dwordx16) - one round trip decides whether and what to scan
     const bool peek = !FIND && slice_major && slice != 0;
     int seen0 = 0, seen1 = 0;
-    if (PLAN) {
+    if (MULTI) {
         if (peek) {
-            seen0 = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].word[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seen1 = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].word[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen0 = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].half[0].word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen1 = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].half[1].word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else if (peek) {
         seen0 = __hip_atomic_load(reinterpret_cast<int *>(&rec->pad[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -654,7 +664,9 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     BatchDesc d = *dp;
     unsigned long long run_word = 0;
     // (issued behind the descriptor's load and waited for together with it: one scalar round trip)
-    if (PLAN) __asm__ volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(run_word) : "s"(ctl) : "memory");
+    static_assert(PLAN || !MULTI, "only plans have runs");
+    constexpr bool multi = MULTI;
+    if (multi) __asm__ volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(run_word) : "s"(ctl) : "memory");
     if (COUNTED) {
         // The hot fields are pinned in scalar registers HERE, in front of the first store of the kernel (the LDS words'
         // initial values, the control word, the trivial problem's answer below): a load the compiler sinks behind a store cannot go through the scalar cache any more, so it became a
@@ -667,7 +679,7 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
             __hip_atomic_store(&s_wg[threadIdx.x / kWave], FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     uint32_t parity = 0;
-    if (PLAN) {
+    if (multi) {
         const unsigned long long me = plan_run_identity();
         const bool mine = (run_word >> 1) == me;
         parity = mine ? (uint32_t)(run_word & 1ull) : (uint32_t)(run_word & 1ull) ^ 1u;
@@ -681,9 +693,10 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
             __hip_atomic_store(&ctl->run_word, (me << 1) | parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    const int seen = PLAN ? (parity ? seen1 : seen0) : seen0;
-    int *found = FIND ? nullptr : (PLAN ? reinterpret_cast<int *>(&states[prob].word[parity]) : reinterpret_cast<int *>(&rec->pad[1]));
-    void *sink = FIND ? (PLAN ? static_cast<void *>(&states[prob].word[parity]) : static_cast<void *>(&rec->pad[0])) : static_cast<void *>(found);
+    // (MULTI = false: every problem publishes from LDS; the word the tiles poll is the idle one in the cold record, as in the calls)
+    const int seen = MULTI ? (parity ? seen1 : seen0) : seen0;
+    int *found = FIND ? nullptr : (MULTI ? reinterpret_cast<int *>(&states[prob].half[parity].word) : reinterpret_cast<int *>(&rec->pad[1]));
+    void *sink = FIND ? (MULTI ? static_cast<void *>(&states[prob].half[parity].word) : static_cast<void *>(&rec->pad[0])) : static_cast<void *>(found);
     const uint32_t mis = d.shifts & 15;
     const uint64_t npieces = ((mis + d.end + 15) / 16 + 63) / 64;
     const uint64_t ntiles = (npieces + kWavesPerBlock * U - 1) / (kWavesPerBlock * U);
@@ -712,14 +725,15 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
     }
     work = work && t0 < te;
     if (!work) return;                              // (a plan's single-workgroup problem always has work: t0 = 0 < te)
-    const bool opener = COUNTED && eff > 1 && slice == 0 && threadIdx.x == 0;      // (slice 0 always has work: its first tile is tile 0)
+    const bool opener = MULTI && eff > 1 && slice == 0 && threadIdx.x == 0;      // (slice 0 always has work: its first tile is tile 0)
     if (opener) {
         // one lane per problem and run: the OTHER parity's state word back to idle for the run after this one (nobody looks at it in
         // this run), and the caller's output to its idle value - every finder writes the output BEHIND its update of the state word
         // that this lane re-reads at its own end (below)
-        __hip_atomic_store(&states[prob].word[parity ^ 1u], FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (FIND) __hip_atomic_store(a.best + prob, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(a.found + prob, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&states[prob].half[parity ^ 1u].word, FIND ? ~0ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (read-modify-write atomics: performed AT the device's coherence point, where the finders' atomics on the same words are)
+        if (FIND) (void)__hip_atomic_exchange(a.best + prob, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else (void)__hip_atomic_exchange(a.found + prob, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     if (work) {
@@ -744,11 +758,11 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         // -DSS_NO_PLAN_COLD, profiles/r05/ab_plan_cold.jsonl: absent needles on random bytes the same to +-1 %, every second needle
         // present 16,384 x 64 KiB 0.154 ms instead of 0.183, 65,536 x 16 KiB 0.271 instead of 0.447)
         constexpr bool READY = PLAN;
-        typename std::conditional<READY, ColdInPlan, ColdInCall>::type cold;
+        typename std::conditional<READY, ColdInPlanT<MULTI>, ColdInCall>::type cold;
         // (a plan's problem scanned by several workgroups: the finding wave writes the caller's output behind the state word)
         if constexpr (READY)
-            cold = ColdInPlan{dp, colds + prob, a.needles, eff > 1 ? (FIND ? static_cast<void *>(a.best + prob) : static_cast<void *>(a.found + prob)) : nullptr,
-                              eff > 1 && h_tally ? &ctl->tally[parity] : nullptr};
+            cold = ColdInPlanT<MULTI>{dp, colds + prob, a.needles, MULTI && eff > 1 ? (FIND ? static_cast<void *>(a.best + prob) : static_cast<void *>(a.found + prob)) : nullptr,
+                              MULTI && eff > 1 && h_tally ? &ctl->tally[parity] : nullptr};
         else cold = ColdInCall{dp, colds + prob, a.needles, FIND ? static_cast<void *>(a.best + prob) : static_cast<void *>(a.found + prob)};
         // single stream, non-temporal loads; the second byte's window is run-time data (kQDynamic)
         // (Measured and not adopted - commit 7511606 (-DSS_SIBLING_POLL), profiles/r05/ab_sibling_poll.jsonl: the waves of such a workgroup polling EACH
@@ -759,15 +773,18 @@ scan_batched_plan_kernel(const BatchArgs a, const BatchDesc *__restrict__ descs,
         else scan_tiles<kQDynamic, 0, false, U, 1, FIND, false, true>(pr, cold, s_needle, t0, step, te, sink, wg_sink);
     }
     if (opener) {
-        // ... the wave's own scan is over: the idle value has been PERFORMED by now (the fence waits for it), so a state word that is
-        // still idle here means that whoever raises it later writes the output later too
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        // ... the wave's own scan is over: the idle value has been PERFORMED by now (device-scope stores are acknowledged from the
+        // device's coherence point, and the wait below has seen the acknowledgement), so a state word that is still idle here means
+        // that whoever raises it later writes the output later too.  A WAIT, not a fence: an agent-scope fence writes back and
+        // invalidates the XCD's whole L2 - with one such workgroup per problem and run that cost a slice-major plan a third of its
+        // rate (profiles/r06/ab_plan_one_launch_with_fences.jsonl: 1,024 x 1 MiB 0.203 ms a run instead of 0.156)
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (FIND) {
-            const uint64_t v = __hip_atomic_load(&states[prob].word[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t v = __hip_atomic_load(&states[prob].half[parity].word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v != ~0ull) __hip_atomic_fetch_min(a.best + prob, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            const int v = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].word[parity]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v != 0) __hip_atomic_store(a.found + prob, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int v = __hip_atomic_load(reinterpret_cast<int *>(&states[prob].half[parity].word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0) (void)__hip_atomic_exchange(a.found + prob, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (COUNTED && eff == 1) {

@@ -507,10 +507,13 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         } else if (lane == 0 && mine < __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             if constexpr (SingleLaunchPlan<ColdT>::value) {
                                 // a plan's run: the state word FIRST (the old value tells the first finder of the problem), the
-                                // caller's output behind it - in that order, settled by the fence: the workgroup that initialises
+                                // caller's output behind it - in that order: the workgroup that initialises
                                 // the output re-reads the state word afterwards (scan_batched_plan_kernel)
                                 const uint64_t old = __hip_atomic_fetch_min(best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                                // (the atomic has RETURNED - performed at the device's coherence point - before the output is touched.
+                                // A wait, not a fence: a release / acquire fence at agent scope writes back and invalidates the whole
+                                // L2 of the XCD, which is what the ordering of two device-scope atomics does not need)
+                                __asm__ volatile("s_waitcnt vmcnt(0)" : : "v"(old) : "memory");
                                 const auto c = cold();
                                 uint64_t *out_best = reinterpret_cast<uint64_t *>(c->host_flag);
                                 if (out_best) __hip_atomic_fetch_min(out_best, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -550,10 +553,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                         if constexpr (SingleLaunchPlan<ColdT>::value) {
                             // a plan's run: the exchange has RETURNED (the state word is set) before the caller's output is
                             // written behind it; the first finder of the problem counts it into the plan's tally
-                            if (old != pr.epoch) {
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            if (old != pr.epoch) {                  // (the exchange has returned: performed at the device's coherence point)
                                 const auto c = cold();
-                                if (c->host_flag) __hip_atomic_store(c->host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (c->host_flag) (void)__hip_atomic_exchange(c->host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 if (c->tally) __hip_atomic_fetch_add(c->tally, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                         } else {

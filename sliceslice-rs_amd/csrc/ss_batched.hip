@@ -514,14 +514,18 @@ int ss_batch_plan_run(const ss_batch_plan *p, void *hip_stream, void *d_out)
     // initialised by the host, so a run can be captured into a hipGraph and replayed.
     const uint32_t run = ++p->runs == 0 ? ++p->runs : p->runs;
     unsigned long long *h_tally = p->has_alt ? p->h_tally : nullptr;
+    // (a plan whose every problem is scanned by one workgroup - one slice - launches the instantiation without the run machinery)
+    const bool multi = sh.slices > 1;
+    const dim3 block(ss::kBlock);
+    const uint32_t n = (uint32_t)p->count, pad = batch_lds_pad();
     if (p->find) {
         a.best = static_cast<uint64_t *>(d_out);
-        ss::scan_batched_plan_kernel<4, true, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds(),
-                                                                                                     p->ctl(), p->states(), h_tally, run);
+        if (multi) ss::scan_batched_plan_kernel<4, true, true, true><<<grid, block, pad, st>>>(a, descs, n, sh.slices, p->colds(), p->ctl(), p->states(), h_tally, run);
+        else ss::scan_batched_plan_kernel<4, true, true, false><<<grid, block, pad, st>>>(a, descs, n, sh.slices, p->colds(), nullptr, nullptr, nullptr, run);
     } else {
         a.found = static_cast<int *>(d_out);
-        ss::scan_batched_plan_kernel<4, false, true><<<grid, dim3(ss::kBlock), batch_lds_pad(), st>>>(a, descs, (uint32_t)p->count, sh.slices, p->colds(),
-                                                                                                      p->ctl(), p->states(), h_tally, run);
+        if (multi) ss::scan_batched_plan_kernel<4, false, true, true><<<grid, block, pad, st>>>(a, descs, n, sh.slices, p->colds(), p->ctl(), p->states(), h_tally, run);
+        else ss::scan_batched_plan_kernel<4, false, true, false><<<grid, block, pad, st>>>(a, descs, n, sh.slices, p->colds(), nullptr, nullptr, nullptr, run);
     }
     HIP_TRY(hipGetLastError());
     return SS_OK;

@@ -43,6 +43,7 @@ namespace {
 // 70, 10-30 % from 150 on - and in between the two are within 3 % of each other; any threshold from 40 to 56 loses 0.3 % on average
 // over the set against always picking the faster one (four everywhere: 7 %, six everywhere: 3 %).
 constexpr uint32_t kCensusDenseTiles = 48, kCensusDenseLanes = 256;
+constexpr uint32_t kCensusVeryDenseTiles = 224, kCensusVeryDenseLanes = 1024;     // six workgroups per CU from here (five in between)
 // Filter pairs 16 or more apart (ss_searcher_set_filter3 only; the cross-lane kernels): the third first-phase byte pays on text,
 // where the reference's own pair (0, n-1) passes at percent rates, and costs where the pair alone rarely matches (random bytes:
 // equal at 1 GiB, 5-6 % at 8 GiB; profiles/r05/mode3_probe.jsonl).  The pair runs alone (MODE 3) when at most this many of the
@@ -69,7 +70,7 @@ constexpr uint32_t kNearFormSlackTiles = 64;
 // dependent round trip with the workgroup's slot held - counting as kDeepWeight of them.  (profiles/r06/survival_probe_v2.jsonl: the
 // i386 phrase through with_position(n-1) lost 3 % to a third byte with a quarter of the candidates, every one of them deep.)
 constexpr uint32_t kDeepWeight = 8;
-constexpr uint32_t kCensusDeepLanes = 24;          // six workgroups per CU from this many deep candidates in the sample
+constexpr uint32_t kCensusDeepLanes = 24;          // five workgroups per CU from this many deep candidates in the sample
 constexpr uint32_t kDescentMaxRounds = 12;         // censuses a (searcher, haystack) pair may spend on improving its bytes, per 256 scans
 constexpr uint32_t kOrderMinLanes = 4;             // triple candidates in the sample below which the static schedule order stays
 static_assert(ss::kCensusStatWords == 2 * 64 + 3 && ss::kCensusCheck == 64, "PerDevice::Census and the control blocks are laid out for 64 positions");
@@ -582,7 +583,11 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     if (c->state != 2) return;                          // the first census is in flight
     const CensusCounts cc = census_counts(c->sums);
     out->have_counts = true;
-    out->workgroups_per_cu = cc.match_tiles != 0 ? 4 : (cc.tiles3 >= kCensusDenseTiles || cc.lanes >= kCensusDenseLanes || c->deep_lanes >= kCensusDeepLanes ? 6 : 4);
+    // four / five / six (round 6: profiles/r06/wg_probe.jsonl - pinned triples of 0 to 250 candidate tiles under forced shapes: four is
+    // best up to ~45 candidate tiles in 1,024, FIVE from there to ~210 (3-5 % over six, 4-12 % over four), six beyond)
+    out->workgroups_per_cu = cc.match_tiles != 0 ? 4
+                             : (cc.tiles3 >= kCensusVeryDenseTiles || cc.lanes >= kCensusVeryDenseLanes ? 6
+                                : (cc.tiles3 >= kCensusDenseTiles || cc.lanes >= kCensusDenseLanes || c->deep_lanes >= kCensusDeepLanes ? 5 : 4));
     out->sparse_pair = cc.tiles2 <= kCensusSparsePairTiles;
     // A buffer may be refilled in place: everything is looked at again every kCensusRefreshEvery scans, starting from the bytes in
     // force (the old counts serve until the new ones are in).

@@ -29,4 +29,6 @@ SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/mode3_probe.py --
 SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/triple_probe.py > $X/triple_probe.jsonl 2>/dev/null
 SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/batch_triple_probe.py > $X/batch_triple_probe.jsonl 2>/dev/null
 SLICESLICE_RCCL_LIB=$R/tests/native/libfake_rccl.so tools/native_bench set 8 8 200 2>/dev/null | grep '^{' > $X/native_set8.json
+SLICESLICE_HIP_LIB=$L/libsliceslice_hip_tuning.so python tools/survival_probe.py > $X/survival_probe.jsonl 2>/dev/null
+SLICESLICE_AUTOTUNE=0 python $R/bench.py --haystack-gib 8 --no-cpu-baseline --no-traffic > $X/bench8g_autotune_off.json 2> $X/bench8g_autotune_off.err
 tail -3 $X/capture.log
