@@ -314,7 +314,7 @@ def _family(name):
 def test_kernels_the_library_launches_by_default_keep_four_waves_per_simd():
     """build() records what the register allocator did with every kernel (csrc/kernel_resources.json).  The product library
     holds exactly what the constructors and ss_searcher_set_filter3 can select - 22 scan kernels (scan_launch.hpp::kernel_built),
-    37 kernels in all; the tuning residue (U = 8, plain loads, two-byte 8-byte phases) lives in the tuning build, and the
+    37 kernels in all (round 6: minus the service and publish kernels, plus the plan kernels' single-workgroup instantiations); the tuning residue (U = 8, plain loads, two-byte 8-byte phases) lives in the tuning build, and the
     two-stream kernels of rounds 1-3 (MODE 1) are gone.  Every one of them keeps >= 4 waves per SIMD, without scratch and without
     spilled vector registers - which side of a register-count step a kernel lands on has moved with unrelated edits before (at
     three waves the scan runs at 6.3 TB/s) - and within its family's ceiling of spilled scalar registers."""
@@ -322,8 +322,11 @@ def test_kernels_the_library_launches_by_default_keep_four_waves_per_simd():
     rows = build.kernel_resources()
     names = [r["name"] for r in rows]
     assert len(rows) <= 37, len(rows)
-    assert any("scan_batched_plan_kernel<4, false, false>" in n for n in names) and any("scan_pairs_kernel" in n for n in names)
-    assert any("scan_batched_plan_kernel<4, false, true>" in n for n in names)          # the plan-run form
+    assert any("scan_batched_plan_kernel<4, false, false, false>" in n for n in names) and any("scan_pairs_kernel" in n for n in names)
+    # the plan-run forms: with the run machinery (problems scanned by several workgroups) and without (every problem one workgroup);
+    # a run is ONE launch - no publish kernel, and no service kernel in the product
+    assert any("scan_batched_plan_kernel<4, false, true, true>" in n for n in names) and any("scan_batched_plan_kernel<4, false, true, false>" in n for n in names)
+    assert not any("publish_kernel" in n or "service_kernel" in n for n in names)
     scans = set()
     for r in rows:
         m = re.match(r"void ss::scan_kernel<(\d), (\d), (true|false), (\d), (\d), (true|false), (true|false)>", r["name"])
