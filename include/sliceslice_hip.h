@@ -29,15 +29,17 @@
  * immutable after construction (ss_searcher_set_filter3 aside, which is refused
  * while a search runs); any number of threads may call ss_search_* on one handle
  * concurrently (each call uses its own flag slot).  What a handle does carry as
- * mutable state, per device, is LAUNCH TUNING for scans of 256 MiB and more: the
- * candidate census of the haystacks it has been used on and whether its latest
- * synchronous search found the needle decide between four and six workgroups per
- * CU (ss_searcher_last_launch reports the choice), and for searchers built by
- * ss_searcher_new - whose caller chose no filter bytes - a sampled byte histogram
- * of the haystack may replace the three filter bytes FOR THAT HAYSTACK by rarer
- * bytes of the needle (ss_searcher_filter3 keeps reporting the searcher's own).
- * No result depends on any of it; for a given haystack and needle the choices are
- * the same from the third scan on.
+ * mutable state, per device, is LAUNCH TUNING for scans of 256 MiB and more: a
+ * candidate census of the haystacks it has been used on - candidate counts, and
+ * per needle position how many of the sampled candidates match there - decides
+ * between four, five and six workgroups per CU (ss_searcher_last_launch reports
+ * the choice), orders the second level's schedule, and moves the first-phase
+ * bytes THE LIBRARY owns (all three for ss_searcher_new, never a caller's) to
+ * positions that let fewer candidates through, FOR THAT HAYSTACK
+ * (ss_searcher_filter3 keeps reporting the searcher's own).  No result depends on
+ * any of it; for a given haystack and needle the choices are the same once the
+ * handle has settled (a dozen scans at most).  See "launch tuning" below:
+ * ss_searcher_tuning_state reports all of it, ss_set_autotune(0) switches it off.
  * A call synchronises only the stream it was given.
  *
  * No CPU fallback exists: every ss_search_* that has to look at haystack bytes
@@ -48,6 +50,7 @@
  *     SLICESLICE_NO_BAR_WRITES=1  never write device memory from the CPU (control blocks go by hipMemcpy; no service, no relay)
  *     SLICESLICE_RCCL_LIB=<path>  the RCCL library to dlopen instead of librccl.so.1 / librccl.so
  *     SLICESLICE_SET_THREADS=0    communicator sets issue their per-device work from the calling thread (SS_ISSUE_SERIAL)
+ *     SLICESLICE_AUTOTUNE=0       launch tuning off (the initial value of ss_set_autotune): static choices, no sampling kernels
  */
 #ifndef SLICESLICE_HIP_H
 #define SLICESLICE_HIP_H
@@ -242,7 +245,7 @@ SS_API int ss_search_pairs(const void *d_haystacks, const uint64_t *d_hay_begin,
  * (milliseconds) - what a roofline figure for the scan kernel is computed from (bench.py). */
 SS_API int ss_searcher_set_timing(ss_searcher *s, int enabled);
 SS_API int ss_searcher_last_kernel_ms(const ss_searcher *s, float *ms);
-/* Launch shape of the latest scan enqueued through `s` on the current device: workgroups per CU (4 or 6: see "Threading" above)
+/* Launch shape of the latest scan enqueued through `s` on the current device: workgroups per CU (4, 5 or 6: see "Threading" above)
  * and workgroups in the grid.  Read-only diagnostics - what a benchmark line reports next to its kernel times. */
 SS_API int ss_searcher_last_launch(const ss_searcher *s, int *workgroups_per_cu, unsigned *grid);
 
@@ -323,7 +326,7 @@ SS_API int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards
  * handle learns about the haystacks it meets only moves necessary conditions around and picks launch shapes:
  *   - per (searcher, device, haystack >= 256 MiB): a candidate census of 1,024 sampled 4 KiB tiles, taken by a small kernel in
  *     front of the first scan (and every 256th after it) on the scan's own stream, never waited for: workgroups per CU (four /
- *     six), the cross-lane kernels with or without a third byte, the THIRD first-phase byte where the library owns it and the near
+ *     five / six), the cross-lane kernels with or without a third byte, the THIRD first-phase byte where the library owns it and the near
  *     bytes that stand in for a far pair (by the measured number of candidates each position lets through, on trial against the
  *     next census), and the ORDER of the second level's schedule (the needle byte that kills most of the sampled candidates
  *     first);

@@ -606,7 +606,9 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     size_t prop[3];
     uint32_t kind = 0;
     // (1) searchers built by ss_searcher_new: the triple the haystack's HISTOGRAM suggests, once, when it promises 16 x fewer candidates
-    if (s->auto_filter && s->n >= 3 && !c->hist_tried && !c->adopted) {
+    //     (... and the bytes in force meet candidates at all: a filter that never fires has nothing to gain - on random bytes the
+    //     histogram would otherwise trade the searcher's triple for one with a byte that does not occur, to no effect)
+    if (s->auto_filter && s->n >= 3 && !c->hist_tried && !c->adopted && cc.tiles3 != 0) {
         uint64_t hist[256];
         if (stats_lookup(pd->dev, d_hay, len, st, hist)) {
             c->hist_tried = true;
