@@ -70,6 +70,9 @@ SS_API int ss_debug_set_epochs(ss_searcher *s, int value);
  * the needle (wraps at 2^32) and the decreasing key of find()'s minimum (starts over at 0). */
 SS_API int ss_debug_set_completion_state(ss_searcher *s, uint32_t workgroups, uint32_t found_workgroups, uint32_t find_key);
 SS_API int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value);
+/* How many sharded searches of this process got their answer words only after the spin on them had run out of its budget (a
+ * collective that took longer than the scan's estimate: the stream wait / drain-and-re-read path). */
+SS_API uint64_t ss_debug_late_answers(void);
 /* ... and make the next `count` scans launched through `s` fail before they reach the device (SS_ERR_HIP): how the tests
  * check that a rank-local failure leaves no other rank waiting in the collective of ss_search_sharded / ss_find_sharded. */
 SS_API int ss_debug_fail_next_scans(ss_searcher *s, int count);

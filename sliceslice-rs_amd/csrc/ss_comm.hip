@@ -469,6 +469,13 @@ int ss_debug_set_comm_epoch(ss_comm *c, ss_comm_set *set, int value)
     if (set) set->epoch = value;
     return SS_OK;
 }
+// how many searches of this process collected their answer words only AFTER the spin had run out of its budget (the drain-and-
+// re-read path of ss_search_sharded_all / the stream wait of the pair form): what a test with a slow collective must have taken
+static std::atomic<unsigned long long> g_late_answers{0};
+uint64_t ss_debug_late_answers(void) { return (uint64_t)g_late_answers.load(std::memory_order_relaxed); }
+#define SS_COUNT_LATE_ANSWER() g_late_answers.fetch_add(1, std::memory_order_relaxed)
+#else
+#define SS_COUNT_LATE_ANSWER() ((void)0)
 #endif
 
 // Which collective library the communicators of this process are made of: the file the resolved ncclAllReduce lives in (dladdr) and
@@ -544,6 +551,7 @@ int ss_search_sharded(const ss_searcher *s, const void *d_shard, size_t shard_le
             if ((epoch & 255) == 0) HIP_TRY(hipStreamSynchronize(st));
             return done(failed);
         }
+        SS_COUNT_LATE_ANSWER();
         HIP_TRY(hipStreamSynchronize(st));
         if (!spin_for_shard_word(c->h_word, epoch, 0.0, found, &failed)) return fail(SS_ERR_HIP, "the answer word was not written");
         return done(failed);
@@ -982,6 +990,7 @@ int ss_search_sharded_all(const ss_searcher *s, const void *const *d_shards, con
         // The spin ran out of its budget (a first ncclAllReduce that connects lazily, a device busy with other work) and the streams
         // have been drained since: the G answer words ARE written now - every chain ends with its answer-word kernel, and only the
         // non-signal chains enqueue the read-back into h_recv.  A word that is still missing is an error, never "not found".
+        SS_COUNT_LATE_ANSWER();
         for (int g = 0; g < G; ++g) {
             const unsigned long long v = (unsigned long long)__atomic_load_n(set->h_words + g, __ATOMIC_ACQUIRE);
             if ((v >> 2) != (unsigned long long)(uint32_t)epoch)

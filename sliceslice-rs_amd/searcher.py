@@ -113,6 +113,7 @@ HOOKS_ABI = {
     "ss_debug_set_epochs": (_int, [_vp, _int]),
     "ss_debug_set_completion_state": (_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "ss_debug_set_comm_epoch": (_int, [_vp, _vp, _int]),
+    "ss_debug_late_answers": (_u64, []),
     "ss_debug_fail_next_scans": (_int, [_vp, _int]),
     "ss_debug_census": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32)]),
     "ss_debug_census_stats": (_int, [_vp, _vp, _sz, ctypes.POINTER(ctypes.c_uint32), _pint]),

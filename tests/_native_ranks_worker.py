@@ -158,9 +158,10 @@ def rank_main(rank, nranks, id_file, loops):
             saved = plant(total - n)
             assert R.search(shard) == (0, 1), it
             plant(total - n, False, saved)
+    late = int(ss.lib().ss_debug_late_answers()) if R.L.has_hooks else -1
     R.close()
-    print("rank %d of %d ok: %d spots, %d back-to-back searches at %.1f us each, %d injected failures" %
-          (rank, nranks, len(spots), loops, per_call_us, failures), flush=True)
+    print("rank %d of %d ok: %d spots, %d back-to-back searches at %.1f us each, %d injected failures, %d late answers" %
+          (rank, nranks, len(spots), loops, per_call_us, failures, late), flush=True)
 
 
 def set_main(G):
@@ -238,8 +239,9 @@ def set_main(G):
             logical[total - n:] = pn
             assert node.search_in(shards()) is True
             ss.fill_random_device(logical, SEED)
+    late = int(ss.lib().ss_debug_late_answers()) if node._L.has_hooks else -1
     node.close()
-    print("set of %d ok: %d spots per combine and issue mode" % (G, checked // 4), flush=True)
+    print("set of %d ok: %d spots per combine and issue mode, %d late answers" % (G, checked // 4, late), flush=True)
 
 
 def relay_main():

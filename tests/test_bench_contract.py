@@ -7,7 +7,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-@pytest.mark.parametrize("rnd", ["r02", "r03", "r05"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r05", "r06"])
 def test_committed_bench_line_has_the_contract_fields(rnd):
     with open(os.path.join(ROOT, "profiles", rnd, "bench64g.json")) as fh:
         d = json.loads(fh.read())
@@ -34,6 +34,17 @@ def test_committed_bench_line_has_the_contract_fields(rnd):
         rows = other["configs"]["text_non_latin"]["rows"]
         assert len(rows) == 3 and all(x["found"] is False and x["automatic"]["frac"] > 0.9 for x in rows)
         assert all(x["automatic"]["frac"] >= x["static_triple_pinned"]["frac"] for x in rows)
+    if rnd == "r06":
+        # round 6: the line as printed ends with the summary, says which way launch tuning was and what the handle had settled on,
+        # and every text row carries what the handle reports and its time with tuning off
+        assert list(d)[-1] == "configs_summary" and list(d)[-2] == "cpu_baseline" and len(json.dumps(d["configs_summary"])) <= 600
+        assert d["config"]["autotune"] == "on" and d["configs_summary"]["autotune"] == "on" and isinstance(d["config"]["tuning"], dict)
+        rows = d["configs"]["text"]["rows"]
+        assert len(rows) == 4 and all(x["found"] is False and "bytes_in_force" in x and x["autotune_off"]["found"] is False for x in rows)
+        assert all(x["frac"] >= 0.885 and x["frac"] >= x["autotune_off"]["frac"] for x in rows)
+        assert d["configs"]["1_random"]["hits"] == d["configs"]["1_random"]["hits_expected"] == 106
+        off = json.load(open(os.path.join(ROOT, "profiles", rnd, "bench8g_autotune_off.json")))
+        assert off["config"]["autotune"] == "off" and off["configs_summary"]["autotune"] == "off"
     if rnd == "r02":
         assert r["traffic_source"].startswith("stored ratio")
     else:                       # since round 3 the counter pass runs inside the bench run, and the launch time is the median

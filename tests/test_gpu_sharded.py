@@ -292,6 +292,22 @@ def test_native_collectives_survive_a_failing_rank(world, tmp_path):
     assert all("3 injected failures" in o for o in outs)
 
 
+def test_a_collective_slower_than_the_spin_budget_still_gives_the_answer(tmp_path):
+    """a sharded search whose bounded spin on the answer words runs out - a first ncclAllReduce that connects
+    lazily, a rank that arrives late - must collect the words behind the drain, not read a buffer nobody wrote.  The stand-in's every
+    third all-reduce sleeps 3 ms (the budget for these shards is ~0.5 ms): the single-process set of three devices and two
+    processes of the pair form, hooks build, every answer as without the delay - and the late path WAS taken (ss_debug_late_answers)."""
+    import re
+    env, build = _fake_env({"FAKE_RCCL_SLOW_US": "3000", "FAKE_RCCL_SLOW_EVERY": "3"})
+    env["SLICESLICE_HIP_LIB"] = build.build_tuning()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_native_ranks_worker.py"), "set", "3"], capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "set of 3 ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    assert int(re.search(r"(\d+) late answers", out.stdout).group(1)) >= 100, out.stdout[-300:]
+    outs = _run_ranks(2, 600, env, tmp_path)
+    assert all(int(re.search(r"(\d+) late answers", o).group(1)) >= 3 for o in outs), outs
+
+
 @pytest.mark.parametrize("G", [3, 8])
 def test_single_process_set_with_the_grouped_all_reduce_on_one_gpu(G):
     """ss_comm_init_all / ss_search_sharded_all / ss_find_sharded_all with G = 3 and 8 shards on one GPU: ncclCommInitAll, the G

@@ -6,7 +6,7 @@ workgroups per CU by the candidate count) next to the SAME searcher with it OFF 
 schedule, needle-byte guess) - the two taking turns in one process on one buffer, hipEvents on the launch stream - and what the
 handle reports about the haystack afterwards (ss_searcher_tuning_state).
 
-    python tools/survival_probe.py [--phrases 48] [--seed 1] [--modes new,refpair,wp]
+    python tools/survival_probe.py [--phrases 48] [--seed 1] [--modes new,refpair,wp] [--kinds text,random]
 """
 import argparse
 import json
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--phrases", type=int, default=48)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--modes", default="new,refpair,wp")
+    ap.add_argument("--kinds", default="text,random")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     nbytes = 1 << 30
@@ -95,6 +96,7 @@ def main():
     nd[8] = 0xFF
     cases += [("random", bytes(nd)), ("random", b"privilege level zero!"), ("random", b"there is not another one of these")]
     modes = args.modes.split(",")
+    cases = [c for c in cases if c[0] in args.kinds.split(",")]
     for kind, ph in cases:
         hay = text if kind == "text" else rnd
         for mode in modes:
