@@ -17,8 +17,9 @@
  *     ncclGroupStart/End (real RCCL's rule for ONE thread driving several peers) are carried out in ncclGroupEnd; issued
  *     outside a group - one THREAD per peer, real RCCL's other form - the peers meet at the segment's barrier like the
  *     ranks of separate processes.
- *   * FAKE_RCCL_SLOW_US=<us> (+ FAKE_RCCL_SLOW_EVERY=<k>, default 3): every k-th all-reduce of a thread sleeps that long before it
- *     does anything - a collective that connects lazily or meets a late rank, as seen from the caller's bounded spin.
+ *   * FAKE_RCCL_SLOW_US=<us> (+ FAKE_RCCL_SLOW_EVERY=<k>, default 3): every k-th all-reduce of a thread leaves a host function
+ *     that sleeps that long on the caller's stream behind its result - a collective kernel that connects lazily or waits for a
+ *     late rank, as seen from the caller's bounded spin on what it enqueued behind the all-reduce.
  *   * every wait is bounded (FAKE_RCCL_TIMEOUT_S, default 120 s): a rank that never arrives gives the others
  *     ncclSystemError instead of a hang.
  * Built by sliceslice_rs_amd._build.build_fake_rccl() into tests/native/libfake_rccl.so and handed to the library
@@ -286,12 +287,36 @@ static int fetch(const Pending *p, int dev, unsigned char *dst)
     return e == hipSuccess ? kOk : kHipError;
 }
 
+/* FAKE_RCCL_SLOW_US: every k-th delivery is followed, IN STREAM ORDER, by a host function that sleeps - what the caller has
+ * enqueued behind the all-reduce (the library's answer-word kernel) waits for it like for a slow collective kernel, while the call
+ * itself has long returned (as real RCCL's does). */
+static void slow_host_fn(void *arg)
+{
+    const long us = (long)(intptr_t)arg;
+    struct timespec ts = {us / 1000000, (us % 1000000) * 1000};
+    nanosleep(&ts, NULL);
+}
+
+static void maybe_slow(hipStream_t stream)
+{
+    static _Thread_local unsigned calls = 0;
+    static atomic_int slow_us = -1, every = 3;
+    if (atomic_load(&slow_us) < 0) {
+        const char *e = getenv("FAKE_RCCL_SLOW_US"), *k = getenv("FAKE_RCCL_SLOW_EVERY");
+        atomic_store(&every, k && atoi(k) > 0 ? atoi(k) : 3);
+        atomic_store(&slow_us, e ? atoi(e) : 0);
+    }
+    const int us = atomic_load(&slow_us);
+    if (us > 0 && ++calls % (unsigned)atomic_load(&every) == 0) (void)hipLaunchHostFunc(stream, slow_host_fn, (void *)(intptr_t)us);
+}
+
 static int deliver(const Pending *p, int dev, const unsigned char *src)
 {
     int cur = -1;
     (void)hipGetDevice(&cur);
     hipError_t e = hipSetDevice(dev);
     if (e == hipSuccess) e = hipMemcpy(p->recv, src, p->bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) maybe_slow(p->stream);
     if (cur >= 0) (void)hipSetDevice(cur);
     return e == hipSuccess ? kOk : kHipError;
 }
@@ -331,25 +356,9 @@ int ncclGroupEnd(void)
     return rc;
 }
 
-static void maybe_slow(void)
-{
-    static _Thread_local unsigned calls = 0;
-    static int slow_us = -1, every = 3;
-    if (slow_us < 0) {
-        const char *e = getenv("FAKE_RCCL_SLOW_US"), *k = getenv("FAKE_RCCL_SLOW_EVERY");
-        every = k && atoi(k) > 0 ? atoi(k) : 3;
-        slow_us = e ? atoi(e) : 0;
-    }
-    if (slow_us > 0 && ++calls % (unsigned)every == 0) {
-        struct timespec ts = {slow_us / 1000000, (long)(slow_us % 1000000) * 1000};
-        nanosleep(&ts, NULL);
-    }
-}
-
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, fake_comm *c, hipStream_t stream)
 {
     const size_t eb = dtype_bytes(dtype);
-    maybe_slow();
     if (!c || !send || !recv || eb == 0 || (op != kMax && op != kMin) || count == 0 || count * eb > kSlotBytes) return kInvalidArgument;
     Pending p = {send, recv, count * eb, dtype, op, stream};
     if (c->in_process) {
