@@ -42,8 +42,24 @@ namespace {
 // profiles/r05/occ_census_thresholds.jsonl): below ~40 candidate tiles in 1,024 four is 3-8 % faster, above ~70 six is - by 3 % at
 // 70, 10-30 % from 150 on - and in between the two are within 3 % of each other; any threshold from 40 to 56 loses 0.3 % on average
 // over the set against always picking the faster one (four everywhere: 7 %, six everywhere: 3 %).
-constexpr uint32_t kCensusDenseTiles = 48, kCensusDenseLanes = 256;
-constexpr uint32_t kCensusVeryDenseTiles = 224, kCensusVeryDenseLanes = 1024;     // six workgroups per CU from here (five in between)
+//
+// Round 6, second look (profiles/r06/shape_probe_1g.jsonl, _4g, _256m: 48 settled (phrase, triple) cases of the survival probe under
+// forced workgroups per CU x TILES PER WORKGROUP, taking turns in one process): a wave that meets a candidate ends later than its three
+// neighbours and the workgroup's slot is held until it does; with TWO tiles per workgroup the delay is spread over a workgroup that
+// lives twice as long.  At four workgroups per CU that is worth 1-6 % between ~28 and ~56 candidate tiles of 1,024 at every size
+// (1 GiB, 44 tiles: 0.865-0.870 -> 0.892-0.899 of the peak; 54 tiles: 0.846 -> 0.906, five workgroups of one tile: 0.883), below
+// that one tile per workgroup stays ahead by 1-2 % at 1 GiB.  From ~56 tiles FIVE workgroups per CU of ONE tile are ahead - up to ~80
+// tiles also from 2 GiB up, where a launch otherwise takes two tiles per workgroup (4 GiB, 63-78 tiles: 0.935-0.943 with one tile,
+// 0.910-0.922 with two) - and six from ~160 (1 GiB alone would say ~220, 256 MiB and 4 GiB ~110) or when the candidates are DEEP ones by the
+// hundred (a needle of box-drawing bytes, 869 deep candidates in the sample: 0.786 at five, 0.862 at six).
+constexpr uint32_t kCensusTwoTilesFrom = 28;       // four workgroups per CU, two tiles each from here ...
+constexpr uint32_t kCensusDenseTiles = 56, kCensusDenseLanes = 256;               // ... five of one tile from here
+constexpr uint32_t kCensusVeryDenseTiles = 160, kCensusVeryDenseLanes = 1024;     // six workgroups per CU from here
+constexpr uint32_t kCensusVeryDeepLanes = 256;     // ... or from this many deep candidates in the sample
+// ... and ONE tile per workgroup at five / six workgroups per CU below these counts (it is what a launch below 2 GiB takes anyway; from
+// 2 GiB up: 4 GiB, 52-69 tiles at five: +0.8-3.1 % with one tile, 81-123 tiles: -0.6-4.7 %; at six, needles of blanks - hundreds of
+// candidate tiles, thousands of lanes - lose 5-10 % with one: profiles/r06/ab_text_shapes_v1_4g.jsonl)
+constexpr uint32_t kCensusOneTileBelowAtFive = 80, kCensusOneTileBelowAtSix = 256;
 // Filter pairs 16 or more apart (ss_searcher_set_filter3 only; the cross-lane kernels): the third first-phase byte pays on text,
 // where the reference's own pair (0, n-1) passes at percent rates, and costs where the pair alone rarely matches (random bytes:
 // equal at 1 GiB, 5-6 % at 8 GiB; profiles/r05/mode3_probe.jsonl).  The pair runs alone (MODE 3) when at most this many of the
@@ -526,6 +542,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     out->have_triple = false;
     out->have_order = false;
     out->workgroups_per_cu = 0;
+    out->tiles_per_workgroup = 0;
     out->sparse_pair = false;
     if (len < kCensusMinBytes || s->n < 2 || len < s->n || !autotune_enabled()) return;
     if (__atomic_exchange_n(&pd->census_lock, 1u, __ATOMIC_ACQUIRE) != 0) return;         // another thread is at it
@@ -586,8 +603,17 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     // four / five / six (round 6: profiles/r06/wg_probe.jsonl - pinned triples of 0 to 250 candidate tiles under forced shapes: four is
     // best up to ~45 candidate tiles in 1,024, FIVE from there to ~210 (3-5 % over six, 4-12 % over four), six beyond)
     out->workgroups_per_cu = cc.match_tiles != 0 ? 4
-                             : (cc.tiles3 >= kCensusVeryDenseTiles || cc.lanes >= kCensusVeryDenseLanes ? 6
+                             : (cc.tiles3 >= kCensusVeryDenseTiles || cc.lanes >= kCensusVeryDenseLanes || c->deep_lanes >= kCensusVeryDeepLanes ? 6
                                 : (cc.tiles3 >= kCensusDenseTiles || cc.lanes >= kCensusDenseLanes || c->deep_lanes >= kCensusDeepLanes ? 5 : 4));
+    // tiles per workgroup (single-stream kernels; 0 = the launch's own choice): two at four workgroups per CU once candidate tiles are
+    // no rarity; ONE at five and six while the candidates are spread thinly enough for a workgroup to meet one or none - where they
+    // crowd (needles of blanks, deep candidates by the hundred) longer-lived workgroups are ahead again
+    out->tiles_per_workgroup = 0;
+    if (cc.match_tiles == 0) {
+        if (out->workgroups_per_cu == 4) out->tiles_per_workgroup = cc.tiles3 >= kCensusTwoTilesFrom ? 2 : 0;
+        else if (out->workgroups_per_cu == 5) out->tiles_per_workgroup = cc.tiles3 < kCensusOneTileBelowAtFive ? 1 : 0;
+        else out->tiles_per_workgroup = cc.tiles3 < kCensusOneTileBelowAtSix && cc.lanes < kCensusVeryDenseLanes && c->deep_lanes < kCensusVeryDeepLanes ? 1 : 0;
+    }
     out->sparse_pair = cc.tiles2 <= kCensusSparsePairTiles;
     // A buffer may be refilled in place: everything is looked at again every kCensusRefreshEvery scans, starting from the bytes in
     // force (the old counts serve until the new ones are in).

@@ -249,7 +249,8 @@ size_t choose_third(const uint8_t *needle, size_t n, size_t fa, size_t fb, const
 constexpr size_t kCensusMinBytes = (size_t)256 << 20;
 struct LaunchHints {
     bool have_counts;           // the census of (searcher, haystack) is in:
-    int workgroups_per_cu;      //   four or six
+    int workgroups_per_cu;      //   four, five or six
+    int tiles_per_workgroup;    //   0: the launch's own choice (one below 2 GiB, two from there); 1 or 2: by the candidate density
     bool sparse_pair;           //   the first two filter bytes alone rarely match (cross-lane kernels: no third byte needed)
     bool have_triple;           // filter bytes chosen for this haystack (from its histogram, or from the census's own match counts):
     size_t tri[3];              //   first <= second, third, all within 15 of the first

@@ -336,6 +336,10 @@ int enqueue_scan(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t 
             tpb = ntiles / ((uint64_t)di.cus * (l.mode == 0 ? 256 : 128));
             if (tpb > (uint64_t)kAutoTilesPerBlock) tpb = kAutoTilesPerBlock;
             if (tpb < 1) tpb = 1;
+            // ... unless the census has counted candidates (ss_census.hip: two tiles at four workgroups per CU where candidate tiles are
+            // no rarity, one at five and six whatever the size; single-stream kernels, launches that follow the census's shape)
+            if (l.mode == 0 && s->variant == 0 && hints.have_counts && hints.tiles_per_workgroup != 0 && occ == hints.workgroups_per_cu)
+                tpb = (uint64_t)hints.tiles_per_workgroup;
         }
         blocks = (ntiles + tpb - 1) / tpb;
         while (blocks > 0x7fffffffull) {        // gridDim.x limit

@@ -582,14 +582,26 @@ def _settle(s, h, want_found=False, scans=16):
 def _rule(st):
     if st["match_tiles"]:
         return 4
-    if st["tiles3"] >= 224 or st["lanes"] >= 1024:
+    if st["tiles3"] >= 160 or st["lanes"] >= 1024 or st["deep_lanes"] >= 256:
         return 6
-    return 5 if st["tiles3"] >= 48 or st["lanes"] >= 256 or st["deep_lanes"] >= 24 else 4
+    return 5 if st["tiles3"] >= 56 or st["lanes"] >= 256 or st["deep_lanes"] >= 24 else 4
+
+
+def _tiles_rule(st, default=1):
+    """Tiles per workgroup of a single-stream launch that follows the census (ss_census.hip): two at four workgroups per CU from 28
+    candidate tiles of 1,024, one at five and six while the candidates are thinly spread, else the launch's own choice (one below 2 GiB)."""
+    if st["match_tiles"]:
+        return default
+    if _rule(st) == 5:
+        return 1 if st["tiles3"] < 80 else default
+    if _rule(st) == 6:
+        return 1 if st["tiles3"] < 256 and st["lanes"] < 1024 and st["deep_lanes"] < 256 else default
+    return 2 if st["tiles3"] >= 28 else default
 
 
 @pytest.mark.gpu
 def test_workgroups_per_cu_follow_the_candidate_census(O):
-    """VERDICT r04 item 2: four or six workgroups per CU is decided by what a census of the HAYSTACK counts (ss_census.hip;
+    """VERDICT r04 item 2: four, five or six workgroups per CU (and one or two tiles per workgroup) is decided by what a census of the HAYSTACK counts (ss_census.hip;
     aux_kernels.hpp: census_kernel), not by the wall-clock time of earlier scans: deterministic for a given haystack and needle,
     nothing timed, observable through ss_searcher_last_launch and ss_searcher_tuning_state.  Hooks build for ss_debug_census.  The
     counts equal a numpy restatement of the sampling - for the searcher's own bytes after the first scan and for the bytes in force
@@ -630,7 +642,8 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
                 assert s.search_in(h) is False
                 picks.add(s.last_launch()[0])
             assert picks == {want}, (needle, st, picks)
-            assert s.last_launch()[1] in (gib // 16384, gib // 16384 + 1), "one 16 KiB tile per workgroup at 1 GiB"
+            per_wg = 16384 * _tiles_rule(st)
+            assert s.last_launch()[1] in (gib // per_wg, gib // per_wg + 1), "16 KiB tiles: one per workgroup at 1 GiB, two where the census counted 28-55 candidate tiles"
             # a needle that is found: the next launch is at four, whatever the census says; absent again: back to the census
             h2 = h[: 300 << 20].clone()
             h2[12345:12345 + len(needle)] = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
@@ -650,7 +663,7 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
         s.set_filter(*s.filter3)                            # (the stock triple pinned: 209 candidate tiles in 1,024 on this text)
         for _ in range(3):
             assert s.search_in(text) is False
-        assert s.last_launch()[0] == 5
+        assert s.last_launch()[0] == 6
         ss.fill_random_device(text, 0x5EED0001)            # the same bytes as `hay`: no candidates at all
         for _ in range(260):
             assert s.search_in(text) is False
