@@ -384,7 +384,8 @@ def other_configs(ss, shard, reps=20):
             st = s.tuning_state(text)
             row = _row(gib, ms, needle=nd.decode("latin1"), how=how, found=res, filter_bytes=list(s.filter3),
                        bytes_in_force=st["in_force"], candidate_tiles_of_1024=st["tiles3"], deep_candidates=st["deep_lanes"],
-                       schedule_by_census=bool(st["order_measured"]), workgroups_per_cu=s.last_launch()[0], kernel_mode=st["kernel_mode"])
+                       schedule_by_census=bool(st["order_measured"]), workgroups_per_cu=s.last_launch()[0],
+                       tiles_per_workgroup=max(1, round(text.numel() / 16384 / max(1, s.last_launch()[1]))), kernel_mode=st["kernel_mode"])
             # the same searcher with launch tuning OFF: the static bytes (a caller's pair verbatim, in the cross-lane kernels where it is
             # 16 or more apart), the static schedule, the needle-byte guess for workgroups per CU
             was = ss.set_autotune(False)

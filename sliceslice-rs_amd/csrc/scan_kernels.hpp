@@ -48,6 +48,16 @@
 
 namespace ss {
 
+#ifdef SS_CAND_PROF   // instrumented A/B builds only (tools/cand_prof.py): what a wave spends in the candidate path, in s_memtime ticks
+constexpr int kCandProfSlots = 4096;                        // one 64-byte row per (workgroup mod 4096): no two neighbours on one line
+static __device__ unsigned long long g_cand_prof[kCandProfSlots][8];   // tiles with candidates | ticks: total | cold part | second level | compare | - | per-piece tiles
+#define SS_PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define SS_PROF_ADD(k, d) do { if (lane == 0) atomicAdd(&g_cand_prof[blockIdx.x % kCandProfSlots][k], (unsigned long long)(d)); } while (0)
+#else
+#define SS_PROF_T(v)
+#define SS_PROF_ADD(k, d)
+#endif
+
 // MODE selects where the position-byte flags of a candidate come from (position = 16*d + 4*Q + r):
 //   0  d == 0: same chunk / next lane (DPP) - every needle of <= 16 bytes with the default position;
 //   2  0 < d < 64, small: ONE (non-temporal) load stream; the flags computed by the lane that owns chunk
@@ -341,6 +351,10 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
             return;
         }
         if (cand_tile) {
+            SS_PROF_T(prof_t0);
+#ifdef SS_CAND_PRIO
+            __builtin_amdgcn_s_setprio(SS_CAND_PRIO);
+#endif
             // Kernels whose Problem sits in the kernarg segment re-read the cold fields for EVERY tile with candidates (scalar
             // cache hits, the lines were touched at entry) instead of carrying ~25 scalar registers from tile to tile: carried,
             // they pushed as many loop invariants out to vector lanes in front of every workgroup's first load.  Kernels that
@@ -410,6 +424,7 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
             // second-level filter (next to nobody, on random bytes and on text alike): staging costs a pass over
             // min(n, 2 KiB) needle bytes, which at 2^-16 candidates per offset and short-lived workgroups made a
             // 2000-byte needle 13 % slower than a 16-byte one.
+            SS_PROF_T(prof_t1);
             auto stage_once = [&]() {
                 if (!staged && !ONE_BYTE) {
                     stage_needle_wave(s_needle, va.needle, va.n, lane);
@@ -452,13 +467,28 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // even those: the compare costs a lane ~40 operations per candidate, a schedule byte ~24 per PIECE.
                     const bool exact = EXACT_OK && exact_len != 0;
                     const uint32_t max_steps = exact ? (cand_lanes <= kExactSparseLanes ? 0u : kExactRefineSteps) : 15u;
-                    if (max_steps != 0 && !refine_tile<U, MODE>(A, H, ro, G, max_steps)) continue;
+                    if (max_steps != 0 && !refine_tile<U, MODE>(A, H, ro, G, max_steps)) {
+#ifdef SS_CAND_PRIO
+                        __builtin_amdgcn_s_setprio(0);
+#endif
+                        SS_PROF_T(prof_tx);
+                        SS_PROF_ADD(0, 1);
+                        SS_PROF_ADD(1, prof_tx - prof_t0);
+                        SS_PROF_ADD(2, prof_t1 - prof_t0);
+                        SS_PROF_ADD(3, prof_tx - prof_t1);
+                        continue;
+                    }
                 }
             }
             bool hit = false;
+#ifdef SS_CAND_PROF
+            unsigned long long prof_refine = 0, prof_verify = 0;
+            SS_PROF_T(prof_t2);
+#endif
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 uint32_t *g = G[u];
+                SS_PROF_T(prof_p0);
                 if (!ONE_BYTE && per_piece) {
                     if (((pm >> u) & 1u) == 0) continue;
                     NextPiece np;
@@ -469,10 +499,19 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     // With the needle's dwords at hand the exact compare below settles a lane's candidates in ~50 VALU
                     // operations, all lanes at once - about what TWO steps of the byte-wise schedule cost - and a true match
                     // would sit through every one of its up to 13 steps first (a microsecond of ballots and branches).
-                    if (!(EXACT_OK && exact_len != 0) && !refine_piece(A[u], np, ro, g)) continue;
+                    if (!(EXACT_OK && exact_len != 0) && !refine_piece(A[u], np, ro, g)) {
+#ifdef SS_CAND_PROF
+                        prof_refine += __builtin_readcyclecounter() - prof_p0;
+#endif
+                        continue;
+                    }
                 } else if (__ballot(((g[0] | g[1] | g[2] | g[3]) & 0x80808080u) != 0) == 0) {
                     continue;
                 }
+                SS_PROF_T(prof_p1);
+#ifdef SS_CAND_PROF
+                prof_refine += prof_p1 - prof_p0;
+#endif
                 uint64_t where = 0;
                 bool h;
                 if (EXACT_OK && exact_len != 0) {               // wave-uniform: the needle's dwords are at hand
@@ -490,6 +529,9 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     h = verify_flags<ONE_BYTE>(g, chunk0 + 64 * u + lane, pr, va, s_needle, where, far_off);
                 }
                 hit |= h;
+#ifdef SS_CAND_PROF
+                prof_verify += __builtin_readcyclecounter() - prof_p1;
+#endif
                 // search_in: the first piece with a match settles the wave (a text full of matches holds one in every piece)
                 if (!FIND && __ballot(h) != 0) break;
                 if (FIND) {
@@ -568,6 +610,21 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     return;
                 }
             }
+#ifdef SS_CAND_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef SS_CAND_PROF
+            {
+                SS_PROF_T(prof_tz);
+                SS_PROF_ADD(0, 1);
+                SS_PROF_ADD(1, prof_tz - prof_t0);
+                SS_PROF_ADD(2, prof_t1 - prof_t0);
+                SS_PROF_ADD(3, prof_refine);
+                SS_PROF_ADD(4, prof_verify);
+                SS_PROF_ADD(5, prof_t2 - prof_t1);
+                if (per_piece) SS_PROF_ADD(6, 1);
+            }
+#endif
         }
     }
 }
