@@ -32,8 +32,8 @@
  * mutable state, per device, is LAUNCH TUNING for scans of 256 MiB and more: a
  * candidate census of the haystacks it has been used on - candidate counts, and
  * per needle position how many of the sampled candidates match there - decides
- * between four, five and six workgroups per CU (ss_searcher_last_launch reports
- * the choice), orders the second level's schedule, and moves the first-phase
+ * between four, five and six workgroups per CU and one or two tiles per workgroup
+ * (ss_searcher_last_launch reports the choice), orders the second level's schedule, and moves the first-phase
  * bytes THE LIBRARY owns (all three for ss_searcher_new, never a caller's) to
  * positions that let fewer candidates through, FOR THAT HAYSTACK
  * (ss_searcher_filter3 keeps reporting the searcher's own).  No result depends on
@@ -326,7 +326,7 @@ SS_API int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards
  * handle learns about the haystacks it meets only moves necessary conditions around and picks launch shapes:
  *   - per (searcher, device, haystack >= 256 MiB): a candidate census of 1,024 sampled 4 KiB tiles, taken by a small kernel in
  *     front of the first scan (and every 256th after it) on the scan's own stream, never waited for: workgroups per CU (four /
- *     five / six), the cross-lane kernels with or without a third byte, the THIRD first-phase byte where the library owns it and the near
+ *     five / six) and 16 KiB tiles per workgroup (one / two), the cross-lane kernels with or without a third byte, the THIRD first-phase byte where the library owns it and the near
  *     bytes that stand in for a far pair (by the measured number of candidates each position lets through, on trial against the
  *     next census), and the ORDER of the second level's schedule (the needle byte that kills most of the sampled candidates
  *     first);

@@ -663,7 +663,17 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         __asm__ volatile("s_load_dword %0, %2, 0x80\n\ts_load_dword %1, %2, 0xc0" : "=&s"(touch0), "=&s"(touch1) : "s"(kp));
     }
     const unsigned tile_shift = (unsigned)__builtin_ctz(blockDim.x / kWave) + (unsigned)__builtin_ctz(U);
+#ifdef SS_XCD_CHUNK   // A/B builds only: workgroup b runs on XCD b % 8 (observed, for speed only) - give every XCD runs of SS_XCD_CHUNK
+                      // consecutive workgroups' worth of the haystack instead of every eighth one (a page is then walked by one XCD)
+    uint32_t bx = blockIdx.x;
+    {
+        constexpr uint32_t K = SS_XCD_CHUNK, G = 8 * K;
+        if (tiles_per_block && bx < (gridDim.x / G) * G) bx = (bx / G) * G + (bx % 8) * K + (bx / 8) % K;
+    }
+    uint64_t t0 = tiles_per_block ? (uint64_t)bx * tiles_per_block : bx;
+#else
     uint64_t t0 = tiles_per_block ? (uint64_t)blockIdx.x * tiles_per_block : blockIdx.x;
+#endif
     // completion-word launches of the bool kernels: "a wave of this workgroup has found the needle"
     __shared__ int s_wg_found;
     const bool counted = !FIND && (pr.flags & kProblemCounted) != 0;   // wave-uniform (kernel argument)
