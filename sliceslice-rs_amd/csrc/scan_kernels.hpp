@@ -352,9 +352,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
         }
         if (cand_tile) {
             SS_PROF_T(prof_t0);
-#ifdef SS_CAND_PRIO
-            __builtin_amdgcn_s_setprio(SS_CAND_PRIO);
-#endif
             // Kernels whose Problem sits in the kernarg segment re-read the cold fields for EVERY tile with candidates (scalar
             // cache hits, the lines were touched at entry) instead of carrying ~25 scalar registers from tile to tile: carried,
             // they pushed as many loop invariants out to vector lanes in front of every workgroup's first load.  Kernels that
@@ -468,9 +465,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     const bool exact = EXACT_OK && exact_len != 0;
                     const uint32_t max_steps = exact ? (cand_lanes <= kExactSparseLanes ? 0u : kExactRefineSteps) : 15u;
                     if (max_steps != 0 && !refine_tile<U, MODE>(A, H, ro, G, max_steps)) {
-#ifdef SS_CAND_PRIO
-                        __builtin_amdgcn_s_setprio(0);
-#endif
                         SS_PROF_T(prof_tx);
                         SS_PROF_ADD(0, 1);
                         SS_PROF_ADD(1, prof_tx - prof_t0);
@@ -610,9 +604,6 @@ __device__ __forceinline__ void scan_tiles(const Problem &pr, ColdT cold, uint8_
                     return;
                 }
             }
-#ifdef SS_CAND_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef SS_CAND_PROF
             {
                 SS_PROF_T(prof_tz);
@@ -663,17 +654,7 @@ __global__ void SS_SCAN_OCCUPANCY __launch_bounds__(kMaxBlock) scan_kernel(const
         __asm__ volatile("s_load_dword %0, %2, 0x80\n\ts_load_dword %1, %2, 0xc0" : "=&s"(touch0), "=&s"(touch1) : "s"(kp));
     }
     const unsigned tile_shift = (unsigned)__builtin_ctz(blockDim.x / kWave) + (unsigned)__builtin_ctz(U);
-#ifdef SS_XCD_CHUNK   // A/B builds only: workgroup b runs on XCD b % 8 (observed, for speed only) - give every XCD runs of SS_XCD_CHUNK
-                      // consecutive workgroups' worth of the haystack instead of every eighth one (a page is then walked by one XCD)
-    uint32_t bx = blockIdx.x;
-    {
-        constexpr uint32_t K = SS_XCD_CHUNK, G = 8 * K;
-        if (tiles_per_block && bx < (gridDim.x / G) * G) bx = (bx / G) * G + (bx % 8) * K + (bx / 8) % K;
-    }
-    uint64_t t0 = tiles_per_block ? (uint64_t)bx * tiles_per_block : bx;
-#else
     uint64_t t0 = tiles_per_block ? (uint64_t)blockIdx.x * tiles_per_block : blockIdx.x;
-#endif
     // completion-word launches of the bool kernels: "a wave of this workgroup has found the needle"
     __shared__ int s_wg_found;
     const bool counted = !FIND && (pr.flags & kProblemCounted) != 0;   // wave-uniform (kernel argument)
