@@ -644,6 +644,17 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             assert picks == {want}, (needle, st, picks)
             per_wg = 16384 * _tiles_rule(st)
             assert s.last_launch()[1] in (gib // per_wg, gib // per_wg + 1), "16 KiB tiles: one per workgroup at 1 GiB, two where the census counted 28-55 candidate tiles"
+            # the census's shape must not cost an answer: the needle planted flush against the end of the haystack, and across the
+            # border of two 16 KiB tiles in the middle (one workgroup's two tiles where the shape says two), found by the launch
+            # that follows the census - then taken out again
+            nb = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
+            for at in (gib - len(needle), (gib // 2 // 32768) * 32768 + 16384 - 5, (gib // 3 // 32768) * 32768 + 32768 - 7):
+                keep = h[at:at + len(needle)].clone()
+                h[at:at + len(needle)] = nb
+                assert s.search_in(h) is True and s.last_launch()[0] == want, (needle, at)     # (the launch BEFORE this one found nothing)
+                assert s.find(h) == at
+                h[at:at + len(needle)] = keep
+                assert s.search_in(h) is False and s.search_in(h) is False and s.last_launch()[0] == want
             # a needle that is found: the next launch is at four, whatever the census says; absent again: back to the census
             h2 = h[: 300 << 20].clone()
             h2[12345:12345 + len(needle)] = torch.from_numpy(np.frombuffer(needle, dtype=np.uint8).copy()).cuda()
