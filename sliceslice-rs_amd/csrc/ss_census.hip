@@ -58,7 +58,9 @@ constexpr uint32_t kCensusVeryDenseTiles = 160, kCensusVeryDenseLanes = 1024;   
 constexpr uint32_t kCensusVeryDeepLanes = 256;     // ... or from this many deep candidates in the sample
 // ... and ONE tile per workgroup at five / six workgroups per CU below these counts (it is what a launch below 2 GiB takes anyway; from
 // 2 GiB up: 4 GiB, 52-69 tiles at five: +0.8-3.1 % with one tile, 81-123 tiles: -0.6-4.7 %; at six, needles of blanks - hundreds of
-// candidate tiles, thousands of lanes - lose 5-10 % with one: profiles/r06/ab_text_shapes_v1_4g.jsonl)
+// candidate tiles, thousands of lanes - lose 5-10 % with one: profiles/r06/ab_text_shapes_v1_4g.jsonl; and gain 4-9 % with TWO below
+// 2 GiB, where a launch takes one by itself - 1 GiB, 400 / 508 / 840 candidate tiles: 0.831 / 0.746 / 0.779 -> 0.866 / 0.813 / 0.831,
+// profiles/r06/shape_probe_dense_1g.jsonl, columns 6x1 and 20x2: six workgroups per CU of two tiles)
 constexpr uint32_t kCensusOneTileBelowAtFive = 80, kCensusOneTileBelowAtSix = 256;
 // Filter pairs 16 or more apart (ss_searcher_set_filter3 only; the cross-lane kernels): the third first-phase byte pays on text,
 // where the reference's own pair (0, n-1) passes at percent rates, and costs where the pair alone rarely matches (random bytes:
@@ -612,7 +614,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     if (cc.match_tiles == 0) {
         if (out->workgroups_per_cu == 4) out->tiles_per_workgroup = cc.tiles3 >= kCensusTwoTilesFrom ? 2 : 0;
         else if (out->workgroups_per_cu == 5) out->tiles_per_workgroup = cc.tiles3 < kCensusOneTileBelowAtFive ? 1 : 0;
-        else out->tiles_per_workgroup = cc.tiles3 < kCensusOneTileBelowAtSix && cc.lanes < kCensusVeryDenseLanes && c->deep_lanes < kCensusVeryDeepLanes ? 1 : 0;
+        else out->tiles_per_workgroup = cc.tiles3 < kCensusOneTileBelowAtSix && cc.lanes < kCensusVeryDenseLanes && c->deep_lanes < kCensusVeryDeepLanes ? 1 : 2;
     }
     out->sparse_pair = cc.tiles2 <= kCensusSparsePairTiles;
     // A buffer may be refilled in place: everything is looked at again every kCensusRefreshEvery scans, starting from the bytes in
