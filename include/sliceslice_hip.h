@@ -352,7 +352,7 @@ typedef struct ss_tuning_state {
     uint32_t accepted, settled;     /* ... and how many of them replaced the bytes in force; 1: no byte is being looked at any more */
     uint32_t proposal;              /* the latest proposal: 1 from the haystack's histogram, 2 one byte moved by the census's match counts,
                                        3 the near form of a pair 16 or more apart, 4 a jump to the needle byte that kills most of the sampled
-                                       candidates */
+                                       candidates, 5 the compact form (all three bytes within eight) of a filter that meets no candidates */
     uint32_t own[3], in_force[3];   /* needle indices of the three first-phase bytes: the searcher's own / on this haystack */
     uint32_t order_measured, norder;/* the second level's schedule is ordered by the census (else by the static rarity table) */
     uint8_t order[16];              /* ... needle indices, first tested first (norder of them) */

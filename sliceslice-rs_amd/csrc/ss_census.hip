@@ -89,7 +89,14 @@ constexpr uint32_t kNearFormSlackTiles = 64;
 // i386 phrase through with_position(n-1) lost 3 % to a third byte with a quarter of the candidates, every one of them deep.)
 constexpr uint32_t kDeepWeight = 8;
 constexpr uint32_t kCensusDeepLanes = 24;          // five workgroups per CU from this many deep candidates in the sample
-constexpr uint32_t kDescentMaxRounds = 12;         // censuses a (searcher, haystack) pair may spend on improving its bytes, per 256 scans
+// The COMPACT form of a filter that has nothing to do (propose_compact): with no candidate in the sample the choice of bytes decides
+// nothing but what the first phase costs, and that is less when the two further bytes lie within kCompactSpan bytes of the first - the
+// next lane's dwords 0 and 1 instead of 0 ... 3 (one DPP move and one v_alignbyte window less per piece and dword).  Measured on 64 GiB
+// of random bytes, fourteen pinned triples of one needle taking turns in one process (profiles/r06/headline_triple_probe_windows.jsonl):
+// 0.9166-0.9200 of the peak with a byte 12-15 behind the first, 0.9245-0.9256 with the farthest 8-11 behind, 0.9267-0.9276 within 7;
+// the same order at 8 GiB (0.920-0.924 / 0.925-0.929 / 0.928-0.931).  Proposed only from 12 bytes of span on.
+constexpr size_t kCompactSpan = 7, kCompactFromSpan = 12;
+constexpr uint32_t kDescentMaxRounds = 14;         // censuses a (searcher, haystack) pair may spend on improving its bytes, per 256 scans
 constexpr uint32_t kOrderMinLanes = 4;             // triple candidates in the sample below which the static schedule order stays
 static_assert(ss::kCensusStatWords == 2 * 64 + 3 && ss::kCensusCheck == 64, "PerDevice::Census and the control blocks are laid out for 64 positions");
 
@@ -171,6 +178,7 @@ void complete_pending(const ss_searcher *s, PerDevice *pd)
         bool better;
         if (c.prop_kind == 3) better = now.tiles3 <= was.tiles3 + kNearFormSlackTiles && deep_now <= c.deep_lanes + kNearFormSlackTiles / 4;   // one load stream instead of the cross-lane kernels
         else if (c.prop_kind == 1) better = now.tiles3 <= was.tiles3 && cost_now <= cost_was;
+        else if (c.prop_kind == 5) better = now.tiles3 == 0 && now.lanes == 0 && now.match_tiles == 0 && deep_now == 0;   // still nothing to do
         else better = now.tiles3 <= was.tiles3 && cost_now < cost_was;
         if (better) {
             if (c.prop_kind == 3) c.free_mask = 6;      // the near form keeps the caller's first byte; the other two are the library's
@@ -184,7 +192,7 @@ void complete_pending(const ss_searcher *s, PerDevice *pd)
             take = true;
         } else {
             ++c.stale;                                  // (the counters at hand describe the rejected triple; cur[]'s order stays)
-            if (c.prop_kind == 4) c.stale = (uint32_t)__builtin_popcount(c.free_mask);      // a rejected jump ends the look
+            if (c.prop_kind == 4 || c.prop_kind == 5) c.stale = (uint32_t)__builtin_popcount(c.free_mask);      // a rejected jump / compact form ends the look
             c.stats_roles = -1;
         }
     }
@@ -474,6 +482,70 @@ bool propose_near_form(const ss_searcher *s, const PerDevice::Census &c, size_t 
     return true;
 }
 
+// The COMPACT form (see kCompactSpan): the bytes the library owns re-chosen so that all three lie within kCompactSpan of the smallest
+// index - the cheapest such set by `cost` (the haystack's histogram when it is in, else the static classes), later positions among
+// equals; a caller's bytes stay where they are (no compact form when they alone span more).  On trial like every proposal: kept only if
+// its census meets no candidate either.
+bool propose_compact(const ss_searcher *s, const PerDevice::Census &c, const ByteCost &cost, size_t prop[3])
+{
+    if (s->n < 3 || c.free_mask == 0) return false;
+    size_t tri[3];
+    normalised(c.cur, tri);
+    if (std::max(tri[1], tri[2]) - tri[0] < kCompactFromSpan || tri[1] - tri[0] > 15) return false;
+    const size_t lim = std::min<size_t>(s->n, ss::kCensusCheck);
+    size_t lo_fixed = lim, hi_fixed = 0;
+    for (int j = 0; j < 3; ++j)
+        if (!((c.free_mask >> j) & 1u)) {
+            lo_fixed = std::min(lo_fixed, c.cur[j]);
+            hi_fixed = std::max(hi_fixed, c.cur[j]);
+        }
+    const bool any_fixed = lo_fixed <= hi_fixed;
+    if (any_fixed && (hi_fixed - lo_fixed > kCompactSpan || hi_fixed >= lim)) return false;
+    // candidates for a free slot: everything that can share a window of kCompactSpan with the fixed bytes (or anything, with none fixed)
+    const size_t k0 = any_fixed ? (hi_fixed >= kCompactSpan ? hi_fixed - kCompactSpan : 0) : 0;
+    const size_t k1 = any_fixed ? std::min(lim, lo_fixed + kCompactSpan + 1) : lim;
+    int best = INT_MAX;
+    size_t bt[3] = {0, 0, 0};
+    size_t t[3];
+    auto consider = [&]() {
+        const size_t lo = std::min(t[0], std::min(t[1], t[2])), hi = std::max(t[0], std::max(t[1], t[2]));
+        if (hi - lo > kCompactSpan || t[0] == t[1] || t[0] == t[2] || t[1] == t[2]) return;
+        int total = 0;
+        for (int j = 0; j < 3; ++j)
+            if ((c.free_mask >> j) & 1u) total += cost(s->needle[t[j]]);
+        if (total <= best) {                            // (later positions among equals, as everywhere)
+            best = total;
+            bt[0] = t[0];
+            bt[1] = t[1];
+            bt[2] = t[2];
+        }
+    };
+    auto range = [&](int j, size_t *a, size_t *b) {     // positions slot j may take
+        if ((c.free_mask >> j) & 1u) {
+            *a = k0;
+            *b = k1;
+        } else {
+            *a = c.cur[j];
+            *b = c.cur[j] + 1;
+        }
+    };
+    size_t a0, b0, a1, b1, a2, b2;
+    range(0, &a0, &b0);
+    range(1, &a1, &b1);
+    range(2, &a2, &b2);
+    for (t[0] = a0; t[0] < b0; ++t[0])
+        for (t[1] = a1; t[1] < b1 && t[1] <= t[0] + kCompactSpan; ++t[1]) {
+            if (t[1] + kCompactSpan < t[0]) continue;
+            for (t[2] = a2; t[2] < b2; ++t[2]) consider();
+        }
+    if (best == INT_MAX) return false;
+    if (same_triple(bt, c.cur)) return false;
+    prop[0] = bt[0];
+    prop[1] = bt[1];
+    prop[2] = bt[2];
+    return true;
+}
+
 }  // namespace
 
 // ss_set_autotune / SLICESLICE_AUTOTUNE: everything this file does, on or off, process-wide.  Off: the constructors' static triple,
@@ -620,7 +692,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     // A buffer may be refilled in place: everything is looked at again every kCensusRefreshEvery scans, starting from the bytes in
     // force (the old counts serve until the new ones are in).
     if (++c->uses % kCensusRefreshEvery == 0) {
-        c->settled = c->near_tried = c->jump_tried = false;
+        c->settled = c->near_tried = c->jump_tried = c->compact_tried = false;
         c->stale = c->rounds = 0;
         c->stats_roles = -1;
     }
@@ -676,6 +748,17 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
                 c->settled = false;
             }
         }
+        if (c->settled && kind == 0 && !c->compact_tried && c->free_mask != 0 && cc.tiles3 == 0 && cc.lanes == 0 && cc.match_tiles == 0 &&
+            c->deep_lanes == 0) {
+            // a filter that meets no candidates on this haystack: its compact form (once per look), before the handle settles
+            c->compact_tried = true;
+            uint64_t hist[256];
+            const bool have_hist = stats_lookup(pd->dev, d_hay, len, st, hist);
+            if (propose_compact(s, *c, ByteCost(have_hist ? hist : nullptr), prop)) {
+                kind = 5;
+                c->settled = false;
+            }
+        }
         if (c->settled) {
             // the counts and the order at hand must describe cur[]: after a rejected trial they do not
             if (c->stats_roles >= 0) return;
@@ -685,7 +768,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     }
     if (kind != 0) {
         // the trial's census gathers its per-position counts for the coordinate that comes next, so that an accepted proposal goes on
-        const int roles = kind == 2 ? next_free(c->free_mask, (int)c->coord) : 2;     // (a histogram / near-form / jump proposal starts over at slot 2)
+        const int roles = kind == 2 ? next_free(c->free_mask, (int)c->coord) : 2;     // (a histogram / near-form / jump / compact proposal starts over at slot 2)
         if (!launch_census(s, pd, c, prop, roles, d_hay, len, st)) return;
         c->prop[0] = prop[0];
         c->prop[1] = prop[1];

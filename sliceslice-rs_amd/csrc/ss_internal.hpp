@@ -116,11 +116,12 @@ struct PerDevice {
         int roles = 2;
         size_t prop[3] = {0, 0, 0};
         uint32_t prop_kind = 0;     // 1 = from the haystack's histogram, 2 = one coordinate moved by measurement, 3 = the near form of a far pair,
-                                    // 4 = a jump to the byte that kills most of today's candidates
+                                    // 4 = a jump to the byte that kills most of today's candidates, 5 = the compact form of a filter that
+                                    // meets no candidates (all three bytes within eight)
         uint32_t trials = 0, accepted = 0;
         // the descent: coordinates the library may move (bit j), the next one to look at, coordinates looked at since the last improvement
         uint32_t free_mask = 0, coord = 2, stale = 0, rounds = 0;
-        bool settled = false, hist_tried = false, near_tried = false, jump_tried = false;
+        bool settled = false, hist_tried = false, near_tried = false, jump_tried = false, compact_tried = false;
         // what the latest census of cur[] MEASURED about survival: how many of the sampled pair / triple candidates match the needle at
         // position k (< 64); stats_roles = the coordinate they were gathered for (-1: none at hand)
         int stats_roles = -1;

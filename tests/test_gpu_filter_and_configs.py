@@ -637,6 +637,11 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             want = _rule(st)
             if h is hay:
                 assert want == 4 and st["tiles3"] == 0
+                # a filter that meets no candidates takes its COMPACT form (all three bytes within eight: the first phase's cheapest
+                # windows) - on trial like every proposal, kept because the compact bytes meet no candidate on random bytes either
+                # (proposed from a span of twelve on: the further dwords of the next lane's chunk are what it saves)
+                own_span = max(st["own"]) - min(st["own"])
+                assert st["own"] == list(s.filter3) and max(st["in_force"]) - min(st["in_force"]) <= (7 if own_span >= 12 else own_span), st
             picks = set()
             for _ in range(5):
                 assert s.search_in(h) is False

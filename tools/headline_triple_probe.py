@@ -32,7 +32,7 @@ def main():
     for _ in range(16):                                         # the handle settles
         auto.search_in(hay)
     names, searchers = ["auto"], [auto]
-    for tri in ((0, 15, 13), (1, 8, 15), (0, 15, 8), (0, 8, 15), (0, 4, 8), (8, 9, 10), (0, 15, 14), (2, 15, 13)):
+    for tri in ((0, 15, 13), (1, 8, 15), (0, 1, 2), (0, 3, 2), (0, 4, 5), (0, 7, 6), (0, 4, 8), (0, 8, 9), (0, 11, 10), (0, 8, 12), (0, 12, 13), (0, 15, 12), (8, 9, 10)):
         s = ss.DynamicHipSearcher.new(nd)
         s.set_filter(*tri)
         names.append("pinned %d,%d,%d" % tri)
