@@ -61,7 +61,7 @@ constexpr uint32_t kCensusVeryDeepLanes = 256;     // ... or from this many deep
 // candidate tiles, thousands of lanes - lose 5-10 % with one: profiles/r06/ab_text_shapes_v1_4g.jsonl; and gain 4-9 % with TWO below
 // 2 GiB, where a launch takes one by itself - 1 GiB, 400 / 508 / 840 candidate tiles: 0.831 / 0.746 / 0.779 -> 0.866 / 0.813 / 0.831,
 // profiles/r06/shape_probe_dense_1g.jsonl, columns 6x1 and 20x2: six workgroups per CU of two tiles)
-constexpr uint32_t kCensusOneTileBelowAtFive = 80, kCensusOneTileBelowAtSix = 256;
+constexpr uint32_t kCensusOneTileBelowAtFive = 80, kCensusOneTileBelowAtSix = 330;     // (six: 214-275 tiles want one tile at 1 and 4 GiB, 385-400 two: shape_probe_dense_*.jsonl)
 // Filter pairs 16 or more apart (ss_searcher_set_filter3 only; the cross-lane kernels): the third first-phase byte pays on text,
 // where the reference's own pair (0, n-1) passes at percent rates, and costs where the pair alone rarely matches (random bytes:
 // equal at 1 GiB, 5-6 % at 8 GiB; profiles/r05/mode3_probe.jsonl).  The pair runs alone (MODE 3) when at most this many of the

@@ -595,7 +595,7 @@ def _tiles_rule(st, default=1):
     if _rule(st) == 5:
         return 1 if st["tiles3"] < 80 else default
     if _rule(st) == 6:
-        return 1 if st["tiles3"] < 256 and st["lanes"] < 1024 and st["deep_lanes"] < 256 else 2
+        return 1 if st["tiles3"] < 330 and st["lanes"] < 1024 and st["deep_lanes"] < 256 else 2
     return 2 if st["tiles3"] >= 28 else default
 
 
