@@ -44,7 +44,7 @@ def test_committed_bench_line_has_the_contract_fields(rnd):
         # (rows of ONE process on ONE box: +-2 % from run to run - the capture's box runs every 1 GiB row 1-1.5 % under the other
         # box of the final build; the in-process comparisons are profiles/r06/ab_text_shapes_*.jsonl and survival_probe_*.jsonl)
         assert all(x["frac"] >= 0.87 and x["frac"] >= x["autotune_off"]["frac"] - 0.025 and "tiles_per_workgroup" in x for x in rows)
-        for name in ("bench64g_second_box_final.json", "bench64g_third_box_final.json"):
+        for name in ("bench64g_second_box_final.json", "bench64g_third_box_final.json", "bench64g_fourth_box_final.json"):
             other = json.load(open(os.path.join(ROOT, "profiles", rnd, name)))
             assert all(x["frac"] >= 0.90 and x["frac"] >= x["autotune_off"]["frac"] - 0.01 for x in other["configs"]["text"]["rows"]), name
         assert d["configs"]["1_random"]["hits"] == d["configs"]["1_random"]["hits_expected"] == 106
