@@ -688,6 +688,56 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
 
 
 @pytest.mark.gpu
+def test_a_filter_that_meets_no_candidates_takes_its_compact_form():
+    """Where the census meets NO candidate the choice of filter bytes decides nothing but what the first phase costs, and that is
+    least with all three bytes within eight (ss_census.hip, propose_compact; profiles/r06/headline_triple_probe_windows.jsonl): a
+    `new`-built searcher whose own bytes span 12 or more moves them - on trial, kept because the compact bytes meet no candidate
+    either - and answers as before; a caller's bytes (with_position: the byte; an explicit triple: all three) stay; with
+    ss_set_autotune(0) nothing moves."""
+    import sliceslice_rs_amd as ss
+    gib = 1 << 30
+    hay = torch.empty(gib, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, 0x5EED0001)
+    nd = bytearray(ss.fill_random_host(16, 0x5EED0002).tobytes())
+    nd[8] = 0xFF                                            # (0xFF never occurs in the generator's bytes: absent)
+    nd = bytes(nd)
+    s = ss.DynamicHipSearcher.new(nd)
+    own = list(s.filter3)
+    assert max(own) - min(own) >= 12, own                   # (the static choice: the reference's pair (0, n-1) + a third byte)
+    st = _settle(s, hay, scans=24)
+    assert st["tiles3"] == 0 and st["lanes"] == 0 and st["own"] == own and st["accepted"] >= 1, st
+    assert max(st["in_force"]) - min(st["in_force"]) <= 7 and st["triple_state"] == 2, st
+    assert list(s.filter3) == own, "ss_searcher_filter3 keeps reporting the searcher's own choice"
+    # ... and the answers are what they were: planted flush against the end and across a tile border, found, leftmost offset right
+    nb = torch.from_numpy(np.frombuffer(nd, dtype=np.uint8).copy()).cuda()
+    for at in (gib - len(nd), (gib // 2 // 16384) * 16384 - 9, 5):
+        keep = hay[at:at + len(nd)].clone()
+        hay[at:at + len(nd)] = nb
+        assert s.search_in(hay) is True and s.find(hay) == at, at
+        hay[at:at + len(nd)] = keep
+        assert s.search_in(hay) is False
+    # a caller's byte stays: with_position(15) of a 16-byte needle fixes the span at 15 - no compact form
+    wp = ss.DynamicHipSearcher.with_position(nd, 15)
+    stw = _settle(wp, hay, scans=24)
+    assert 0 in stw["in_force"] and 15 in stw["in_force"] and stw["proposal"] != 5, stw
+    # an explicit triple is the caller's: nothing is put on trial
+    ex = ss.DynamicHipSearcher.new(nd)
+    ex.set_filter(*own)
+    ste = _settle(ex, hay, scans=24)
+    assert ste["in_force"] == own and ste["trials"] == 0, ste
+    # launch tuning off: the static bytes
+    was = ss.set_autotune(False)
+    try:
+        off = ss.DynamicHipSearcher.new(nd)
+        for _ in range(8):
+            assert off.search_in(hay) is False
+        sto = off.tuning_state(hay)
+        assert sto["in_force"] == own and sto["census_state"] == 0 and sto["trials"] == 0, sto
+    finally:
+        ss.set_autotune(was)
+
+
+@pytest.mark.gpu
 def test_census_measures_survival_and_moves_the_bytes_the_library_owns(O):
     """what a candidate costs is how deep it survives - measured, not modelled.  The census counts, per needle
     position, how many of the sampled pair / triple candidates MATCH the needle there (checked against a numpy restatement, for
