@@ -35,7 +35,8 @@
  * between four, five and six workgroups per CU and one or two tiles per workgroup
  * (ss_searcher_last_launch reports the choice), orders the second level's schedule, and moves the first-phase
  * bytes THE LIBRARY owns (all three for ss_searcher_new, never a caller's) to
- * positions that let fewer candidates through, FOR THAT HAYSTACK
+ * positions that let fewer candidates through - or, where none get through, that
+ * cost the first phase least - FOR THAT HAYSTACK
  * (ss_searcher_filter3 keeps reporting the searcher's own).  No result depends on
  * any of it; for a given haystack and needle the choices are the same once the
  * handle has settled (a dozen scans at most).  See "launch tuning" below:
