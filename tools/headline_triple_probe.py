@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The headline workload (random bytes, 16-byte absent needle) under different first-phase triples, taking turns in ONE process on
 ONE buffer: what ss_searcher_new settles on with launch tuning on, the searcher's own static triple pinned, and other pinned
-triples - next to the plain-read ceiling of the same buffer.  Answers whether the triple a handle adopts on random bytes (the
-histogram mechanism trades a byte for the needle's 0xFF, which never occurs) costs or gains anything there.
+triples of different SPAN (how far the two further bytes lie behind the first: the next lane's dwords the first phase has to fetch)
+- next to the plain-read ceiling of the same buffer.  What the compact form (ss_census.hip, propose_compact) stands on.
     python tools/headline_triple_probe.py [--gib 64]"""
 import argparse
 import json
@@ -37,11 +37,6 @@ def main():
         s.set_filter(*tri)
         names.append("pinned %d,%d,%d" % tri)
         searchers.append(s)
-    off = None
-    was = ss.set_autotune(False)
-    off = ss.DynamicHipSearcher.new(nd)
-    off.search_in(hay)
-    ss.set_autotune(was)
     for rep in range(2):
         res, ms = paired_ms(searchers, hay, rounds=args.rounds)
         row = {"found": res, "rep": rep}
