@@ -159,9 +159,58 @@ def nonlatin(seconds, seed):
                       "triples_from_the_histogram": adopted if ss.lib().has_hooks else None}))
 
 
+def compact(seconds, seed):
+    """Filters that meet no candidates and take their compact form (ss_census.hip, propose_compact): 512 MiB of random bytes (0xFF-free),
+    random needles of 12-200 bytes - absent (a 0xFF inside), or planted at a random offset / flush against either end - through `new`
+    and `with_position`; fourteen scans per searcher, search_in and find alternating, so that the static triple, the histogram's, the
+    trials and the settled compact form all answer."""
+    rng = random.Random(seed)
+    n_bytes = 512 << 20
+    hay = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    ss.fill_random_device(hay, 0xC0DE + seed)
+    t_end = time.time() + seconds
+    rounds = searches = moved = 0
+    while time.time() < t_end:
+        n = rng.choice([12, 13, 16, 17, 24, 32, 40, 64, 200])
+        nd = bytearray(rng.randbytes(n))
+        for k in range(n):
+            if nd[k] == 0xFF:
+                nd[k] = 0
+        plant = rng.random() < 0.5
+        if not plant:
+            nd[rng.randrange(n)] = 0xFF
+        nd = bytes(nd)
+        at = rng.choice([0, n_bytes - n, rng.randrange(n_bytes - n + 1)])
+        keep = None
+        pos = None if rng.random() < 0.7 else rng.randrange(n)
+        s = ss.DynamicHipSearcher(nd, pos)
+        for it in range(14):
+            if plant and it == 7:                                     # from the eighth scan on the needle is there
+                keep = hay[at:at + n].clone()
+                hay[at:at + n] = torch.from_numpy(np.frombuffer(nd, dtype=np.uint8).copy()).cuda()
+            want = at if (plant and it >= 7) else -1
+            got = s.search_in(hay) if it % 2 == 0 else s.find(hay)
+            ok = got == (want >= 0) if it % 2 == 0 else got == (want if want >= 0 else None)
+            searches += 1
+            if not ok:
+                print(json.dumps({"MISMATCH": True, "mode": "compact", "needle_len": n, "position": pos, "at": at, "want": want, "scan": it,
+                                  "got": got, "seed": seed, "round": rounds, "state": s.tuning_state(hay)}))
+                sys.exit(1)
+            if it == 6:
+                st = s.tuning_state(hay)
+                moved += st["in_force"] != st["own"]
+        if keep is not None:
+            hay[at:at + n] = keep
+        rounds += 1
+    print(json.dumps({"fuzz": "ok", "mode": "compact", "seconds": seconds, "seed": seed, "searchers": rounds, "searches": searches,
+                      "searchers_whose_bytes_moved": moved}))
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "compact":                # fuzz_gpu.py SECONDS SEED compact: filters that meet no candidates
+        return compact(seconds, seed)
     if len(sys.argv) > 3 and sys.argv[3] == "nonlatin":               # fuzz_gpu.py SECONDS SEED nonlatin: histogram-driven filter bytes
         return nonlatin(seconds, seed)
     if len(sys.argv) > 3:                                             # fuzz_gpu.py SECONDS SEED GIB: the large-haystack mode
