@@ -326,7 +326,7 @@ SS_API int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards
  * No search RESULT depends on anything here (src/lib.rs:375-378: the reference asserts the same for every `position`).  What a
  * handle learns about the haystacks it meets only moves necessary conditions around and picks launch shapes:
  *   - per (searcher, device, haystack >= 256 MiB): a candidate census of 1,024 sampled 4 KiB tiles, taken by a small kernel in
- *     front of the first scan (and every 256th after it) on the scan's own stream, never waited for: workgroups per CU (four /
+ *     front of the SECOND scan of the pair (the first only leaves its name) and every 256th after it, on the scan's own stream, never waited for: workgroups per CU (four /
  *     five / six) and 16 KiB tiles per workgroup (one / two), the cross-lane kernels with or without a third byte, the THIRD first-phase byte where the library owns it and the near
  *     bytes that stand in for a far pair (by the measured number of candidates each position lets through, on trial against the
  *     next census), and the ORDER of the second level's schedule (the needle byte that kills most of the sampled candidates
@@ -342,7 +342,7 @@ SS_API int ss_find_sharded_all(const ss_searcher *s, const void *const *d_shards
  * haystack on the current device. */
 typedef struct ss_tuning_state {
     uint32_t autotune;              /* 1: on (the default) */
-    uint32_t census_state;          /* 0: no census of this haystack, 1: in flight, 2: counts are in */
+    uint32_t census_state;          /* 0: no census of this haystack, 3: seen once (the census is taken in front of the SECOND scan), 1: in flight, 2: counts are in */
     uint32_t census_age;            /* scans that have gone by these counts (taken again every 256) */
     uint32_t tiles, tiles3, tiles2, match_tiles, lanes;   /* sampled tiles; with a candidate of the triple / of the pair alone / with a
                                        prefix match of up to 64 bytes; candidate lanes */

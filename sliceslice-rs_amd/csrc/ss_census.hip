@@ -631,9 +631,10 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
         if (e.inflight == 0 && (victim->inflight != 0 || e.stamp < victim->stamp)) victim = &e;
     }
     if (!c) {
-        // first meeting: a census of the searcher's own triple in front of this scan (and, for searchers built by ss_searcher_new, the
-        // haystack's histogram next to it); the scan itself goes by the static choices
-        if (pd->census_pending >= 0 || victim->inflight != 0) return;                     // one census in flight per searcher and device
+        // first meeting: the pair only leaves its NAME - a searcher that scans a haystack once pays nothing for what it will never use
+        // (the census and the histogram sampling are 27-29 us and 18-19 us of kernel time in front of the scan they are launched with,
+        // a fifth of a 1 GiB scan's own time; the batched calls treat their batches the same way: ss_batched.hip)
+        if (victim->inflight != 0) return;                                                // (every entry has a census in flight)
         PerDevice::Census fresh;
         fresh.hay = d_hay;
         fresh.len = len;
@@ -644,12 +645,16 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
         fresh.free_mask = free_slots(s);
         fresh.coord = 2;
         fresh.stamp = ++pd->census_clock;
+        fresh.state = 3;
         *victim = fresh;
-        c = victim;
-        if (!launch_census(s, pd, c, c->cur, 2, d_hay, len, st)) {
-            c->state = 0;
-            return;
-        }
+        return;
+    }
+    c->stamp = ++pd->census_clock;
+    if (c->state == 3) {
+        // second meeting: a census of the searcher's own triple in front of this scan (and, for searchers built by ss_searcher_new, the
+        // haystack's histogram next to it); the scan itself goes by the static choices
+        if (pd->census_pending >= 0) return;                                              // one census in flight per searcher and device
+        if (!launch_census(s, pd, c, c->cur, 2, d_hay, len, st)) return;                  // (a capturing stream: asked again next time)
         c->state = 1;
         c->inflight = 1;
         if (s->auto_filter && s->n >= 3) {
@@ -658,7 +663,6 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
         }
         return;
     }
-    c->stamp = ++pd->census_clock;
     if (c->adopted) {
         out->have_triple = true;
         normalised(c->cur, out->tri);
@@ -724,6 +728,9 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     int gather = -1;
     if (kind == 0) {
         const uint32_t nfree = (uint32_t)__builtin_popcount(c->free_mask);
+        // (with fewer candidates in the sample than a move needs to be worth a trial - propose_move: kThirdMinLanes - no coordinate is
+        // looked at: each look is a census in front of a scan, 27-29 us, and a handle on random bytes spent six of them on nothing)
+        if (cc.lanes < kThirdMinLanes && c->stale < nfree) c->stale = nfree;
         for (uint32_t tries = 0; tries < 3 && kind == 0 && gather < 0; ++tries) {
             if (nfree == 0 || c->stale >= nfree) {
                 c->settled = true;

@@ -624,8 +624,11 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             assert s.search_in(h[: 1 << 20]) is False and s.census(h[: 1 << 20]) is None, "a 1 MiB scan takes no census"
             guess = s.last_launch()[0]
             assert s.census(h) is None
+            # the FIRST scan of a (searcher, haystack) pair only leaves the pair's name (a searcher that comes once pays for no sampling);
+            # the census is taken in front of the SECOND
+            assert s.search_in(h) is False and s.census(h) is None and s.tuning_state(h)["census_state"] == 3
             assert s.search_in(h) is False
-            assert s.last_launch()[0] == guess, "the first scan of a haystack goes by the needle-byte guess"
+            assert s.last_launch()[0] == guess, "the first scans of a haystack go by the needle-byte guess"
             got = s.census(h)                               # the census ran in front of that scan: its counts are in
             assert got == _census_model(host, needle, s.filter3), (needle, got)
             assert s.device_filter == s.filter3
@@ -671,13 +674,14 @@ def test_workgroups_per_cu_follow_the_candidate_census(O):
             a, b, c = s.filter3
             s.set_filter(a, b, c)
             assert s.census(h) is None
+            assert s.search_in(h) is False and s.census(h) is None          # (new bytes: a new pair - named by its first scan)
             assert s.search_in(h) is False and s.census(h) == got
             st2 = _settle(s, h)
             assert st2["in_force"] == [a, b, c] and st2["trials"] == 0 and st2["triple_state"] == 1
         # a buffer refilled IN PLACE: everything is looked at again every 256 scans, so the choice follows
         s = ss.DynamicHipSearcher.new(b"segment descriptor table entries are")
         s.set_filter(*s.filter3)                            # (the stock triple pinned: 209 candidate tiles in 1,024 on this text)
-        for _ in range(3):
+        for _ in range(4):
             assert s.search_in(text) is False
         assert s.last_launch()[0] == 6
         ss.fill_random_device(text, 0x5EED0001)            # the same bytes as `hay`: no candidates at all
@@ -756,6 +760,7 @@ def test_census_measures_survival_and_moves_the_bytes_the_library_owns(O):
         # (1) the counters themselves, first census: the searcher's own triple, gathered for slot 2
         s = ss.DynamicHipSearcher.new(stock)
         own = list(s.filter3)
+        assert s.search_in(text) is False                   # (the first scan names the pair, the second takes the census)
         assert s.search_in(text) is False
         counts, stats = _census_model(host, stock, own, roles=2)
         assert s.census(text) == counts
@@ -768,7 +773,7 @@ def test_census_measures_survival_and_moves_the_bytes_the_library_owns(O):
         #     stay: the same triple, named through ss_searcher_set_filter3)
         ex = ss.DynamicHipSearcher.new(stock)
         ex.set_filter(*own)
-        assert ex.search_in(text) is False and ex.search_in(text) is False
+        assert ex.search_in(text) is False and ex.search_in(text) is False and ex.search_in(text) is False
         st = ex.tuning_state(text)
         assert st["order_measured"] == 1 and st["order"][0] == killer and st["in_force"] == own, st
         # (3) ... and the bytes move: settled, the filter in force meets (far) fewer candidates than the static one, by the same model
@@ -849,13 +854,14 @@ def test_filter_bytes_follow_the_haystacks_histogram(O):
         s = ss.DynamicHipSearcher.new(word)
         own = s.filter3
         assert 16 not in own, "the static ranking takes 'e' for the needle's most common byte"
-        assert s.search_in(hay) is False                       # first scan: the searcher's own triple; census + histogram sampled
+        assert s.search_in(hay) is False and s.census(hay) is None    # the first scan of the pair only names it
+        assert s.search_in(hay) is False                       # second scan: the searcher's own triple; census + histogram sampled
         first = s.census(hay)
         assert s.device_filter == own and first == _census_model(host, word, own) and first["tiles3"] > 48
-        assert s.search_in(hay) is False                       # second scan: the histogram is in -> a triple with the 'e', on trial
+        assert s.search_in(hay) is False                       # third scan: the histogram is in -> a triple with the 'e', on trial
         s.census(hay)
         assert 16 in s.device_filter and s.filter3 == own and s.triple_trials == 1 and s.triple_state == 2
-        assert s.search_in(hay) is False                       # third: its own census is in
+        assert s.search_in(hay) is False                       # fourth: its own census is in
         settled = s.census(hay)
         model = _census_model(host, word, s.device_filter)
         assert {k: settled[k] for k in ("tiles3", "match_tiles", "lanes")} == {k: model[k] for k in ("tiles3", "match_tiles", "lanes")} and settled["tiles3"] == 0
@@ -893,6 +899,7 @@ def test_filter_bytes_follow_the_haystacks_histogram(O):
         s = ss.DynamicHipSearcher.new(word)
         own = s.filter3
         assert not {0, 1, 2} & set(own), "the static ranking avoids 'e'"
+        assert s.search_in(hay) is want and s.census(hay) is None      # (named)
         assert s.search_in(hay) is want
         first = s.census(hay)
         assert first == _census_model(host, word, own)
@@ -944,8 +951,8 @@ queue_work()
 t0 = time.perf_counter()
 with torch.cuda.stream(side):
     fresh = ss.DynamicHipSearcher.new(b"no such needle!!")
-    r1 = fresh.search_in(small)                                   # first >= 256 MiB search of the process: census + histogram scratch
-    r2 = fresh.search_in(small)
+    r1 = fresh.search_in(small)                                   # (names the pair)
+    r2 = fresh.search_in(small)                                   # first census of the process: census + histogram scratch allocated
     f1 = ss.search_batched(small, hay_off, nblob, nd_off)         # names the batch
     f2 = ss.search_batched(small, hay_off, nblob, nd_off)         # second call: the class table is allocated and sampled
     f3 = ss.search_batched(small, hay_off, nblob, nd_off)
