@@ -111,7 +111,7 @@ SS_API int ss_searcher_info(const ss_searcher *s, size_t *needle_len, size_t *po
  *   ss_searcher_new - whose caller did not choose - picks all three by a static rarity ranking of the needle's
  *     bytes (first byte + the two rarest of the 15 bytes behind it, over the first 1024 needle bytes), so that
  *     text-like haystacks rarely pass the filter.  ss_searcher_info still reports position n-1.  On a haystack of 256 MiB or more
- *     the library samples the haystack's byte histogram in front of the first scan and filters THAT haystack with the needle's
+ *     the library samples the haystack's byte histogram in front of the second scan and filters THAT haystack with the needle's
  *     rarest bytes under it when that promises 16 x fewer candidates (non-Latin UTF-8 text, padding patterns: bytes the static
  *     ranking takes for rare); ss_searcher_filter3 keeps reporting the static choice.
  *   ss_searcher_set_filter3 sets the triple verbatim (third == second: a plain two-byte filter, e.g. the reference's own
