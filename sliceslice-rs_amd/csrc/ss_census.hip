@@ -632,7 +632,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     }
     if (!c) {
         // first meeting: the pair only leaves its NAME - a searcher that scans a haystack once pays nothing for what it will never use
-        // (the census and the histogram sampling are 27-29 us and 18-19 us of kernel time in front of the scan they are launched with,
+        // (the census and the histogram sampling are 10-13 us and 18-22 us of kernel time in front of the scan they are launched with,
         // a fifth of a 1 GiB scan's own time; the batched calls treat their batches the same way: ss_batched.hip)
         if (victim->inflight != 0) return;                                                // (every entry has a census in flight)
         PerDevice::Census fresh;
@@ -729,7 +729,7 @@ void launch_hints(const ss_searcher *s, PerDevice *pd, const void *d_hay, size_t
     if (kind == 0) {
         const uint32_t nfree = (uint32_t)__builtin_popcount(c->free_mask);
         // (with fewer candidates in the sample than a move needs to be worth a trial - propose_move: kThirdMinLanes - no coordinate is
-        // looked at: each look is a census in front of a scan, 27-29 us, and a handle on random bytes spent six of them on nothing)
+        // looked at: each look is a census in front of a scan, 10-13 us, and a handle on random bytes spent six of them on nothing)
         if (cc.lanes < kThirdMinLanes && c->stale < nfree) c->stale = nfree;
         for (uint32_t tries = 0; tries < 3 && kind == 0 && gather < 0; ++tries) {
             if (nfree == 0 || c->stale >= nfree) {
